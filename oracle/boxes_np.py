@@ -1,0 +1,301 @@
+"""CPU oracle for the 3D box ops of the RetinaUNet hot path (numpy, fp32 arithmetic).
+
+TEST INFRASTRUCTURE ONLY: imported by `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` as the *checker*. The product (`nndetection_amd/`) never
+imports this module and has no CPU fallback.
+
+Every function restates one reference function (paths relative to /root/reference) with the same
+operation order so that fp32 results are bit-identical to the reference's CPU path; it is pinned
+against the real reference by `tests/golden/make_golden.py` (fixtures in `tests/golden/*.npz`,
+checked by `tests/test_oracle_golden.py`).
+
+Box layout everywhere: (x1, y1, x2, y2, z1, z2)  [nndet/core/boxes/ops.py:131-159].
+"""
+from itertools import product
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+INF = 100.0  # nndet/core/boxes/matcher/atss.py uses INF = 100 as the "not a candidate" fill value
+BELOW_LOW_THRESHOLD = -1  # nndet/core/boxes/matcher/base.py:14
+BBOX_XFORM_CLIP = float(np.log(1000.0 / 16))  # torchvision BoxCoder default: 4.135166...
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=F32)
+
+
+# --------------------------------------------------------------------------------------
+# pairwise IoU / GIoU / centre distance
+# --------------------------------------------------------------------------------------
+def box_area_3d(b: np.ndarray) -> np.ndarray:
+    """nndet/core/boxes/ops.py:27-38 : ((x2-x1)*(y2-y1))*(z2-z1)"""
+    b = _f(b)
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) * (b[:, 5] - b[:, 4])
+
+
+def box_iou_union_3d(b1, b2, eps: float = 0.0) -> Tuple[np.ndarray, np.ndarray]:
+    """nndet/core/boxes/ops.py:131-159"""
+    b1, b2 = _f(b1), _f(b2)
+    vol1, vol2 = box_area_3d(b1), box_area_3d(b2)
+    x1 = np.maximum(b1[:, None, 0], b2[:, 0])
+    y1 = np.maximum(b1[:, None, 1], b2[:, 1])
+    x2 = np.minimum(b1[:, None, 2], b2[:, 2])
+    y2 = np.minimum(b1[:, None, 3], b2[:, 3])
+    z1 = np.maximum(b1[:, None, 4], b2[:, 4])
+    z2 = np.minimum(b1[:, None, 5], b2[:, 5])
+    inter = (np.maximum(x2 - x1, F32(0)) * np.maximum(y2 - y1, F32(0)) * np.maximum(z2 - z1, F32(0))) + F32(eps)
+    union = (vol1[:, None] + vol2) - inter
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (inter / union).astype(F32), union.astype(F32)
+
+
+def box_iou(b1, b2, eps: float = 0.0) -> np.ndarray:
+    """nndet/core/boxes/ops.py:75-102 (3D branch). Empty input -> empty 1-D array (like tensor([]))."""
+    b1, b2 = _f(b1), _f(b2)
+    if b1.size == 0 or b2.size == 0:
+        return np.zeros((0,), F32)
+    return box_iou_union_3d(b1, b2, eps)[0]
+
+
+def generalized_box_iou(b1, b2, eps: float = 0.0) -> np.ndarray:
+    """nndet/core/boxes/ops.py:162-185. NOTE eps is NOT forwarded to the inner IoU (ops.py:175)."""
+    b1, b2 = _f(b1), _f(b2)
+    if b1.size == 0 or b2.size == 0:
+        return np.zeros((0,), F32)
+    iou, union = box_iou_union_3d(b1, b2)
+    x1 = np.minimum(b1[:, None, 0], b2[:, 0])
+    y1 = np.minimum(b1[:, None, 1], b2[:, 1])
+    x2 = np.maximum(b1[:, None, 2], b2[:, 2])
+    y2 = np.maximum(b1[:, None, 3], b2[:, 3])
+    z1 = np.minimum(b1[:, None, 4], b2[:, 4])
+    z2 = np.maximum(b1[:, None, 5], b2[:, 5])
+    vol = (np.maximum(x2 - x1, F32(0)) * np.maximum(y2 - y1, F32(0)) * np.maximum(z2 - z1, F32(0))) + F32(eps)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (iou - (vol - union) / vol).astype(F32)
+
+
+def box_center(b) -> np.ndarray:
+    """nndet/core/boxes/ops.py:314-327 : (hi + lo) / 2"""
+    b = _f(b)
+    return np.stack([(b[:, 2] + b[:, 0]) / F32(2), (b[:, 3] + b[:, 1]) / F32(2), (b[:, 5] + b[:, 4]) / F32(2)], 1)
+
+
+def box_center_dist(b1, b2) -> np.ndarray:
+    """nndet/core/boxes/ops.py:262-287 (euclidean): sqrt((dx^2 + dy^2) + dz^2) in fp32."""
+    c1, c2 = box_center(b1), box_center(b2)
+    d = c1[:, None, :] - c2[None, :, :]
+    d = d * d
+    return np.sqrt((d[..., 0] + d[..., 1]) + d[..., 2]).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# anchors
+# --------------------------------------------------------------------------------------
+def cell_anchors_3ds(width: Sequence[float], height: Sequence[float], depth: Sequence[float]) -> np.ndarray:
+    """AnchorGenerator3DS.generate_anchors, nndet/core/boxes/anchors.py:526-549 (depth fastest)."""
+    s = np.asarray(list(product(width, height, depth)), dtype=F32) / F32(2)
+    return np.stack([-s[:, 0], -s[:, 1], s[:, 0], s[:, 1], -s[:, 2], s[:, 2]], 1).astype(F32)
+
+
+def grid_anchors_3d(grid_sizes, strides, cells) -> Tuple[List[np.ndarray], List[int]]:
+    """AnchorGenerator3D.grid_anchors, nndet/core/boxes/anchors.py:337-377.
+    Order: x-major (x, y, z) over the grid, then the A cell anchors; per level [Sx*Sy*Sz*A, 6]."""
+    out, per_level = [], []
+    for size, stride, base in zip(grid_sizes, strides, cells):
+        sx = np.arange(size[0], dtype=F32) * F32(stride[0])
+        sy = np.arange(size[1], dtype=F32) * F32(stride[1])
+        sz = np.arange(size[2], dtype=F32) * F32(stride[2])
+        gx, gy, gz = np.meshgrid(sx, sy, sz, indexing="ij")
+        gx, gy, gz = gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)
+        shifts = np.stack([gx, gy, gx, gy, gz, gz], 1)
+        a = (shifts[:, None, :] + base[None, :, :]).reshape(-1, 6).astype(F32)
+        out.append(a)
+        per_level.append(a.shape[0])
+    return out, per_level
+
+
+def anchors_for_image(image_size, fmap_sizes, width, height, depth) -> Tuple[np.ndarray, List[int]]:
+    """AnchorGenerator2D.forward, anchors.py:211-242: stride = int(image/fmap) per axis; levels concatenated."""
+    strides = [[int(i / s) for i, s in zip(image_size, fm)] for fm in fmap_sizes]
+    cells = [cell_anchors_3ds(w, h, d) for w, h, d in zip(width, height, depth)]
+    per, npl = grid_anchors_3d(fmap_sizes, strides, cells)
+    return np.concatenate(per, 0), npl
+
+
+# --------------------------------------------------------------------------------------
+# ATSS matcher
+# --------------------------------------------------------------------------------------
+def atss_match(boxes, anchors, num_anchors_per_level: Sequence[int], num_anchors_per_loc: int,
+               num_candidates: int = 4) -> Tuple[np.ndarray, np.ndarray]:
+    """ATSSMatcher.compute_matches (center_in_gt=False), nndet/core/boxes/matcher/atss.py:48-122,
+    with Matcher.__call__'s no-GT fast path (matcher/base.py:51-56).
+
+    Tie rule (the reference's torch.topk leaves ties implementation-defined): candidates are the
+    k smallest by (distance, anchor index) -- lowest index wins. Returns (iou[G,M] fp32, matches[M] int64).
+    """
+    boxes, anchors = _f(boxes).reshape(-1, 6), _f(anchors)
+    G, M = boxes.shape[0], anchors.shape[0]
+    if G == 0:
+        return np.zeros((0,), F32), np.full((M,), BELOW_LOW_THRESHOLD, np.int64)
+    dist = box_center_dist(boxes, anchors)
+    cand, start = [], 0
+    for apl in num_anchors_per_level:
+        k = min(num_candidates * num_anchors_per_loc, apl)
+        idx = np.argsort(dist[:, start:start + apl], axis=1, kind="stable")[:, :k]
+        cand.append(idx + start)
+        start += apl
+    cand = np.concatenate(cand, 1)                               # [G, K]
+    iou = box_iou(boxes, anchors)                                # [G, M]
+    cov = np.take_along_axis(iou, cand, 1)                       # [G, K]
+    mean = cov.astype(np.float64).mean(1)
+    std = cov.astype(np.float64).std(1, ddof=1) if cov.shape[1] > 1 else np.full((G,), np.nan)
+    thr = (mean + std).astype(F32)                               # atss.py:97-99 (fp32 in the reference)
+    is_pos = cov >= thr[:, None]
+    best = np.full((G, M), -INF, F32)
+    for g in range(G):
+        sel = cand[g][is_pos[g]]
+        best[g, sel] = iou[g, sel]
+    matches = best.argmax(0).astype(np.int64)                    # first max -> lowest GT index on ties
+    matches[best.max(0) == -INF] = BELOW_LOW_THRESHOLD
+    return iou, matches
+
+
+def assign_targets(matches: np.ndarray, gt_boxes, gt_classes, num_anchors: int):
+    """BaseRetinaNet.assign_targets_to_anchors for one image, nndet/core/retina.py:258-288.
+    labels: fp32, 0 background, c+1 foreground; matched boxes [M,6] (zeros when no GT)."""
+    gt_boxes = _f(gt_boxes).reshape(-1, 6)
+    if gt_boxes.shape[0] > 0:
+        m = np.clip(matches, 0, None)
+        mb = gt_boxes[m]
+        lab = _f(gt_classes)[m] + F32(1)
+    else:
+        mb = np.zeros((num_anchors, 6), F32)
+        lab = np.zeros((num_anchors,), F32)
+    lab = lab.copy()
+    lab[matches == -1] = 0.0
+    lab[matches == -2] = -1.0
+    return lab, mb
+
+
+# --------------------------------------------------------------------------------------
+# NMS
+# --------------------------------------------------------------------------------------
+def _iou_one_vs_many(a, b):
+    """devIoU_3d, nndet/csrc/cuda/nms.cu:36-51 (same fp32 ops as ops.py:131-159 with eps=0)."""
+    x1 = np.maximum(a[0], b[:, 0]); y1 = np.maximum(a[1], b[:, 1])
+    x2 = np.minimum(a[2], b[:, 2]); y2 = np.minimum(a[3], b[:, 3])
+    z1 = np.maximum(a[4], b[:, 4]); z2 = np.minimum(a[5], b[:, 5])
+    inter = np.maximum(x2 - x1, F32(0)) * np.maximum(y2 - y1, F32(0)) * np.maximum(z2 - z1, F32(0))
+    sa = (a[2] - a[0]) * (a[3] - a[1]) * (a[5] - a[4])
+    sb = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) * (b[:, 5] - b[:, 4])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return inter / ((sa + sb) - inter)
+
+
+def nms(boxes, scores, thr: float) -> np.ndarray:
+    """Greedy 3D NMS = nms_cuda (nndet/csrc/cuda/nms.cu:148-221) == nms_cpu (nndet/core/boxes/nms.py:31-53):
+    sort by descending score (ties: lower index first -- the reference's sort is unstable there),
+    box j is suppressed iff IoU(kept i, j) > thr (NaN never suppresses, as in the CUDA kernel).
+    Returns int64 indices into the input, in decreasing score order."""
+    boxes, scores = _f(boxes).reshape(-1, 6), _f(scores)
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros((0,), np.int64)
+    order = np.argsort(-scores, kind="stable")
+    b = boxes[order]
+    alive = np.ones(n, bool)
+    keep = []
+    thr = F32(thr)
+    for i in range(n):
+        if not alive[i]:
+            continue
+        keep.append(i)
+        if i + 1 < n:
+            sup = _iou_one_vs_many(b[i], b[i + 1:]) > thr
+            alive[i + 1:] &= ~sup
+    return order[np.asarray(keep, np.int64)]
+
+
+def batched_nms(boxes, scores, idxs, thr: float) -> np.ndarray:
+    """nndet/core/boxes/nms.py:81-106: offset boxes by class * (max_coordinate + 1) in fp32, then nms."""
+    boxes = _f(boxes).reshape(-1, 6)
+    if boxes.size == 0:
+        return np.zeros((0,), np.int64)
+    off = _f(idxs) * (boxes.max() + F32(1))
+    return nms(boxes + off[:, None], scores, thr)
+
+
+# --------------------------------------------------------------------------------------
+# box coder / clip / post-processing front end
+# --------------------------------------------------------------------------------------
+def decode_single(rel_codes, boxes, weights=(1.,) * 6, clip: float = BBOX_XFORM_CLIP) -> np.ndarray:
+    """nndet/core/boxes/coder.py:90-155 for [N,6] codes (dx, dy, dw, dh, dz, dd)."""
+    r, b = _f(rel_codes).reshape(-1, 6), _f(boxes)
+    w = b[:, 2] - b[:, 0]; h = b[:, 3] - b[:, 1]; d = b[:, 5] - b[:, 4]
+    cx = b[:, 0] + F32(0.5) * w; cy = b[:, 1] + F32(0.5) * h; cz = b[:, 4] + F32(0.5) * d
+    dx = r[:, 0] / F32(weights[0]); dy = r[:, 1] / F32(weights[1])
+    dw = np.minimum(r[:, 2] / F32(weights[2]), F32(clip)); dh = np.minimum(r[:, 3] / F32(weights[3]), F32(clip))
+    dz = r[:, 4] / F32(weights[4]); dd = np.minimum(r[:, 5] / F32(weights[5]), F32(clip))
+    pcx = dx * w + cx; pcy = dy * h + cy; pcz = dz * d + cz
+    pw = np.exp(dw) * w; ph = np.exp(dh) * h; pd = np.exp(dd) * d
+    half = F32(0.5)
+    return np.stack([pcx - half * pw, pcy - half * ph, pcx + half * pw, pcy + half * ph,
+                     pcz - half * pd, pcz + half * pd], 1).astype(F32)
+
+
+def clip_boxes_to_image(boxes, img_shape) -> np.ndarray:
+    """clip_boxes_to_image_3d_, nndet/core/boxes/clip.py:83-101 (x,y,z limits = s0,s1,s2)."""
+    b = _f(boxes).copy()
+    s0, s1, s2 = [F32(s) for s in img_shape]
+    b[:, 0] = np.clip(b[:, 0], 0, s0); b[:, 2] = np.clip(b[:, 2], 0, s0)
+    b[:, 1] = np.clip(b[:, 1], 0, s1); b[:, 3] = np.clip(b[:, 3], 0, s1)
+    b[:, 4] = np.clip(b[:, 4], 0, s2); b[:, 5] = np.clip(b[:, 5], 0, s2)
+    return b
+
+
+def remove_small_boxes(boxes, min_size: float) -> np.ndarray:
+    """nndet/core/boxes/ops.py:241-259 -> indices to keep."""
+    b = _f(boxes)
+    m = F32(min_size)
+    k = ((b[:, 2] - b[:, 0]) >= m) & ((b[:, 3] - b[:, 1]) >= m) & ((b[:, 5] - b[:, 4]) >= m)
+    return np.nonzero(k)[0]
+
+
+def sigmoid(x):
+    x = np.asarray(x, np.float64)
+    return (1.0 / (1.0 + np.exp(-x))).astype(F32)
+
+
+def postprocess_single_image(boxes, probs, image_shape, num_classes=1, topk=10000, score_thresh=0.0,
+                             min_size=0.01, nms_thresh=0.6, detections_per_img=100):
+    """BaseRetinaNet.postprocess_detections_single_image, nndet/core/retina.py:332-379.
+    boxes: decoded [M,6]; probs [M,C]. Sort ties: lower flat index first."""
+    boxes = clip_boxes_to_image(boxes, image_shape)
+    p = _f(probs).reshape(-1)
+    k = min(topk, boxes.shape[0])
+    idx = np.argsort(-p, kind="stable")[:k]
+    p = p[idx]
+    keep = p > F32(score_thresh)
+    p, idx = p[keep], idx[keep]
+    a_idx, labels = idx // num_classes, idx % num_classes
+    b = boxes[a_idx]
+    keep = remove_small_boxes(b, min_size)
+    b, p, labels = b[keep], p[keep], labels[keep]
+    keep = batched_nms(b, p, labels, nms_thresh)[:detections_per_img]
+    return b[keep], p[keep], labels[keep].astype(np.int64)
+
+
+# --------------------------------------------------------------------------------------
+# hard-negative sampler bookkeeping (RNG itself stays in torch on both sides)
+# --------------------------------------------------------------------------------------
+def hnm_counts(num_positive: int, num_negative: int, batch_size: int, batch_size_per_image: int = 32,
+               positive_fraction: float = 0.33, min_neg: int = 1, pool_size: float = 20):
+    """HardNegativeSamplerBatched counts, nndet/core/boxes/sampler.py:154-185,237-262."""
+    bs = batch_size_per_image * batch_size
+    num_pos = min(num_positive, int(bs * positive_fraction))
+    num_neg = int(max(1, num_pos) * abs(1 - 1. / float(positive_fraction)))
+    num_neg = min(num_negative, max(num_neg, min_neg))
+    pool = min(num_negative, int(num_neg * pool_size))
+    return num_pos, num_neg, pool

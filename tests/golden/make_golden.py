@@ -1,0 +1,262 @@
+"""Generate the golden fixtures in tests/golden/ from the UNMODIFIED reference (run in the build
+container, where /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+For every fixture the script (1) runs the reference function on seeded inputs, (2) checks the
+`oracle/` restatement against it right here (bit-exact for box/index work, 1e-5 for the network)
+and (3) stores inputs + reference outputs as small .npz files. The reference cannot travel to the
+GPU box, the fixtures do; tests/test_oracle_golden.py re-checks the oracle against them everywhere.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from oracle.refimport import load_reference  # noqa: E402
+load_reference()
+from oracle import boxes_np as bx  # noqa: E402
+from oracle.retina_torch import OracleRetinaUNet  # noqa: E402
+from oracle.detweights import fill_state  # noqa: E402
+from nndetection_amd.plans import get_plan, MODEL_CFG_V001  # noqa: E402
+
+import nndet.core.boxes as rb  # noqa: E402
+from nndet.core.boxes.nms import nms_cpu  # noqa: E402
+from nndet.core.boxes.ops import box_center_dist  # noqa: E402
+from nndet.core.boxes.coder import BoxCoderND  # noqa: E402
+from nndet.core.boxes.anchors import get_anchor_generator  # noqa: E402
+
+
+def rand_boxes(rng, n, extent=(160, 160, 96), smin=2, smax=26):
+    c = rng.uniform(0, 1, (n, 3)) * np.asarray(extent)
+    s = rng.uniform(smin, smax, (n, 3))
+    lo, hi = c - s / 2, c + s / 2
+    return np.stack([lo[:, 0], lo[:, 1], hi[:, 0], hi[:, 1], lo[:, 2], hi[:, 2]], 1).astype(np.float32)
+
+
+def eq(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.dtype.kind == "f":
+        ok = np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+        if not ok:  # allow NaN==NaN
+            ok = np.array_equal(a, b, equal_nan=True)
+        assert ok, f"{what}: oracle != reference (max abs diff {np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))})"
+    else:
+        assert np.array_equal(a, b), f"{what}: oracle != reference"
+    print(f"  [bit-exact] {what} {a.shape}")
+
+
+def golden_boxes():
+    rng = np.random.default_rng(0)
+    g = {}
+    # ---- pairwise IoU / GIoU / centre distance
+    b1, b2 = rand_boxes(rng, 37), rand_boxes(rng, 501)
+    b2[5] = b1[3]                      # an identical pair
+    b2[6] = [10, 10, 10, 20, 5, 9]     # zero-volume box
+    t1, t2 = torch.from_numpy(b1), torch.from_numpy(b2)
+    g["iou_b1"], g["iou_b2"] = b1, b2
+    g["iou"] = rb.box_iou(t1, t2).numpy()
+    g["iou_eps"] = rb.box_iou(t1, t2, eps=1e-6).numpy()
+    g["giou"] = rb.generalized_box_iou(t1, t2).numpy()
+    g["giou_eps"] = rb.generalized_box_iou(t1, t2, eps=1e-7).numpy()
+    g["cdist"] = box_center_dist(t1, t2)[0].numpy()
+    eq(bx.box_iou(b1, b2), g["iou"], "box_iou")
+    eq(bx.box_iou(b1, b2, 1e-6), g["iou_eps"], "box_iou eps")
+    eq(bx.generalized_box_iou(b1, b2), g["giou"], "generalized_box_iou")
+    eq(bx.generalized_box_iou(b1, b2, 1e-7), g["giou_eps"], "generalized_box_iou eps")
+    # torch-CPU's vectorised sqrt (MKL/SLEEF build in this container) is not correctly rounded: 0.5 % of
+    # the values are 1 ulp off IEEE sqrt. CUDA sqrtf and HIP sqrtf are correctly rounded, numpy too; the
+    # squared distance (before sqrt) is bit-exact. So the distance fixture is pinned to <= 1 ulp.
+    d_or = bx.box_center_dist(b1, b2)
+    ulp = np.abs(d_or.view(np.int32).astype(np.int64) - g["cdist"].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, ulp.max()
+    print(f"  [<=1 ulp] box_center_dist {d_or.shape}: {int((ulp > 0).sum())} of {ulp.size} values differ by 1 ulp (torch-CPU sqrt)")
+    g["cdist_sq"] = (torch.from_numpy(bx.box_center(b1))[:, None] - torch.from_numpy(bx.box_center(b2))[None]).pow(2).sum(-1).numpy()
+    eq((d_or.astype(np.float64) ** 2 * 0 + ((lambda d: (d[..., 0] + d[..., 1]) + d[..., 2])((bx.box_center(b1)[:, None, :] - bx.box_center(b2)[None, :, :]) ** 2))).astype(np.float32), g["cdist_sq"], "squared centre distance")
+    # ---- anchors (AnchorGenerator3DS through its forward())
+    W = [(4, 8, 16), (8, 16, 32), (16, 32, 64)]
+    gen = get_anchor_generator(3, s_param=True)(width=W, height=W, depth=W, stride=1)
+    img = torch.zeros(2, 1, 48, 40, 24)
+    fms = [torch.zeros(2, 8, 12, 10, 6), torch.zeros(2, 8, 6, 5, 3), torch.zeros(2, 8, 3, 3, 3)]
+    anc = gen(img, fms)
+    g["anchors"] = anc[0].numpy()
+    g["anchors_per_level"] = np.asarray(gen.get_num_acnhors_per_level())
+    a_or, npl = bx.anchors_for_image((48, 40, 24), [(12, 10, 6), (6, 5, 3), (3, 3, 3)], W, W, W)
+    eq(a_or, g["anchors"], "anchors")
+    assert npl == list(g["anchors_per_level"])
+    # ---- ATSS (tie-free GT placement: centres off the anchor-centre lattice)
+    gt = np.asarray([[5.3, 7.1, 17.9, 22.2, 3.7, 12.4],
+                     [20.6, 11.3, 41.1, 30.9, 6.2, 21.7],
+                     [30.2, 2.9, 36.8, 9.7, 14.1, 19.9],
+                     [1.1, 30.4, 9.8, 38.6, 1.3, 6.6]], np.float32)
+    matcher = rb.ATSSMatcher(num_candidates=4, similarity_fn=rb.box_iou, center_in_gt=False)
+    mq, matches = matcher(torch.from_numpy(gt), anc[0], num_anchors_per_level=npl, num_anchors_per_loc=27)
+    g["atss_gt"], g["atss_matches"] = gt, matches.numpy()
+    iou_or, m_or = bx.atss_match(gt, a_or, npl, 27, 4)
+    eq(m_or, g["atss_matches"], "atss matches")
+    eq(iou_or, mq.numpy(), "atss match_quality_matrix")
+    print("    positives per gt:", [(g["atss_matches"] == i).sum() for i in range(4)])
+    mq0, m0 = matcher(torch.zeros(0, 6), anc[0], num_anchors_per_level=npl, num_anchors_per_loc=27)
+    assert mq0.numel() == 0 and (m0 == -1).all()
+    lab_or, mb_or = bx.assign_targets(m_or, gt, np.asarray([0, 0, 0, 0], np.float32), a_or.shape[0])
+    # reference assign (retina.py:258-288) restated through torch ops on the reference outputs
+    mt = matches.clamp(min=0)
+    lab_ref = torch.zeros(4)[mt] + 1
+    lab_ref[matches == -1] = 0
+    eq(lab_or, lab_ref.numpy(), "assigned labels")
+    eq(mb_or, torch.from_numpy(gt)[mt].numpy(), "matched gt boxes")
+    # ---- NMS (distinct scores), reference CPU path nms_cpu == CUDA semantics for non-degenerate boxes
+    for n, thr in ((300, 0.6), (1500, 0.1), (1500, 0.6)):
+        b = rand_boxes(rng, n, extent=(60, 60, 40), smin=4, smax=24)
+        s = (rng.permutation(n).astype(np.float32) + 1) / np.float32(n + 1)
+        keep = nms_cpu(torch.from_numpy(b), torch.from_numpy(s), thr).numpy()
+        g[f"nms_boxes_{n}_{thr}"], g[f"nms_scores_{n}_{thr}"], g[f"nms_keep_{n}_{thr}"] = b, s, keep
+        eq(bx.nms(b, s, thr), keep, f"nms n={n} thr={thr}")
+    b = rand_boxes(rng, 800, extent=(60, 60, 40), smin=4, smax=24)
+    s = (rng.permutation(800).astype(np.float32) + 1) / np.float32(801)
+    cls = rng.integers(0, 3, 800)
+    keep = rb.batched_nms(torch.from_numpy(b), torch.from_numpy(s), torch.from_numpy(cls), 0.5).numpy()
+    g["bnms_boxes"], g["bnms_scores"], g["bnms_cls"], g["bnms_keep"] = b, s, cls, keep
+    eq(bx.batched_nms(b, s, cls, 0.5), keep, "batched_nms")
+    # ---- decode / clip / small boxes
+    coder = BoxCoderND(weights=(1.,) * 6)
+    rel = (rng.standard_normal((a_or.shape[0], 6)) * 0.5).astype(np.float32)
+    rel[7, 2] = 9.0  # exercises the exp clamp
+    dec = coder.decode_single(torch.from_numpy(rel), torch.from_numpy(a_or)).numpy()
+    g["dec_rel"], g["dec_boxes"] = rel, dec
+    d_or = bx.decode_single(rel, a_or)
+    err = np.abs(d_or - dec).max()
+    assert err < 1e-4, err
+    print(f"  [<=1e-4] decode_single max abs err {err:.2e} (exp is library-dependent)")
+    clipped = rb.clip_boxes_to_image_(torch.from_numpy(dec.copy()), (48, 40, 24)).numpy()
+    g["clip_boxes"] = clipped
+    eq(bx.clip_boxes_to_image(dec, (48, 40, 24)), clipped, "clip_boxes_to_image_3d_")
+    eq(bx.remove_small_boxes(clipped, 0.01), rb.remove_small_boxes(torch.from_numpy(clipped), 0.01).numpy(), "remove_small_boxes")
+    np.savez_compressed(os.path.join(OUT, "boxes_golden.npz"), **g)
+
+
+# ----------------------------------------------------------------------------------------------
+def build_reference_net(plan):
+    """RetinaUNetModule.from_config_plan's constructor calls (retinaunet/base.py:388-466) for V001."""
+    from nndet.arch.conv import Generator, ConvInstanceRelu, ConvGroupRelu
+    from nndet.arch.blocks.basic import StackedConvBlock2
+    from nndet.arch.encoder.modular import Encoder
+    from nndet.arch.decoder.base import UFPNModular
+    from nndet.arch.heads.classifier import BCECLassifier
+    from nndet.arch.heads.regressor import GIoURegressor
+    from nndet.arch.heads.comb import DetectionHeadHNMNative
+    from nndet.arch.heads.segmenter import DiCESegmenterFgBg
+    from nndet.core.boxes.sampler import HardNegativeSamplerBatched
+    from nndet.core.retina import BaseRetinaNet
+    pa, pan, mc = plan["arch"], plan["anchors"], MODEL_CFG_V001
+    coder = BoxCoderND(weights=(1.,) * 6)
+    anchors = get_anchor_generator(3, s_param=True)(**pan)
+    conv, hconv = Generator(ConvInstanceRelu, 3), Generator(ConvGroupRelu, 3)
+    enc = Encoder(conv=conv, conv_kernels=pa["conv_kernels"], strides=pa["strides"], block_cls=StackedConvBlock2,
+                  in_channels=pa["in_channels"], start_channels=pa["start_channels"], stage_kwargs=None,
+                  max_channels=pa["max_channels"])
+    dec = UFPNModular(conv=conv, conv_kernels=pa["conv_kernels"], strides=enc.get_strides(),
+                      in_channels=enc.get_channels(), decoder_levels=pa["decoder_levels"],
+                      fixed_out_channels=pa["fpn_channels"], **mc["decoder_kwargs"])
+    matcher = rb.ATSSMatcher(similarity_fn=rb.box_iou, **mc["matcher_kwargs"])
+    A = anchors.num_anchors_per_location()[0]
+    cls = BCECLassifier(conv=hconv, in_channels=pa["fpn_channels"], internal_channels=pa["head_channels"],
+                        num_classes=pa["classifier_classes"], anchors_per_pos=A,
+                        num_levels=len(pa["decoder_levels"]), **mc["head_classifier_kwargs"])
+    reg = GIoURegressor(conv=hconv, in_channels=pa["fpn_channels"], internal_channels=pa["head_channels"],
+                        anchors_per_pos=A, num_levels=len(pa["decoder_levels"]), **mc["head_regressor_kwargs"])
+    head = DetectionHeadHNMNative(classifier=cls, regressor=reg, coder=coder,
+                                  sampler=HardNegativeSamplerBatched(**mc["head_sampler_kwargs"]), log_num_anchors=None)
+    seg = DiCESegmenterFgBg(conv, seg_classes=pa["seg_classes"], in_channels=dec.get_channels(),
+                            decoder_levels=pa["decoder_levels"], **mc["segmenter_kwargs"])
+    return BaseRetinaNet(dim=3, encoder=enc, decoder=dec, head=head, anchor_generator=anchors, matcher=matcher,
+                         num_classes=pa["classifier_classes"], decoder_levels=pa["decoder_levels"], segmenter=seg,
+                         detections_per_img=100, score_thresh=0, topk_candidates=10000,
+                         remove_small_boxes=0.01, nms_thresh=0.6)
+
+
+def det_randperm(n, *a, **k):
+    """Deterministic stand-in for torch.randperm in the sampler (identical on every device)."""
+    return torch.arange(n - 1, -1, -1, device=k.get("device", None))
+
+
+def synth_inputs(plan, seed=0):
+    P, B = plan["patch_size"], plan["batch_size"]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 1, *P, generator=g)
+    boxes, classes = [], []
+    seg = torch.zeros(B, *P)
+    rng = np.random.default_rng(seed + 1)
+    for b in range(B):
+        n = 2 if b % 2 == 0 else 1
+        c = rng.uniform(0.25, 0.75, (n, 3)) * np.asarray(P) + 0.137
+        s = rng.uniform(5, 11, (n, 3))
+        lo, hi = np.maximum(c - s / 2, 0), np.minimum(c + s / 2, np.asarray(P))
+        bb = np.stack([lo[:, 0], lo[:, 1], hi[:, 0], hi[:, 1], lo[:, 2], hi[:, 2]], 1).astype(np.float32)
+        boxes.append(torch.from_numpy(bb)); classes.append(torch.zeros(n))
+        for q in bb:
+            seg[b, int(q[0]):int(q[2]) + 1, int(q[1]):int(q[3]) + 1, int(q[4]):int(q[5]) + 1] = 1
+    return x, {"target_boxes": boxes, "target_classes": classes, "target_seg": seg}
+
+
+def golden_net(name):
+    plan = get_plan(name)
+    ref = build_reference_net(plan)
+    ora = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys()), "state-dict keys differ"
+    for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), ora.state_dict().items()):
+        assert v1.shape == v2.shape, (k1, v1.shape, v2.shape)
+    fill_state(ref); fill_state(ora)
+    x, tg = synth_inputs(plan)
+    orig = torch.randperm
+    torch.randperm = det_randperm
+    try:
+        tgr = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in tg.items()}
+        lr, pr = ref.train_step(x, tgr, evaluation=True, batch_num=0)
+        sum(lr.values()).backward()
+        tgo = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in tg.items()}
+        lo, po = ora.train_step(x, tgo, evaluation=True)
+        sum(lo.values()).backward()
+    finally:
+        torch.randperm = orig
+    g = {"x": x.numpy(), "target_seg": tg["target_seg"].numpy().astype(np.uint8)}
+    for i, (b, c) in enumerate(zip(tg["target_boxes"], tg["target_classes"])):
+        g[f"gt_boxes_{i}"], g[f"gt_classes_{i}"] = b.numpy(), c.numpy()
+    print(f"  [{name}] reference losses:", {k: float(v) for k, v in lr.items()})
+    for k in lr:
+        g[f"loss_{k}"] = np.float32(lr[k].item())
+        assert abs(lr[k].item() - lo[k].item()) < 1e-5, (k, lr[k].item(), lo[k].item())
+    gn_ref = {k: (p.grad.norm().item() if p.grad is not None else -1.0) for k, p in ref.named_parameters()}
+    gn_ora = {k: (p.grad.norm().item() if p.grad is not None else -1.0) for k, p in ora.named_parameters()}
+    for k in gn_ref:
+        assert abs(gn_ref[k] - gn_ora[k]) <= 1e-4 * max(1.0, abs(gn_ref[k])), (k, gn_ref[k], gn_ora[k])
+    g["grad_names"] = np.asarray(list(gn_ref.keys()))
+    g["grad_norms"] = np.asarray(list(gn_ref.values()), np.float32)
+    # a few raw gradient slices for spot checks
+    for k in ("encoder.stages.0.convs.0.0.conv.weight", "head.regressor.conv_out.conv.bias",
+              "decoder.up.P1.conv.weight", "segmenter.conv_out.conv.weight"):
+        g["grad::" + k] = dict(ref.named_parameters())[k].grad.numpy().reshape(-1)[:512].copy()
+    for b in range(x.shape[0]):
+        g[f"det_boxes_{b}"] = pr["pred_boxes"][b].numpy()
+        g[f"det_scores_{b}"] = pr["pred_scores"][b].numpy()
+        g[f"det_labels_{b}"] = pr["pred_labels"][b].numpy()
+        assert np.allclose(po["pred_boxes"][b], g[f"det_boxes_{b}"], atol=1e-4), "detections differ"
+        assert np.allclose(po["pred_scores"][b], g[f"det_scores_{b}"], atol=1e-5)
+    g["pred_seg_sum"] = np.float64(pr["pred_seg"].double().sum().item())
+    print(f"  [{name}] oracle == reference: losses 1e-5, all {len(gn_ref)} grad norms 1e-4, detections 1e-4 "
+          f"({[len(b) for b in pr['pred_boxes']]} boxes)")
+    np.savez_compressed(os.path.join(OUT, f"net_{name}_golden.npz"), **g)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    print("box ops:"); golden_boxes()
+    print("network:"); golden_net("tiny")
+    if "--toy64" in sys.argv:
+        golden_net("toy64")
