@@ -1,0 +1,198 @@
+/*
+ * nndet_amd.h -- C ABI of the MI355X-native (gfx950) RetinaUNet hot path for nnDetection.
+ *
+ * This is the drop-in boundary below nnDetection's Python plugin surface. The
+ * reference has exactly one native entry point, `nndet._C.nms` (nndet/csrc/ops.cpp:13-15,
+ * nndet/csrc/cpu/nms.cpp:18-34, nndet/csrc/cuda/nms.cu:148-221); every other function of the hot
+ * path is PyTorch-Python there. Each entry below names the reference function it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - the caller owns every buffer (PyTorch's caching allocator in the Python binding);
+ *   - return value: 0 on success, a hipError_t (>0) for HIP failures, negative for argument errors
+ *     (NNDET_EINVAL ...). Nothing is thrown.
+ *   - boxes are fp32 (x1, y1, x2, y2, z1, z2), nndet/core/boxes/ops.py:131-159;
+ *   - activations are NDHWC (channels-last-3d) with the channel count padded to a multiple of 32,
+ *     dtype NNDET_BF16 or NNDET_F32; accumulation is always fp32.
+ */
+#ifndef NNDET_AMD_H
+#define NNDET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNDET_OK 0
+#define NNDET_EINVAL (-1)      /* bad argument (shape, alignment, unsupported channel count) */
+#define NNDET_EWORKSPACE (-2)  /* workspace too small */
+
+#define NNDET_F32 0
+#define NNDET_BF16 1
+
+const char* nndet_version(void);
+/* Number of bytes of LDS / registers are compile-time; this reports the arch the library was built for. */
+const char* nndet_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3D NMS -- replaces nndet._C.nms (nms_cuda, nndet/csrc/cuda/nms.cu:148-221; kernel :99-145;
+ * IoU :36-51) including its score sort and, unlike the reference, the greedy scan stays on the GPU
+ * (no mask D2H, no host loop).
+ *   boxes [n,6] fp32, scores [n] fp32 (input order).
+ *   keep_out [n] int64: indices into the INPUT order of the kept boxes, by decreasing score
+ *                       (ties: lower index first); entries >= *n_keep are set to -1.
+ *   n_keep_out [1] int64 (device).
+ * Box j is suppressed iff IoU(kept i, j) > iou_threshold (NaN never suppresses).
+ * workspace: nndet_nms3d_workspace_bytes(n) bytes, 256-B aligned.
+ * ---------------------------------------------------------------------------------------------- */
+size_t nndet_nms3d_workspace_bytes(int64_t n);
+int nndet_nms3d_f32(const float* boxes, const float* scores, int64_t n, float iou_threshold,
+                    int64_t* keep_out, int64_t* n_keep_out, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* Same, but the caller supplies the order (descending score) -- the mask + scan part only.
+ * `order` [n] int32 indices into boxes. Used by batched post-processing that already sorted. */
+int nndet_nms3d_sorted_f32(const float* boxes, const int32_t* order, int64_t n, float iou_threshold,
+                           int64_t* keep_out, int64_t* n_keep_out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pairwise IoU / GIoU -- replace box_iou / generalized_box_iou
+ * (nndet/core/boxes/ops.py:75-102,106-128,131-185). out [n,m] fp32 row-major.
+ * `eps` is added to the intersection (IoU) resp. to the hull volume only (GIoU), as the reference.
+ * ---------------------------------------------------------------------------------------------- */
+int nndet_iou3d_pairwise_f32(const float* a, int64_t n, const float* b, int64_t m, float eps,
+                             float* out, void* stream);
+int nndet_giou3d_pairwise_f32(const float* a, int64_t n, const float* b, int64_t m, float eps,
+                              float* out, void* stream);
+/* Element-wise (diagonal) GIoU with gradient w.r.t. `a`: what GIoULoss needs
+ * (nndet/losses/regression.py:147-162 takes torch.diag of the [P,P] matrix). */
+int nndet_giou3d_diag_fwd_f32(const float* a, const float* b, int64_t n, float eps, float* out, void* stream);
+int nndet_giou3d_diag_bwd_f32(const float* a, const float* b, const float* grad_out, int64_t n, float eps,
+                              float* grad_a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Anchor grid -- replaces AnchorGenerator3D.grid_anchors (nndet/core/boxes/anchors.py:337-377).
+ *   cell [A,6] fp32 (AnchorGenerator3DS.generate_anchors, anchors.py:526-549)
+ *   out  [sx*sy*sz*A, 6] fp32, x-major over the grid then the A cell anchors.
+ * ---------------------------------------------------------------------------------------------- */
+int nndet_anchors3d_grid_f32(const float* cell, int32_t A, int32_t sx, int32_t sy, int32_t sz,
+                             int32_t stride_x, int32_t stride_y, int32_t stride_z, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ATSS matching -- replaces ATSSMatcher.compute_matches with center_in_gt=False
+ * (nndet/core/boxes/matcher/atss.py:48-122) + Matcher.__call__ (matcher/base.py:27-63) and the
+ * label/box gather of BaseRetinaNet.assign_targets_to_anchors (nndet/core/retina.py:258-288).
+ * Never materialises the [G,M] distance / IoU matrices.
+ *   gt [G,6], anchors [M,6]; level_offsets [L+1] int64 HOST array (prefix sums of anchors per level);
+ *   k = num_candidates * num_anchors_per_loc (clamped per level to the level size).
+ *   matches [M] int64: index of the matched GT or -1 (BELOW_LOW_THRESHOLD).
+ * Candidate rule: the k anchors with the smallest (centre distance, anchor index) per GT and level
+ * (the reference's torch.topk leaves ties implementation-defined); positives: IoU >= mean + std
+ * (unbiased) over the GT's candidates; an anchor positive for several GTs takes the highest IoU
+ * (ties: lowest GT index).
+ * G == 0 -> all -1. G <= NNDET_ATSS_MAX_GT.
+ * ---------------------------------------------------------------------------------------------- */
+#define NNDET_ATSS_MAX_GT 64
+size_t nndet_atss3d_workspace_bytes(int64_t G, int64_t M, int32_t L, int32_t k);
+int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* anchors, int64_t M,
+                           const int64_t* level_offsets_host, int32_t L, int32_t k,
+                           int64_t* matches, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Box decode + clip -- replaces decode_single (nndet/core/boxes/coder.py:90-155, weights = 1) followed
+ * by clip_boxes_to_image_3d_ (nndet/core/boxes/clip.py:83-101). img_* <= 0 disables clipping.
+ * rel [n,6], anchors [n_anchor,6] (anchor index = row % n_anchor), out [n,6].
+ * ---------------------------------------------------------------------------------------------- */
+int nndet_decode_clip3d_f32(const float* rel, const float* anchors, int64_t n, int64_t n_anchor,
+                            float clip_exp, float img_x, float img_y, float img_z, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution stack (implicit GEMM on MFMA; NDHWC; fp32 accumulate) -- replaces the
+ * torch.nn.Conv3d / ConvTranspose3d calls inside ConvInstanceRelu / ConvGroupRelu
+ * (nndet/arch/conv.py:54-143,297-348) for the encoder (nndet/arch/encoder/modular.py:110-126),
+ * decoder (nndet/arch/decoder/base.py:391-417) and heads (nndet/arch/heads/classifier.py:160-181,
+ * regressor.py:153-173, segmenter.py:167-182).
+ *
+ * A NndetConv describes one (possibly transposed) convolution problem; the three entry points are
+ * the forward pass, the data gradient and the weight gradient. Weights are passed PACKED (see
+ * nndet_pack_weight) in the activation dtype; the weight gradient is accumulated in fp32 directly in
+ * PyTorch's [Cout, Cin, kd, kh, kw] (or [Cin, Cout, ...] for transposed) layout.
+ * ---------------------------------------------------------------------------------------------- */
+#define NNDET_STATS_REPLICAS 32   /* stats buffers are [NNDET_STATS_REPLICAS][N][C_p][2] fp64 (atomic-contention spreading) */
+
+typedef struct NndetConv {
+    int32_t dtype;            /* NNDET_F32 | NNDET_BF16 (activations + packed weights) */
+    int32_t transposed;       /* 0: Conv3d, 1: ConvTranspose3d (requires kernel == stride, padding 0) */
+    int32_t batch;
+    int32_t cin, cout;        /* logical channels */
+    int32_t cin_p, cout_p;    /* physical (padded) channels of the in / out tensors, multiples of 32 (cin_p == 1 allowed for the stem) */
+    int32_t in_d, in_h, in_w;     /* input spatial size (x, y, z of the reference = d, h, w here) */
+    int32_t out_d, out_h, out_w;  /* output spatial size */
+    int32_t k[3], s[3], p[3];     /* kernel, stride, padding per axis */
+} NndetConv;
+
+/* pack W (fp32, PyTorch layout) -> [taps][rows_p][k_p] in `dtype`, zero padded.
+ * mode 0: rows = Cout, k = Cin (forward of Conv3d)
+ * mode 1: rows = Cin,  k = Cout (data gradient of Conv3d)
+ * For ConvTranspose3d (weight [Cin, Cout, ...]) mode 0 gives rows = Cout, k = Cin (its forward) and
+ * mode 1 rows = Cin, k = Cout (its data gradient). */
+size_t nndet_packed_weight_elems(const NndetConv* c, int32_t mode);
+int nndet_pack_weight(const NndetConv* c, int32_t mode, const float* w, void* packed, void* stream);
+
+/* y[N,od,oh,ow,cout_p] = conv(x[N,id,ih,iw,cin_p]) + bias ; bias may be NULL ([cout_p] fp32, zero padded).
+ * Stem special case cin_p == 1: `w_packed_mode0` is the UNPACKED fp32 weight [cout, 1, kd, kh, kw].
+ * If stats != NULL ([NNDET_STATS_REPLICAS, N, cout_p, 2] fp64, zeroed by the caller) the epilogue accumulates per-(n, channel)
+ * sum and sum of squares of the ROUNDED outputs: the InstanceNorm / GroupNorm statistics pass is fused away. */
+int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w_packed_mode0, const float* bias,
+                         void* y, double* stats, void* stream);
+/* dx[N,id,ih,iw,cin_p] = conv^T(dy[N,od,oh,ow,cout_p]) */
+int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w_packed_mode1,
+                               void* dx, void* stream);
+/* dw (fp32, PyTorch layout, ACCUMULATED into: zero it first) ; dbias ([cout] fp32, accumulated) may be NULL.
+ * NOTE accumulation uses fp32 atomics: the summation order (not the result beyond fp32 round-off) varies run to run. */
+int nndet_conv3d_backward_weight(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * InstanceNorm3d / GroupNorm (+ReLU) on NDHWC -- replaces nn.InstanceNorm3d / nndet GroupNorm + nn.ReLU
+ * inside ConvInstanceRelu / ConvGroupRelu (nndet/arch/conv.py:195,271; nndet/arch/layers/norm.py:26-50).
+ * Statistics are per (n, group) over the group's channels and all voxels; groups == C is InstanceNorm.
+ *   stats [NNDET_STATS_REPLICAS, N, C_p, 2] fp64 per-channel (sum, sumsq) -- produced by the conv epilogue or
+ *   nndet_norm_stats; consumers add the replicas.
+ * ---------------------------------------------------------------------------------------------- */
+int nndet_norm_stats(int32_t dtype, const void* x, int32_t batch, int64_t spatial, int32_t c_p,
+                     double* stats /* zeroed */, void* stream);
+/* y = relu?((x - mean) * rstd * gamma + beta); mean_rstd_out [N, C_p, 2] fp32 is written for backward. */
+int nndet_norm_apply(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
+                     int32_t batch, int64_t spatial, int32_t c, int32_t c_p, int32_t groups, float eps,
+                     int32_t relu, void* y, float* mean_rstd_out, void* stream);
+/* backward of y = relu?(norm(x)): dx, and dgamma / dbeta ([c] fp32, accumulated -> zero first).
+ * red_ws: [N, C_p, 2] fp64 scratch (zeroed). */
+int nndet_norm_backward(int32_t dtype, const void* x, const void* dy, const float* mean_rstd,
+                        const float* gamma, const float* beta, int32_t batch, int64_t spatial, int32_t c,
+                        int32_t c_p, int32_t groups, int32_t relu, void* dx, float* dgamma, float* dbeta,
+                        double* red_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segmentation loss (2-class) -- replaces DiCESegmenterFgBg.compute_loss: 0.5*CE + 0.5*SoftDice(softmax,
+ * batch_dice, no background, smooth 1e-5) (nndet/arch/heads/segmenter.py:184-206,273-289;
+ * nndet/losses/segmentation.py:32-151). logits [N, spatial, c_p] (channels 0,1 used); target uint8 (>0 = fg).
+ *   sums_out [4] fp64 (zeroed): {sum CE, tp, fp, fn} of the foreground channel.
+ *   backward: dlogits = g_ce * dCEsum/dl + g_tp*dtp/dl + g_fp*dfp/dl + g_fn*dfn/dl (padded channels get 0).
+ * ---------------------------------------------------------------------------------------------- */
+int nndet_segloss_forward(int32_t dtype, const void* logits, const uint8_t* target, int64_t nvox, int32_t c_p,
+                          double* sums_out, void* stream);
+int nndet_segloss_backward(int32_t dtype, const void* logits, const uint8_t* target, int64_t nvox, int32_t c_p,
+                           const float* coeffs /* device [4]: g_ce, g_tp, g_fp, g_fn */, void* dlogits, void* stream);
+
+/* sigmoid + max over classes of the (padded-free) logits [n, C] fp32 -> probs [n] ; used by the hard-negative
+ * sampler (DetectionHeadHNM.select_indices, nndet/arch/heads/comb.py:247-276). */
+int nndet_sigmoid_max_f32(const float* logits, int64_t n, int32_t C, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNDET_AMD_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of the C-ABI library `csrc/libnndet_amd.so` (declared in include/nndet_amd.h).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised. PyTorch is
+only used for device memory (caching allocator) and the current stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnndet_amd.so")
+
+F32, BF16 = 0, 1
+STATS_REPLICAS = 32
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+class NndetError(RuntimeError):
+    pass
+
+
+class NndetConv(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("transposed", C.c_int32), ("batch", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("cin_p", C.c_int32), ("cout_p", C.c_int32),
+                ("in_d", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("out_d", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("k", C.c_int32 * 3), ("s", C.c_int32 * 3), ("p", C.c_int32 * 3)]
+
+
+_P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+_CONVP = C.POINTER(NndetConv)
+
+# name -> (restype, argtypes); every symbol include/nndet_amd.h declares
+SIGNATURES = {
+    "nndet_version": (C.c_char_p, []),
+    "nndet_arch": (C.c_char_p, []),
+    "nndet_nms3d_workspace_bytes": (_SZ, [_I64]),
+    "nndet_nms3d_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
+    "nndet_nms3d_sorted_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
+    "nndet_iou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
+    "nndet_giou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
+    "nndet_giou3d_diag_fwd_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P]),
+    "nndet_giou3d_diag_bwd_f32": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
+    "nndet_anchors3d_grid_f32": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "nndet_atss3d_workspace_bytes": (_SZ, [_I64, _I64, _I32, _I32]),
+    "nndet_atss3d_match_f32": (C.c_int, [_P, _I64, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _SZ, _P]),
+    "nndet_decode_clip3d_f32": (C.c_int, [_P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P]),
+    "nndet_packed_weight_elems": (_SZ, [_CONVP, _I32]),
+    "nndet_pack_weight": (C.c_int, [_CONVP, _I32, _P, _P, _P]),
+    "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P]),
+    "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
+    "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
+    "nndet_norm_stats": (C.c_int, [_I32, _P, _I32, _I64, _I32, _P, _P]),
+    "nndet_norm_apply": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
+    "nndet_norm_backward": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nndet_segloss_forward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P, _P]),
+    "nndet_segloss_backward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P, _P, _P]),
+    "nndet_sigmoid_max_f32": (C.c_int, [_P, _I64, _I32, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once). Raises NndetError if it is absent: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise NndetError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             f"or nndetection_amd/csrc/build.sh (hipcc --offload-arch=gfx950). No CPU fallback exists.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise NndetError(f"unsupported activation dtype {t.dtype}; use float32 or bfloat16")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NndetError("nndetection_amd kernels need tensors on the GPU (no CPU path)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "workspace too small"}.get(rc, f"hipError {rc}")
+        raise NndetError(f"{what} failed: {kind}")
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,227 @@
+"""Conv -> norm -> activation blocks on hand-written HIP kernels, behind the reference's conv factory
+contract (nndet/arch/conv.py:28-51,54-143,146-294).
+
+`ConvInstanceRelu(dim, in_ch, out_ch, kernel_size, stride, padding, ..., add_norm, add_act, transposed)` and
+`ConvGroupRelu(..., norm_channels_per_group=16)` are `nn.Sequential`s whose children are named `conv`,
+`norm`, `act` exactly like the reference (state-dict keys `...conv.weight`, `...norm.weight`), `conv` IS an
+`nn.Conv3d` / `nn.ConvTranspose3d` (so the heads' `init_weights` isinstance loops work) and `norm` IS an
+`nn.InstanceNorm3d` / `nn.GroupNorm` (so `get_params_no_wd_on_norm` finds it). Only `forward` differs: it runs
+ONE autograd Function over the whole block:
+
+    forward : implicit-GEMM conv (MFMA, NDHWC, stats in the epilogue) -> fused norm-apply + ReLU
+    backward: fused norm/ReLU backward -> data gradient (MFMA) + weight gradient (MFMA) + bias gradient
+
+Tensors crossing module boundaries are logical [N, C, D, H, W] views (what the reference's modules exchange)
+of NDHWC storage whose channel count is padded to a multiple of 32 (`layout.py`). Parameters stay fp32 in
+PyTorch's layout; they are re-packed (and cast to the activation dtype) once per optimizer step.
+"""
+import ctypes
+from typing import Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..layout import cpad, phys, logical, mark_padded
+
+__all__ = ["Generator", "ConvInstanceRelu", "ConvGroupRelu", "conv_kwargs_helper", "compute_padding_for_kernel"]
+
+
+class Generator:
+    """Factory helper (nndet/arch/conv.py:28-51): Generator(conv_cls, dim)(*args, **kw) -> conv_cls(dim, *args, **kw)."""
+
+    def __init__(self, conv_cls, dim: int):
+        self.dim = dim
+        self.conv_cls = conv_cls
+
+    def __call__(self, *args, **kwargs):
+        return self.conv_cls(self.dim, *args, **kwargs)
+
+
+def _triple(v):
+    return tuple(int(i) for i in v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+def _desc(x_p: torch.Tensor, cin: int, cout: int, k, s, p, transposed: bool) -> L.NndetConv:
+    N, D, H, W, cin_p = x_p.shape
+    d = L.NndetConv()
+    d.dtype = L.dtype_code(x_p)
+    d.transposed = int(transposed)
+    d.batch, d.cin, d.cout, d.cin_p, d.cout_p = N, cin, cout, cin_p, cpad(cout)
+    d.in_d, d.in_h, d.in_w = D, H, W
+    sp = (D, H, W)
+    out = [sp[i] * s[i] if transposed else (sp[i] + 2 * p[i] - k[i]) // s[i] + 1 for i in range(3)]
+    d.out_d, d.out_h, d.out_w = out
+    d.k = (ctypes.c_int32 * 3)(*k); d.s = (ctypes.c_int32 * 3)(*s); d.p = (ctypes.c_int32 * 3)(*p)
+    return d
+
+
+def _packed(mod, mode: int, weight: torch.Tensor, desc: L.NndetConv, dtype: torch.dtype) -> torch.Tensor:
+    """Packed + cast weights, cached per (mode, dtype) until the parameter changes (optimizer step)."""
+    key = (mode, dtype)
+    ver = (weight._version, weight.data_ptr())
+    hit = mod._pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    n = L.load().nndet_packed_weight_elems(ctypes.byref(desc), mode)
+    buf = torch.empty((n,), dtype=dtype, device=weight.device)
+    w32 = weight.detach().float().contiguous()
+    L.call("nndet_pack_weight", ctypes.byref(desc), mode, L.ptr(w32), L.ptr(buf), L.stream())
+    mod._pack_cache[key] = (ver, buf)
+    return buf
+
+
+def _pad1d(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
+    if v is None:
+        return None
+    v = v.detach().float()
+    return v.contiguous() if v.numel() == n else torch.nn.functional.pad(v, (0, n - v.numel()))
+
+
+class _ConvBlockFn(torch.autograd.Function):
+    """conv (+bias) [-> InstanceNorm/GroupNorm (+ReLU)] as one node."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, mod):
+        x_p, cin = phys(x)
+        if cin != mod.in_channels:
+            raise L.NndetError(f"expected {mod.in_channels} input channels, got {cin}")
+        desc = _desc(x_p, mod.in_channels, mod.out_channels, mod.k, mod.s, mod.p, mod.transposed)
+        dev, dt = x_p.device, x_p.dtype
+        N, cout, cout_p = desc.batch, desc.cout, desc.cout_p
+        stem = desc.cin_p == 1
+        w_arg = weight.detach().float().contiguous() if stem else _packed(mod, 0, weight, desc, dt)
+        y = torch.empty((N, desc.out_d, desc.out_h, desc.out_w, cout_p), dtype=dt, device=dev)
+        has_norm = gamma is not None
+        stats = torch.zeros((L.STATS_REPLICAS, N, cout_p, 2), dtype=torch.float64, device=dev) if has_norm else None
+        b_p = _pad1d(bias, cout_p)
+        L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(y), L.ptr(stats), L.stream())
+        ctx.desc, ctx.mod, ctx.has_norm, ctx.has_bias = desc, mod, has_norm, bias is not None
+        if has_norm:
+            out = torch.empty_like(y)
+            mean_rstd = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
+            spatial = desc.out_d * desc.out_h * desc.out_w
+            g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+            L.call("nndet_norm_apply", desc.dtype, L.ptr(y), L.ptr(stats), L.ptr(g32), L.ptr(b32), N, spatial, cout, cout_p,
+                   mod.norm_groups, float(mod.norm_eps), int(mod.relu), L.ptr(out), L.ptr(mean_rstd), L.stream())
+            ctx.save_for_backward(x_p, weight, y, mean_rstd, g32, b32)
+        else:
+            out = y
+            ctx.save_for_backward(x_p, weight)
+        res = logical(out, cout)
+        return res
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        desc, mod = ctx.desc, ctx.mod
+        N, cout, cout_p = desc.batch, desc.cout, desc.cout_p
+        if ctx.has_norm:
+            x_p, weight, y, mean_rstd, g32, b32 = ctx.saved_tensors
+        else:
+            x_p, weight = ctx.saved_tensors
+        dev, dt = x_p.device, x_p.dtype
+        g_p, _ = phys(grad_out, dtype=dt, cp=cout_p)
+        dgamma = dbeta = None
+        if ctx.has_norm:
+            dconv = torch.empty_like(y)
+            dgamma = torch.zeros((cout,), dtype=torch.float32, device=dev)
+            dbeta = torch.zeros((cout,), dtype=torch.float32, device=dev)
+            red = torch.zeros((L.STATS_REPLICAS, N, cout_p, 2), dtype=torch.float64, device=dev)
+            spatial = desc.out_d * desc.out_h * desc.out_w
+            L.call("nndet_norm_backward", desc.dtype, L.ptr(y), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,
+                   cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.ptr(red), L.stream())
+        else:
+            dconv = g_p
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if desc.cin_p == 1:
+                raise L.NndetError("gradient w.r.t. the 1-channel input image is not implemented (never needed in training)")
+            w1 = _packed(mod, 1, weight, desc, dt)
+            dx_p = torch.empty_like(x_p)
+            L.call("nndet_conv3d_backward_data", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.stream())
+            dx = logical(dx_p, desc.cin)
+        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
+        dbias = torch.zeros((cout,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw), L.ptr(dbias), L.stream())
+        return dx, dw.to(weight.dtype), dbias, dgamma, dbeta, None
+
+
+class BaseConvNormAct(nn.Sequential):
+    def __init__(self, dim: int, in_channels: int, out_channels: int, norm: Optional[str], act: Optional[str],
+                 kernel_size, stride=1, padding=0, dilation=1, groups: int = 1, bias: Optional[bool] = None,
+                 transposed: bool = False, norm_kwargs: Optional[dict] = None, act_inplace: Optional[bool] = None,
+                 initializer=None):
+        super().__init__()
+        if dim != 3:
+            raise L.NndetError("only 3D convolutions are on the MI355X hot path")
+        if _triple(dilation) != (1, 1, 1) or groups != 1:
+            raise L.NndetError("dilation / grouped convolutions are not used by RetinaUNetV001 and not implemented")
+        norm_kwargs = {} if norm_kwargs is None else dict(norm_kwargs)
+        bias = bool(norm is None) if bias is None else bias               # conv.py:113
+        conv_cls = nn.ConvTranspose3d if transposed else nn.Conv3d
+        self.add_module("conv", conv_cls(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias))
+        self.in_channels, self.out_channels, self.transposed = in_channels, out_channels, bool(transposed)
+        self.k, self.s, self.p = _triple(kernel_size), _triple(stride), _triple(padding)
+        self.norm_groups, self.norm_eps, self.relu = 0, 1e-5, False
+        if norm is not None:
+            eps = norm_kwargs.get("eps", 1e-5)
+            if not norm_kwargs.get("affine", True):
+                raise L.NndetError("non-affine norms are not used by RetinaUNetV001")
+            if norm.lower() == "instance":
+                self.add_module("norm", nn.InstanceNorm3d(out_channels, eps=eps, affine=True))
+                self.norm_groups = out_channels
+            elif norm.lower() == "group":
+                cpg = norm_kwargs.get("channels_per_group", 16)
+                self.add_module("norm", nn.GroupNorm(out_channels // cpg, out_channels, eps=eps, affine=True))
+                self.norm_groups = out_channels // cpg
+            else:
+                raise L.NndetError(f"norm {norm} is not on the hot path")
+            self.norm_eps = eps
+        if act is not None:
+            if act != "ReLU":
+                raise L.NndetError(f"activation {act} is not on the hot path")
+            if norm is None:
+                raise L.NndetError("an activation without a norm does not occur in RetinaUNetV001")
+            self.add_module("act", nn.ReLU(inplace=bool(norm is not None) if act_inplace is None else act_inplace))
+            self.relu = True
+        self._pack_cache = {}
+        if initializer is not None:
+            self.apply(initializer)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        has_norm = self.norm_groups > 0
+        return _ConvBlockFn.apply(x, self.conv.weight, self.conv.bias,
+                                  self.norm.weight if has_norm else None, self.norm.bias if has_norm else None, self)
+
+
+class ConvInstanceRelu(BaseConvNormAct):
+    """conv -> InstanceNorm3d(affine) -> ReLU (nndet/arch/conv.py:146-217)."""
+
+    def __init__(self, dim, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=None,
+                 transposed=False, add_norm: bool = True, add_act: bool = True, act_inplace=None, norm_eps: float = 1e-5,
+                 norm_affine: bool = True, initializer=None):
+        super().__init__(dim, in_channels, out_channels, "Instance" if add_norm else None, "ReLU" if add_act else None,
+                         kernel_size, stride, padding, dilation, groups, bias, transposed,
+                         {"eps": norm_eps, "affine": norm_affine}, act_inplace, initializer)
+
+
+class ConvGroupRelu(BaseConvNormAct):
+    """conv -> GroupNorm(C / channels_per_group groups) -> ReLU (nndet/arch/conv.py:220-294)."""
+
+    def __init__(self, dim, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=None,
+                 transposed=False, add_norm: bool = True, add_act: bool = True, act_inplace=None, norm_eps: float = 1e-5,
+                 norm_affine: bool = True, norm_channels_per_group: int = 16, initializer=None):
+        super().__init__(dim, in_channels, out_channels, "Group" if add_norm else None, "ReLU" if add_act else None,
+                         kernel_size, stride, padding, dilation, groups, bias, transposed,
+                         {"eps": norm_eps, "affine": norm_affine, "channels_per_group": norm_channels_per_group},
+                         act_inplace, initializer)
+
+
+def compute_padding_for_kernel(kernel_size):
+    """nndet/arch/conv.py:455-470"""
+    return tuple((i - 1) // 2 for i in kernel_size) if isinstance(kernel_size, Sequence) else (kernel_size - 1) // 2
+
+
+def conv_kwargs_helper(norm: bool, activation: bool):
+    """nndet/arch/conv.py:473-489"""
+    return {"add_norm": norm, "add_act": activation}

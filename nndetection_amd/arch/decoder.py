@@ -1,0 +1,80 @@
+"""U-shaped FPN decoder. Mirrors BaseUFPN / UFPNModular (nndet/arch/decoder/base.py:28-417) for the V001
+configuration (transposed-conv upsampling, 1 lateral + 1 out conv per level, no norm / activation, no fusion convs).
+
+One deliberate difference: `skip_unused_out` (default True) does not COMPUTE output convs
+whose result nothing consumes (`out.P1` with decoder_levels (2,3,4,5): heads read levels 2-5, the segmenter
+level 0). The parameters stay in the module (state-dict parity), the forward result for that level is `None`.
+"""
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .conv import conv_kwargs_helper
+
+
+class UFPNModular(nn.Module):
+    def __init__(self, conv: Callable, strides, in_channels: Sequence[int], conv_kernels, decoder_levels,
+                 fixed_out_channels: int, min_out_channels: int = 8, upsampling_mode: str = "nearest",
+                 num_lateral: int = 1, norm_lateral: bool = False, activation_lateral: bool = False,
+                 num_out: int = 1, norm_out: bool = False, activation_out: bool = False,
+                 num_fusion: int = 0, norm_fusion: bool = False, activation_fusion: bool = False,
+                 skip_unused_out: bool = True, used_levels: Optional[Sequence[int]] = None):
+        super().__init__()
+        if len(strides) != len(in_channels):
+            raise ValueError("Strides must contain same number of elements as channels.")
+        if upsampling_mode.lower() != "transpose" or num_fusion != 0 or num_lateral != 1 or num_out != 1:
+            raise NotImplementedError("only the RetinaUNetV001 decoder configuration (v001.yaml:63-73) is on the hot path")
+        self.dim = conv.dim
+        self.num_level = len(in_channels)
+        self.in_channels = list(in_channels)
+        self.decoder_levels = decoder_levels
+        strides = [s if isinstance(s, Sequence) else (s,) * self.dim for s in strides]
+        self.strides = [tuple(int(s1 / s0) for s1, s0 in zip(strides[i], strides[i - 1])) for i in range(1, len(strides))]
+        if isinstance(conv_kernels, int):
+            conv_kernels = [conv_kernels] * self.num_level
+        self.conv_kernels = [tuple([ck] * self.dim) if isinstance(ck, int) else tuple(ck) for ck in conv_kernels]
+        self.conv_paddings = [tuple((i - 1) // 2 for i in ck) for ck in self.conv_kernels]
+        self.fixed_out_channels, self.min_out_channels = fixed_out_channels, min_out_channels
+        self.out_channels = self.compute_output_channels()
+        lat_kw = conv_kwargs_helper(norm_lateral, activation_lateral)
+        out_kw = conv_kwargs_helper(norm_out, activation_out)
+        oc = self.out_channels
+        self.lateral = nn.ModuleDict({f"P{l}": nn.Sequential(conv(self.in_channels[l], oc[l], kernel_size=1, padding=0, stride=1, **lat_kw))
+                                      for l in range(self.num_level)})
+        self.out = nn.ModuleDict({f"P{l}": nn.Sequential(conv(oc[l], oc[l], kernel_size=self.conv_kernels[l],
+                                                              padding=self.conv_paddings[l], stride=1, **out_kw))
+                                  for l in range(self.num_level)})
+        self.up = nn.ModuleDict({f"P{l}": conv(oc[l], oc[l - 1], kernel_size=self.strides[l - 1], stride=self.strides[l - 1],
+                                               transposed=True, add_norm=False, add_act=False)
+                                 for l in range(1, self.num_level)})
+        self.skip_unused_out = skip_unused_out
+        self.used_levels = None if used_levels is None else set(used_levels)
+
+    def compute_output_channels(self) -> List[int]:
+        """decoder/base.py:182-199"""
+        out = [self.fixed_out_channels] * self.num_level
+        if self.decoder_levels is not None:
+            for ol in [l for l in range(self.num_level) if l < min(self.decoder_levels)][::-1]:
+                out[ol] = max(self.min_out_channels, out[ol + 1] // 2)
+        return out
+
+    def get_channels(self) -> List[int]:
+        return self.out_channels
+
+    def forward(self, inp_seq: Sequence[torch.Tensor]) -> List[Optional[torch.Tensor]]:
+        fpn = [self.lateral[f"P{l}"](fm) for l, fm in enumerate(inp_seq)]
+        xs: List[Optional[torch.Tensor]] = [None] * self.num_level
+        up = None
+        for level in range(self.num_level - 1, -1, -1):
+            x = fpn[level] if up is None else fpn[level] + up
+            if level > 0:
+                up = self.up[f"P{level}"](x)
+            xs[level] = x
+        outs = []
+        for level in range(self.num_level):
+            if self.skip_unused_out and self.used_levels is not None and level not in self.used_levels:
+                outs.append(None)
+            else:
+                outs.append(self.out[f"P{level}"](xs[level]))
+        return outs

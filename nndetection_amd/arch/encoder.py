@@ -1,0 +1,52 @@
+"""Modular encoder. Mirrors nndet/arch/encoder/modular.py:28-157 (same ctor arguments and helper methods)."""
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+
+class Encoder(nn.Module):
+    def __init__(self, conv: Callable, conv_kernels, strides, block_cls, in_channels: int, start_channels: int,
+                 stage_kwargs=None, out_stages: Sequence[int] = None, max_channels: int = None, first_block_cls=None):
+        super().__init__()
+        self.num_stages = len(conv_kernels)
+        self.dim = conv.dim
+        if stage_kwargs is None:
+            stage_kwargs = [{}] * self.num_stages
+        elif isinstance(stage_kwargs, dict):
+            stage_kwargs = [stage_kwargs] * self.num_stages
+        assert len(stage_kwargs) == len(conv_kernels)
+        self.out_stages = list(range(self.num_stages)) if out_stages is None else out_stages
+        first_block_cls = block_cls if first_block_cls is None else first_block_cls
+        if isinstance(strides[0], int):
+            strides = [tuple([s] * self.dim) for s in strides]
+        self.strides = strides
+        stages, self.out_channels = [], []
+        for sid in range(self.num_stages):
+            if sid == 0:
+                blk = first_block_cls(conv=conv, in_channels=in_channels, out_channels=start_channels,
+                                      conv_kernel=conv_kernels[sid], stride=None, max_out_channels=max_channels, **stage_kwargs[sid])
+            else:
+                blk = block_cls(conv=conv, in_channels=in_channels, out_channels=None, conv_kernel=conv_kernels[sid],
+                                stride=strides[sid - 1], max_out_channels=max_channels, **stage_kwargs[sid])
+            in_channels = blk.get_output_channels()
+            self.out_channels.append(in_channels)
+            stages.append(blk)
+        self.stages = nn.ModuleList(stages)
+
+    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        outputs = []
+        for sid, module in enumerate(self.stages):
+            x = module(x)
+            if sid in self.out_stages:
+                outputs.append(x)
+        return outputs
+
+    def get_channels(self) -> List[int]:
+        return [self.out_channels[s] for s in range(self.num_stages) if s in self.out_stages]
+
+    def get_strides(self) -> List[List[int]]:
+        out = []
+        for sid in range(self.num_stages):
+            out.append([1] * self.dim if sid == 0 else [a * b for a, b in zip(out[sid - 1], self.strides[sid - 1])])
+        return out

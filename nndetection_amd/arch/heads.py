@@ -1,0 +1,172 @@
+"""Detection heads. Mirrors BCECLassifier / GIoURegressor / DetectionHeadHNMNative
+(nndet/arch/heads/classifier.py:64-292, regressor.py:51-310, comb.py:85-158,170-276,351-405) and `Scale`
+(nndet/arch/layers/scale.py:21-43); same constructor arguments, module names and loss definitions.
+The conv trunks are ConvGroupRelu blocks (HIP), the GIoU of the sampled positives and the fg-probability
+used by the sampler run in HIP kernels; the remaining arithmetic acts on <= 32*B sampled rows."""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import _lib as L
+from ..core.boxes.ops import giou_diag
+from ..core.boxes.coder import decode_clip
+
+CONV_TYPES = (nn.Conv2d, nn.Conv3d)
+
+
+class Scale(nn.Module):
+    def __init__(self, scale: float = 1.):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, inp: Tensor) -> Tensor:
+        return inp * self.scale
+
+
+def _trunk(conv, in_channels, internal_channels, num_convs, **kwargs) -> nn.Sequential:
+    t = nn.Sequential()
+    t.add_module("c_in", conv(in_channels, internal_channels, kernel_size=3, stride=1, padding=1, **kwargs))
+    for i in range(num_convs):
+        t.add_module(f"c_internal{i}", conv(internal_channels, internal_channels, kernel_size=3, stride=1, padding=1, **kwargs))
+    return t
+
+
+def _flatten_head(x: Tensor, last: int) -> Tensor:
+    """[N, A*last, X, Y, Z] -> [N, X*Y*Z*A, last] fp32 (classifier.py:176-181): a plain slice of the NDHWC buffer."""
+    n = x.size(0)
+    return x.permute(0, 2, 3, 4, 1).contiguous().view(n, -1, last).float()
+
+
+class BCECLassifier(nn.Module):
+    def __init__(self, conv, in_channels: int, internal_channels: int, num_classes: int, anchors_per_pos: int,
+                 num_levels: int, num_convs: int = 3, add_norm: bool = True, prior_prob: Optional[float] = None,
+                 weight: Optional[Tensor] = None, reduction: str = "mean", smoothing: float = 0.0,
+                 loss_weight: float = 1., **kwargs):
+        super().__init__()
+        if smoothing != 0.0 or weight is not None:
+            raise NotImplementedError("label smoothing / class weights are not used by RetinaUNetV001")
+        self.dim, self.num_levels, self.num_convs = conv.dim, num_levels, num_convs
+        self.num_classes, self.anchors_per_pos = num_classes, anchors_per_pos
+        self.in_channels, self.internal_channels = in_channels, internal_channels
+        self.prior_prob, self.reduction, self.loss_weight = prior_prob, reduction, loss_weight
+        self.conv_internal = _trunk(conv, in_channels, internal_channels, num_convs, add_norm=add_norm, **kwargs)
+        self.conv_out = conv(internal_channels, num_classes * anchors_per_pos, kernel_size=3, stride=1, padding=1,
+                             add_norm=False, add_act=False, bias=True)
+        self.init_weights()
+
+    def forward(self, x: Tensor, level: int, **kwargs) -> Tensor:
+        return _flatten_head(self.conv_out(self.conv_internal(x)), self.num_classes)
+
+    def compute_loss(self, pred_logits: Tensor, targets: Tensor, **kwargs) -> Tensor:
+        """BCEWithLogitsLossOneHot (nndet/losses/classification.py:137-181): one-hot without the background column."""
+        onehot = F.one_hot(targets.long(), self.num_classes + 1)[:, 1:].float()
+        return self.loss_weight * F.binary_cross_entropy_with_logits(pred_logits, onehot, reduction=self.reduction)
+
+    def box_logits_to_probs(self, box_logits: Tensor) -> Tensor:
+        return torch.sigmoid(box_logits)
+
+    def init_weights(self) -> None:
+        """classifier.py:210-228"""
+        if self.prior_prob is not None:
+            for layer in self.modules():
+                if isinstance(layer, CONV_TYPES):
+                    nn.init.normal_(layer.weight, mean=0, std=0.01)
+                    if layer.bias is not None:
+                        nn.init.constant_(layer.bias, 0)
+            bias_value = -math.log((1 - self.prior_prob) / self.prior_prob)
+            for layer in self.conv_out.modules():
+                if isinstance(layer, CONV_TYPES):
+                    nn.init.constant_(layer.bias, bias_value)
+
+
+class GIoURegressor(nn.Module):
+    def __init__(self, conv, in_channels: int, internal_channels: int, anchors_per_pos: int, num_levels: int,
+                 num_convs: int = 3, add_norm: bool = True, reduction: Optional[str] = "sum", loss_weight: float = 1.,
+                 learn_scale: bool = False, **kwargs):
+        super().__init__()
+        self.dim, self.num_levels, self.num_convs = conv.dim, num_levels, num_convs
+        self.learn_scale, self.anchors_per_pos = learn_scale, anchors_per_pos
+        self.in_channels, self.internal_channels = in_channels, internal_channels
+        self.reduction, self.loss_weight, self.eps = reduction, loss_weight, 1e-7
+        self.conv_internal = _trunk(conv, in_channels, internal_channels, num_convs, add_norm=add_norm, **kwargs)
+        self.conv_out = conv(internal_channels, anchors_per_pos * self.dim * 2, kernel_size=3, stride=1, padding=1,
+                             add_norm=False, add_act=False, bias=True)
+        if self.learn_scale:
+            self.scales = nn.ModuleList([Scale() for _ in range(num_levels)])
+        self.init_weights()
+
+    def forward(self, x: Tensor, level: int, **kwargs) -> Tensor:
+        bb = _flatten_head(self.conv_out(self.conv_internal(x)), self.dim * 2)
+        if self.learn_scale:
+            bb = self.scales[level](bb)          # a scalar multiply commutes with the permute/view of regressor.py:165-172
+        return bb
+
+    def compute_loss(self, pred_boxes: Tensor, target_boxes: Tensor, **kwargs) -> Tensor:
+        """GIoULoss (nndet/losses/regression.py:118-162): -sum(diag(GIoU(pred, target, eps=1e-7)))."""
+        g = giou_diag(pred_boxes, target_boxes, eps=self.eps)
+        red = g.sum() if self.reduction == "sum" else (g.mean() if self.reduction == "mean" else g)
+        return self.loss_weight * -1 * red
+
+    def init_weights(self) -> None:
+        """regressor.py:194-201"""
+        for layer in self.modules():
+            if isinstance(layer, CONV_TYPES):
+                nn.init.normal_(layer.weight, mean=0, std=0.01)
+                if layer.bias is not None:
+                    nn.init.constant_(layer.bias, 0)
+
+
+class DetectionHeadHNMNative(nn.Module):
+    """classifier + regressor + hard-negative sampling; loss on decoded boxes (comb.py:351-405)."""
+
+    def __init__(self, classifier, regressor, coder, sampler, log_num_anchors=None):
+        super().__init__()
+        self.classifier, self.regressor, self.coder, self.fg_bg_sampler = classifier, regressor, coder, sampler
+
+    def forward(self, fmaps: List[Tensor]) -> Dict[str, Tensor]:
+        logits, offsets = [], []
+        for level, p in enumerate(fmaps):
+            logits.append(self.classifier(p, level=level))
+            offsets.append(self.regressor(p, level=level))
+        sdim = fmaps[0].ndim - 2
+        return {"box_deltas": torch.cat(offsets, dim=1).reshape(-1, sdim * 2),
+                "box_logits": torch.cat(logits, dim=1).flatten(0, -2)}
+
+    @torch.no_grad()
+    def select_indices(self, target_labels: List[Tensor], boxes_scores: Tensor) -> Tuple[Tensor, Tensor]:
+        """comb.py:247-276; max-over-classes foreground probability from one fused HIP pass."""
+        sc = boxes_scores.detach().float().contiguous()
+        probs = torch.empty((sc.shape[0],), dtype=torch.float32, device=sc.device)
+        L.call("nndet_sigmoid_max_f32", L.ptr(sc), sc.shape[0], sc.shape[1], L.ptr(probs), L.stream())
+        pos, neg = self.fg_bg_sampler(target_labels, probs)
+        return torch.where(torch.cat(pos, dim=0))[0], torch.where(torch.cat(neg, dim=0))[0]
+
+    def compute_loss(self, prediction: Dict[str, Tensor], target_labels: List[Tensor], matched_gt_boxes: List[Tensor],
+                     anchors: List[Tensor]):
+        box_logits, box_deltas = prediction["box_logits"], prediction["box_deltas"]
+        losses = {}
+        sampled_pos_inds, sampled_neg_inds = self.select_indices(target_labels, box_logits)
+        sampled_inds = torch.cat([sampled_pos_inds, sampled_neg_inds], dim=0)
+        labels = torch.cat(target_labels, dim=0)
+        n_img, m = len(anchors), anchors[0].shape[0]
+        same = all(a is anchors[0] for a in anchors)
+        if same:                                                   # no [B*M, 6] concatenation of identical anchors
+            anchors_pos = anchors[0][sampled_pos_inds % m]
+        else:
+            anchors_pos = torch.cat(anchors, dim=0)[sampled_pos_inds]
+        pred_boxes_sampled = self.coder.decode_single(box_deltas[sampled_pos_inds], anchors_pos)
+        if isinstance(matched_gt_boxes, (list, tuple)):
+            matched_gt_boxes = torch.cat(matched_gt_boxes, dim=0)
+        target_boxes_sampled = matched_gt_boxes[sampled_pos_inds]
+        if sampled_pos_inds.numel() > 0:
+            losses["reg"] = self.regressor.compute_loss(pred_boxes_sampled, target_boxes_sampled) / max(1, sampled_pos_inds.numel())
+        losses["cls"] = self.classifier.compute_loss(box_logits[sampled_inds], labels[sampled_inds])
+        return losses, sampled_pos_inds, sampled_neg_inds
+
+    def postprocess_for_inference(self, prediction: Dict[str, Tensor], anchors: List[Tensor]) -> Dict[str, Tensor]:
+        return {"pred_boxes": self.coder.decode(prediction["box_deltas"], anchors),
+                "pred_probs": self.classifier.box_logits_to_probs(prediction["box_logits"])}

@@ -1,0 +1,50 @@
+"""ATSS matcher on the GPU (csrc/atss3d.hip). Mirrors ATSSMatcher / Matcher
+(nndet/core/boxes/matcher/atss.py:20-122, matcher/base.py:13-91) for center_in_gt=False (V001)."""
+from typing import Callable, Sequence, Tuple
+
+import ctypes
+import torch
+from torch import Tensor
+
+from ... import _lib as L
+from .ops import box_iou
+
+
+class ATSSMatcher:
+    BELOW_LOW_THRESHOLD: int = -1
+    BETWEEN_THRESHOLDS: int = -2
+
+    def __init__(self, num_candidates: int, similarity_fn: Callable = box_iou, center_in_gt: bool = True,
+                 return_match_quality: bool = False):
+        if center_in_gt:
+            raise L.NndetError("center_in_gt=True is not used by RetinaUNetV001 (v001.yaml:107) and not implemented in HIP")
+        self.similarity_fn = similarity_fn
+        self.num_candidates = num_candidates
+        self.min_dist = 0.01
+        self.center_in_gt = center_in_gt
+        self.return_match_quality = return_match_quality
+
+    def __call__(self, boxes: Tensor, anchors: Tensor, num_anchors_per_level: Sequence[int],
+                 num_anchors_per_loc: int) -> Tuple[Tensor, Tensor]:
+        """-> (match_quality_matrix, matches [M] int64 with -1 for background).
+        The dense [G,M] IoU matrix is only produced when `return_match_quality` is set (the detector only reads
+        `.numel() > 0` of it, nndet/core/retina.py:267); otherwise a 1-element placeholder is returned."""
+        M = anchors.shape[0]
+        if boxes.numel() == 0:                                          # matcher/base.py:51-56
+            mq = torch.tensor([]).to(anchors)
+            return mq, torch.full((M,), self.BELOW_LOW_THRESHOLD, dtype=torch.int64, device=anchors.device)
+        gt = boxes.detach().float().contiguous().to(anchors.device)
+        an = anchors.detach().float().contiguous()
+        G, Lv = gt.shape[0], len(num_anchors_per_level)
+        offs = [0]
+        for n in num_anchors_per_level:
+            offs.append(offs[-1] + int(n))
+        assert offs[-1] == M, "num_anchors_per_level does not sum to the number of anchors"
+        k = self.num_candidates * num_anchors_per_loc
+        matches = torch.empty((M,), dtype=torch.int64, device=an.device)
+        ws_bytes = L.load().nndet_atss3d_workspace_bytes(G, M, Lv, k)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=an.device)
+        offs_c = (ctypes.c_int64 * (Lv + 1))(*offs)
+        L.call("nndet_atss3d_match_f32", L.ptr(gt), G, L.ptr(an), M, offs_c, Lv, k, L.ptr(matches), L.ptr(ws), ws_bytes, L.stream())
+        mq = self.similarity_fn(gt, an) if self.return_match_quality else an.new_ones(1)
+        return mq, matches

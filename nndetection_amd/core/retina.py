@@ -1,0 +1,138 @@
+"""Retina(U)Net detector: forward, target assignment, losses, post-processing. Mirrors BaseRetinaNet
+(nndet/core/retina.py:30-414): same constructor, `train_step(images, targets, evaluation, batch_num)`,
+`inference_step(images)`, `forward(inp)`, loss keys (reg, cls, seg_ce, seg_dice) and prediction keys."""
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import boxes as box_utils
+from .boxes.coder import decode_clip
+
+
+class BaseRetinaNet(nn.Module):
+    def __init__(self, dim: int, encoder, decoder, head, num_classes: int, anchor_generator, matcher,
+                 decoder_levels: tuple = (2, 3, 4, 5), score_thresh: float = None, detections_per_img: int = 100,
+                 topk_candidates: int = 10000, remove_small_boxes: float = 1e-2, nms_thresh: float = 0.9,
+                 segmenter=None):
+        super().__init__()
+        assert dim == 3
+        self.dim = dim
+        self.decoder_levels = decoder_levels
+        self.encoder, self.decoder, self.head = encoder, decoder, head
+        self.num_foreground_classes = num_classes
+        self.anchor_generator = anchor_generator
+        self.proposal_matcher = matcher
+        self.score_thresh, self.topk_candidates = score_thresh, topk_candidates
+        self.detections_per_img, self.remove_small_boxes, self.nms_thresh = detections_per_img, remove_small_boxes, nms_thresh
+        self.segmenter = segmenter
+        if hasattr(self.decoder, "used_levels") and self.decoder.used_levels is None:
+            used = set(decoder_levels)
+            if segmenter is not None:
+                used.add(0)
+            self.decoder.used_levels = used          # out convs nobody reads are not computed
+
+    # ------------------------------------------------------------------ forward (retina.py:198-226)
+    def forward(self, inp: Tensor):
+        features_maps_all = self.decoder(self.encoder(inp))
+        feature_maps_head = [features_maps_all[i] for i in self.decoder_levels]
+        pred_detection = self.head(feature_maps_head)
+        anchors = self.anchor_generator(inp, feature_maps_head)
+        pred_seg = self.segmenter(features_maps_all) if self.segmenter is not None else None
+        return pred_detection, anchors, pred_seg
+
+    # ------------------------------------------------------------------ train step (retina.py:86-159)
+    def train_step(self, images: Tensor, targets: dict, evaluation: bool, batch_num: int = 0):
+        target_boxes: List[Tensor] = targets["target_boxes"]
+        target_classes: List[Tensor] = targets["target_classes"]
+        target_seg: Tensor = targets["target_seg"]
+        pred_detection, anchors, pred_seg = self(images)
+        labels, matched_gt_boxes = self.assign_targets_to_anchors(anchors, target_boxes, target_classes)
+        losses = {}
+        head_losses, pos_idx, neg_idx = self.head.compute_loss(pred_detection, labels, matched_gt_boxes, anchors)
+        losses.update(head_losses)
+        if self.segmenter is not None:
+            losses.update(self.segmenter.compute_loss(pred_seg, target_seg))
+        prediction = None
+        if evaluation:
+            prediction = self.postprocess_for_inference(images=images, pred_detection=pred_detection,
+                                                        pred_seg=pred_seg, anchors=anchors)
+        return losses, prediction
+
+    @torch.no_grad()
+    def assign_targets_to_anchors(self, anchors: List[Tensor], target_boxes: List[Tensor], target_classes: List[Tensor]):
+        """retina.py:228-290 with the fused ATSS kernel as matcher."""
+        labels, matched_gt_boxes = [], []
+        npl = None
+        for anchors_per_image, gt_boxes, gt_classes in zip(anchors, target_boxes, target_classes):
+            if npl is None:
+                npl = self.anchor_generator.get_num_acnhors_per_level()
+            dev = anchors_per_image.device
+            gt_boxes = gt_boxes.to(dev, torch.float32)
+            gt_classes = gt_classes.to(dev)
+            mq, matched_idxs = self.proposal_matcher(gt_boxes, anchors_per_image, num_anchors_per_level=npl,
+                                                     num_anchors_per_loc=self.anchor_generator.num_anchors_per_location()[0])
+            matched_idxs = matched_idxs.to(dev)
+            if mq.numel() > 0:
+                clamped = matched_idxs.clamp(min=0)
+                matched_gt_boxes_per_image = gt_boxes[clamped]
+                labels_per_image = gt_classes[clamped].to(dtype=anchors_per_image.dtype) + 1
+            else:
+                matched_gt_boxes_per_image = torch.zeros_like(anchors_per_image)
+                labels_per_image = torch.zeros(anchors_per_image.shape[0], dtype=anchors_per_image.dtype, device=dev)
+            labels_per_image[matched_idxs == self.proposal_matcher.BELOW_LOW_THRESHOLD] = 0.0
+            labels_per_image[matched_idxs == self.proposal_matcher.BETWEEN_THRESHOLDS] = -1.0
+            labels.append(labels_per_image)
+            matched_gt_boxes.append(matched_gt_boxes_per_image)
+        return labels, matched_gt_boxes
+
+    # ------------------------------------------------------------------ post-processing (retina.py:161-196,292-379)
+    @torch.no_grad()
+    def postprocess_for_inference(self, images: Tensor, pred_detection: Dict[str, Tensor], pred_seg, anchors: List[Tensor]):
+        image_shapes = [images.shape[2:]] * images.shape[0]
+        boxes, probs, labels = self.postprocess_detections(pred_detection, anchors, image_shapes)
+        prediction = {"pred_boxes": boxes, "pred_scores": probs, "pred_labels": labels}
+        if self.segmenter is not None:
+            prediction["pred_seg"] = self.segmenter.postprocess_for_inference(pred_seg)["pred_seg"]
+        return prediction
+
+    def postprocess_detections(self, pred_detection: Dict[str, Tensor], anchors: List[Tensor], image_shapes):
+        boxes_per_image = [len(b) for b in anchors]
+        pred = self.head.postprocess_for_inference(pred_detection, anchors)
+        pred_boxes = pred["pred_boxes"].split(boxes_per_image, 0)
+        pred_probs = pred["pred_probs"].split(boxes_per_image, 0)
+        all_boxes, all_probs, all_labels = [], [], []
+        for boxes, probs, image_shape in zip(pred_boxes, pred_probs, image_shapes):
+            b, p, l = self.postprocess_detections_single_image(boxes, probs, image_shape)
+            all_boxes.append(b); all_probs.append(p); all_labels.append(l)
+        return all_boxes, all_probs, all_labels
+
+    def postprocess_detections_single_image(self, boxes: Tensor, probs: Tensor, image_shape):
+        assert boxes.shape[0] == probs.shape[0]
+        boxes = box_utils.clip_boxes_to_image_(boxes, image_shape)
+        probs = probs.flatten()
+        if self.topk_candidates is not None:
+            num_topk = min(self.topk_candidates, boxes.size(0))
+            probs, idx = probs.sort(descending=True)
+            probs, idx = probs[:num_topk], idx[:num_topk]
+        else:
+            idx = torch.arange(probs.numel(), device=probs.device)
+        if self.score_thresh is not None:
+            keep_idxs = probs > self.score_thresh
+            probs, idx = probs[keep_idxs], idx[keep_idxs]
+        anchor_idxs = torch.div(idx, self.num_foreground_classes, rounding_mode="floor")
+        labels = idx % self.num_foreground_classes
+        boxes = boxes[anchor_idxs]
+        if self.remove_small_boxes is not None:
+            keep = box_utils.remove_small_boxes(boxes, min_size=self.remove_small_boxes)
+            boxes, probs, labels = boxes[keep], probs[keep], labels[keep]
+        keep = box_utils.batched_nms(boxes, probs, labels, self.nms_thresh)
+        if self.detections_per_img is not None:
+            keep = keep[:self.detections_per_img]
+        return boxes[keep], probs[keep], labels[keep]
+
+    @torch.no_grad()
+    def inference_step(self, images: Tensor, **kwargs) -> Dict[str, Any]:
+        pred_detection, anchors, pred_seg = self(images)
+        return self.postprocess_for_inference(images=images, pred_detection=pred_detection, pred_seg=pred_seg, anchors=anchors)

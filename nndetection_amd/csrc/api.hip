@@ -1,0 +1,55 @@
+// C-ABI dispatch for the convolution entry points + library identification.
+#include "common.h"
+#include "conv_common.h"
+
+extern "C" const char* nndet_version(void) { return "nndetection_amd 0.1.0 (round 1)"; }
+extern "C" const char* nndet_arch(void) { return "gfx950"; }
+
+static int check_conv(const NndetConv* c) {
+    if (!c) return NNDET_EINVAL;
+    if (c->dtype != NNDET_F32 && c->dtype != NNDET_BF16) return NNDET_EINVAL;
+    if (c->batch <= 0 || c->cin <= 0 || c->cout <= 0 || c->cin > c->cin_p || c->cout > c->cout_p) return NNDET_EINVAL;
+    if (c->cout_p % 32) return NNDET_EINVAL;
+    if (c->cin_p != 1 && c->cin_p % 32) return NNDET_EINVAL;
+    return 0;
+}
+
+extern "C" int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w, const float* bias, void* y,
+                                    double* stats, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!x || !w || !y) return NNDET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (c->cin_p == 1) {
+        rc = stem_forward(c, x, (const float*)w, bias, y, st);
+        if (rc) return rc;
+        if (stats) {
+            const int64_t spatial = (int64_t)c->out_d * c->out_h * c->out_w;
+            return norm_stats_run(c->dtype, y, c->batch, spatial, c->cout_p, stats, st);
+        }
+        return 0;
+    }
+    return igemm_run(c, 0, x, w, bias, y, stats, st);
+}
+
+extern "C" int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w, void* dx, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!dy || !w || !dx || c->cin_p == 1) return NNDET_EINVAL;
+    return igemm_run(c, 1, dy, w, nullptr, dx, nullptr, as_stream(stream));
+}
+
+extern "C" int nndet_conv3d_backward_weight(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias,
+                                            void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!x || !dy || !dw) return NNDET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    rc = (c->cin_p == 1) ? stem_wgrad(c, x, dy, dw, st) : wgrad_run(c, x, dy, dw, st);
+    if (rc) return rc;
+    if (dbias) {
+        const int64_t rows = (int64_t)c->batch * c->out_d * c->out_h * c->out_w;
+        rc = colsum_run(c->dtype, dy, rows, c->cout_p, c->cout, dbias, st);
+    }
+    return rc;
+}

@@ -1,0 +1,278 @@
+// Fused ATSS matcher for gfx950 -- replaces ATSSMatcher.compute_matches (center_in_gt=False),
+// nndet/core/boxes/matcher/atss.py:48-122, and never materialises the [G, M] distance / IoU /
+// overlaps_inf matrices (3 x 4*G*M bytes + a [G,M,3] temporary in the reference).
+//
+// Per (GT g, level l) the candidate set is "the k anchors with the smallest (centre distance, index)".
+// It is found with an exact MSB-first radix SELECT on the 64-bit key (dist_bits << 32 | anchor index):
+// 8-bit digits, LDS histograms per workgroup flushed with global atomics, a tiny "pick" kernel between
+// passes. Digits that are known to be zero (index bytes above log2(M)) are skipped. Distances are
+// recomputed in every pass (24 B per anchor re-read from L2/HBM; no [G,M] storage). Then
+//   stats  : sum / sum-of-squares of the candidate IoUs per GT (fp64 atomics) -> thr = mean + std(unbiased)
+//   assign : per anchor arg-max over the GTs for which it is a candidate with IoU >= thr, else -1.
+// Distance: sqrt((dx^2 + dy^2) + dz^2) with centres (hi + lo) / 2, fp32, correctly rounded sqrt
+// (ops.py:262-287,314-327); IoU as box_iou_union_3d (ops.py:131-159). Compile with -ffp-contract=off.
+#include "common.h"
+
+typedef unsigned long long u64;
+#define GT_TILE 16
+#define MAXL 8
+
+struct AtssArgs {
+    int64_t lvl_off[MAXL + 1];   // anchor offsets per level
+    int32_t blk_off[MAXL + 1];   // workgroup offsets per level (256 anchors per workgroup)
+    int32_t k[MAXL];             // candidates per level (clamped)
+    int32_t L, G;
+    int64_t M;
+};
+
+__device__ __forceinline__ float ctr_dist(const float* g, const float* a) {
+    float gx = (g[2] + g[0]) / 2.f, gy = (g[3] + g[1]) / 2.f, gz = (g[5] + g[4]) / 2.f;
+    float ax = (a[2] + a[0]) / 2.f, ay = (a[3] + a[1]) / 2.f, az = (a[5] + a[4]) / 2.f;
+    float dx = gx - ax, dy = gy - ay, dz = gz - az;
+    return __fsqrt_rn((dx * dx + dy * dy) + dz * dz);
+}
+
+__device__ __forceinline__ float iou3(const float* a, const float* b) {
+    float va = (a[2] - a[0]) * (a[3] - a[1]) * (a[5] - a[4]);
+    float vb = (b[2] - b[0]) * (b[3] - b[1]) * (b[5] - b[4]);
+    float x1 = fmaxf(a[0], b[0]), y1 = fmaxf(a[1], b[1]), x2 = fminf(a[2], b[2]), y2 = fminf(a[3], b[3]);
+    float z1 = fmaxf(a[4], b[4]), z2 = fminf(a[5], b[5]);
+    float inter = fmaxf(x2 - x1, 0.f) * fmaxf(y2 - y1, 0.f) * fmaxf(z2 - z1, 0.f);
+    return inter / ((va + vb) - inter);
+}
+
+__device__ __forceinline__ int level_of_block(const AtssArgs& A, int b) {
+    int l = 0;
+    while (l + 1 < A.L && b >= A.blk_off[l + 1]) ++l;
+    return l;
+}
+
+// state layout per (g, l): prefix (u64), krem (int). hist: [G][L][256] u32
+// grid (total_blocks, ceil(G / GT_TILE)), block 256
+__global__ __launch_bounds__(256) void k_atss_hist(AtssArgs A, const float* __restrict__ gt,
+                                                   const float* __restrict__ anchors, const u64* __restrict__ prefix,
+                                                   unsigned* __restrict__ hist, int shift) {
+    __shared__ unsigned h[GT_TILE][256];
+    __shared__ float g_s[GT_TILE][6];
+    __shared__ u64 p_s[GT_TILE];
+    const int l = level_of_block(A, blockIdx.x);
+    const int g0 = blockIdx.y * GT_TILE;
+    const int ng = min(GT_TILE, A.G - g0);
+    for (int i = threadIdx.x; i < GT_TILE * 256; i += 256) (&h[0][0])[i] = 0;
+    if ((int)threadIdx.x < ng * 6) (&g_s[0][0])[threadIdx.x] = gt[g0 * 6 + threadIdx.x];
+    if ((int)threadIdx.x < ng) p_s[threadIdx.x] = prefix[(int64_t)(g0 + threadIdx.x) * A.L + l];
+    __syncthreads();
+    const int64_t a = A.lvl_off[l] + (int64_t)(blockIdx.x - A.blk_off[l]) * 256 + threadIdx.x;
+    if (a < A.lvl_off[l + 1]) {
+        float ab[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ab[q] = anchors[a * 6 + q];
+        for (int g = 0; g < ng; ++g) {
+            const u64 key = ((u64)__float_as_uint(ctr_dist(g_s[g], ab)) << 32) | (u64)(uint32_t)a;
+            const bool match = (shift >= 56) || ((key >> (shift + 8)) == (p_s[g] >> (shift + 8)));
+            if (match) atomicAdd(&h[g][(unsigned)(key >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ng * 256; i += 256) {
+        const unsigned v = (&h[0][0])[i];
+        if (v) atomicAdd(&hist[((int64_t)(g0 + (i >> 8)) * A.L + l) * 256 + (i & 255)], v);
+    }
+}
+
+// one thread per (g, l): choose the digit, update prefix / remaining rank, clear the histogram
+__global__ void k_atss_pick(int GL, u64* __restrict__ prefix, int* __restrict__ krem, unsigned* __restrict__ hist,
+                            int shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= GL) return;
+    unsigned* h = hist + (int64_t)i * 256;
+    int rem = krem[i];
+    int b = 0;
+    unsigned cum = 0;
+    for (; b < 256; ++b) {
+        const unsigned c = h[b];
+        if (cum + c >= (unsigned)rem) break;
+        cum += c;
+    }
+    if (b > 255) b = 255;  // cannot happen when k <= level size
+    prefix[i] |= ((u64)b) << shift;
+    krem[i] = rem - (int)cum;
+    for (int q = 0; q < 256; ++q) h[q] = 0;
+}
+
+__global__ void k_atss_init(int G, int L, AtssArgs A, u64* prefix, int* krem) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * L) return;
+    prefix[i] = 0;
+    krem[i] = A.k[i % L];
+}
+
+// candidate IoU statistics per GT. grid (total_blocks, ceil(G/GT_TILE))
+__global__ __launch_bounds__(256) void k_atss_stats(AtssArgs A, const float* __restrict__ gt,
+                                                    const float* __restrict__ anchors, const u64* __restrict__ kth,
+                                                    double* __restrict__ sums /* [G][2] */) {
+    __shared__ float g_s[GT_TILE][6];
+    __shared__ u64 p_s[GT_TILE];
+    __shared__ double red[GT_TILE][2];
+    const int l = level_of_block(A, blockIdx.x);
+    const int g0 = blockIdx.y * GT_TILE;
+    const int ng = min(GT_TILE, A.G - g0);
+    if ((int)threadIdx.x < ng * 6) (&g_s[0][0])[threadIdx.x] = gt[g0 * 6 + threadIdx.x];
+    if ((int)threadIdx.x < ng) p_s[threadIdx.x] = kth[(int64_t)(g0 + threadIdx.x) * A.L + l];
+    if ((int)threadIdx.x < GT_TILE * 2) (&red[0][0])[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int64_t a = A.lvl_off[l] + (int64_t)(blockIdx.x - A.blk_off[l]) * 256 + threadIdx.x;
+    if (a < A.lvl_off[l + 1]) {
+        float ab[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ab[q] = anchors[a * 6 + q];
+        for (int g = 0; g < ng; ++g) {
+            const u64 key = ((u64)__float_as_uint(ctr_dist(g_s[g], ab)) << 32) | (u64)(uint32_t)a;
+            if (key <= p_s[g]) {
+                const double v = (double)iou3(g_s[g], ab);
+                atomicAdd(&red[g][0], v);
+                atomicAdd(&red[g][1], v * v);
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ng * 2) {
+        const double v = (&red[0][0])[threadIdx.x];
+        if (v != 0.0) atomicAdd(&sums[(int64_t)g0 * 2 + threadIdx.x], v);
+    }
+}
+
+__global__ void k_atss_thr(int G, int ncand, const double* __restrict__ sums, float* __restrict__ thr) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double n = (double)ncand;
+    const double mean = sums[g * 2] / n;
+    float t;
+    if (ncand > 1) {
+        double var = (sums[g * 2 + 1] - n * mean * mean) / (n - 1.0);
+        if (var < 0.0) var = 0.0;
+        t = (float)mean + (float)sqrt(var);   // atss.py:97-99: fp32 mean + fp32 std
+    } else {
+        t = __uint_as_float(0x7fc00000u);     // unbiased std of one sample is NaN -> nothing is positive
+    }
+    thr[g] = t;
+}
+
+// per anchor arg-max over the GTs. grid total_blocks, block 256
+__global__ __launch_bounds__(256) void k_atss_assign(AtssArgs A, const float* __restrict__ gt,
+                                                     const float* __restrict__ anchors, const u64* __restrict__ kth,
+                                                     const float* __restrict__ thr, int64_t* __restrict__ matches) {
+    __shared__ float g_s[GT_TILE][6];
+    __shared__ u64 p_s[GT_TILE];
+    __shared__ float t_s[GT_TILE];
+    const int l = level_of_block(A, blockIdx.x);
+    const int64_t a = A.lvl_off[l] + (int64_t)(blockIdx.x - A.blk_off[l]) * 256 + threadIdx.x;
+    const bool valid = a < A.lvl_off[l + 1];
+    float ab[6] = {0, 0, 0, 0, 0, 0};
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ab[q] = anchors[a * 6 + q];
+    }
+    float best = -100.f;  // -INF of the reference (atss.py:16)
+    int bi = -1;
+    for (int g0 = 0; g0 < A.G; g0 += GT_TILE) {
+        const int ng = min(GT_TILE, A.G - g0);
+        __syncthreads();
+        if ((int)threadIdx.x < ng * 6) (&g_s[0][0])[threadIdx.x] = gt[g0 * 6 + threadIdx.x];
+        if ((int)threadIdx.x < ng) {
+            p_s[threadIdx.x] = kth[(int64_t)(g0 + threadIdx.x) * A.L + l];
+            t_s[threadIdx.x] = thr[g0 + threadIdx.x];
+        }
+        __syncthreads();
+        if (valid) {
+            for (int g = 0; g < ng; ++g) {
+                const u64 key = ((u64)__float_as_uint(ctr_dist(g_s[g], ab)) << 32) | (u64)(uint32_t)a;
+                if (key <= p_s[g]) {
+                    const float v = iou3(g_s[g], ab);
+                    if (v >= t_s[g] && v > best) { best = v; bi = g0 + g; }
+                }
+            }
+        }
+    }
+    if (valid) matches[a] = (int64_t)bi;
+}
+
+__global__ void k_fill_i64(int64_t* p, int64_t n, int64_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+struct AtssWs { u64* prefix; int* krem; unsigned* hist; double* sums; float* thr; size_t total; };
+
+static void atss_layout(int64_t G, int32_t L, char* base, AtssWs* w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    size_t o_p = take((size_t)G * L * 8), o_k = take((size_t)G * L * 4), o_h = take((size_t)G * L * 256 * 4);
+    size_t o_s = take((size_t)G * 2 * 8), o_t = take((size_t)G * 4);
+    w->prefix = (u64*)(base + o_p); w->krem = (int*)(base + o_k); w->hist = (unsigned*)(base + o_h);
+    w->sums = (double*)(base + o_s); w->thr = (float*)(base + o_t); w->total = off;
+}
+
+extern "C" size_t nndet_atss3d_workspace_bytes(int64_t G, int64_t M, int32_t L, int32_t k) {
+    (void)M; (void)k;
+    AtssWs w;
+    atss_layout(G > 0 ? G : 1, L > 0 ? L : 1, nullptr, &w);
+    return w.total;
+}
+
+extern "C" int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* anchors, int64_t M,
+                                      const int64_t* level_offsets_host, int32_t L, int32_t k, int64_t* matches,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = as_stream(stream);
+    if (G < 0 || M < 0 || L <= 0 || L > MAXL || k <= 0 || !level_offsets_host) return NNDET_EINVAL;
+    if (M == 0) return 0;
+    if (!matches || !anchors) return NNDET_EINVAL;
+    if (M >= (1LL << 32)) return NNDET_EINVAL;
+    if (G == 0) {  // Matcher.__call__ fast path (matcher/base.py:51-56)
+        k_fill_i64<<<(unsigned)ceil_div64(M, 256), 256, 0, st>>>(matches, M, -1);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (!gt || !workspace) return NNDET_EINVAL;
+    if (level_offsets_host[0] != 0 || level_offsets_host[L] != M) return NNDET_EINVAL;
+    AtssWs w;
+    atss_layout(G, L, (char*)workspace, &w);
+    if (w.total > workspace_bytes) return NNDET_EWORKSPACE;
+    AtssArgs A;
+    A.L = L; A.G = (int32_t)G; A.M = M;
+    int ncand = 0;
+    A.blk_off[0] = 0;
+    for (int l = 0; l < L; ++l) {
+        A.lvl_off[l] = level_offsets_host[l];
+        const int64_t sz = level_offsets_host[l + 1] - level_offsets_host[l];
+        if (sz <= 0) return NNDET_EINVAL;
+        A.k[l] = (int32_t)(sz < k ? sz : k);
+        ncand += A.k[l];
+        A.blk_off[l + 1] = A.blk_off[l] + (int32_t)ceil_div64(sz, 256);
+    }
+    A.lvl_off[L] = M;
+    const int nblk = A.blk_off[L];
+    const int GL = (int)G * L;
+    const dim3 grid(nblk, ceil_div((int)G, GT_TILE));
+    k_atss_init<<<ceil_div(GL, 256), 256, 0, st>>>((int)G, L, A, w.prefix, w.krem);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemsetAsync(w.hist, 0, (size_t)GL * 256 * 4, st));
+    HIP_TRY(hipMemsetAsync(w.sums, 0, (size_t)G * 16, st));
+    // digits of the low (index) word above the highest set bit of (M - 1) are zero for every key: skip them
+    int idx_bits = 1;
+    while (((int64_t)1 << idx_bits) < M) ++idx_bits;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (shift < 32 && shift >= idx_bits) continue;
+        k_atss_hist<<<grid, 256, 0, st>>>(A, gt, anchors, w.prefix, w.hist, shift);
+        LAUNCH_CHECK();
+        k_atss_pick<<<ceil_div(GL, 64), 64, 0, st>>>(GL, w.prefix, w.krem, w.hist, shift);
+        LAUNCH_CHECK();
+    }
+    k_atss_stats<<<grid, 256, 0, st>>>(A, gt, anchors, w.prefix, w.sums);
+    LAUNCH_CHECK();
+    k_atss_thr<<<ceil_div((int)G, 64), 64, 0, st>>>((int)G, ncand, w.sums, w.thr);
+    LAUNCH_CHECK();
+    k_atss_assign<<<nblk, 256, 0, st>>>(A, gt, anchors, w.prefix, w.thr, matches);
+    LAUNCH_CHECK();
+    return 0;
+}

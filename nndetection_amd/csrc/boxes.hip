@@ -1,0 +1,253 @@
+// Box-op kernels for gfx950: pairwise IoU / GIoU, diagonal GIoU (+grad), anchor grid, decode+clip, sigmoid-max.
+// Reference: nndet/core/boxes/ops.py:75-185, anchors.py:337-377, coder.py:90-155, clip.py:83-101.
+// All fp32; the operation order follows the reference expression by expression (bit-exact for + - * / min max
+// with -ffp-contract=off and IEEE division). These kernels are HBM-bound: IoU writes 4 B per pair
+// (float4 stores, 1 KiB per wave-instruction), anchors write 24 B per anchor.
+#include "common.h"
+
+struct Box { float x1, y1, x2, y2, z1, z2; };
+
+__device__ __forceinline__ Box ldbox(const float* p) { return Box{p[0], p[1], p[2], p[3], p[4], p[5]}; }
+__device__ __forceinline__ float vol3(const Box& b) { return (b.x2 - b.x1) * (b.y2 - b.y1) * (b.z2 - b.z1); }
+
+// inter / union exactly as box_iou_union_3d (ops.py:131-159); returns union through *u
+__device__ __forceinline__ float iou_union(const Box& a, float va, const Box& b, float vb, float eps, float* u) {
+    float x1 = fmaxf(a.x1, b.x1), y1 = fmaxf(a.y1, b.y1), x2 = fminf(a.x2, b.x2), y2 = fminf(a.y2, b.y2);
+    float z1 = fmaxf(a.z1, b.z1), z2 = fminf(a.z2, b.z2);
+    float inter = (fmaxf(x2 - x1, 0.f) * fmaxf(y2 - y1, 0.f) * fmaxf(z2 - z1, 0.f)) + eps;
+    float un = (va + vb) - inter;
+    *u = un;
+    return inter / un;
+}
+
+__device__ __forceinline__ float giou_val(const Box& a, float va, const Box& b, float vb, float eps) {
+    float un;
+    float iou = iou_union(a, va, b, vb, 0.f, &un);  // eps is NOT forwarded to the inner IoU (ops.py:175)
+    float x1 = fminf(a.x1, b.x1), y1 = fminf(a.y1, b.y1), x2 = fmaxf(a.x2, b.x2), y2 = fmaxf(a.y2, b.y2);
+    float z1 = fminf(a.z1, b.z1), z2 = fmaxf(a.z2, b.z2);
+    float vol = (fmaxf(x2 - x1, 0.f) * fmaxf(y2 - y1, 0.f) * fmaxf(z2 - z1, 0.f)) + eps;
+    return iou - (vol - un) / vol;
+}
+
+// grid (ceil(m/1024), ceil(n/ROWS)); block 256; each thread owns 4 consecutive columns and ROWS rows.
+template <bool GIOU, int ROWS>
+__global__ __launch_bounds__(256) void k_pairwise(const float* __restrict__ a, int64_t n, const float* __restrict__ b,
+                                                  int64_t m, float eps, float* __restrict__ out) {
+    __shared__ float arow[ROWS * 6];
+    const int64_t r0 = (int64_t)blockIdx.y * ROWS;
+    const int nr = (int)min((int64_t)ROWS, n - r0);
+    if ((int)threadIdx.x < nr * 6) arow[threadIdx.x] = a[r0 * 6 + threadIdx.x];
+    __syncthreads();
+    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= m) return;
+    Box bb[4];
+    float vb[4];
+    const int nc = (int)min((int64_t)4, m - c0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bb[j] = ldbox(b + (c0 + (j < nc ? j : 0)) * 6);
+        vb[j] = vol3(bb[j]);
+    }
+    const bool vec = (nc == 4) && ((m & 3) == 0);
+    for (int r = 0; r < nr; ++r) {
+        Box ab = ldbox(arow + r * 6);
+        float va = vol3(ab);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float un;
+            v[j] = GIOU ? giou_val(ab, va, bb[j], vb[j], eps) : iou_union(ab, va, bb[j], vb[j], eps, &un);
+        }
+        float* o = out + (r0 + r) * m + c0;
+        if (vec) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int j = 0; j < nc; ++j) o[j] = v[j];
+        }
+    }
+}
+
+template <bool GIOU>
+static int pairwise(const float* a, int64_t n, const float* b, int64_t m, float eps, float* out, void* stream) {
+    if (n < 0 || m < 0) return NNDET_EINVAL;
+    if (n == 0 || m == 0) return 0;
+    if (!a || !b || !out) return NNDET_EINVAL;
+    constexpr int ROWS = 16;
+    dim3 grid((unsigned)ceil_div64(m, 1024), (unsigned)ceil_div64(n, ROWS));
+    k_pairwise<GIOU, ROWS><<<grid, 256, 0, as_stream(stream)>>>(a, n, b, m, eps, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nndet_iou3d_pairwise_f32(const float* a, int64_t n, const float* b, int64_t m, float eps, float* out,
+                                        void* stream) { return pairwise<false>(a, n, b, m, eps, out, stream); }
+extern "C" int nndet_giou3d_pairwise_f32(const float* a, int64_t n, const float* b, int64_t m, float eps, float* out,
+                                         void* stream) { return pairwise<true>(a, n, b, m, eps, out, stream); }
+
+// ------------------------------------------------------------------ diagonal GIoU (loss) + gradient w.r.t. a
+__global__ void k_giou_diag_fwd(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float eps,
+                                float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Box ab = ldbox(a + i * 6), bb = ldbox(b + i * 6);
+    out[i] = giou_val(ab, vol3(ab), bb, vol3(bb), eps);
+}
+
+// Analytic gradient (same sub-gradient conventions as autograd of the reference expression:
+// max/min route the gradient to the selected operand -- on ties torch.max/min(a, b) split 0.5/0.5 --
+// and clamp(min=0) passes gradient where the argument is > 0... torch passes it for >= 0? No: clamp's
+// backward mask is (x >= min), so exactly-0 extents still receive gradient.
+__global__ void k_giou_diag_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ go,
+                                int64_t n, float eps, float* __restrict__ ga) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* A = a + i * 6;
+    const float* B = b + i * 6;
+    // axis k: lo index, hi index
+    const int LO[3] = {0, 1, 4}, HI[3] = {2, 3, 5};
+    float ext[3], iw[3], hw[3];           // box extent, clamped intersection extent, clamped hull extent
+    float ilo_w[3], ihi_w[3], hlo_w[3], hhi_w[3];  // d(unclamped extents)/d(a.lo / a.hi) weights (0, 0.5 or 1)
+    float iraw[3], hraw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float alo = A[LO[k]], ahi = A[HI[k]], blo = B[LO[k]], bhi = B[HI[k]];
+        ext[k] = ahi - alo;
+        // intersection: lo = max(alo, blo), hi = min(ahi, bhi)
+        ilo_w[k] = alo > blo ? 1.f : (alo == blo ? 0.5f : 0.f);
+        ihi_w[k] = ahi < bhi ? 1.f : (ahi == bhi ? 0.5f : 0.f);
+        iraw[k] = fminf(ahi, bhi) - fmaxf(alo, blo);
+        iw[k] = fmaxf(iraw[k], 0.f);
+        // hull: lo = min(alo, blo), hi = max(ahi, bhi)
+        hlo_w[k] = alo < blo ? 1.f : (alo == blo ? 0.5f : 0.f);
+        hhi_w[k] = ahi > bhi ? 1.f : (ahi == bhi ? 0.5f : 0.f);
+        hraw[k] = fmaxf(ahi, bhi) - fminf(alo, blo);
+        hw[k] = fmaxf(hraw[k], 0.f);
+    }
+    float va = ext[0] * ext[1] * ext[2];
+    float vb = (B[2] - B[0]) * (B[3] - B[1]) * (B[5] - B[4]);
+    float inter = iw[0] * iw[1] * iw[2];
+    float un = va + vb - inter;
+    float vol = hw[0] * hw[1] * hw[2] + eps;
+    // giou = inter/un - (vol - un)/vol = inter/un - 1 + un/vol
+    float g = go[i];
+    float d_inter = g * (1.f / un);
+    float d_un = g * (-inter / (un * un) + 1.f / vol);
+    float d_vol = g * (-un / (vol * vol));
+    // un = va + vb - inter
+    float d_va = d_un;
+    d_inter -= d_un;
+    float gout[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        // d va / d ext_k
+        float d_ext = d_va * ext[k1] * ext[k2];
+        gout[HI[k]] += d_ext;
+        gout[LO[k]] -= d_ext;
+        // d inter / d iw_k (clamp passes gradient when raw >= 0)
+        float d_iw = (iraw[k] >= 0.f) ? d_inter * iw[k1] * iw[k2] : 0.f;
+        gout[HI[k]] += d_iw * ihi_w[k];
+        gout[LO[k]] -= d_iw * ilo_w[k];
+        float d_hw = (hraw[k] >= 0.f) ? d_vol * hw[k1] * hw[k2] : 0.f;
+        gout[HI[k]] += d_hw * hhi_w[k];
+        gout[LO[k]] -= d_hw * hlo_w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ga[i * 6 + k] = gout[k];
+}
+
+extern "C" int nndet_giou3d_diag_fwd_f32(const float* a, const float* b, int64_t n, float eps, float* out, void* stream) {
+    if (n < 0) return NNDET_EINVAL;
+    if (n == 0) return 0;
+    k_giou_diag_fwd<<<(unsigned)ceil_div64(n, 256), 256, 0, as_stream(stream)>>>(a, b, n, eps, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int nndet_giou3d_diag_bwd_f32(const float* a, const float* b, const float* grad_out, int64_t n, float eps,
+                                         float* grad_a, void* stream) {
+    if (n < 0) return NNDET_EINVAL;
+    if (n == 0) return 0;
+    k_giou_diag_bwd<<<(unsigned)ceil_div64(n, 256), 256, 0, as_stream(stream)>>>(a, b, grad_out, n, eps, grad_a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ anchors
+// one thread per (cell, anchor): writes 6 floats = 24 B; consecutive threads write consecutive 24-B records.
+__global__ void k_anchor_grid(const float* __restrict__ cell, int A, int sx, int sy, int sz, float stx, float sty,
+                              float stz, float* __restrict__ out, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int a = (int)(i % A);
+    int64_t c = i / A;
+    int z = (int)(c % sz);
+    int64_t t = c / sz;
+    int y = (int)(t % sy);
+    int x = (int)(t / sy);
+    // shifts = arange(size) * stride (anchors.py:361-363), anchors = shifts + base (anchors.py:371)
+    float fx = (float)x * stx, fy = (float)y * sty, fz = (float)z * stz;
+    const float* b = cell + a * 6;
+    float* o = out + i * 6;
+    o[0] = fx + b[0]; o[1] = fy + b[1]; o[2] = fx + b[2]; o[3] = fy + b[3]; o[4] = fz + b[4]; o[5] = fz + b[5];
+}
+
+extern "C" int nndet_anchors3d_grid_f32(const float* cell, int32_t A, int32_t sx, int32_t sy, int32_t sz,
+                                        int32_t stride_x, int32_t stride_y, int32_t stride_z, float* out, void* stream) {
+    if (A <= 0 || sx <= 0 || sy <= 0 || sz <= 0 || !cell || !out) return NNDET_EINVAL;
+    int64_t total = (int64_t)sx * sy * sz * A;
+    k_anchor_grid<<<(unsigned)ceil_div64(total, 256), 256, 0, as_stream(stream)>>>(
+        cell, A, sx, sy, sz, (float)stride_x, (float)stride_y, (float)stride_z, out, total);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ decode + clip
+__global__ void k_decode_clip(const float* __restrict__ rel, const float* __restrict__ anchors, int64_t n,
+                              int64_t n_anchor, float clip_exp, float ix, float iy, float iz, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rel + i * 6;
+    const float* b = anchors + (i % n_anchor) * 6;
+    // coder.py:107-151 with weights == 1 (x / 1 == x)
+    float w = b[2] - b[0], h = b[3] - b[1], d = b[5] - b[4];
+    float cx = b[0] + 0.5f * w, cy = b[1] + 0.5f * h, cz = b[4] + 0.5f * d;
+    float dw = fminf(r[2], clip_exp), dh = fminf(r[3], clip_exp), dd = fminf(r[5], clip_exp);
+    float pcx = r[0] * w + cx, pcy = r[1] * h + cy, pcz = r[4] * d + cz;
+    float pw = expf(dw) * w, ph = expf(dh) * h, pd = expf(dd) * d;
+    float o0 = pcx - 0.5f * pw, o1 = pcy - 0.5f * ph, o2 = pcx + 0.5f * pw, o3 = pcy + 0.5f * ph;
+    float o4 = pcz - 0.5f * pd, o5 = pcz + 0.5f * pd;
+    if (ix > 0.f) {  // clip.py:95-100
+        o0 = fminf(fmaxf(o0, 0.f), ix); o2 = fminf(fmaxf(o2, 0.f), ix);
+        o1 = fminf(fmaxf(o1, 0.f), iy); o3 = fminf(fmaxf(o3, 0.f), iy);
+        o4 = fminf(fmaxf(o4, 0.f), iz); o5 = fminf(fmaxf(o5, 0.f), iz);
+    }
+    float* o = out + i * 6;
+    o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4; o[5] = o5;
+}
+
+extern "C" int nndet_decode_clip3d_f32(const float* rel, const float* anchors, int64_t n, int64_t n_anchor,
+                                       float clip_exp, float img_x, float img_y, float img_z, float* out, void* stream) {
+    if (n < 0 || n_anchor <= 0) return NNDET_EINVAL;
+    if (n == 0) return 0;
+    k_decode_clip<<<(unsigned)ceil_div64(n, 256), 256, 0, as_stream(stream)>>>(rel, anchors, n, n_anchor, clip_exp,
+                                                                              img_x, img_y, img_z, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ sigmoid + max over classes
+__global__ void k_sigmoid_max(const float* __restrict__ logits, int64_t n, int C, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, logits[i * C + c]);
+    out[i] = 1.f / (1.f + expf(-m));  // sigmoid is monotone: max(sigmoid(x)) == sigmoid(max(x))
+}
+
+extern "C" int nndet_sigmoid_max_f32(const float* logits, int64_t n, int32_t C, float* out, void* stream) {
+    if (n < 0 || C <= 0) return NNDET_EINVAL;
+    if (n == 0) return 0;
+    k_sigmoid_max<<<(unsigned)ceil_div64(n, 256), 256, 0, as_stream(stream)>>>(logits, n, C, out);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Build libnndet_amd.so for gfx950 (cross-compiles without a GPU). Usage: csrc/build.sh [-j N]
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
+mkdir -p _obj
+pids=()
+build() { # src extra-flags
+  local src=$1; shift
+  local obj=_obj/${src%.hip}.o
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ conv_common.h -nt "$obj" ] || [ ../../include/nndet_amd.h -nt "$obj" ]; then
+    $HIPCC $COMMON "$@" -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+}
+# bit-exact box kernels: no FMA contraction (IEEE division / sqrt are hipcc defaults)
+build nms3d.hip -ffp-contract=off
+build boxes.hip -ffp-contract=off
+build atss3d.hip -ffp-contract=off
+build conv_igemm.hip
+build conv_wgrad.hip
+build conv_stem.hip
+build norm.hip
+build segloss.hip
+build api.hip
+rc=0
+for p in "${pids[@]}"; do wait $p || rc=1; done
+[ $rc -eq 0 ] || { echo "compile failed"; exit 1; }
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libnndet_amd.so _obj/*.o
+echo "built $(pwd)/libnndet_amd.so"

@@ -1,0 +1,63 @@
+// Shared device/host helpers for the gfx950 kernels. Written for CDNA4 only (wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nndet_amd.h"
+
+#define NNDET_WAVE 64
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return (int)_e;           \
+    } while (0)
+
+#define LAUNCH_CHECK()                                  \
+    do {                                                \
+        hipError_t _e = hipGetLastError();              \
+        if (_e != hipSuccess) return (int)_e;           \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved), bit-identical to torch's conversion
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    __device__ static __forceinline__ float ld(float v) { return v; }
+    __device__ static __forceinline__ float st(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    __device__ static __forceinline__ float ld(bf16_t v) { return bf16_to_f32(v); }
+    __device__ static __forceinline__ bf16_t st(float v) { return f32_to_bf16(v); }
+};
+
+// 16-byte vector used for every global <-> LDS <-> register fragment move
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

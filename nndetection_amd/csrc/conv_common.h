@@ -1,0 +1,20 @@
+// Declarations shared by the convolution translation units.
+#pragma once
+#include "common.h"
+#include <string.h>
+
+// fp64 (sum, sumsq) statistics are accumulated into this many replicas to spread atomic contention;
+// consumers (norm_apply) add the replicas up. Layout [NNDET_STATS_REPLICAS][N][C_p][2].
+#define NNDET_STATS_REPLICAS 32
+
+// conv_igemm.hip
+int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x, const void* w, const float* bias,
+              void* y, double* stats, hipStream_t st);
+// conv_wgrad.hip
+int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipStream_t st);
+// conv_stem.hip (Cin_p == 1)
+int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const float* bias, void* y, hipStream_t st);
+int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hipStream_t st);
+// norm.hip
+int colsum_run(int dtype, const void* x, int64_t rows, int c_p, int c, float* out, hipStream_t st);
+int norm_stats_run(int dtype, const void* x, int batch, int64_t spatial, int c_p, double* stats, hipStream_t st);

@@ -1,0 +1,451 @@
+// Implicit-GEMM 3D convolution on MFMA for gfx950 (forward, data gradient, transposed conv): NDHWC,
+// bf16 or fp32 storage, fp32 accumulation.
+//
+// One kernel family covers Conv3d forward, Conv3d backward-data, ConvTranspose3d(k == s) forward and
+// backward-data by describing each as a "gather GEMM" over a LATTICE of output points:
+//     out[o_off + o_step * i][r] = sum_{tap t} sum_k  W_t[r][k] * in[in_step * i + delta_t][k]
+//   - Conv3d forward:      lattice = output grid, in_step = stride, delta_t = t - pad, all k^3 taps
+//   - Conv3d backward-data: one lattice per output parity class c in [0, s)^3 (o_off = c, o_step = s),
+//                           in_step = 1, only the taps with (c + pad - t) % s == 0, delta = (c + pad - t) / s
+//                           -> no wasted MFMA work on structurally-zero taps of strided convolutions
+//   - ConvTranspose3d (k == s, pad 0) forward: class c has the single tap t = c with delta 0 (a pure GEMM)
+//   - ConvTranspose3d backward-data: a strided conv (in_step = s) with all taps.
+//
+// Workgroup = 256 threads = 4 waves. The input halo tile of the workgroup's lattice tile is staged
+// through LDS once per 64-byte channel chunk (32 bf16 / 16 fp32 channels) with 16-byte coalesced NDHWC
+// loads (zero-filled outside the tensor = the conv padding) and is then re-used by every tap; the
+// activation fragments of all taps are ds_read_b128 from that tile, the weight fragments (shared by all
+// four waves, L1/L2 resident) come straight from global memory. MFMA operands: A = weights (rows = output
+// channels), B = activations (cols = lattice points), so a lane ends up with 4 consecutive output
+// channels of one voxel -> 8/16-byte NDHWC stores.
+//   bf16: v_mfma_f32_16x16x32_bf16 (one per 16-byte fragment pair)
+//   fp32: v_mfma_f32_16x16x4_f32 x4 (exact fp32, the parity path); the K slot <-> channel assignment is
+//         any bijection as long as A and B agree, so both dtypes use the same 16-byte fragment geometry.
+// Optional epilogue: + bias, per-(n, channel) sum / sum-of-squares of the rounded outputs (InstanceNorm /
+// GroupNorm statistics fused into the producer; fp64 atomics into NNDET_STATS_REPLICAS replicas).
+#include "common.h"
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int KC = 32;   // channels per 64-byte chunk
+    static constexpr int EPL = 8;   // elements per 16-byte fragment
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KC = 16;
+    static constexpr int EPL = 4;
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    uint2 v;
+    v.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    v.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ float round_to(float v, float*) { return v; }
+__device__ __forceinline__ float round_to(float v, bf16_t*) { return bf16_to_f32(f32_to_bf16(v)); }
+
+#define IG_MAXP 24   // max 16-byte halo pieces per thread per chunk (=> halo <= 1536 voxels = 96 KiB)
+
+struct IgClass {
+    int32_t out_off[3];
+    int32_t L[3];         // lattice size of this class
+    int32_t in_base[3];   // min delta per axis (input coordinate of lattice point 0, tap offset 0)
+    int32_t tap0, ntap;
+};
+struct IgTap { int32_t d[3]; int32_t wt; };   // delta - in_base (>= 0), weight tap index
+
+struct IgArgs {
+    const void* x; const void* w; const float* bias; void* y; double* stats;
+    int32_t N;
+    int32_t I[3], Cx;     // input tensor spatial dims, physical channels (= K)
+    int32_t O[3], Cy;     // output tensor spatial dims, physical channels (= rows)
+    int32_t in_step[3], out_step[3];
+    int32_t T[3];         // lattice tile
+    int32_t nt[3];        // tiles per axis
+    int32_t H[3];         // halo dims (max over classes)
+    int32_t ncls;
+    IgClass cls[8];
+    IgTap taps[27];
+};
+
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
+    using M = Mma<T>;
+    constexpr int KC = M::KC, EPL = M::EPL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+
+    const int cls_i = blockIdx.z % A.ncls;
+    const int n = blockIdx.z / A.ncls;
+    const IgClass& C = A.cls[cls_i];
+    int tt = blockIdx.x;
+    const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
+    const int th_i = tt % A.nt[1];
+    const int td_i = tt / A.nt[1];
+    const int l0d = td_i * A.T[0], l0h = th_i * A.T[1], l0w = tw_i * A.T[2];
+    if (l0d >= C.L[0] || l0h >= C.L[1] || l0w >= C.L[2]) return;   // uniform: tile outside this class' lattice
+    const int row0 = blockIdx.y * (MT * 16);
+
+    const int HD = A.H[0], HH = A.H[1], HW = A.H[2];
+    const int HV4 = HD * HH * HW * 4;
+    const int i0d = l0d * A.in_step[0] + C.in_base[0];
+    const int i0h = l0h * A.in_step[1] + C.in_base[1];
+    const int i0w = l0w * A.in_step[2] + C.in_base[2];
+    const T* xn = reinterpret_cast<const T*>(A.x) + (int64_t)n * A.I[0] * A.I[1] * A.I[2] * A.Cx;
+
+    // global element offsets of this thread's halo pieces (identical for every channel chunk)
+    int32_t goff[IG_MAXP];
+#pragma unroll
+    for (int s = 0; s < IG_MAXP; ++s) {
+        const int p = tid + s * 256;
+        int32_t o = -1;
+        if (p < HV4) {
+            const int hv = p >> 2, part = p & 3;
+            const int hw = hv % HW;
+            const int t2 = hv / HW;
+            const int hh = t2 % HH, hd = t2 / HH;
+            const int id = i0d + hd, ih = i0h + hh, iw = i0w + hw;
+            if ((unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
+                o = ((id * A.I[1] + ih) * A.I[2] + iw) * A.Cx + part * EPL;
+        }
+        goff[s] = o;
+    }
+    // LDS byte offsets of this lane's lattice points (tap offset 0) for its NT B-fragments
+    int boff[NT];
+    int pd_[NT], ph_[NT], pw_[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int p = (wv * NT + j) * 16 + li;
+        const int pw = p % A.T[2];
+        const int t2 = p / A.T[2];
+        const int ph = t2 % A.T[1], pd = t2 / A.T[1];
+        pd_[j] = pd; ph_[j] = ph; pw_[j] = pw;
+        boff[j] = (((pd * A.in_step[0]) * HH + ph * A.in_step[1]) * HW + pw * A.in_step[2]) * 64 + q * 16;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + li) * A.Cx + q * EPL;
+    const int nchunk = A.Cx / KC;
+    for (int kc = 0; kc < nchunk; ++kc) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < IG_MAXP; ++s) {
+            const int p = tid + s * 256;
+            if (p < HV4) {
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (goff[s] >= 0) v = *reinterpret_cast<const u32x4*>(xn + goff[s] + kc * KC);
+                *reinterpret_cast<u32x4*>(smem + p * 16) = v;
+            }
+        }
+        __syncthreads();
+        for (int tp = 0; tp < C.ntap; ++tp) {
+            const IgTap& tap = A.taps[C.tap0 + tp];
+            const int toff = ((tap.d[0] * HH + tap.d[1]) * HW + tap.d[2]) * 64;
+            const T* wt = wl + ((int64_t)tap.wt * A.Cy) * A.Cx + kc * KC;
+            u32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4*>(wt + (int64_t)i * 16 * A.Cx);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + boff[j] + toff);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) M::mma(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    // ---------------- epilogue: lane holds rows row0 + i*16 + q*4 + {0..3} of voxel (tile j, li)
+    T* yb = reinterpret_cast<T*>(A.y);
+    float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ld = l0d + pd_[j], lh = l0h + ph_[j], lw = l0w + pw_[j];
+        const bool valid = (ld < C.L[0]) && (lh < C.L[1]) && (lw < C.L[2]);
+        if (valid) {
+            const int od = C.out_off[0] + ld * A.out_step[0];
+            const int oh = C.out_off[1] + lh * A.out_step[1];
+            const int ow = C.out_off[2] + lw * A.out_step[2];
+            T* yo = yb + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * A.Cy;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r0 = row0 + i * 16 + q * 4;
+                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                if (A.bias) { v0 += A.bias[r0]; v1 += A.bias[r0 + 1]; v2 += A.bias[r0 + 2]; v3 += A.bias[r0 + 3]; }
+                store4<T>(yo + r0, v0, v1, v2, v3);
+                if (A.stats) {
+                    v0 = round_to(v0, (T*)nullptr); v1 = round_to(v1, (T*)nullptr);
+                    v2 = round_to(v2, (T*)nullptr); v3 = round_to(v3, (T*)nullptr);
+                    ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
+                    ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
+                }
+            }
+        }
+    }
+    if (A.stats) {
+        // reduce over the 16 voxel lanes (li), then over the 4 waves through LDS, then one fp64 atomic per row
+        __syncthreads();                       // all waves are done reading the halo tile
+        double* red = reinterpret_cast<double*>(smem);   // [MT*16][2]
+        if (tid < MT * 16 * 2) red[tid] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[i][r], s2 = ssq[i][r];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (li == 0) {
+                    atomicAdd(&red[(i * 16 + q * 4 + r) * 2 + 0], (double)s);
+                    atomicAdd(&red[(i * 16 + q * 4 + r) * 2 + 1], (double)s2);
+                }
+            }
+        __syncthreads();
+        if (tid < MT * 16 * 2) {
+            const int rep = (blockIdx.x + blockIdx.z * 7) % NNDET_STATS_REPLICAS;
+            double* dst = A.stats + (((int64_t)rep * A.N + n) * A.Cy + row0 + (tid >> 1)) * 2 + (tid & 1);
+            atomicAdd(dst, red[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Plan {
+    IgArgs a;
+    int cfg;          // 0: (2,8) 1: (4,4) 2: (4,2) 3: (2,2)
+    dim3 grid;
+    size_t lds;
+};
+
+static const int CFG_MT[4] = {2, 4, 4, 2};
+static const int CFG_NT[4] = {8, 4, 2, 2};
+
+static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[3], int points, int T[3], int H[3]) {
+    double best = 1e300;
+    bool found = false;
+    for (int td = 1; td <= points; td *= 2)
+        for (int th = 1; td * th <= points; th *= 2) {
+            const int tw = points / (td * th);
+            if (td * th * tw != points) continue;
+            const int t[3] = {td, th, tw};
+            int h[3];
+            int64_t hv = 1;
+            double padded = 1.0;
+            for (int a = 0; a < 3; ++a) {
+                h[a] = (t[a] - 1) * in_step[a] + span[a];
+                hv *= h[a];
+                padded *= (double)ceil_div(Lmax[a], t[a]) * t[a];
+            }
+            if (hv * 4 > 256 * IG_MAXP) continue;
+            const double cost = padded * (1.0 + 0.15 * (double)hv / points);   // padding waste first, halo amplification second
+            if (cost < best) { best = cost; found = true; for (int a = 0; a < 3; ++a) { T[a] = t[a]; H[a] = h[a]; } }
+        }
+    return found;
+}
+
+// kind: 0 forward, 1 backward-data
+static int build_plan(const NndetConv* c, int kind, Plan* P) {
+    IgArgs& a = P->a;
+    memset(&a, 0, sizeof(a));
+    const int KCb = c->dtype == NNDET_BF16 ? 32 : 16;
+    const bool tr = c->transposed != 0;
+    if (tr) for (int i = 0; i < 3; ++i) if (c->k[i] != c->s[i] || c->p[i] != 0) return NNDET_EINVAL;
+    // which tensor is read / written
+    const bool reads_in = (kind == 0);   // forward reads the conv input, backward-data reads dY
+    const int in_sp[3] = {c->in_d, c->in_h, c->in_w}, out_sp[3] = {c->out_d, c->out_h, c->out_w};
+    const int* xs = reads_in ? in_sp : out_sp;
+    const int* ys = reads_in ? out_sp : in_sp;
+    a.N = c->batch;
+    a.Cx = reads_in ? c->cin_p : c->cout_p;
+    a.Cy = reads_in ? c->cout_p : c->cin_p;
+    if (a.Cx % KCb != 0 || a.Cy % 32 != 0) return NNDET_EINVAL;
+    for (int i = 0; i < 3; ++i) { a.I[i] = xs[i]; a.O[i] = ys[i]; }
+    // "gather" form (one class, strided input walk) vs "class" form (parity classes, unit input step)
+    const bool gather = (kind == 0) != tr;   // conv fwd, convT bwd-data
+    int span[3] = {1, 1, 1}, Lmax[3];
+    int ntaps = 0;
+    if (gather) {
+        a.ncls = 1;
+        IgClass& C = a.cls[0];
+        for (int i = 0; i < 3; ++i) {
+            a.in_step[i] = c->s[i]; a.out_step[i] = 1; C.out_off[i] = 0; C.L[i] = ys[i];
+            C.in_base[i] = -c->p[i]; span[i] = c->k[i]; Lmax[i] = ys[i];
+            // consistency of the declared shapes
+            const int expect = tr ? in_sp[i] * c->s[i] : (in_sp[i] + 2 * c->p[i] - c->k[i]) / c->s[i] + 1;
+            if (out_sp[i] != expect) return NNDET_EINVAL;
+        }
+        C.tap0 = 0;
+        for (int td = 0; td < c->k[0]; ++td) for (int th = 0; th < c->k[1]; ++th) for (int tw = 0; tw < c->k[2]; ++tw) {
+            if (ntaps >= 27) return NNDET_EINVAL;
+            IgTap& t = a.taps[ntaps++];
+            t.d[0] = td; t.d[1] = th; t.d[2] = tw;
+            t.wt = (td * c->k[1] + th) * c->k[2] + tw;
+        }
+        C.ntap = ntaps;
+    } else {
+        const int S = c->s[0] * c->s[1] * c->s[2];
+        if (S > 8) return NNDET_EINVAL;
+        a.ncls = S;
+        for (int i = 0; i < 3; ++i) { a.in_step[i] = 1; a.out_step[i] = c->s[i]; Lmax[i] = 0; }
+        int ci = 0;
+        for (int cd = 0; cd < c->s[0]; ++cd) for (int ch = 0; ch < c->s[1]; ++ch) for (int cw = 0; cw < c->s[2]; ++cw, ++ci) {
+            IgClass& C = a.cls[ci];
+            const int cc[3] = {cd, ch, cw};
+            int lo[3], hi[3], cnt[3];
+            int tl[3][3], dl[3][3];   // valid taps / deltas per axis
+            for (int i = 0; i < 3; ++i) {
+                C.out_off[i] = cc[i];
+                C.L[i] = ys[i] > cc[i] ? (ys[i] - cc[i] + c->s[i] - 1) / c->s[i] : 0;
+                if (C.L[i] > Lmax[i]) Lmax[i] = C.L[i];
+                cnt[i] = 0; lo[i] = 1 << 30; hi[i] = -(1 << 30);
+                for (int t = 0; t < c->k[i]; ++t) {
+                    const int num = cc[i] + c->p[i] - t;
+                    if (((num % c->s[i]) + c->s[i]) % c->s[i] != 0) continue;
+                    const int d = num >= 0 ? num / c->s[i] : -((-num) / c->s[i]);
+                    if (cnt[i] >= 3) return NNDET_EINVAL;
+                    tl[i][cnt[i]] = t; dl[i][cnt[i]] = d; ++cnt[i];
+                    if (d < lo[i]) lo[i] = d;
+                    if (d > hi[i]) hi[i] = d;
+                }
+                if (cnt[i] == 0) { lo[i] = 0; hi[i] = 0; }
+                C.in_base[i] = lo[i];
+                if (hi[i] - lo[i] + 1 > span[i]) span[i] = hi[i] - lo[i] + 1;
+            }
+            C.tap0 = ntaps;
+            if (cnt[0] && cnt[1] && cnt[2])
+                for (int x = 0; x < cnt[0]; ++x) for (int y = 0; y < cnt[1]; ++y) for (int z = 0; z < cnt[2]; ++z) {
+                    if (ntaps >= 27) return NNDET_EINVAL;
+                    IgTap& t = a.taps[ntaps++];
+                    t.d[0] = dl[0][x] - lo[0]; t.d[1] = dl[1][y] - lo[1]; t.d[2] = dl[2][z] - lo[2];
+                    t.wt = (tl[0][x] * c->k[1] + tl[1][y]) * c->k[2] + tl[2][z];
+                }
+            C.ntap = ntaps - C.tap0;
+        }
+        for (int i = 0; i < 3; ++i) {
+            const int expect = tr ? in_sp[i] * c->s[i] : (in_sp[i] + 2 * c->p[i] - c->k[i]) / c->s[i] + 1;
+            if (out_sp[i] != expect) return NNDET_EINVAL;
+        }
+    }
+    const bool strided = a.in_step[0] > 1 || a.in_step[1] > 1 || a.in_step[2] > 1;
+    const bool r64 = (a.Cy % 64) == 0;
+    P->cfg = strided ? (r64 ? 2 : 3) : (r64 ? 1 : 0);
+    const int points = 4 * CFG_NT[P->cfg] * 16;
+    for (int i = 0; i < 3; ++i) if (Lmax[i] <= 0) return NNDET_EINVAL;
+    if (!choose_tile(Lmax, a.in_step, span, points, a.T, a.H)) return NNDET_EINVAL;
+    for (int i = 0; i < 3; ++i) a.nt[i] = ceil_div(Lmax[i], a.T[i]);
+    P->grid = dim3(a.nt[0] * a.nt[1] * a.nt[2], a.Cy / (CFG_MT[P->cfg] * 16), a.N * a.ncls);
+    P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64;
+    if (P->lds < 1024) P->lds = 1024;   // room for the stats reduction
+    return 0;
+}
+
+template <typename T>
+static int launch_cfg(const Plan& P, hipStream_t st) {
+    switch (P.cfg) {
+        case 0: k_igemm<T, 2, 8><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 1: k_igemm<T, 4, 4><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 2: k_igemm<T, 4, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        default: k_igemm<T, 2, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int MT, int NT>
+static int set_lds_attr() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, MT, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+}
+static int g_attr_done = 0;
+static int ensure_attrs() {
+    if (g_attr_done) return 0;
+    int rc = 0;
+    rc |= set_lds_attr<bf16_t, 2, 8>(); rc |= set_lds_attr<bf16_t, 4, 4>(); rc |= set_lds_attr<bf16_t, 4, 2>(); rc |= set_lds_attr<bf16_t, 2, 2>();
+    rc |= set_lds_attr<float, 2, 8>(); rc |= set_lds_attr<float, 4, 4>(); rc |= set_lds_attr<float, 4, 2>(); rc |= set_lds_attr<float, 2, 2>();
+    if (rc) return rc;
+    g_attr_done = 1;
+    return 0;
+}
+
+int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, void* y, double* stats,
+              hipStream_t st) {
+    Plan P;
+    int rc = build_plan(c, kind, &P);
+    if (rc) return rc;
+    rc = ensure_attrs();
+    if (rc) return rc;
+    P.a.x = x; P.a.w = w; P.a.bias = bias; P.a.y = y; P.a.stats = stats;
+    return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t>(P, st) : launch_cfg<float>(P, st);
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ void k_pack(const float* __restrict__ w, T* __restrict__ out, int R, int K, int Rp, int Kp, int taps,
+                       int64_t sr, int64_t sk, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % Kp);
+    int64_t t2 = i / Kp;
+    const int r = (int)(t2 % Rp);
+    const int t = (int)(t2 / Rp);
+    float v = 0.f;
+    if (r < R && k < K) v = w[r * sr + k * sk + t];
+    out[i] = Elem<T>::st(v);
+}
+
+static void pack_dims(const NndetConv* c, int mode, int* R, int* K, int* Rp, int* Kp, int* taps, int64_t* sr, int64_t* sk) {
+    *taps = c->k[0] * c->k[1] * c->k[2];
+    const int64_t T = *taps;
+    if (mode == 0) { *R = c->cout; *Rp = c->cout_p; *K = c->cin; *Kp = c->cin_p; }
+    else { *R = c->cin; *Rp = c->cin_p; *K = c->cout; *Kp = c->cout_p; }
+    if (!c->transposed) {   // [Cout][Cin][T]
+        if (mode == 0) { *sr = (int64_t)c->cin * T; *sk = T; } else { *sr = T; *sk = (int64_t)c->cin * T; }
+    } else {                // [Cin][Cout][T]
+        if (mode == 0) { *sr = T; *sk = (int64_t)c->cout * T; } else { *sr = (int64_t)c->cout * T; *sk = T; }
+    }
+}
+
+extern "C" size_t nndet_packed_weight_elems(const NndetConv* c, int32_t mode) {
+    int R, K, Rp, Kp, taps; int64_t sr, sk;
+    pack_dims(c, mode, &R, &K, &Rp, &Kp, &taps, &sr, &sk);
+    return (size_t)taps * Rp * Kp;
+}
+
+extern "C" int nndet_pack_weight(const NndetConv* c, int32_t mode, const float* w, void* packed, void* stream) {
+    if (!c || !w || !packed || (mode != 0 && mode != 1)) return NNDET_EINVAL;
+    int R, K, Rp, Kp, taps; int64_t sr, sk;
+    pack_dims(c, mode, &R, &K, &Rp, &Kp, &taps, &sr, &sk);
+    const int64_t total = (int64_t)taps * Rp * Kp;
+    const unsigned nb = (unsigned)ceil_div64(total, 256);
+    if (c->dtype == NNDET_BF16)
+        k_pack<bf16_t><<<nb, 256, 0, as_stream(stream)>>>(w, (bf16_t*)packed, R, K, Rp, Kp, taps, sr, sk, total);
+    else
+        k_pack<float><<<nb, 256, 0, as_stream(stream)>>>(w, (float*)packed, R, K, Rp, Kp, taps, sr, sk, total);
+    LAUNCH_CHECK();
+    return 0;
+}

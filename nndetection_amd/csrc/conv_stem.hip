@@ -1,0 +1,168 @@
+// Stem convolution (Cin == 1): forward and weight gradient. The contraction is only k^3 = 27 deep, so this
+// layer is HBM-bound (reads 1 channel, writes 32) and runs on the vector ALUs; no data gradient is needed
+// (the image does not require grad). Replaces encoder.stages.0.convs.0.0.conv of the reference
+// (nndet/arch/encoder/modular.py:79-108 with in_channels = 1).
+#include "common.h"
+#include "conv_common.h"
+
+struct StemArgs {
+    const void* x; const float* w; const float* bias; void* y; float* dw; const void* dy;
+    int32_t N, I[3], O[3], Cy, cout;
+    int32_t k[3], s[3], p[3];
+    int64_t total;   // N * O0 * O1 * O2
+};
+
+template <typename T> __device__ __forceinline__ void store_row32(T* p, const float* v);
+template <> __device__ __forceinline__ void store_row32<float>(float* p, const float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+template <> __device__ __forceinline__ void store_row32<bf16_t>(bf16_t* p, const float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint4 u;
+        u.x = (uint32_t)f32_to_bf16(v[8 * i + 0]) | ((uint32_t)f32_to_bf16(v[8 * i + 1]) << 16);
+        u.y = (uint32_t)f32_to_bf16(v[8 * i + 2]) | ((uint32_t)f32_to_bf16(v[8 * i + 3]) << 16);
+        u.z = (uint32_t)f32_to_bf16(v[8 * i + 4]) | ((uint32_t)f32_to_bf16(v[8 * i + 5]) << 16);
+        u.w = (uint32_t)f32_to_bf16(v[8 * i + 6]) | ((uint32_t)f32_to_bf16(v[8 * i + 7]) << 16);
+        reinterpret_cast<uint4*>(p)[i] = u;
+    }
+}
+
+// grid (ceil(total/256), Cy/32); thread = one output voxel x 32 output channels
+template <typename T>
+__global__ __launch_bounds__(256) void k_stem_fwd(const StemArgs A) {
+    __shared__ float ws[27 * 32];
+    __shared__ float bs[32];
+    const int taps = A.k[0] * A.k[1] * A.k[2];
+    const int c0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < taps * 32; i += 256) {
+        const int t = i >> 5, c = i & 31;
+        ws[i] = (c0 + c < A.cout) ? A.w[(int64_t)(c0 + c) * taps + t] : 0.f;
+    }
+    if (threadIdx.x < 32) bs[threadIdx.x] = (A.bias && c0 + (int)threadIdx.x < A.cout) ? A.bias[c0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= A.total) return;
+    int64_t t2 = v;
+    const int ow = (int)(t2 % A.O[2]); t2 /= A.O[2];
+    const int oh = (int)(t2 % A.O[1]); t2 /= A.O[1];
+    const int od = (int)(t2 % A.O[0]);
+    const int n = (int)(t2 / A.O[0]);
+    const T* xn = reinterpret_cast<const T*>(A.x) + (int64_t)n * A.I[0] * A.I[1] * A.I[2];
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = bs[c];
+    int t = 0;
+    for (int kd = 0; kd < A.k[0]; ++kd)
+        for (int kh = 0; kh < A.k[1]; ++kh)
+            for (int kw = 0; kw < A.k[2]; ++kw, ++t) {
+                const int id = od * A.s[0] - A.p[0] + kd, ih = oh * A.s[1] - A.p[1] + kh, iw = ow * A.s[2] - A.p[2] + kw;
+                float xv = 0.f;
+                if ((unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
+                    xv = Elem<T>::ld(xn[((int64_t)id * A.I[1] + ih) * A.I[2] + iw]);
+                const float4* w4 = reinterpret_cast<const float4*>(ws + t * 32);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4 w = w4[c];
+                    acc[4 * c + 0] = fmaf(xv, w.x, acc[4 * c + 0]);
+                    acc[4 * c + 1] = fmaf(xv, w.y, acc[4 * c + 1]);
+                    acc[4 * c + 2] = fmaf(xv, w.z, acc[4 * c + 2]);
+                    acc[4 * c + 3] = fmaf(xv, w.w, acc[4 * c + 3]);
+                }
+            }
+    store_row32<T>(reinterpret_cast<T*>(A.y) + v * A.Cy + c0, acc);
+}
+
+// persistent grid; block 256: thread = (tap, group of 4 output channels); chunk of 256 voxels staged in LDS
+template <typename T>
+__global__ __launch_bounds__(256) void k_stem_wgrad(const StemArgs A) {
+    __shared__ float xs[27 * 257];       // [tap][voxel], row stride 257: taps land in different banks
+    __shared__ float dys[256 * 32];      // [voxel][32 channels] fp32
+    const int taps = A.k[0] * A.k[1] * A.k[2];
+    const int c0 = blockIdx.y * 32;
+    const int tap = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int64_t nchunks = (A.total + 255) / 256;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        __syncthreads();
+        const int64_t v = ch * 256 + threadIdx.x;
+        const bool valid = v < A.total;
+        int64_t t2 = valid ? v : 0;
+        const int ow = (int)(t2 % A.O[2]); t2 /= A.O[2];
+        const int oh = (int)(t2 % A.O[1]); t2 /= A.O[1];
+        const int od = (int)(t2 % A.O[0]);
+        const int n = (int)(t2 / A.O[0]);
+        const T* xn = reinterpret_cast<const T*>(A.x) + (int64_t)n * A.I[0] * A.I[1] * A.I[2];
+        int t = 0;
+        for (int kd = 0; kd < A.k[0]; ++kd)
+            for (int kh = 0; kh < A.k[1]; ++kh)
+                for (int kw = 0; kw < A.k[2]; ++kw, ++t) {
+                    const int id = od * A.s[0] - A.p[0] + kd, ih = oh * A.s[1] - A.p[1] + kh, iw = ow * A.s[2] - A.p[2] + kw;
+                    float xv = 0.f;
+                    if (valid && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
+                        xv = Elem<T>::ld(xn[((int64_t)id * A.I[1] + ih) * A.I[2] + iw]);
+                    xs[t * 257 + threadIdx.x] = xv;
+                }
+        const T* dyv = reinterpret_cast<const T*>(A.dy) + v * A.Cy + c0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) dys[threadIdx.x * 32 + c] = valid ? Elem<T>::ld(dyv[c]) : 0.f;
+        __syncthreads();
+        if (tap < taps) {
+            const float* xr = xs + tap * 257;
+            const float* dr = dys + cg * 4;
+#pragma unroll 4
+            for (int i = 0; i < 256; ++i) {
+                const float xv = xr[i];
+                const float4 d = *reinterpret_cast<const float4*>(dr + i * 32);
+                a0 = fmaf(xv, d.x, a0); a1 = fmaf(xv, d.y, a1); a2 = fmaf(xv, d.z, a2); a3 = fmaf(xv, d.w, a3);
+            }
+        }
+    }
+    if (tap < taps) {
+        const int c = c0 + cg * 4;
+        if (c + 0 < A.cout) atomicAdd(A.dw + (int64_t)(c + 0) * taps + tap, a0);
+        if (c + 1 < A.cout) atomicAdd(A.dw + (int64_t)(c + 1) * taps + tap, a1);
+        if (c + 2 < A.cout) atomicAdd(A.dw + (int64_t)(c + 2) * taps + tap, a2);
+        if (c + 3 < A.cout) atomicAdd(A.dw + (int64_t)(c + 3) * taps + tap, a3);
+    }
+}
+
+static int stem_args(const NndetConv* c, StemArgs* a) {
+    if (c->cin_p != 1 || c->cin != 1 || c->transposed || c->cout_p % 32) return NNDET_EINVAL;
+    if (c->k[0] * c->k[1] * c->k[2] > 27) return NNDET_EINVAL;
+    memset(a, 0, sizeof(*a));
+    a->N = c->batch; a->Cy = c->cout_p; a->cout = c->cout;
+    const int in_sp[3] = {c->in_d, c->in_h, c->in_w}, out_sp[3] = {c->out_d, c->out_h, c->out_w};
+    for (int i = 0; i < 3; ++i) {
+        a->I[i] = in_sp[i]; a->O[i] = out_sp[i]; a->k[i] = c->k[i]; a->s[i] = c->s[i]; a->p[i] = c->p[i];
+        if (out_sp[i] != (in_sp[i] + 2 * c->p[i] - c->k[i]) / c->s[i] + 1) return NNDET_EINVAL;
+    }
+    a->total = (int64_t)c->batch * out_sp[0] * out_sp[1] * out_sp[2];
+    return 0;
+}
+
+int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const float* bias, void* y, hipStream_t st) {
+    StemArgs a;
+    int rc = stem_args(c, &a);
+    if (rc) return rc;
+    a.x = x; a.w = w_f32; a.bias = bias; a.y = y;
+    dim3 grid((unsigned)ceil_div64(a.total, 256), c->cout_p / 32);
+    if (c->dtype == NNDET_BF16) k_stem_fwd<bf16_t><<<grid, 256, 0, st>>>(a);
+    else k_stem_fwd<float><<<grid, 256, 0, st>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hipStream_t st) {
+    StemArgs a;
+    int rc = stem_args(c, &a);
+    if (rc) return rc;
+    a.x = x; a.dy = dy; a.dw = dw;
+    int64_t nchunks = ceil_div64(a.total, 256);
+    dim3 grid((unsigned)(nchunks < 2048 ? nchunks : 2048), c->cout_p / 32);
+    if (c->dtype == NNDET_BF16) k_stem_wgrad<bf16_t><<<grid, 256, 0, st>>>(a);
+    else k_stem_wgrad<float><<<grid, 256, 0, st>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}

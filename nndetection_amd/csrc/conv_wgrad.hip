@@ -1,0 +1,300 @@
+// Weight gradient of (transposed) 3D convolutions on MFMA for gfx950.
+//
+//   dW[r][k][tap] = sum_{n, lattice point i}  P[n, i][r] * Q[n, step * i + delta_tap][k]
+//     Conv3d:           P = dY (rows r = Cout), Q = X  (k = Cin),  lattice = output grid, step = stride
+//     ConvTranspose3d:  P = X  (rows r = Cin),  Q = dY (k = Cout), lattice = input grid,  step = stride (= kernel)
+//
+// The contraction runs over VOXELS, but NDHWC keeps channels contiguous, so the MFMA operands (which want
+// the contraction index contiguous per lane) need a transposition. v1 does it on the LDS read side: tiles
+// are staged [voxel][32 channels] (+ padding that makes the strided 2-/4-byte reads bank-conflict free) and
+// each lane gathers its 8 contraction values with scalar LDS reads. (A ds_read_b64_tr_b16 / write-side
+// transposed variant is the planned v2; see DESIGN.md.)
+//
+// Workgroup = 4 waves, owns a 32(r) x 32(k) block of dW for ALL taps and loops over a slice of the
+// spatial tiles (TD x TH x 8 lattice points, halo of Q staged once and shared by all taps). Waves split
+// the taps (>= 4 taps) or the contraction steps (< 4 taps). Accumulators stay in registers for the whole
+// slice; the slice result is added to dW (PyTorch layout, fp32) with atomics.
+#include "common.h"
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define WG_MAXT 7    // tap slots per wave
+#define WG_MAXQ 24   // Q halo pieces per thread
+#define WG_MAXP 8    // P tile pieces per thread
+
+struct WgTap { int32_t d[3]; int32_t wt; };
+struct WgArgs {
+    const void* p; const void* q; float* dw;
+    int32_t N;
+    int32_t PL[3], Cp;
+    int32_t QD[3], Cq;
+    int32_t step[3], qbase[3];
+    int32_t TD, TH;
+    int32_t nt[3];
+    int32_t H[3];
+    int32_t R, K;
+    int64_t sr, sk;
+    int32_t ntap, total_tiles;
+    WgTap taps[27];
+};
+
+template <typename T> struct WF;
+template <> struct WF<bf16_t> {
+    uint32_t v[4];
+    __device__ __forceinline__ void set(int j, const char* p) {
+        const uint32_t e = *reinterpret_cast<const uint16_t*>(p);
+        if (j & 1) v[j >> 1] |= e << 16; else v[j >> 1] = e;
+    }
+    __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) {
+        const u32x4 ua = {a.v[0], a.v[1], a.v[2], a.v[3]}, ub = {b.v[0], b.v[1], b.v[2], b.v[3]};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), c, 0, 0, 0);
+    }
+};
+template <> struct WF<float> {
+    float v[8];
+    __device__ __forceinline__ void set(int j, const char* p) { v[j] = *reinterpret_cast<const float*>(p); }
+    __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+    }
+};
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
+    constexpr int RB = 32 * (int)sizeof(T);      // bytes of one voxel's 32-channel block
+    constexpr int PPV = RB / 16;                  // 16-byte pieces per voxel
+    constexpr int E16 = 16 / (int)sizeof(T);      // elements per piece
+    constexpr int POINTS = KS * 32;
+    constexpr int PBYTES = POINTS * RB + (POINTS / 8) * (RB / 2);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sp = smem;
+    char* const sq = smem + PBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.y * 32, k0 = blockIdx.z * 32;
+    const int H0 = A.H[0], H1 = A.H[1], H2 = A.H[2];
+    const int QROW = H2 * RB + RB / 2;            // bytes of one halo row incl. padding
+    const int NQP = H0 * H1 * H2 * PPV;           // number of Q pieces
+    const int TH = A.TH;
+
+    // ---- per-thread staging descriptors (relative to the tile origin; no divisions in the tile loop)
+    int32_t qrel[WG_MAXQ];   // part << 27 | hd << 18 | hh << 9 | hw ; -1 = no piece
+    int32_t qdst[WG_MAXQ];
+#pragma unroll
+    for (int s = 0; s < WG_MAXQ; ++s) {
+        const int pp = tid + s * 256;
+        int32_t rel = -1, dst = 0;
+        if (pp < NQP) {
+            const int hv = pp / PPV, part = pp % PPV;
+            const int hw = hv % H2, row = hv / H2;
+            const int hh = row % H1, hd = row / H1;
+            rel = (part << 27) | (hd << 18) | (hh << 9) | hw;
+            dst = row * QROW + hw * RB + part * 16;
+        }
+        qrel[s] = rel; qdst[s] = dst;
+    }
+    int32_t prel[WG_MAXP], pdst[WG_MAXP];
+#pragma unroll
+    for (int s = 0; s < WG_MAXP; ++s) {
+        const int pp = tid + s * 256;
+        int32_t rel = -1, dst = 0;
+        if (pp < POINTS * PPV) {
+            const int pt = pp / PPV, part = pp % PPV;
+            const int tr = pt >> 3, pw = pt & 7;
+            const int pd = tr / TH, ph = tr % TH;
+            rel = (part << 27) | (pd << 18) | (ph << 9) | pw;
+            dst = pt * RB + tr * (RB / 2) + part * 16;
+        }
+        prel[s] = rel; pdst[s] = dst;
+    }
+    // ---- per-lane fragment bases
+    int qrow0[KS];   // halo row of lattice row (ks*4 + q) at tap offset 0
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int tr = ks * 4 + q;
+        const int pd = tr / TH, ph = tr % TH;
+        qrow0[ks] = (pd * A.step[0]) * H1 + ph * A.step[1];
+    }
+    // ---- work split between the waves
+    const bool split_taps = A.ntap >= 4;
+    const int nslots = split_taps ? (A.ntap - wv + 3) / 4 : A.ntap;   // taps handled by this wave
+
+    f32x4 acc[WG_MAXT][2][2];
+#pragma unroll
+    for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* pbase = reinterpret_cast<const T*>(A.p);
+    const T* qbase_ptr = reinterpret_cast<const T*>(A.q);
+    const int tiles_per_n = A.nt[0] * A.nt[1] * A.nt[2];
+
+    for (int tile = blockIdx.x; tile < A.total_tiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_n;
+        int tt = tile - n * tiles_per_n;
+        const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
+        const int th_i = tt % A.nt[1];
+        const int td_i = tt / A.nt[1];
+        const int l0d = td_i * A.TD, l0h = th_i * TH, l0w = tw_i * 8;
+        const int q0d = l0d * A.step[0] + A.qbase[0], q0h = l0h * A.step[1] + A.qbase[1], q0w = l0w * A.step[2] + A.qbase[2];
+        __syncthreads();
+        const T* pn = pbase + (int64_t)n * A.PL[0] * A.PL[1] * A.PL[2] * A.Cp + r0;
+        const T* qn = qbase_ptr + (int64_t)n * A.QD[0] * A.QD[1] * A.QD[2] * A.Cq + k0;
+#pragma unroll
+        for (int s = 0; s < WG_MAXP; ++s) {
+            if (prel[s] >= 0) {
+                const int ld = l0d + ((prel[s] >> 18) & 511), lh = l0h + ((prel[s] >> 9) & 511), lw = l0w + (prel[s] & 511);
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2]) {
+                    const int part = prel[s] >> 27;
+                    v = *reinterpret_cast<const u32x4*>(pn + ((int64_t)(ld * A.PL[1] + lh) * A.PL[2] + lw) * A.Cp + part * E16);
+                }
+                *reinterpret_cast<u32x4*>(sp + pdst[s]) = v;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < WG_MAXQ; ++s) {
+            if (qrel[s] >= 0) {
+                const int qd = q0d + ((qrel[s] >> 18) & 511), qh = q0h + ((qrel[s] >> 9) & 511), qw = q0w + (qrel[s] & 511);
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if ((unsigned)qd < (unsigned)A.QD[0] && (unsigned)qh < (unsigned)A.QD[1] && (unsigned)qw < (unsigned)A.QD[2]) {
+                    const int part = qrel[s] >> 27;
+                    v = *reinterpret_cast<const u32x4*>(qn + ((int64_t)(qd * A.QD[1] + qh) * A.QD[2] + qw) * A.Cq + part * E16);
+                }
+                *reinterpret_cast<u32x4*>(sq + qdst[s]) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (!split_taps && (ks & 3) != wv) continue;
+            // P fragments of this contraction step: point = ks*32 + q*8 + j, channels it*16 + li
+            WF<T> pf[2];
+            {
+                const int tr = ks * 4 + q;
+                const char* b0 = sp + (tr * 8) * RB + tr * (RB / 2) + li * (int)sizeof(T);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pf[0].set(j, b0 + j * RB);
+                    pf[1].set(j, b0 + j * RB + 16 * (int)sizeof(T));
+                }
+            }
+#pragma unroll
+            for (int ts = 0; ts < WG_MAXT; ++ts) {
+                if (ts < nslots) {
+                    const WgTap& tap = A.taps[split_taps ? wv + ts * 4 : ts];
+                    const int hrow = qrow0[ks] + tap.d[0] * H1 + tap.d[1];
+                    const char* b0 = sq + hrow * QROW + tap.d[2] * RB + li * (int)sizeof(T);
+                    const int wstep = A.step[2] * RB;
+                    WF<T> qf[2];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        qf[0].set(j, b0 + j * wstep);
+                        qf[1].set(j, b0 + j * wstep + 16 * (int)sizeof(T));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) WF<T>::mma(pf[i], qf[j], acc[ts][i][j]);
+                }
+            }
+        }
+    }
+    // ---- slice result -> dW (fp32 atomics, PyTorch layout)
+#pragma unroll
+    for (int ts = 0; ts < WG_MAXT; ++ts) {
+        if (ts < nslots) {
+            const int wt = A.taps[split_taps ? wv + ts * 4 : ts].wt;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = k0 + j * 16 + li;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = r0 + i * 16 + q * 4 + rr;
+                        if (r < A.R && k < A.K) atomicAdd(A.dw + r * A.sr + k * A.sk + wt, acc[ts][i][j][rr]);
+                    }
+                }
+        }
+    }
+}
+
+template <typename T, int KS>
+static int wg_launch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 2048));
+        attr = true;
+    }
+    k_wgrad<T, KS><<<grid, 256, lds, st>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipStream_t st) {
+    WgArgs a;
+    memset(&a, 0, sizeof(a));
+    const bool tr = c->transposed != 0;
+    const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
+    const int RB = 32 * esz, PPV = RB / 16;
+    const int in_sp[3] = {c->in_d, c->in_h, c->in_w}, out_sp[3] = {c->out_d, c->out_h, c->out_w};
+    const int64_t T = (int64_t)c->k[0] * c->k[1] * c->k[2];
+    if (T > 27) return NNDET_EINVAL;
+    a.N = c->batch; a.dw = dw;
+    if (!tr) {   // P = dY, Q = X ; dW [Cout][Cin][T]
+        a.p = dy; a.q = x; a.Cp = c->cout_p; a.Cq = c->cin_p; a.R = c->cout; a.K = c->cin;
+        a.sr = (int64_t)c->cin * T; a.sk = T;
+        for (int i = 0; i < 3; ++i) { a.PL[i] = out_sp[i]; a.QD[i] = in_sp[i]; a.step[i] = c->s[i]; a.qbase[i] = -c->p[i]; }
+    } else {     // P = X, Q = dY ; dW [Cin][Cout][T]
+        for (int i = 0; i < 3; ++i) if (c->k[i] != c->s[i] || c->p[i] != 0) return NNDET_EINVAL;
+        a.p = x; a.q = dy; a.Cp = c->cin_p; a.Cq = c->cout_p; a.R = c->cin; a.K = c->cout;
+        a.sr = (int64_t)c->cout * T; a.sk = T;
+        for (int i = 0; i < 3; ++i) { a.PL[i] = in_sp[i]; a.QD[i] = out_sp[i]; a.step[i] = c->s[i]; a.qbase[i] = 0; }
+    }
+    if (a.Cp % 32 || a.Cq % 32) return NNDET_EINVAL;
+    a.ntap = (int)T;
+    int nt = 0;
+    for (int td = 0; td < c->k[0]; ++td) for (int th = 0; th < c->k[1]; ++th) for (int tw = 0; tw < c->k[2]; ++tw) {
+        WgTap& t = a.taps[nt++];
+        t.d[0] = td; t.d[1] = th; t.d[2] = tw; t.wt = (td * c->k[1] + th) * c->k[2] + tw;
+    }
+    const bool strided = a.step[0] > 1 || a.step[1] > 1 || a.step[2] > 1;
+    const int KS = strided ? 2 : 8;
+    const int rows = KS * 4;
+    // tile (TD, TH, 8): minimise padded volume, respect LDS and piece limits
+    double best = 1e300; int bTD = 0, bTH = 0;
+    for (int td = 1; td <= rows; td *= 2) {
+        const int th = rows / td;
+        const int t3[3] = {td, th, 8};
+        int h[3]; int64_t hv = 1; double padded = 1.0;
+        for (int i = 0; i < 3; ++i) {
+            h[i] = (t3[i] - 1) * a.step[i] + c->k[i];
+            hv *= h[i];
+            padded *= (double)ceil_div(a.PL[i], t3[i]) * t3[i];
+        }
+        if (hv * PPV > 256 * WG_MAXQ) continue;
+        const size_t lds = (size_t)(KS * 32) * RB * 17 / 16 + (size_t)h[0] * h[1] * (h[2] * RB + RB / 2);
+        if (lds > 150 * 1024) continue;
+        const double cost = padded * (1.0 + 0.1 * (double)hv / (KS * 32));
+        if (cost < best) { best = cost; bTD = td; bTH = th; }
+    }
+    if (!bTD) return NNDET_EINVAL;
+    a.TD = bTD; a.TH = bTH;
+    const int t3[3] = {bTD, bTH, 8};
+    for (int i = 0; i < 3; ++i) { a.H[i] = (t3[i] - 1) * a.step[i] + c->k[i]; a.nt[i] = ceil_div(a.PL[i], t3[i]); }
+    if (a.H[0] > 511 || a.H[1] > 511 || a.H[2] > 511) return NNDET_EINVAL;
+    a.total_tiles = a.N * a.nt[0] * a.nt[1] * a.nt[2];
+    const size_t lds = (size_t)(KS * 32) * RB + (size_t)(KS * 4) * (RB / 2) + (size_t)a.H[0] * a.H[1] * (a.H[2] * RB + RB / 2) + 64;
+    const int rb = a.Cp / 32, kb = a.Cq / 32;
+    int S = 1536 / (rb * kb);
+    if (S < 1) S = 1;
+    if (S > a.total_tiles) S = a.total_tiles;
+    dim3 grid(S, rb, kb);
+    if (c->dtype == NNDET_BF16) return KS == 8 ? wg_launch<bf16_t, 8>(a, grid, lds, st) : wg_launch<bf16_t, 2>(a, grid, lds, st);
+    return KS == 8 ? wg_launch<float, 8>(a, grid, lds, st) : wg_launch<float, 2>(a, grid, lds, st);
+}

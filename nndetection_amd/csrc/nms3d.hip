@@ -1,0 +1,266 @@
+// 3D NMS for gfx950 -- replaces nndet._C.nms (nndet/csrc/cuda/nms.cu:99-221).
+//
+// Pipeline (all on `stream`, no host synchronisation, no D2H of the mask):
+//   1. stable descending radix sort of the scores (rocPRIM device primitive; index payload)
+//   2. gather boxes in score order
+//   3. k_nms_mask:   one wave per 64x64 tile of the UPPER triangle; lane = row box, the 64 column
+//                    boxes sit in LDS and are read as broadcasts; word (i, c) bit j <=> IoU(i, 64c+j) > thr
+//                    (same bit-matrix as the reference kernel, lower-triangle tiles are never touched)
+//   4. greedy scan, blocked in "super chunks" of 64 x 64 = 4096 boxes:
+//        k_nms_scan_super  (1 workgroup): resolves the 64 chunks of the super chunk sequentially; the
+//                          64-row dependency chain of a chunk is resolved inside ONE wave with readlane
+//                          (wave = 64 = bits of a mask word), rows OR-reduced into the removed-words in LDS
+//        k_nms_propagate   (whole GPU): ORs the kept rows of the finished super chunk into the removed-words
+//                          of all later columns
+//   5. k_nms_compact: ordered compaction of the keep bits -> indices into the input order.
+// IoU arithmetic is the reference's devIoU_3d (nms.cu:36-51) operation for operation; compile with
+// -ffp-contract=off (no FMA contraction) and correctly rounded fp32 division (hipcc default).
+#include "common.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float iou3d(const float* a, const float* b) {
+    // (x1, y1, x2, y2, z1, z2). width/height naming of the reference is irrelevant: the first product commutes.
+    float bottom = fmaxf(a[0], b[0]), top = fminf(a[2], b[2]);
+    float left = fmaxf(a[1], b[1]), right = fminf(a[3], b[3]);
+    float front = fmaxf(a[4], b[4]), back = fminf(a[5], b[5]);
+    float width = fmaxf(right - left, 0.f), height = fmaxf(top - bottom, 0.f);
+    float depth = fmaxf(back - front, 0.f);
+    float inter = width * height * depth;
+    float sa = (a[2] - a[0]) * (a[3] - a[1]) * (a[5] - a[4]);
+    float sb = (b[2] - b[0]) * (b[3] - b[1]) * (b[5] - b[4]);
+    return inter / (sa + sb - inter);
+}
+
+__global__ void k_iota(int32_t* v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+__global__ void k_gather_boxes(const float* __restrict__ boxes, const int32_t* __restrict__ order, int64_t n,
+                               float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 6) return;
+    int64_t r = i / 6;
+    int k = (int)(i - r * 6);
+    out[i] = boxes[(int64_t)order[r] * 6 + k];
+}
+
+// grid (col_blocks, ceil(col_blocks/4)), block 256 = 4 waves; wave w handles row block 4*by + w.
+__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, int64_t n, float thr,
+                                                  u64* __restrict__ mask, int col_blocks) {
+    __shared__ float cbox[64 * 6];
+    const int cb = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int rb = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (cb < (int)blockIdx.y * 4) return;  // the whole block is below the diagonal (uniform exit)
+    const int col_size = (int)min((int64_t)64, n - (int64_t)cb * 64);
+    for (int i = threadIdx.x; i < col_size * 6; i += 256) cbox[i] = boxes[(int64_t)cb * 64 * 6 + i];
+    __syncthreads();
+    if (rb > cb || rb >= col_blocks) return;
+    const int64_t row = (int64_t)rb * 64 + lane;
+    if (row >= n) return;
+    float a[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = boxes[row * 6 + k];
+    u64 t = 0;
+    const int start = (rb == cb) ? lane + 1 : 0;
+    for (int j = start; j < col_size; ++j) {
+        if (iou3d(a, cbox + j * 6) > thr) t |= 1ULL << j;
+    }
+    mask[row * col_blocks + cb] = t;
+}
+
+// One workgroup of 1024 threads. Chunks [c0, c1) (c1 - c0 <= 64).
+__global__ __launch_bounds__(1024) void k_nms_scan_super(const u64* __restrict__ mask, int64_t n, int col_blocks,
+                                                         int c0, int c1, u64* __restrict__ remv,
+                                                         u64* __restrict__ keepbits) {
+    __shared__ u64 remv_l[64];
+    __shared__ u64 keep_l;
+    const int tid = threadIdx.x;
+    if (tid < c1 - c0) remv_l[tid] = remv[c0 + tid];
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+        if (tid < 64) {
+            const int64_t row = (int64_t)c * 64 + tid;
+            u64 d = (row < n) ? mask[row * col_blocks + c] : 0ULL;
+            const uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
+            u64 rem = remv_l[c - c0];
+            const int valid = (int)min((int64_t)64, n - (int64_t)c * 64);
+            u64 keep = 0;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                const uint32_t lo = __builtin_amdgcn_readlane(dlo, r);
+                const uint32_t hi = __builtin_amdgcn_readlane(dhi, r);
+                if (r < valid && !((rem >> r) & 1ULL)) {
+                    keep |= 1ULL << r;
+                    rem |= ((u64)hi << 32) | lo;
+                }
+            }
+            if (tid == 0) {
+                keepbits[c] = keep;
+                keep_l = keep;
+            }
+        }
+        __syncthreads();
+        const u64 keep = keep_l;
+        // OR the kept rows of chunk c into the removed-words of the later chunks of this super chunk
+        {
+            const int r = tid >> 4, jj = tid & 15;
+            if ((keep >> r) & 1ULL) {
+                const int64_t row = (int64_t)c * 64 + r;
+                for (int j = c + 1 + jj; j < c1; j += 16) {
+                    u64 v = mask[row * col_blocks + j];
+                    if (v) atomicOr(&remv_l[j - c0], v);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// grid (ceil((col_blocks - c1)/256), c1 - c0), block 256: thread = one later column word, block row = chunk.
+__global__ __launch_bounds__(256) void k_nms_propagate(const u64* __restrict__ mask, int col_blocks, int c0, int c1,
+                                                       const u64* __restrict__ keepbits, u64* __restrict__ remv) {
+    const int c = c0 + blockIdx.y;
+    const int j = c1 + blockIdx.x * 256 + threadIdx.x;
+    const u64 keep = keepbits[c];
+    if (j >= col_blocks || keep == 0) return;
+    u64 v = 0;
+    for (int r = 0; r < 64; ++r) {
+        if ((keep >> r) & 1ULL) v |= mask[((int64_t)c * 64 + r) * col_blocks + j];
+    }
+    if (v) atomicOr(&remv[j], v);
+}
+
+// single block of 1024 threads: ordered compaction
+__global__ __launch_bounds__(1024) void k_nms_compact(const u64* __restrict__ keepbits, int col_blocks,
+                                                      const int32_t* __restrict__ order, int64_t* __restrict__ keep_out,
+                                                      int64_t* __restrict__ n_keep) {
+    __shared__ int wsum[16];
+    __shared__ int running;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < col_blocks; base += 1024) {
+        const int idx = base + tid;
+        const u64 bits = (idx < col_blocks) ? keepbits[idx] : 0ULL;
+        const int cnt = __popcll(bits);
+        int incl = cnt;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        int pos = running + woff + incl - cnt;
+        u64 b = bits;
+        while (b) {
+            const int r = __ffsll((long long)b) - 1;
+            b &= b - 1;
+            keep_out[pos++] = (int64_t)order[(int64_t)idx * 64 + r];
+        }
+        __syncthreads();
+        if (tid == 1023) running += woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *n_keep = running;
+}
+
+struct NmsWs {
+    float* sboxes;
+    float* keys_out;
+    int32_t* vals_in;
+    int32_t* order;
+    u64* mask;
+    u64* remv;
+    u64* keepbits;
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
+    size_t total;
+};
+
+static int nms_layout(int64_t n, char* base, NmsWs* ws) {
+    const int64_t cb = ceil_div64(n, 64);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    size_t o_sb = take((size_t)n * 6 * 4), o_ko = take((size_t)n * 4), o_vi = take((size_t)n * 4), o_or = take((size_t)n * 4);
+    size_t o_mask = take((size_t)n * cb * 8), o_remv = take((size_t)cb * 8), o_keep = take((size_t)cb * 8);
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs_desc<rocprim::default_config, const float*, float*, const int32_t*, int32_t*>(
+        nullptr, tmp, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, 32, (hipStream_t)0, false);
+    if (e != hipSuccess) return (int)e;
+    size_t o_tmp = take(tmp);
+    ws->sboxes = (float*)(base + o_sb); ws->keys_out = (float*)(base + o_ko);
+    ws->vals_in = (int32_t*)(base + o_vi); ws->order = (int32_t*)(base + o_or);
+    ws->mask = (u64*)(base + o_mask); ws->remv = (u64*)(base + o_remv); ws->keepbits = (u64*)(base + o_keep);
+    ws->sort_tmp = base + o_tmp; ws->sort_tmp_bytes = tmp; ws->total = off;
+    return 0;
+}
+
+static int nms_core(const float* boxes, const int32_t* order, int64_t n, float thr, int64_t* keep_out,
+                    int64_t* n_keep_out, NmsWs& ws, hipStream_t st) {
+    const int cb = (int)ceil_div64(n, 64);
+    k_gather_boxes<<<(unsigned)ceil_div64(n * 6, 256), 256, 0, st>>>(boxes, order, n, ws.sboxes);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemsetAsync(ws.remv, 0, (size_t)cb * 8, st));
+    HIP_TRY(hipMemsetAsync(keep_out, 0xFF, (size_t)n * 8, st));
+    k_nms_mask<<<dim3(cb, ceil_div(cb, 4)), 256, 0, st>>>(ws.sboxes, n, thr, ws.mask, cb);
+    LAUNCH_CHECK();
+    for (int c0 = 0; c0 < cb; c0 += 64) {
+        const int c1 = c0 + 64 < cb ? c0 + 64 : cb;
+        k_nms_scan_super<<<1, 1024, 0, st>>>(ws.mask, n, cb, c0, c1, ws.remv, ws.keepbits);
+        LAUNCH_CHECK();
+        if (c1 < cb) {
+            k_nms_propagate<<<dim3(ceil_div(cb - c1, 256), c1 - c0), 256, 0, st>>>(ws.mask, cb, c0, c1, ws.keepbits, ws.remv);
+            LAUNCH_CHECK();
+        }
+    }
+    k_nms_compact<<<1, 1024, 0, st>>>(ws.keepbits, cb, order, keep_out, n_keep_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t nndet_nms3d_workspace_bytes(int64_t n) {
+    if (n <= 0) return 256;
+    NmsWs ws;
+    if (nms_layout(n, nullptr, &ws) != 0) return 0;
+    return ws.total;
+}
+
+extern "C" int nndet_nms3d_f32(const float* boxes, const float* scores, int64_t n, float thr, int64_t* keep_out,
+                               int64_t* n_keep_out, void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = as_stream(stream);
+    if (n < 0 || !n_keep_out) return NNDET_EINVAL;
+    if (n == 0) return (int)hipMemsetAsync(n_keep_out, 0, 8, st);
+    if (!boxes || !scores || !keep_out || !workspace) return NNDET_EINVAL;
+    NmsWs ws;
+    int rc = nms_layout(n, (char*)workspace, &ws);
+    if (rc) return rc;
+    if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
+    k_iota<<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(ws.vals_in, n);
+    LAUNCH_CHECK();
+    size_t tmp = ws.sort_tmp_bytes;
+    HIP_TRY((rocprim::radix_sort_pairs_desc<rocprim::default_config, const float*, float*, const int32_t*, int32_t*>(
+        ws.sort_tmp, tmp, scores, ws.keys_out, ws.vals_in, ws.order, (size_t)n, 0, 32, st, false)));
+    return nms_core(boxes, ws.order, n, thr, keep_out, n_keep_out, ws, st);
+}
+
+extern "C" int nndet_nms3d_sorted_f32(const float* boxes, const int32_t* order, int64_t n, float thr,
+                                      int64_t* keep_out, int64_t* n_keep_out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    hipStream_t st = as_stream(stream);
+    if (n < 0 || !n_keep_out) return NNDET_EINVAL;
+    if (n == 0) return (int)hipMemsetAsync(n_keep_out, 0, 8, st);
+    if (!boxes || !order || !keep_out || !workspace) return NNDET_EINVAL;
+    NmsWs ws;
+    int rc = nms_layout(n, (char*)workspace, &ws);
+    if (rc) return rc;
+    if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
+    return nms_core(boxes, order, n, thr, keep_out, n_keep_out, ws, st);
+}

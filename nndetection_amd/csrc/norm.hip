@@ -1,0 +1,373 @@
+// InstanceNorm3d / GroupNorm (+ReLU) forward/backward and column sums on NDHWC for gfx950.
+// Replaces nn.InstanceNorm3d / nndet GroupNorm (nndet/arch/layers/norm.py:26-50) + nn.ReLU inside
+// ConvInstanceRelu / ConvGroupRelu (nndet/arch/conv.py:146-294). All kernels are HBM-bound streaming
+// passes with 16-byte loads/stores; statistics are accumulated in fp64 (fp32 inside a thread).
+//
+// Thread mapping used everywhere: a row = one voxel's c_p channels = PPR pieces of 16 bytes; thread t of a
+// workgroup owns piece (t % PPR) of rows (t / PPR) + k * (256 / PPR), so its channels never change and the
+// per-channel scale/shift live in registers.
+#include "common.h"
+#include "conv_common.h"
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int E = 4;
+    __device__ static __forceinline__ void ld(const float* p, float* v) {
+        const float4 f = *reinterpret_cast<const float4*>(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    }
+    __device__ static __forceinline__ void st(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int E = 8;
+    __device__ static __forceinline__ void ld(const bf16_t* p, float* v) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
+        uint4 u;
+        u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+        u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+        *reinterpret_cast<uint4*>(p) = u;
+    }
+};
+
+#define ROWS_PER_BLOCK 512   // rows (voxels) handled by one workgroup in the streaming kernels
+
+// ------------------------------------------------------------------ statistics: sum / sumsq per (n, channel)
+// grid (ceil(spatial / ROWS_PER_BLOCK), N)
+template <typename T>
+__global__ __launch_bounds__(256) void k_norm_stats(const T* __restrict__ x, int64_t spatial, int c_p, int N,
+                                                    double* __restrict__ stats) {
+    constexpr int E = Vec16<T>::E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);   // [c_p][2]
+    const int ppr = c_p / E;
+    const int rpi = 256 / ppr;                        // rows per iteration
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < c_p * 2; i += 256) red[i] = 0.0;
+    __syncthreads();
+    const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+    float s[E], s2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s[e] = 0.f; s2[e] = 0.f; }
+    if (rr < rpi) {
+        const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+        const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
+        const T* xb = x + ((int64_t)n * spatial) * c_p + cp * E;
+        for (int64_t r = r0 + rr; r < r1; r += rpi) {
+            float v[E];
+            Vec16<T>::ld(xb + r * c_p, v);
+#pragma unroll
+            for (int e = 0; e < E; ++e) { s[e] += v[e]; s2[e] += v[e] * v[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            atomicAdd(&red[(cp * E + e) * 2 + 0], (double)s[e]);
+            atomicAdd(&red[(cp * E + e) * 2 + 1], (double)s2[e]);
+        }
+    }
+    __syncthreads();
+    const int rep = blockIdx.x % NNDET_STATS_REPLICAS;
+    double* dst = stats + ((int64_t)rep * N + n) * c_p * 2;
+    for (int i = threadIdx.x; i < c_p * 2; i += 256) atomicAdd(&dst[i], red[i]);
+}
+
+int norm_stats_run(int dtype, const void* x, int batch, int64_t spatial, int c_p, double* stats, hipStream_t st) {
+    if (c_p % 32 || c_p > 1024 || batch <= 0 || spatial <= 0) return NNDET_EINVAL;
+    dim3 grid((unsigned)ceil_div64(spatial, ROWS_PER_BLOCK), batch);
+    const size_t lds = (size_t)c_p * 16;
+    if (dtype == NNDET_BF16) k_norm_stats<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)x, spatial, c_p, batch, stats);
+    else k_norm_stats<float><<<grid, 256, lds, st>>>((const float*)x, spatial, c_p, batch, stats);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nndet_norm_stats(int32_t dtype, const void* x, int32_t batch, int64_t spatial, int32_t c_p, double* stats,
+                                void* stream) {
+    if (!x || !stats) return NNDET_EINVAL;
+    return norm_stats_run(dtype, x, batch, spatial, c_p, stats, as_stream(stream));
+}
+
+// ------------------------------------------------------------------ finalize: replicas -> per-channel (mean, rstd) of its group
+// grid N, block 256 (loops channels)
+__global__ void k_norm_finalize(const double* __restrict__ stats, int N, int c, int c_p, int groups, int64_t spatial,
+                                float eps, float* __restrict__ mean_rstd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ch = reinterpret_cast<double*>(smem);   // [c_p][2]
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < c_p * 2; i += blockDim.x) {
+        double v = 0.0;
+        for (int r = 0; r < NNDET_STATS_REPLICAS; ++r) v += stats[(((int64_t)r * N + n) * c_p) * 2 + i];
+        ch[i] = v;
+    }
+    __syncthreads();
+    const int cpg = c / groups;
+    for (int i = threadIdx.x; i < c_p; i += blockDim.x) {
+        float mean = 0.f, rstd = 0.f;
+        if (i < c) {
+            const int g = i / cpg;
+            double s = 0.0, s2 = 0.0;
+            for (int k = 0; k < cpg; ++k) { s += ch[(g * cpg + k) * 2]; s2 += ch[(g * cpg + k) * 2 + 1]; }
+            const double m = (double)cpg * (double)spatial;
+            const double mu = s / m;
+            double var = s2 / m - mu * mu;          // biased variance, as torch's instance/group norm
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            rstd = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        mean_rstd[((int64_t)n * c_p + i) * 2 + 0] = mean;
+        mean_rstd[((int64_t)n * c_p + i) * 2 + 1] = rstd;
+    }
+}
+
+// ------------------------------------------------------------------ apply: y = relu?((x - mean) * rstd * gamma + beta)
+template <typename T>
+__global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    int64_t spatial, int c, int c_p, int relu, T* __restrict__ y) {
+    constexpr int E = Vec16<T>::E;
+    const int ppr = c_p / E, rpi = 256 / ppr;
+    const int n = blockIdx.y;
+    const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+    if (rr >= rpi) return;
+    float sc[E], sh[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int ci = cp * E + e;
+        float a = 0.f, b = 0.f;
+        if (ci < c) {
+            const float mean = mean_rstd[((int64_t)n * c_p + ci) * 2], rstd = mean_rstd[((int64_t)n * c_p + ci) * 2 + 1];
+            a = rstd * gamma[ci];
+            b = beta[ci] - mean * a;
+        }
+        sc[e] = a; sh[e] = b;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
+    const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
+    for (int64_t r = r0 + rr; r < r1; r += rpi) {
+        float v[E];
+        Vec16<T>::ld(x + base + r * c_p, v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float o = fmaf(v[e], sc[e], sh[e]);
+            if (relu) o = fmaxf(o, 0.f);
+            v[e] = o;
+        }
+        Vec16<T>::st(y + base + r * c_p, v);
+    }
+}
+
+extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
+                                int32_t batch, int64_t spatial, int32_t c, int32_t c_p, int32_t groups, float eps,
+                                int32_t relu, void* y, float* mean_rstd_out, void* stream) {
+    if (!x || !stats || !gamma || !beta || !y || !mean_rstd_out) return NNDET_EINVAL;
+    if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    k_norm_finalize<<<batch, 256, (size_t)c_p * 16, st>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out);
+    LAUNCH_CHECK();
+    dim3 grid((unsigned)ceil_div64(spatial, ROWS_PER_BLOCK), batch);
+    if (dtype == NNDET_BF16)
+        k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (bf16_t*)y);
+    else
+        k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (float*)y);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ backward
+// pass 1: per (n, channel): A = sum g, B = sum g * xhat, with g = dy * [relu mask]
+template <typename T>
+__global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int64_t spatial, int c, int c_p,
+                                                         int N, int relu, double* __restrict__ red_ws) {
+    constexpr int E = Vec16<T>::E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);
+    const int ppr = c_p / E, rpi = 256 / ppr;
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < c_p * 2; i += 256) red[i] = 0.0;
+    __syncthreads();
+    const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+    if (rr < rpi) {
+        float mu[E], rs[E], sc[E], sh[E], sa[E], sb[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int ci = cp * E + e;
+            const bool ok = ci < c;
+            mu[e] = ok ? mean_rstd[((int64_t)n * c_p + ci) * 2] : 0.f;
+            rs[e] = ok ? mean_rstd[((int64_t)n * c_p + ci) * 2 + 1] : 0.f;
+            sc[e] = ok ? rs[e] * gamma[ci] : 0.f;
+            sh[e] = ok ? beta[ci] - mu[e] * sc[e] : 0.f;
+            sa[e] = 0.f; sb[e] = 0.f;
+        }
+        const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+        const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
+        const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
+        for (int64_t r = r0 + rr; r < r1; r += rpi) {
+            float xv[E], gv[E];
+            Vec16<T>::ld(x + base + r * c_p, xv);
+            Vec16<T>::ld(dy + base + r * c_p, gv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float xh = (xv[e] - mu[e]) * rs[e];
+                float g = gv[e];
+                if (relu && !(fmaf(xv[e], sc[e], sh[e]) > 0.f)) g = 0.f;   // same expression as the forward pass
+                sa[e] += g; sb[e] += g * xh;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            atomicAdd(&red[(cp * E + e) * 2 + 0], (double)sa[e]);
+            atomicAdd(&red[(cp * E + e) * 2 + 1], (double)sb[e]);
+        }
+    }
+    __syncthreads();
+    const int rep = blockIdx.x % NNDET_STATS_REPLICAS;
+    double* dst = red_ws + ((int64_t)rep * N + n) * c_p * 2;
+    for (int i = threadIdx.x; i < c_p * 2; i += 256) atomicAdd(&dst[i], red[i]);
+}
+
+// pass 2 (grid N): dgamma/dbeta and the per-channel group coefficients (s1/m, s2/m) written over replica 0
+__global__ void k_norm_bwd_finalize(double* __restrict__ red_ws, const float* __restrict__ gamma, int N, int c, int c_p,
+                                    int groups, int64_t spatial, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ch = reinterpret_cast<double*>(smem);   // [c_p][2]
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < c_p * 2; i += blockDim.x) {
+        double v = 0.0;
+        for (int r = 0; r < NNDET_STATS_REPLICAS; ++r) v += red_ws[(((int64_t)r * N + n) * c_p) * 2 + i];
+        ch[i] = v;
+    }
+    __syncthreads();
+    const int cpg = c / groups;
+    float* coef = reinterpret_cast<float*>(red_ws + ((int64_t)n * c_p) * 2);   // replica 0, this n: [c_p][2] fp32 (first half)
+    for (int i = threadIdx.x; i < c_p; i += blockDim.x) {
+        float c1 = 0.f, c2 = 0.f;
+        if (i < c) {
+            atomicAdd(&dbeta[i], (float)ch[i * 2]);
+            atomicAdd(&dgamma[i], (float)ch[i * 2 + 1]);
+            const int g = i / cpg;
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < cpg; ++k) {
+                const double gm = (double)gamma[g * cpg + k];
+                s1 += gm * ch[(g * cpg + k) * 2];
+                s2 += gm * ch[(g * cpg + k) * 2 + 1];
+            }
+            const double m = (double)cpg * (double)spatial;
+            c1 = (float)(s1 / m); c2 = (float)(s2 / m);
+        }
+        // all reads of this n's slices happened before the __syncthreads above
+        coef[i * 2 + 0] = c1;
+        coef[i * 2 + 1] = c2;
+    }
+}
+
+// pass 3: dx = rstd * (g * gamma - s1/m - xhat * s2/m)
+template <typename T>
+__global__ __launch_bounds__(256) void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy,
+                                                        const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const double* __restrict__ red_ws,
+                                                        int64_t spatial, int c, int c_p, int relu, T* __restrict__ dx) {
+    constexpr int E = Vec16<T>::E;
+    const int ppr = c_p / E, rpi = 256 / ppr;
+    const int n = blockIdx.y;
+    const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+    if (rr >= rpi) return;
+    const float* coef = reinterpret_cast<const float*>(red_ws + ((int64_t)n * c_p) * 2);
+    float mu[E], rs[E], ga[E], sc[E], sh[E], k1[E], k2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int ci = cp * E + e;
+        const bool ok = ci < c;
+        mu[e] = ok ? mean_rstd[((int64_t)n * c_p + ci) * 2] : 0.f;
+        rs[e] = ok ? mean_rstd[((int64_t)n * c_p + ci) * 2 + 1] : 0.f;
+        ga[e] = ok ? gamma[ci] : 0.f;
+        sc[e] = ok ? rs[e] * ga[e] : 0.f;
+        sh[e] = ok ? beta[ci] - mu[e] * sc[e] : 0.f;
+        k1[e] = ok ? coef[ci * 2] : 0.f;
+        k2[e] = ok ? coef[ci * 2 + 1] : 0.f;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
+    const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
+    for (int64_t r = r0 + rr; r < r1; r += rpi) {
+        float xv[E], gv[E];
+        Vec16<T>::ld(x + base + r * c_p, xv);
+        Vec16<T>::ld(dy + base + r * c_p, gv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            float g = gv[e];
+            if (relu && !(fmaf(xv[e], sc[e], sh[e]) > 0.f)) g = 0.f;
+            xv[e] = rs[e] * (g * ga[e] - k1[e] - xh * k2[e]);
+        }
+        Vec16<T>::st(dx + base + r * c_p, xv);
+    }
+}
+
+extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma,
+                                   const float* beta, int32_t batch, int64_t spatial, int32_t c, int32_t c_p, int32_t groups,
+                                   int32_t relu, void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream) {
+    if (!x || !dy || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red_ws) return NNDET_EINVAL;
+    if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    dim3 grid((unsigned)ceil_div64(spatial, ROWS_PER_BLOCK), batch);
+    const size_t lds = (size_t)c_p * 16;
+    if (dtype == NNDET_BF16)
+        k_norm_bwd_reduce<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws);
+    else
+        k_norm_bwd_reduce<float><<<grid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws);
+    LAUNCH_CHECK();
+    k_norm_bwd_finalize<<<batch, 256, lds, st>>>(red_ws, gamma, batch, c, c_p, groups, spatial, dgamma, dbeta);
+    LAUNCH_CHECK();
+    if (dtype == NNDET_BF16)
+        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx);
+    else
+        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (float*)dx);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradient): out[c] += sum_rows x[row][c]
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ x, int64_t rows, int c_p, int c, float* __restrict__ out) {
+    constexpr int E = Vec16<T>::E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    const int ppr = c_p / E, rpi = 256 / ppr;
+    for (int i = threadIdx.x; i < c_p; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+    if (rr < rpi) {
+        float s[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] = 0.f;
+        const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+        const int64_t r1 = min(r0 + ROWS_PER_BLOCK, rows);
+        for (int64_t r = r0 + rr; r < r1; r += rpi) {
+            float v[E];
+            Vec16<T>::ld(x + r * c_p + cp * E, v);
+#pragma unroll
+            for (int e = 0; e < E; ++e) s[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) atomicAdd(&red[cp * E + e], s[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += 256) atomicAdd(&out[i], red[i]);
+}
+
+int colsum_run(int dtype, const void* x, int64_t rows, int c_p, int c, float* out, hipStream_t st) {
+    if (c_p % 32 || c_p > 1024 || rows <= 0) return NNDET_EINVAL;
+    const unsigned nb = (unsigned)ceil_div64(rows, ROWS_PER_BLOCK);
+    if (dtype == NNDET_BF16) k_colsum<bf16_t><<<nb, 256, (size_t)c_p * 4, st>>>((const bf16_t*)x, rows, c_p, c, out);
+    else k_colsum<float><<<nb, 256, (size_t)c_p * 4, st>>>((const float*)x, rows, c_p, c, out);
+    LAUNCH_CHECK();
+    return 0;
+}

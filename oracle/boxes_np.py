@@ -151,7 +151,7 @@ def atss_match(boxes, anchors, num_anchors_per_level: Sequence[int], num_anchors
     cov = np.take_along_axis(iou, cand, 1)                       # [G, K]
     mean = cov.astype(np.float64).mean(1)
     std = cov.astype(np.float64).std(1, ddof=1) if cov.shape[1] > 1 else np.full((G,), np.nan)
-    thr = (mean + std).astype(F32)                               # atss.py:97-99 (fp32 in the reference)
+    thr = mean.astype(F32) + std.astype(F32)                     # atss.py:97-99: fp32 mean + fp32 std
     is_pos = cov >= thr[:, None]
     best = np.full((G, M), -INF, F32)
     for g in range(G):

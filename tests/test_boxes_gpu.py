@@ -1,0 +1,180 @@
+"""GPU parity of the box-op kernels against the CPU oracle and the reference golden vectors (bit-exact)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes_np as bx
+from oracle import nms_c
+from tests.gpu_util import rand_boxes, distinct_scores, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "boxes_golden.npz"))
+
+
+def biteq(a, b, what=""):
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if not np.array_equal(a, b, equal_nan=True):
+        bad = np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b))))
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} differ, first at {bad[0]}: {a[tuple(bad[0])]} vs {b[tuple(bad[0])]}")
+
+
+def test_iou_giou_golden(g):
+    from nndetection_amd.core.boxes import box_iou, generalized_box_iou
+    b1, b2 = t(g["iou_b1"]), t(g["iou_b2"])
+    biteq(box_iou(b1, b2), g["iou"], "iou")
+    biteq(box_iou(b1, b2, eps=1e-6), g["iou_eps"], "iou eps")
+    biteq(generalized_box_iou(b1, b2), g["giou"], "giou")
+    biteq(generalized_box_iou(b1, b2, eps=1e-7), g["giou_eps"], "giou eps")
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 1023), (17, 1024), (16, 1025), (33, 4100)])
+def test_iou_shapes_vs_oracle(n, m):
+    from nndetection_amd.core.boxes import box_iou, generalized_box_iou
+    rng = np.random.default_rng(n * 7 + m)
+    a, b = rand_boxes(rng, n), rand_boxes(rng, m)
+    biteq(box_iou(t(a), t(b)), bx.box_iou(a, b), "iou")
+    biteq(generalized_box_iou(t(a), t(b), eps=1e-7), bx.generalized_box_iou(a, b, 1e-7), "giou")
+
+
+def test_iou_empty():
+    from nndetection_amd.core.boxes import box_iou
+    e = box_iou(torch.zeros(0, 6, device="cuda"), torch.rand(4, 6, device="cuda"))
+    assert e.numel() == 0
+
+
+def test_anchors_golden(g):
+    from nndetection_amd.core.boxes import AnchorGenerator3DS
+    W = [(4, 8, 16), (8, 16, 32), (16, 32, 64)]
+    gen = AnchorGenerator3DS(width=W, height=W, depth=W, stride=1)
+    img = torch.zeros(2, 1, 48, 40, 24, device="cuda")
+    fms = [torch.zeros(2, 8, 12, 10, 6, device="cuda"), torch.zeros(2, 8, 6, 5, 3, device="cuda"), torch.zeros(2, 8, 3, 3, 3, device="cuda")]
+    anc = gen(img, fms)
+    assert len(anc) == 2 and anc[0] is anc[1]
+    biteq(anc[0], g["anchors"], "anchors")
+    assert gen.get_num_acnhors_per_level() == list(g["anchors_per_level"])
+    assert gen.num_anchors_per_location() == [27, 27, 27]
+
+
+def test_atss_golden(g):
+    from nndetection_amd.core.boxes import ATSSMatcher
+    m = ATSSMatcher(num_candidates=4, center_in_gt=False, return_match_quality=True)
+    mq, matches = m(t(g["atss_gt"]), t(g["anchors"]), list(g["anchors_per_level"]), 27)
+    biteq(matches, g["atss_matches"], "atss matches")
+    biteq(mq, bx.box_iou(g["atss_gt"], g["anchors"]), "match quality")
+    mq0, m0 = m(torch.zeros(0, 6, device="cuda"), t(g["anchors"]), list(g["anchors_per_level"]), 27)
+    assert mq0.numel() == 0 and bool((m0 == -1).all())
+
+
+@pytest.mark.parametrize("G,seed", [(1, 0), (7, 1), (19, 2), (40, 3)])
+def test_atss_random_vs_oracle(G, seed):
+    """Larger anchor set, many GTs (tile boundaries of the GT loop), incl. GT centres ON the anchor lattice
+    (distance ties -> lowest-index rule)."""
+    from nndetection_amd.core.boxes import ATSSMatcher
+    rng = np.random.default_rng(seed)
+    W = [(4, 8, 16), (8, 16, 32), (16, 32, 64)]
+    anchors, npl = bx.anchors_for_image((64, 48, 40), [(16, 12, 10), (8, 6, 5), (4, 3, 3)], W, W, W)
+    gt = rand_boxes(rng, G, extent=(64, 48, 40), smin=4, smax=24)
+    if G > 1:
+        gt[0] = [10, 6, 22, 18, 2, 14]      # centre (16, 12, 8): exactly on the level-0 lattice (stride 4)
+    _, ref = bx.atss_match(gt, anchors, npl, 27, 4)
+    _, got = ATSSMatcher(num_candidates=4, center_in_gt=False)(t(gt), t(anchors), npl, 27)
+    biteq(got, ref, f"atss G={G}")
+
+
+def test_nms_golden(g):
+    from nndetection_amd.core.boxes import nms, batched_nms
+    for key in ["300_0.6", "1500_0.1", "1500_0.6"]:
+        thr = float(key.split("_")[1])
+        biteq(nms(t(g[f"nms_boxes_{key}"]), t(g[f"nms_scores_{key}"]), thr), g[f"nms_keep_{key}"], f"nms {key}")
+    biteq(batched_nms(t(g["bnms_boxes"]), t(g["bnms_scores"]), t(g["bnms_cls"]), 0.5), g["bnms_keep"], "batched_nms")
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 1000, 4096, 4097, 8200, 10000])
+@pytest.mark.parametrize("thr", [0.1, 0.6])
+def test_nms_sizes_vs_oracle(n, thr):
+    """chunk (64) and super-chunk (4096) boundaries; clustered boxes so that suppression chains are long."""
+    from nndetection_amd.core.boxes import nms
+    rng = np.random.default_rng(n)
+    b = rand_boxes(rng, n, extent=(50, 50, 30), smin=6, smax=20)
+    s = distinct_scores(rng, n)
+    biteq(nms(t(b), t(s), thr), nms_c.nms(b, s, thr), f"nms n={n} thr={thr}")
+
+
+def test_nms_edge_cases():
+    from nndetection_amd.core.boxes import nms, batched_nms
+    assert nms(torch.zeros(0, 6, device="cuda"), torch.zeros(0, device="cuda"), 0.5).shape == (0,)
+    assert batched_nms(torch.zeros(0, 6, device="cuda"), torch.zeros(0, device="cuda"), torch.zeros(0, device="cuda"), 0.5).shape == (0,)
+    same = np.tile(np.asarray([[1, 2, 9, 8, 3, 7]], np.float32), (300, 1))
+    s = distinct_scores(np.random.default_rng(0), 300)
+    k = nms(t(same), t(s), 0.5).cpu().numpy()
+    assert list(k) == [int(np.argmax(s))]
+    # disjoint boxes: everything survives, ordered by score
+    far = np.stack([np.asarray([10 * i, 0, 10 * i + 5, 5, 0, 5], np.float32) for i in range(200)])
+    k = nms(t(far), t(s[:200]), 0.5).cpu().numpy()
+    assert np.array_equal(k, np.argsort(-s[:200], kind="stable"))
+    # degenerate (zero-volume) boxes give NaN IoU against each other: never suppressed (CUDA kernel semantics)
+    deg = np.tile(np.asarray([[1, 1, 1, 1, 1, 1]], np.float32), (5, 1))
+    assert len(nms(t(deg), t(s[:5]), 0.5)) == 5
+
+
+def test_nms_100k_properties():
+    """BASELINE.json config 5 size: bit-exact against the matrix-free C oracle, plus size-independent properties."""
+    from nndetection_amd.core.boxes import nms, box_iou
+    rng = np.random.default_rng(5)
+    n = 100_000
+    b = rand_boxes(rng, n, extent=(160, 160, 160), smin=2, smax=26)
+    s = distinct_scores(rng, n)
+    keep = nms(t(b), t(s), 0.1)
+    kc = keep.cpu().numpy()
+    assert np.all(np.diff(s[kc]) < 0), "keep is not sorted by decreasing score"
+    again = nms(t(b[kc]), t(s[kc]), 0.1).cpu().numpy()
+    assert np.array_equal(again, np.arange(len(kc))), "NMS is not idempotent on its own output"
+    sub = kc[:3000]
+    iou = box_iou(t(b[sub]), t(b[sub])).cpu().numpy()
+    np.fill_diagonal(iou, 0)
+    assert iou.max() <= 0.1, "two kept boxes overlap more than the threshold"
+    biteq(kc, nms_c.nms(b, s, 0.1), "nms 100k vs C oracle")
+
+
+def test_decode_clip_and_giou_diag():
+    from nndetection_amd.core.boxes.coder import decode_clip, decode_single
+    from nndetection_amd.core.boxes import giou_diag
+    from oracle.retina_torch import giou_t, decode_single_t
+    rng = np.random.default_rng(3)
+    anchors = rand_boxes(rng, 5000)
+    rel = (rng.standard_normal((2 * 5000, 6)) * 0.5).astype(np.float32)
+    rel[11, 5] = 8.0
+    ref = bx.decode_single(rel, np.tile(anchors, (2, 1)))
+    got = decode_clip(t(rel), t(anchors), None).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+    gotc = decode_clip(t(rel), t(anchors), (160, 160, 96)).cpu().numpy()
+    assert np.abs(gotc - bx.clip_boxes_to_image(ref, (160, 160, 96))).max() <= 2e-3
+    # differentiable torch decode on device == oracle decode
+    d2 = decode_single(t(rel[:100]), t(anchors[:100])).cpu().numpy()
+    assert np.abs(d2 - ref[:100]).max() <= 2e-4 * np.abs(ref[:100]).max()
+    # GIoU diag forward (bit-exact vs oracle diag) and backward (vs autograd of the reference expression)
+    p = rand_boxes(rng, 64, extent=(40, 40, 40), smin=5, smax=20)
+    q = rand_boxes(rng, 64, extent=(40, 40, 40), smin=5, smax=20)
+    pt = t(p).requires_grad_(True)
+    out = giou_diag(pt, t(q), eps=1e-7)
+    biteq(out.detach(), np.diag(bx.generalized_box_iou(p, q, 1e-7)).copy(), "giou diag")
+    (-out.sum()).backward()
+    pc = torch.from_numpy(p).requires_grad_(True)
+    (-torch.diag(giou_t(pc, torch.from_numpy(q), 1e-7)).sum()).backward()
+    assert torch.allclose(pt.grad.cpu(), pc.grad, atol=1e-6, rtol=1e-4), (pt.grad.cpu() - pc.grad).abs().max()
+
+
+def test_sigmoid_max():
+    from nndetection_amd import _lib as L
+    x = torch.randn(10001, 3, device="cuda")
+    out = torch.empty(10001, device="cuda")
+    L.call("nndet_sigmoid_max_f32", L.ptr(x), 10001, 3, L.ptr(out), L.stream())
+    assert torch.allclose(out, torch.sigmoid(x).max(1)[0], atol=1e-6)

@@ -1,0 +1,180 @@
+"""GPU parity of the convolution / norm / loss kernels against plain PyTorch fp32 on the CPU.
+
+fp32 kernels (exact-fp32 MFMA): relative error <= 2e-5 of the tensor's max (summation order only).
+bf16 kernels: the reference is fed the SAME bf16-rounded inputs / weights, so the only differences are the
+fp32 accumulation order and the final rounding of the output to bf16: <= 1 bf16 ulp = 2^-8 relative to the
+tensor's max; gradients of weights are fp32 sums of bf16 products: 5e-3.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: dict(fwd=2e-5, dx=2e-5, dw=5e-5), torch.bfloat16: dict(fwd=6e-3, dx=8e-3, dw=8e-3)}
+
+# (cin, cout, kernel, stride, padding, transposed, spatial)
+CONVS = [
+    ("c32_k3", 32, 32, 3, 1, 1, False, (9, 10, 12)),            # cfg (2,8), ragged tiles
+    ("c64_k3", 64, 64, 3, 1, 1, False, (8, 8, 8)),              # cfg (4,4)
+    ("c128_k3", 128, 128, 3, 1, 1, False, (5, 5, 6)),           # 4 K-chunks, tiny map
+    ("c32to64_s2", 32, 64, 3, 2, 1, False, (10, 9, 12)),        # strided: cfg (4,2); dgrad parity classes, odd dims
+    ("c32to32_s2", 32, 32, 3, 2, 1, False, (8, 8, 8)),          # strided, rows % 64 != 0: cfg (2,2)
+    ("c64_s221", 64, 64, 3, (2, 2, 1), 1, False, (10, 10, 6)),  # anisotropic stride of the last encoder stage
+    ("head_cls", 128, 27, 3, 1, 1, False, (5, 6, 6)),           # padded output channels 27 -> 32
+    ("head_reg", 64, 162, 3, 1, 1, False, (5, 6, 6)),           # 162 -> 192
+    ("lateral", 64, 32, 1, 1, 0, False, (6, 7, 8)),             # 1x1x1
+    ("seg_out", 32, 2, 1, 1, 0, False, (8, 8, 8)),              # 2 -> 32 padded
+    ("up_222", 64, 32, 2, 2, 0, True, (4, 5, 6)),               # ConvTranspose k = s
+    ("up_221", 128, 128, (2, 2, 1), (2, 2, 1), 0, True, (3, 3, 6)),
+    ("stem", 1, 32, 3, 1, 1, False, (9, 10, 12)),
+]
+
+
+def _mk(name, dtype, norm=None, act=False):
+    from nndetection_amd.arch.conv import ConvInstanceRelu, ConvGroupRelu
+    cfg = {c[0]: c for c in CONVS}[name]
+    _, cin, cout, k, s, p, tr, sp = cfg
+    cls = ConvGroupRelu if norm == "group" else ConvInstanceRelu
+    torch.manual_seed(hash(name) % 1000)
+    m = cls(3, cin, cout, k, stride=s, padding=p, transposed=tr, add_norm=norm is not None, add_act=act)
+    with torch.no_grad():
+        for pname, prm in m.named_parameters():
+            if prm.ndim == 5:
+                prm.copy_(torch.randn_like(prm) * (1.0 / (prm[0].numel() ** 0.5)))
+            else:
+                prm.copy_(torch.randn_like(prm) * 0.3 + (1.0 if pname.endswith("norm.weight") else 0.0))
+    x = torch.randn(2, cin, *sp)
+    return m, x, cfg
+
+
+def _ref_forward(m, x, cfg, dtype, norm, act):
+    """plain torch fp32 on CPU with the same (rounded) operands"""
+    _, cin, cout, k, s, p, tr, sp = cfg
+    rd = (lambda t: t.to(dtype).float())
+    w = rd(m.conv.weight.detach()).requires_grad_(True)
+    b = m.conv.bias.detach().clone().requires_grad_(True) if m.conv.bias is not None else None
+    xr = rd(x).requires_grad_(True)
+    y = F.conv_transpose3d(xr, w, b, stride=s) if tr else F.conv3d(xr, w, b, stride=s, padding=p)
+    g = be = None
+    if norm is not None:
+        if dtype == torch.bfloat16:
+            y = y.to(dtype).float() + (y - y.detach())          # the kernel normalises the bf16-rounded conv output
+        g = m.norm.weight.detach().clone().requires_grad_(True)
+        be = m.norm.bias.detach().clone().requires_grad_(True)
+        if norm == "instance":
+            y = F.instance_norm(y, weight=g, bias=be, eps=1e-5)
+        else:
+            y = F.group_norm(y, cout // 16, g, be, eps=1e-5)
+    if act:
+        y = F.relu(y)
+    return xr, w, b, g, be, y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", [c[0] for c in CONVS])
+def test_conv_fwd_bwd(name, dtype):
+    m, x, cfg = _mk(name, dtype)
+    tol = TOL[dtype]
+    xr, w, b, _, _, yref = _ref_forward(m, x, cfg, dtype, None, False)
+    gy = torch.randn_like(yref)
+    if dtype == torch.bfloat16:
+        gy = gy.to(dtype).float()
+    yref.backward(gy)
+    m = m.cuda()
+    xg = x.cuda().to(dtype).requires_grad_(cfg[1] != 1)
+    y = m(xg)
+    assert y.shape == yref.shape and y.dtype == dtype
+    e = relerr(y.float(), yref)
+    assert e <= tol["fwd"], f"forward rel err {e:.3e}"
+    y.backward(gy.cuda().to(dtype))
+    torch.cuda.synchronize()
+    if cfg[1] != 1:
+        e = relerr(xg.grad.float(), xr.grad)
+        assert e <= tol["dx"], f"dgrad rel err {e:.3e}"
+    e = relerr(m.conv.weight.grad, w.grad)
+    assert e <= tol["dw"], f"wgrad rel err {e:.3e}"
+    if b is not None:
+        e = relerr(m.conv.bias.grad, b.grad)
+        assert e <= tol["dw"], f"bias grad rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name,norm", [("c32_k3", "instance"), ("c64_k3", "instance"), ("c32to64_s2", "instance"),
+                                        ("stem", "instance"), ("c128_k3", "group"), ("c64_k3", "group")])
+def test_conv_norm_relu_block(name, norm, dtype):
+    m, x, cfg = _mk(name, dtype, norm, True)
+    xr, w, b, g, be, yref = _ref_forward(m, x, cfg, dtype, norm, True)
+    gy = torch.randn_like(yref)
+    if dtype == torch.bfloat16:
+        gy = gy.to(dtype).float()
+    yref.backward(gy)
+    m = m.cuda()
+    xg = x.cuda().to(dtype).requires_grad_(cfg[1] != 1)
+    y = m(xg)
+    ft = 2e-5 if dtype == torch.float32 else 1.2e-2
+    gt = 1e-4 if dtype == torch.float32 else 3e-2
+    e = relerr(y.float(), yref)
+    assert e <= ft, f"block forward rel err {e:.3e}"
+    y.backward(gy.cuda().to(dtype))
+    torch.cuda.synchronize()
+    errs = {"dw": relerr(m.conv.weight.grad, w.grad), "dgamma": relerr(m.norm.weight.grad, g.grad),
+            "dbeta": relerr(m.norm.bias.grad, be.grad)}
+    if cfg[1] != 1:
+        errs["dx"] = relerr(xg.grad.float(), xr.grad)
+    bad = {k: v for k, v in errs.items() if v > gt}
+    assert not bad, f"block backward rel errs {errs}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_segloss(dtype):
+    from nndetection_amd.arch import Generator, ConvInstanceRelu, DiCESegmenterFgBg
+    torch.manual_seed(0)
+    seg = DiCESegmenterFgBg(Generator(ConvInstanceRelu, 3), seg_classes=1, in_channels=[32, 64], decoder_levels=(1,),
+                            dice_kwargs={"batch_dice": True})
+    x = torch.randn(2, 32, 8, 9, 10)
+    tgt = (torch.rand(2, 8, 9, 10) > 0.8).float() * 3
+    rd = lambda t_: t_.to(dtype).float()
+    xr = rd(x).requires_grad_(True)
+    w = rd(seg.conv_out.conv.weight.detach()).requires_grad_(True)
+    b = seg.conv_out.conv.bias.detach().clone().requires_grad_(True)
+    sl = F.conv3d(xr, w, b)
+    if dtype == torch.bfloat16:
+        sl = sl.to(dtype).float() + (sl - sl.detach())
+    t = (tgt > 0).long()
+    ce = 0.5 * F.cross_entropy(sl, t)
+    p = torch.softmax(sl, 1)
+    oh = torch.zeros_like(p).scatter_(1, t[:, None], 1)
+    ax = [0, 2, 3, 4]
+    tp = (p * oh).sum(ax); fp = (p * (1 - oh)).sum(ax); fn = ((1 - p) * oh).sum(ax)
+    dice = 0.5 * (1 - ((2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5))[1:].mean())
+    (ce + dice).backward()
+    seg = seg.cuda()
+    xg = x.cuda().to(dtype).requires_grad_(True)
+    out = seg.compute_loss(seg([xg]), tgt.cuda())
+    assert abs(out["seg_ce"].item() - ce.item()) < 2e-5 and abs(out["seg_dice"].item() - dice.item()) < 2e-5, (out, ce, dice)
+    (out["seg_ce"] + out["seg_dice"]).backward()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert relerr(xg.grad.float(), xr.grad) < tol
+    assert relerr(seg.conv_out.conv.weight.grad, w.grad) < tol
+    assert relerr(seg.conv_out.conv.bias.grad, b.grad) < tol
+    pr = seg.postprocess_for_inference(seg([xg]))["pred_seg"]
+    assert torch.allclose(pr.sum(1).cpu(), torch.ones(2, 8, 9, 10), atol=1e-5)
+
+
+def test_full_size_layer_against_torch_gpu():
+    """Full-resolution layer shapes of BASELINE config 2 (too slow for the CPU oracle at batch 4): compare against
+    PyTorch's own GPU conv (MIOpen) in fp32 on a 1-patch slice, plus linearity as a size-independent property."""
+    from nndetection_amd.arch.conv import ConvInstanceRelu
+    torch.manual_seed(1)
+    m = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=False, add_act=False).cuda()
+    x = torch.randn(1, 32, 160, 160, 96, device="cuda")
+    y = m(x)
+    yref = F.conv3d(x, m.conv.weight, m.conv.bias, padding=1)
+    assert relerr(y, yref) < 2e-5
+    y2 = m(2.5 * x)
+    b = m.conv.bias.view(1, -1, 1, 1, 1)
+    assert relerr(y2 - b, 2.5 * (y - b)) < 1e-5

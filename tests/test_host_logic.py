@@ -1,0 +1,131 @@
+"""CPU: host-side logic that needs no GPU -- plans, state-dict parity with the reference-shaped oracle, NDHWC layout
+helpers, optimizer groups / LR schedule, and the N > 1 gradient all-reduce path on gloo (world_size 2)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plans_and_state_dict_keys_match_reference_shape():
+    from nndetection_amd.plans import get_plan, MODEL_CFG_V001
+    from nndetection_amd.ptmodule import build_model
+    from oracle.retina_torch import OracleRetinaUNet
+    for name, nparam in (("tiny", None), ("toy64", 13_356_771), ("luna160", 18_902_019), ("lidc192", 18_967_555)):
+        p = get_plan(name)
+        m = build_model(p)
+        o = OracleRetinaUNet(p["arch"], p["anchors"], MODEL_CFG_V001)
+        assert list(m.state_dict().keys()) == list(o.state_dict().keys())
+        assert all(a.shape == b.shape for a, b in zip(m.state_dict().values(), o.state_dict().values()))
+        if nparam is not None:                       # parameter counts of the reference architecture
+            assert sum(x.numel() for x in m.parameters()) == nparam
+    keys = list(build_model(get_plan("luna160")).state_dict().keys())
+    assert len(keys) == 92
+    for k in ("encoder.stages.0.convs.0.0.conv.weight", "encoder.stages.5.convs.0.1.norm.bias", "decoder.lateral.P3.0.conv.bias",
+              "decoder.up.P5.conv.weight", "decoder.out.P1.0.conv.weight", "head.classifier.conv_internal.c_in.norm.weight",
+              "head.regressor.conv_out.conv.bias", "head.regressor.scales.3.scale", "segmenter.conv_out.conv.weight"):
+        assert k in keys, k
+
+
+def test_factory_contract_types():
+    """conv child IS nn.Conv3d, norm child IS an InstanceNorm3d / GroupNorm; bias only without norm."""
+    from nndetection_amd.arch import Generator, ConvInstanceRelu, ConvGroupRelu
+    c = Generator(ConvInstanceRelu, 3)(32, 64, kernel_size=3, stride=2, padding=1)
+    assert isinstance(c.conv, nn.Conv3d) and isinstance(c.norm, nn.InstanceNorm3d) and isinstance(c.act, nn.ReLU)
+    assert c.conv.bias is None and c.norm.weight.shape == (64,)
+    g = Generator(ConvGroupRelu, 3)(128, 128, kernel_size=3, padding=1, norm_channels_per_group=16)
+    assert isinstance(g.norm, nn.GroupNorm) and g.norm.num_groups == 8
+    u = Generator(ConvInstanceRelu, 3)(64, 32, kernel_size=(2, 2, 1), stride=(2, 2, 1), transposed=True, add_norm=False, add_act=False)
+    assert isinstance(u.conv, nn.ConvTranspose3d) and u.conv.bias is not None and list(u._modules) == ["conv"]
+
+
+def test_classifier_prior_init():
+    from nndetection_amd.ptmodule import build_model
+    from nndetection_amd.plans import get_plan
+    m = build_model(get_plan("tiny"))
+    b = m.head.classifier.conv_out.conv.bias
+    assert torch.allclose(b, torch.full_like(b, -4.59511985))       # -log(99), classifier.py:223
+    assert abs(m.head.regressor.conv_out.conv.weight.std().item() - 0.01) < 2e-3
+
+
+def test_layout_roundtrip_cpu():
+    from nndetection_amd.layout import phys, logical, cpad
+    assert [cpad(c) for c in (1, 2, 27, 32, 33, 162, 320)] == [32, 32, 32, 32, 64, 192, 320]
+    x = torch.randn(2, 27, 3, 4, 5)
+    p, c = phys(x)
+    assert p.shape == (2, 3, 4, 5, 32) and c == 27 and p.is_contiguous()
+    assert torch.equal(p[..., :27].permute(0, 4, 1, 2, 3), x) and (p[..., 27:] == 0).all()
+    v = logical(p, 27)
+    assert v.shape == x.shape and torch.equal(v, x)
+    p2, _ = phys(v)                                   # our own padded view: zero-copy
+    assert p2.data_ptr() == p.data_ptr()
+    y = torch.randn(2, 64, 3, 4, 5).to(memory_format=torch.channels_last_3d)
+    p3, _ = phys(y)
+    assert p3.data_ptr() == y.data_ptr()              # channels_last_3d tensors are already NDHWC
+    img = torch.randn(2, 1, 3, 4, 5)
+    pi, ci = phys(img, dtype=torch.bfloat16)
+    assert pi.shape == (2, 3, 4, 5, 1) and ci == 1 and pi.dtype == torch.bfloat16
+
+
+def test_optimizer_groups_and_schedule():
+    from nndetection_amd.ptmodule import build_model, configure_optimizer
+    from nndetection_amd.plans import get_plan
+    m = build_model(get_plan("luna160"))
+    opt, sched = configure_optimizer(m)
+    no_wd, wd = opt.param_groups
+    assert no_wd["weight_decay"] == 0.0 and wd["weight_decay"] == 3e-5
+    assert len(no_wd["params"]) == 2 * 16 and len(no_wd["params"]) + len(wd["params"]) == 92 - 0   # 16 norm modules
+    assert opt.defaults["nesterov"] and opt.defaults["momentum"] == 0.9
+    assert abs(opt.param_groups[0]["lr"] - 1e-6) < 1e-9                                              # warm-up start
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from nndetection_amd.ddp import GradAllReducer
+    torch.manual_seed(rank)                            # different init per rank: must be broadcast from rank 0
+    model = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4), nn.Linear(4, 4))
+    ddp = GradAllReducer(model, first_bucket_mb=1e-4, bucket_mb=2e-4)
+    w0 = model[0].weight.detach().clone()
+    torch.manual_seed(100 + rank)
+    x = torch.randn(5, 8)
+    h = model[2](model[1](model[0](x)))
+    loss = h.sum() if rank == 0 else (model[3](h)).sum()   # rank 0 never uses the last layer: its grads are None there
+    loss.backward()
+    ddp.finish()
+    q.put((rank, w0, [p.grad.clone() for p in model.parameters()], len(ddp.buckets)))
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    (r0, w0a, g0, nb), (r1, w0b, g1, _) = res
+    assert torch.equal(w0a, w0b), "parameters were not broadcast from rank 0"
+    assert nb >= 2, "expected several buckets"
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, atol=1e-6), "ranks disagree after the all-reduce"
+    # reference: average of the two local gradients with the unused layer zero-filled on rank 0
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4), nn.Linear(4, 4))
+    grads = []
+    for rank in range(2):
+        model.zero_grad()
+        torch.manual_seed(100 + rank)
+        x = torch.randn(5, 8)
+        h = model[2](model[1](model[0](x)))
+        (h.sum() if rank == 0 else model[3](h).sum()).backward()
+        grads.append([torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in model.parameters()])
+    for got, a, b in zip(g0, *grads):
+        assert torch.allclose(got, (a + b) / 2, atol=1e-6)

