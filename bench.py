@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native RetinaUNet hot path.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one full training step of RetinaUNetV001 on one batch of synthetic 160x160x96 patches
+(BASELINE.json configs[1]: Task016_Luna-like plan, batch 4 per GPU, bf16 activations): forward, ATSS target
+assignment, hard-negative sampling, losses, backward, gradient all-reduce (N > 1), SGD(nesterov) step, LR step.
+Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0:
+  metric/value = patches/s (whole job), roofline = dominant conv kernel vs the HBM roofline (HIP-event timed here),
+  cpu_baseline = the CPU oracle ("port" of the reference, plain PyTorch fp32) timed on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def synth_batch(plan, batch, dtype, device, seed):
+    P = plan["patch_size"]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, 1, *P, generator=g).to(device=device, dtype=dtype)
+    rng = np.random.default_rng(seed + 1)
+    boxes, classes = [], []
+    seg = torch.zeros(batch, *P)
+    for b in range(batch):
+        c = rng.uniform(0, 1, (3, 3)) * np.asarray(P)
+        s = rng.uniform(4, 24, (3, 3))
+        lo, hi = np.clip(c - s / 2, 0, None), np.minimum(c + s / 2, np.asarray(P))
+        bb = np.stack([lo[:, 0], lo[:, 1], hi[:, 0], hi[:, 1], lo[:, 2], hi[:, 2]], 1).astype(np.float32)
+        boxes.append(torch.from_numpy(bb).to(device)); classes.append(torch.zeros(3, device=device))
+        for q in bb:
+            seg[b, int(q[0]):int(q[2]) + 1, int(q[1]):int(q[3]) + 1, int(q[4]):int(q[5]) + 1] = 1
+    return x, {"target_boxes": boxes, "target_classes": classes, "target_seg": seg.to(device)}
+
+
+def conv_roofline(plan, batch, dtype, device, iters=10):
+    """Dominant kernel: the 3x3x3 implicit-GEMM conv at full resolution (encoder.stages.0.convs.0.1 and
+    decoder.out.P0 have this shape: 32 -> 32 channels, 135.9 GFLOP per patch each).
+    Algorithmic traffic per launch = read the input once + write the output once."""
+    from nndetection_amd.arch.conv import ConvInstanceRelu
+    P = plan["patch_size"]
+    c = plan["arch"]["start_channels"]
+    m = ConvInstanceRelu(3, c, c, 3, stride=1, padding=1, add_norm=False, add_act=False).to(device)
+    x = torch.randn(batch, c, *P, device=device).to(dtype).contiguous(memory_format=torch.channels_last_3d)
+    with torch.no_grad():
+        for _ in range(3):
+            m(x)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+        ev[0].record()
+        for i in range(iters):
+            m(x)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+    ms = np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(iters)])
+    nvox = batch * P[0] * P[1] * P[2]
+    esz = torch.tensor([], dtype=dtype).element_size()
+    alg_bytes = 2 * nvox * c * esz + 27 * c * c * esz
+    flops = 2.0 * nvox * 27 * c * c
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_igemm<bf16,2,8> conv3d 3x3x3 32->32 @%dx%dx%d, batch %d" % (*P, batch),
+            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+            "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes), "ms_per_launch": round(float(ms), 4),
+            "tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500TF": round(flops / (ms * 1e-3) / 2.5e15, 4)}
+
+
+def nms_rate(device, n=10000, iters=5):
+    from nndetection_amd.core.boxes import nms
+    rng = np.random.default_rng(0)
+    c = rng.uniform(0, 160, (n, 3)); s = rng.uniform(2, 26, (n, 3))
+    b = np.stack([c[:, 0] - s[:, 0] / 2, c[:, 1] - s[:, 1] / 2, c[:, 0] + s[:, 0] / 2, c[:, 1] + s[:, 1] / 2,
+                  c[:, 2] - s[:, 2] / 2, c[:, 2] + s[:, 2] / 2], 1).astype(np.float32)
+    sc = ((rng.permutation(n) + 1) / (n + 1)).astype(np.float32)
+    bt, st = torch.from_numpy(b).to(device), torch.from_numpy(sc).to(device)
+    nms(bt, st, 0.6); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        k = nms(bt, st, 0.6)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"n": n, "thr": 0.6, "kept": int(k.numel()), "boxes_per_s": round(n / dt, 1), "ms": round(dt * 1e3, 3)}
+
+
+def cpu_baseline(plan):
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference, oracle/retina_torch.py) on this host:
+    ONE patch forward + loss + backward (bounded sample of the same workload)."""
+    from oracle.retina_torch import OracleRetinaUNet
+    from nndetection_amd.plans import MODEL_CFG_V001
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
+    x, tg = synth_batch(plan, 1, torch.float32, "cpu", 0)
+    t0 = time.perf_counter()
+    losses, _ = net.train_step(x, tg, evaluation=False)
+    sum(losses.values()).backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "1 patch %dx%dx%d fp32: forward + ATSS + losses + backward of the CPU oracle (%.1f s)" % (*plan["patch_size"], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--plan", default="luna160")
+    ap.add_argument("--batch", type=int, default=None, help="patches per GPU (default: the plan's batch size, 4)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / NMS / CPU legs (only the timed steps)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from nndetection_amd.plans import get_plan
+    from nndetection_amd.ptmodule import build_model, configure_optimizer
+    from nndetection_amd.ddp import GradAllReducer
+
+    plan = get_plan(args.plan)
+    batch = args.batch or plan["batch_size"]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    net = build_model(plan).to(device)
+    opt, sched = configure_optimizer(net)
+    ddp = GradAllReducer(net) if world > 1 else None
+    x, tg = synth_batch(plan, batch, dtype, device, seed=1000 + rank)
+    torch.manual_seed(1234 + rank)
+
+    def step():
+        losses, _ = net.train_step(x, tg, evaluation=False, batch_num=0)
+        loss = sum(losses.values())
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        sched.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(args.warmup):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(last.detach().float().item())
+    peak_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
+
+    if rank == 0:
+        out = {
+            "metric": "patches/sec (fwd+bwd) 160x160x96 RetinaUNet", "value": round(batch * world * args.steps / dt, 3),
+            "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: Task016_Luna-like plan (SURVEY 8), RetinaUNetV001 train step "
+                                   "(fwd + ATSS + losses + bwd + SGD), %dx%dx%d patches" % tuple(plan["patch_size"]),
+                       "plan": args.plan, "batch_per_gpu": batch, "global_batch": batch * world,
+                       "parallelism": "dp%d" % world, "params": sum(p.numel() for p in net.parameters())},
+            "final_loss": round(loss_val, 5), "peak_hbm_gib": round(peak_gb, 2),
+        }
+        if not args.no_extras and world == 1:
+            del x, tg
+            torch.cuda.empty_cache()
+            out["roofline"] = conv_roofline(plan, batch, dtype, device)
+            out["nms"] = nms_rate(device)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(plan)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# One GPU-box session: probes, parity tests (each file in its own process), smoke, bench, rocprof. Everything is
+# written under gpurun_out/ (merged back by gpurun). Usage: tools/gpu_round.sh [stages...]  (default: all)
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+STAGES=${@:-probe boxes conv model smoke bench prof}
+echo "== host: $(nproc) cores; $(rocminfo 2>/dev/null | grep -m1 -E 'gfx9[0-9a-f]+' )" | tee gpurun_out/host.txt
+for s in $STAGES; do
+  case $s in
+    probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/probe_mfma.hip -o /tmp/probe 2>/dev/null && timeout 60 /tmp/probe > gpurun_out/probe.txt 2>&1; head -4 gpurun_out/probe.txt;;
+    boxes) timeout 900 python -m pytest tests/test_boxes_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_boxes.txt 2>&1; tail -25 gpurun_out/t_boxes.txt;;
+    conv)  timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_conv.txt 2>&1; tail -40 gpurun_out/t_conv.txt;;
+    model) timeout 900 python -m pytest tests/test_model_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_model.txt 2>&1; tail -30 gpurun_out/t_model.txt;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.txt 2>&1; tail -5 gpurun_out/smoke.txt;;
+    bench) timeout 1200 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.txt 2>&1; tail -5 gpurun_out/bench.txt;;
+    prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-extras > $OLDPWD/gpurun_out/prof.txt 2>&1); find gpurun_out/prof -name "*kernel_stats*" | head -2; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f";;
+    suite) timeout 1800 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/t_suite.txt 2>&1; tail -8 gpurun_out/t_suite.txt;;
+  esac
+done
