@@ -54,7 +54,7 @@ def _mk(name, dtype, norm=None, act=False):
 def _ref_forward(m, x, cfg, dtype, norm, act):
     """plain torch fp32 on CPU with the same (rounded) operands"""
     _, cin, cout, k, s, p, tr, sp = cfg
-    rd = (lambda t: t.to(dtype).float())
+    rd = (lambda t: t.detach().to(dtype).float().clone())
     w = rd(m.conv.weight.detach()).requires_grad_(True)
     b = m.conv.bias.detach().clone().requires_grad_(True) if m.conv.bias is not None else None
     xr = rd(x).requires_grad_(True)
@@ -62,7 +62,7 @@ def _ref_forward(m, x, cfg, dtype, norm, act):
     g = be = None
     if norm is not None:
         if dtype == torch.bfloat16:
-            y = y.to(dtype).float() + (y - y.detach())          # the kernel normalises the bf16-rounded conv output
+            y = y + (y.to(dtype).float() - y).detach()          # the kernel normalises the bf16-rounded conv output
         g = m.norm.weight.detach().clone().requires_grad_(True)
         be = m.norm.bias.detach().clone().requires_grad_(True)
         if norm == "instance":
@@ -85,7 +85,7 @@ def test_conv_fwd_bwd(name, dtype):
         gy = gy.to(dtype).float()
     yref.backward(gy)
     m = m.cuda()
-    xg = x.cuda().to(dtype).requires_grad_(cfg[1] != 1)
+    xg = x.detach().clone().cuda().to(dtype).requires_grad_(cfg[1] != 1)
     y = m(xg)
     assert y.shape == yref.shape and y.dtype == dtype
     e = relerr(y.float(), yref)
@@ -113,7 +113,7 @@ def test_conv_norm_relu_block(name, norm, dtype):
         gy = gy.to(dtype).float()
     yref.backward(gy)
     m = m.cuda()
-    xg = x.cuda().to(dtype).requires_grad_(cfg[1] != 1)
+    xg = x.detach().clone().cuda().to(dtype).requires_grad_(cfg[1] != 1)
     y = m(xg)
     ft = 2e-5 if dtype == torch.float32 else 1.2e-2
     gt = 1e-4 if dtype == torch.float32 else 3e-2
@@ -137,13 +137,13 @@ def test_segloss(dtype):
                             dice_kwargs={"batch_dice": True})
     x = torch.randn(2, 32, 8, 9, 10)
     tgt = (torch.rand(2, 8, 9, 10) > 0.8).float() * 3
-    rd = lambda t_: t_.to(dtype).float()
+    rd = lambda t_: t_.detach().to(dtype).float().clone()
     xr = rd(x).requires_grad_(True)
     w = rd(seg.conv_out.conv.weight.detach()).requires_grad_(True)
     b = seg.conv_out.conv.bias.detach().clone().requires_grad_(True)
     sl = F.conv3d(xr, w, b)
     if dtype == torch.bfloat16:
-        sl = sl.to(dtype).float() + (sl - sl.detach())
+        sl = sl + (sl.to(dtype).float() - sl).detach()
     t = (tgt > 0).long()
     ce = 0.5 * F.cross_entropy(sl, t)
     p = torch.softmax(sl, 1)
@@ -153,7 +153,7 @@ def test_segloss(dtype):
     dice = 0.5 * (1 - ((2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5))[1:].mean())
     (ce + dice).backward()
     seg = seg.cuda()
-    xg = x.cuda().to(dtype).requires_grad_(True)
+    xg = x.detach().clone().cuda().to(dtype).requires_grad_(True)
     out = seg.compute_loss(seg([xg]), tgt.cuda())
     assert abs(out["seg_ce"].item() - ce.item()) < 2e-5 and abs(out["seg_dice"].item() - dice.item()) < 2e-5, (out, ce, dice)
     (out["seg_ce"] + out["seg_dice"]).backward()
