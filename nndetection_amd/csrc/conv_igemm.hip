@@ -61,7 +61,8 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, f
 __device__ __forceinline__ float round_to(float v, float*) { return v; }
 __device__ __forceinline__ float round_to(float v, bf16_t*) { return bf16_to_f32(f32_to_bf16(v)); }
 
-#define IG_MAXP 24   // max 16-byte halo pieces per thread per chunk (=> halo <= 1536 voxels = 96 KiB)
+// max 16-byte halo pieces per thread per chunk: 16 (halo <= 1024 voxels = 64 KiB) for unit-stride tiles,
+// 24 (<= 1536 voxels = 96 KiB) for the strided configurations (template parameter MAXP)
 
 struct IgClass {
     int32_t out_off[3];
@@ -85,7 +86,7 @@ struct IgArgs {
     IgTap taps[27];
 };
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, int MAXP>
 __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     const T* xn = reinterpret_cast<const T*>(A.x) + (int64_t)n * A.I[0] * A.I[1] * A.I[2] * A.Cx;
 
     // global element offsets of this thread's halo pieces (identical for every channel chunk)
-    int32_t goff[IG_MAXP];
+    int32_t goff[MAXP];
 #pragma unroll
-    for (int s = 0; s < IG_MAXP; ++s) {
+    for (int s = 0; s < MAXP; ++s) {
         const int p = tid + s * 256;
         int32_t o = -1;
         if (p < HV4) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     for (int kc = 0; kc < nchunk; ++kc) {
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < IG_MAXP; ++s) {
+        for (int s = 0; s < MAXP; ++s) {
             const int p = tid + s * 256;
             if (p < HV4) {
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
@@ -160,15 +161,25 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
             }
         }
         __syncthreads();
-        for (int tp = 0; tp < C.ntap; ++tp) {
+        // software pipeline over the taps: the fragments of tap tp+1 (weights from L1/L2, activations from LDS)
+        // are in flight while the MFMAs of tap tp issue
+        u32x4 af[MT], bf[NT], afn[MT], bfn[NT];
+        auto load_tap = [&](int tp, u32x4* a_, u32x4* b_) {
             const IgTap& tap = A.taps[C.tap0 + tp];
             const int toff = ((tap.d[0] * HH + tap.d[1]) * HW + tap.d[2]) * 64;
             const T* wt = wl + ((int64_t)tap.wt * A.Cy) * A.Cx + kc * KC;
-            u32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4*>(wt + (int64_t)i * 16 * A.Cx);
+            for (int i = 0; i < MT; ++i) a_[i] = *reinterpret_cast<const u32x4*>(wt + (int64_t)i * 16 * A.Cx);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + boff[j] + toff);
+            for (int j = 0; j < NT; ++j) b_[j] = *reinterpret_cast<const u32x4*>(smem + boff[j] + toff);
+        };
+        if (C.ntap > 0) load_tap(0, afn, bfn);
+        for (int tp = 0; tp < C.ntap; ++tp) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = afn[i];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = bfn[j];
+            if (tp + 1 < C.ntap) load_tap(tp + 1, afn, bfn);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -245,7 +256,7 @@ struct Plan {
 static const int CFG_MT[4] = {2, 4, 4, 2};
 static const int CFG_NT[4] = {8, 4, 2, 2};
 
-static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[3], int points, int T[3], int H[3]) {
+static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[3], int points, int maxp, int T[3], int H[3]) {
     double best = 1e300;
     bool found = false;
     for (int td = 1; td <= points; td *= 2)
@@ -261,7 +272,7 @@ static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[
                 hv *= h[a];
                 padded *= (double)ceil_div(Lmax[a], t[a]) * t[a];
             }
-            if (hv * 4 > 256 * IG_MAXP) continue;
+            if (hv * 4 > 256 * maxp) continue;
             const double cost = padded * (1.0 + 0.15 * (double)hv / points);   // padding waste first, halo amplification second
             if (cost < best) { best = cost; found = true; for (int a = 0; a < 3; ++a) { T[a] = t[a]; H[a] = h[a]; } }
         }
@@ -356,7 +367,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     P->cfg = strided ? (r64 ? 2 : 3) : (r64 ? 1 : 0);
     const int points = 4 * CFG_NT[P->cfg] * 16;
     for (int i = 0; i < 3; ++i) if (Lmax[i] <= 0) return NNDET_EINVAL;
-    if (!choose_tile(Lmax, a.in_step, span, points, a.T, a.H)) return NNDET_EINVAL;
+    if (!choose_tile(Lmax, a.in_step, span, points, strided ? 24 : 16, a.T, a.H)) return NNDET_EINVAL;
     for (int i = 0; i < 3; ++i) a.nt[i] = ceil_div(Lmax[i], a.T[i]);
     P->grid = dim3(a.nt[0] * a.nt[1] * a.nt[2], a.Cy / (CFG_MT[P->cfg] * 16), a.N * a.ncls);
     P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64;
@@ -367,26 +378,26 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
 template <typename T>
 static int launch_cfg(const Plan& P, hipStream_t st) {
     switch (P.cfg) {
-        case 0: k_igemm<T, 2, 8><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 1: k_igemm<T, 4, 4><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 2: k_igemm<T, 4, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        default: k_igemm<T, 2, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 0: k_igemm<T, 2, 8, 16><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 1: k_igemm<T, 4, 4, 16><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 2: k_igemm<T, 4, 2, 24><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        default: k_igemm<T, 2, 2, 24><<<P.grid, 256, P.lds, st>>>(P.a); break;
     }
     LAUNCH_CHECK();
     return 0;
 }
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, int MAXP>
 static int set_lds_attr() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, MT, NT>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, MT, NT, MAXP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 }
 static int g_attr_done = 0;
 static int ensure_attrs() {
     if (g_attr_done) return 0;
     int rc = 0;
-    rc |= set_lds_attr<bf16_t, 2, 8>(); rc |= set_lds_attr<bf16_t, 4, 4>(); rc |= set_lds_attr<bf16_t, 4, 2>(); rc |= set_lds_attr<bf16_t, 2, 2>();
-    rc |= set_lds_attr<float, 2, 8>(); rc |= set_lds_attr<float, 4, 4>(); rc |= set_lds_attr<float, 4, 2>(); rc |= set_lds_attr<float, 2, 2>();
+    rc |= set_lds_attr<bf16_t, 2, 8, 16>(); rc |= set_lds_attr<bf16_t, 4, 4, 16>(); rc |= set_lds_attr<bf16_t, 4, 2, 24>(); rc |= set_lds_attr<bf16_t, 2, 2, 24>();
+    rc |= set_lds_attr<float, 2, 8, 16>(); rc |= set_lds_attr<float, 4, 4, 16>(); rc |= set_lds_attr<float, 4, 2, 24>(); rc |= set_lds_attr<float, 2, 2, 24>();
     if (rc) return rc;
     g_attr_done = 1;
     return 0;

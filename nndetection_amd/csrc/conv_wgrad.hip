@@ -5,10 +5,10 @@
 //     ConvTranspose3d:  P = X  (rows r = Cin),  Q = dY (k = Cout), lattice = input grid,  step = stride (= kernel)
 //
 // The contraction runs over VOXELS, but NDHWC keeps channels contiguous, so the MFMA operands (which want
-// the contraction index contiguous per lane) need a transposition. v1 does it on the LDS read side: tiles
-// are staged [voxel][32 channels] (+ padding that makes the strided 2-/4-byte reads bank-conflict free) and
-// each lane gathers its 8 contraction values with scalar LDS reads. (A ds_read_b64_tr_b16 / write-side
-// transposed variant is the planned v2; see DESIGN.md.)
+// the contraction index contiguous per lane) need a transposition. It happens on the LDS read side: tiles
+// are staged [voxel][32 channels] (+ 32/64 B of padding per 8-voxel row so the q-groups of a wave hit disjoint
+// banks); bf16 fragments are fetched with gfx950's transpose read ds_read_b64_tr_b16 (2 per fragment, voxel
+// offset free per lane, so the 27 tap shifts need no shifted copies), fp32 fragments with scalar reads.
 //
 // Workgroup = 4 waves, owns a 32(r) x 32(k) block of dW for ALL taps and loops over a slice of the
 // spatial tiles (TD x TH x 8 lattice points, halo of Q staged once and shared by all taps). Waves split
@@ -39,21 +39,35 @@ struct WgArgs {
     WgTap taps[27];
 };
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+// One MFMA operand fragment = this lane's 8 contraction values (8 consecutive lattice points of its q-group's run)
+// of channel (tile base + li). `run0` points at [first voxel of the run][first channel of the 16-channel tile],
+// `vstride` = bytes between consecutive voxels of the run.
 template <typename T> struct WF;
 template <> struct WF<bf16_t> {
-    uint32_t v[4];
-    __device__ __forceinline__ void set(int j, const char* p) {
-        const uint32_t e = *reinterpret_cast<const uint16_t*>(p);
-        if (j & 1) v[j >> 1] |= e << 16; else v[j >> 1] = e;
+    u32x4 v;
+    // bf16: the LDS transpose read (ds_read_b64_tr_b16, layout verified by tools/probe_mfma.hip): the 16 lanes of a
+    // q-group each fetch 8 bytes (4 channels of voxel li>>2) and receive, transposed, 4 voxels of channel li.
+    // Two reads (voxels 0-3, 4-7) replace 8 scalar LDS reads; the voxel offset is per lane, so tap shifts cost nothing.
+    __device__ __forceinline__ void load(const char* run0, int vstride, int li) {
+        const char* p = run0 + (li >> 2) * vstride + (li & 3) * 8;
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * vstride));
+        const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+        v = u32x4{ua.x, ua.y, ub.x, ub.y};
     }
     __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) {
-        const u32x4 ua = {a.v[0], a.v[1], a.v[2], a.v[3]}, ub = {b.v[0], b.v[1], b.v[2], b.v[3]};
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
     }
 };
 template <> struct WF<float> {
     float v[8];
-    __device__ __forceinline__ void set(int j, const char* p) { v[j] = *reinterpret_cast<const float*>(p); }
+    __device__ __forceinline__ void load(const char* run0, int vstride, int li) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(run0 + j * vstride + li * 4);
+    }
     __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
@@ -175,26 +189,20 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
             WF<T> pf[2];
             {
                 const int tr = ks * 4 + q;
-                const char* b0 = sp + (tr * 8) * RB + tr * (RB / 2) + li * (int)sizeof(T);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    pf[0].set(j, b0 + j * RB);
-                    pf[1].set(j, b0 + j * RB + 16 * (int)sizeof(T));
-                }
+                const char* b0 = sp + (tr * 8) * RB + tr * (RB / 2);
+                pf[0].load(b0, RB, li);
+                pf[1].load(b0 + 16 * (int)sizeof(T), RB, li);
             }
 #pragma unroll
             for (int ts = 0; ts < WG_MAXT; ++ts) {
                 if (ts < nslots) {
                     const WgTap& tap = A.taps[split_taps ? wv + ts * 4 : ts];
                     const int hrow = qrow0[ks] + tap.d[0] * H1 + tap.d[1];
-                    const char* b0 = sq + hrow * QROW + tap.d[2] * RB + li * (int)sizeof(T);
+                    const char* b0 = sq + hrow * QROW + tap.d[2] * RB;
                     const int wstep = A.step[2] * RB;
                     WF<T> qf[2];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        qf[0].set(j, b0 + j * wstep);
-                        qf[1].set(j, b0 + j * wstep + 16 * (int)sizeof(T));
-                    }
+                    qf[0].load(b0, wstep, li);
+                    qf[1].load(b0 + 16 * (int)sizeof(T), wstep, li);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -14,7 +14,7 @@ for s in $STAGES; do
     model) timeout 900 python -m pytest tests/test_model_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_model.txt 2>&1; tail -30 gpurun_out/t_model.txt;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.txt 2>&1; tail -5 gpurun_out/smoke.txt;;
     bench) timeout 1200 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.txt 2>&1; tail -5 gpurun_out/bench.txt;;
-    prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-extras > $OLDPWD/gpurun_out/prof.txt 2>&1); find gpurun_out/prof -name "*kernel_stats*" | head -2; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f";;
+    prof)  rm -rf gpurun_out/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-extras > $OLDPWD/gpurun_out/prof.txt 2>&1); db=$(find gpurun_out/prof -name "*_results.db" | head -1); [ -n "$db" ] && python tools/rocpd_stats.py "$db" 3 > gpurun_out/kernel_stats.txt && head -22 gpurun_out/kernel_stats.txt | cut -c1-170; rm -rf gpurun_out/prof_old; true;;
     suite) timeout 1800 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/t_suite.txt 2>&1; tail -8 gpurun_out/t_suite.txt;;
   esac
 done
