@@ -151,13 +151,22 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     const int nchunk = A.Cx / KC;
     for (int kc = 0; kc < nchunk; ++kc) {
         __syncthreads();
+        // Stage the halo in batches of 8 UNCONDITIONAL 16-byte loads per thread (out-of-tensor pieces load a clamped,
+        // valid address and are zeroed afterwards): all loads of a batch are in flight together. A conditional load per
+        // piece makes hipcc branch + wait vmcnt(0) per piece, i.e. 16-24 serial HBM round trips per chunk.
 #pragma unroll
-        for (int s = 0; s < MAXP; ++s) {
-            const int p = tid + s * 256;
-            if (p < HV4) {
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (goff[s] >= 0) v = *reinterpret_cast<const u32x4*>(xn + goff[s] + kc * KC);
-                *reinterpret_cast<u32x4*>(smem + p * 16) = v;
+        for (int s0 = 0; s0 < MAXP; s0 += 8) {
+            if (s0 * 256 >= HV4) break;   // uniform
+            u32x4 v[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int o = goff[s0 + b];
+                v[b] = *reinterpret_cast<const u32x4*>(xn + (o < 0 ? 0 : o) + kc * KC);
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int p = tid + (s0 + b) * 256;
+                if (p < HV4) *reinterpret_cast<u32x4*>(smem + p * 16) = goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
             }
         }
         __syncthreads();

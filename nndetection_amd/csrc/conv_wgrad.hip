@@ -157,29 +157,41 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
         __syncthreads();
         const T* pn = pbase + (int64_t)n * A.PL[0] * A.PL[1] * A.PL[2] * A.Cp + r0;
         const T* qn = qbase_ptr + (int64_t)n * A.QD[0] * A.QD[1] * A.QD[2] * A.Cq + k0;
+        // Batches of 8 UNCONDITIONAL 16-byte loads per thread (invalid pieces read a clamped address and are zeroed
+        // afterwards) so that a whole batch is in flight at once; conditional loads would serialise into one HBM
+        // round trip per piece.
+        {
+            u32x4 v[WG_MAXP];
+            bool ok[WG_MAXP];
 #pragma unroll
-        for (int s = 0; s < WG_MAXP; ++s) {
-            if (prel[s] >= 0) {
-                const int ld = l0d + ((prel[s] >> 18) & 511), lh = l0h + ((prel[s] >> 9) & 511), lw = l0w + (prel[s] & 511);
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2]) {
-                    const int part = prel[s] >> 27;
-                    v = *reinterpret_cast<const u32x4*>(pn + ((int64_t)(ld * A.PL[1] + lh) * A.PL[2] + lw) * A.Cp + part * E16);
-                }
-                *reinterpret_cast<u32x4*>(sp + pdst[s]) = v;
+            for (int s = 0; s < WG_MAXP; ++s) {
+                const int r = prel[s] < 0 ? 0 : prel[s];
+                const int ld = l0d + ((r >> 18) & 511), lh = l0h + ((r >> 9) & 511), lw = l0w + (r & 511);
+                ok[s] = prel[s] >= 0 && ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2];
+                const int64_t off = ok[s] ? ((int64_t)(ld * A.PL[1] + lh) * A.PL[2] + lw) * A.Cp + (r >> 27) * E16 : 0;
+                v[s] = *reinterpret_cast<const u32x4*>(pn + off);
             }
+#pragma unroll
+            for (int s = 0; s < WG_MAXP; ++s)
+                if (prel[s] >= 0) *reinterpret_cast<u32x4*>(sp + pdst[s]) = ok[s] ? v[s] : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
-        for (int s = 0; s < WG_MAXQ; ++s) {
-            if (qrel[s] >= 0) {
-                const int qd = q0d + ((qrel[s] >> 18) & 511), qh = q0h + ((qrel[s] >> 9) & 511), qw = q0w + (qrel[s] & 511);
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if ((unsigned)qd < (unsigned)A.QD[0] && (unsigned)qh < (unsigned)A.QD[1] && (unsigned)qw < (unsigned)A.QD[2]) {
-                    const int part = qrel[s] >> 27;
-                    v = *reinterpret_cast<const u32x4*>(qn + ((int64_t)(qd * A.QD[1] + qh) * A.QD[2] + qw) * A.Cq + part * E16);
-                }
-                *reinterpret_cast<u32x4*>(sq + qdst[s]) = v;
+        for (int s0 = 0; s0 < WG_MAXQ; s0 += 8) {
+            if (s0 * 256 >= NQP) break;   // uniform
+            u32x4 v[8];
+            bool ok[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int rel = qrel[s0 + b];
+                const int r = rel < 0 ? 0 : rel;
+                const int qd = q0d + ((r >> 18) & 511), qh = q0h + ((r >> 9) & 511), qw = q0w + (r & 511);
+                ok[b] = rel >= 0 && (unsigned)qd < (unsigned)A.QD[0] && (unsigned)qh < (unsigned)A.QD[1] && (unsigned)qw < (unsigned)A.QD[2];
+                const int64_t off = ok[b] ? ((int64_t)(qd * A.QD[1] + qh) * A.QD[2] + qw) * A.Cq + (r >> 27) * E16 : 0;
+                v[b] = *reinterpret_cast<const u32x4*>(qn + off);
             }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (qrel[s0 + b] >= 0) *reinterpret_cast<u32x4*>(sq + qdst[s0 + b]) = ok[b] ? v[b] : u32x4{0u, 0u, 0u, 0u};
         }
         __syncthreads();
 #pragma unroll
