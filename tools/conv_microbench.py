@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single convolution problems of the RetinaUNet (forward / data gradient / weight gradient),
+HIP-event timed. Usage: tools/conv_microbench.py [name ...]   (default: the layer shapes that dominate config 2)."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from nndetection_amd import _lib as L
+from nndetection_amd.arch.conv import ConvInstanceRelu, _desc, _packed
+from nndetection_amd.layout import cpad
+
+# name: (cin, cout, k, s, p, transposed, spatial, batch)
+SHAPES = {
+    "e0_32x32_full": (32, 32, 3, 1, 1, False, (160, 160, 96), 4),
+    "e1_64x64": (64, 64, 3, 1, 1, False, (80, 80, 48), 4),
+    "p2_128x128": (128, 128, 3, 1, 1, False, (40, 40, 24), 4),
+    "e1_32to64_s2": (32, 64, 3, 2, 1, False, (160, 160, 96), 4),
+    "up_p1_64to32": (64, 32, 2, 2, 0, True, (80, 80, 48), 4),
+    "lat_p0_1x1": (32, 32, 1, 1, 0, False, (160, 160, 96), 4),
+    "head_reg_out": (128, 162, 3, 1, 1, False, (40, 40, 24), 4),
+    "e3_256x256": (256, 256, 3, 1, 1, False, (20, 20, 12), 4),
+}
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(SHAPES)
+    iters = 5
+    dt = torch.bfloat16
+    for name in names:
+        cin, cout, k, s, p, tr, sp, B = SHAPES[name]
+        m = ConvInstanceRelu(3, cin, cout, k, stride=s, padding=p, transposed=tr, add_norm=False, add_act=False).cuda()
+        x = torch.randn(B, *sp, cpad(cin), device="cuda").to(dt)
+        d = _desc(x, cin, cout, m.k, m.s, m.p, tr)
+        w0 = _packed(m, 0, m.conv.weight, d, dt); w1 = _packed(m, 1, m.conv.weight, d, dt)
+        y = torch.empty(B, d.out_d, d.out_h, d.out_w, d.cout_p, dtype=dt, device="cuda")
+        dy = torch.randn_like(y); dx = torch.empty_like(x)
+        dw = torch.zeros_like(m.conv.weight)
+        st = L.stream()
+        f = lambda: L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, L.ptr(y), None, st)
+        g = lambda: L.call("nndet_conv3d_backward_data", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx), st)
+        h = lambda: L.call("nndet_conv3d_backward_weight", ctypes.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), None, st)
+        nvox_out = B * d.out_d * d.out_h * d.out_w
+        taps = m.k[0] * m.k[1] * m.k[2]
+        flops = 2.0 * (B * sp[0] * sp[1] * sp[2] if tr else nvox_out) * taps * cin * cout
+        byts = 2.0 * (x.numel() + y.numel())
+        res = []
+        for nm, fn in (("fwd", f), ("dgrad", g), ("wgrad", h)):
+            ms = timeit(fn, iters)
+            res.append(f"{nm} {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF/s {byts / ms / 1e6:7.0f} GB/s")
+        print(f"{name:16s} {flops / 1e9:7.1f} GF {byts / 1e6:7.0f} MB | " + " | ".join(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
