@@ -36,6 +36,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// packed conversion of two floats with the hardware instruction v_cvt_pk_bf16_f32 (round-to-nearest-even):
+// one VALU op instead of a ~10-instruction software rounding with a NaN branch
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     __device__ static __forceinline__ float ld(float v) { return v; }

@@ -48,18 +48,19 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
-template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+// stores 4 consecutive channels and returns (through a..d) the values as stored (i.e. rounded to T)
+template <typename T> __device__ __forceinline__ void store4r(T* p, float& a, float& b, float& c, float& d);
+template <> __device__ __forceinline__ void store4r<float>(float* p, float& a, float& b, float& c, float& d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+template <> __device__ __forceinline__ void store4r<bf16_t>(bf16_t* p, float& a, float& b, float& c, float& d) {
     uint2 v;
-    v.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-    v.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+    v.x = pack_bf16x2(a, b);
+    v.y = pack_bf16x2(c, d);
     *reinterpret_cast<uint2*>(p) = v;
+    a = __uint_as_float(v.x << 16); b = __uint_as_float(v.x & 0xffff0000u);
+    c = __uint_as_float(v.y << 16); d = __uint_as_float(v.y & 0xffff0000u);
 }
-__device__ __forceinline__ float round_to(float v, float*) { return v; }
-__device__ __forceinline__ float round_to(float v, bf16_t*) { return bf16_to_f32(f32_to_bf16(v)); }
 
 // max 16-byte halo pieces per thread per chunk: 16 (halo <= 1024 voxels = 64 KiB) for unit-stride tiles,
 // 24 (<= 1536 voxels = 96 KiB) for the strided configurations (template parameter MAXP)
@@ -81,6 +82,9 @@ struct IgArgs {
     int32_t T[3];         // lattice tile
     int32_t nt[3];        // tiles per axis
     int32_t H[3];         // halo dims (max over classes)
+    uint32_t mHW, mHH;    // magic multipliers: n / H[2] == umulhi(n, mHW), n / H[1] == umulhi(n, mHH) (0 = divisor 1)
+    int32_t lT1, lT2;     // log2 of the (power-of-two) tile dims T[1], T[2]
+    int32_t swz;          // 1: XOR LDS byte-offset bit 5 with the parity of the halo row (conflict-free ds_read_b128 for unit-stride tiles)
     int32_t ncls;
     IgClass cls[8];
     IgTap taps[27];
@@ -114,15 +118,19 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
 
     // global element offsets of this thread's halo pieces (identical for every channel chunk)
     int32_t goff[MAXP];
+    uint32_t swmask = 0;   // bit s: parity of the halo row of piece s (LDS swizzle)
 #pragma unroll
     for (int s = 0; s < MAXP; ++s) {
         const int p = tid + s * 256;
         int32_t o = -1;
         if (p < HV4) {
+            // no integer division on the GPU: magic-multiplier division by the (runtime) halo dims
             const int hv = p >> 2, part = p & 3;
-            const int hw = hv % HW;
-            const int t2 = hv / HW;
-            const int hh = t2 % HH, hd = t2 / HH;
+            const int t2 = A.mHW ? (int)__umulhi((unsigned)hv, A.mHW) : hv;
+            const int hw = hv - t2 * HW;
+            const int hd = A.mHH ? (int)__umulhi((unsigned)t2, A.mHH) : t2;
+            const int hh = t2 - hd * HH;
+            swmask |= (uint32_t)(t2 & A.swz) << s;
             const int id = i0d + hd, ih = i0h + hh, iw = i0w + hw;
             if ((unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
                 o = ((id * A.I[1] + ih) * A.I[2] + iw) * A.Cx + part * EPL;
@@ -135,11 +143,12 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int p = (wv * NT + j) * 16 + li;
-        const int pw = p % A.T[2];
-        const int t2 = p / A.T[2];
-        const int ph = t2 % A.T[1], pd = t2 / A.T[1];
+        const int pw = p & (A.T[2] - 1);
+        const int t2 = p >> A.lT2;
+        const int ph = t2 & (A.T[1] - 1), pd = t2 >> A.lT1;
         pd_[j] = pd; ph_[j] = ph; pw_[j] = pw;
-        boff[j] = (((pd * A.in_step[0]) * HH + ph * A.in_step[1]) * HW + pw * A.in_step[2]) * 64 + q * 16;
+        const int brow = (pd * A.in_step[0]) * HH + ph * A.in_step[1];
+        boff[j] = ((brow * HW + pw * A.in_step[2]) * 64 + q * 16) ^ ((brow & A.swz) << 5);
     }
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -166,7 +175,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int p = tid + (s0 + b) * 256;
-                if (p < HV4) *reinterpret_cast<u32x4*>(smem + p * 16) = goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
+                if (p < HV4)
+                    *reinterpret_cast<u32x4*>(smem + ((p * 16) ^ (((swmask >> (s0 + b)) & 1u) << 5))) =
+                        goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
             }
         }
         __syncthreads();
@@ -175,12 +186,14 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
         u32x4 af[MT], bf[NT], afn[MT], bfn[NT];
         auto load_tap = [&](int tp, u32x4* a_, u32x4* b_) {
             const IgTap& tap = A.taps[C.tap0 + tp];
-            const int toff = ((tap.d[0] * HH + tap.d[1]) * HW + tap.d[2]) * 64;
+            const int trow = tap.d[0] * HH + tap.d[1];
+            const int toff = (trow * HW + tap.d[2]) * 64;
+            const int flip = (trow & A.swz) << 5;      // row parity of the tap flips the swizzle bit
             const T* wt = wl + ((int64_t)tap.wt * A.Cy) * A.Cx + kc * KC;
 #pragma unroll
             for (int i = 0; i < MT; ++i) a_[i] = *reinterpret_cast<const u32x4*>(wt + (int64_t)i * 16 * A.Cx);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b_[j] = *reinterpret_cast<const u32x4*>(smem + boff[j] + toff);
+            for (int j = 0; j < NT; ++j) b_[j] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ flip) + toff));
         };
         if (C.ntap > 0) load_tap(0, afn, bfn);
         for (int tp = 0; tp < C.ntap; ++tp) {
@@ -217,10 +230,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
                 const int r0 = row0 + i * 16 + q * 4;
                 float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
                 if (A.bias) { v0 += A.bias[r0]; v1 += A.bias[r0 + 1]; v2 += A.bias[r0 + 2]; v3 += A.bias[r0 + 3]; }
-                store4<T>(yo + r0, v0, v1, v2, v3);
+                store4r<T>(yo + r0, v0, v1, v2, v3);
                 if (A.stats) {
-                    v0 = round_to(v0, (T*)nullptr); v1 = round_to(v1, (T*)nullptr);
-                    v2 = round_to(v2, (T*)nullptr); v3 = round_to(v3, (T*)nullptr);
                     ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
                     ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
                 }
@@ -378,6 +389,11 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     for (int i = 0; i < 3; ++i) if (Lmax[i] <= 0) return NNDET_EINVAL;
     if (!choose_tile(Lmax, a.in_step, span, points, strided ? 24 : 16, a.T, a.H)) return NNDET_EINVAL;
     for (int i = 0; i < 3; ++i) a.nt[i] = ceil_div(Lmax[i], a.T[i]);
+    auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); };
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    a.mHW = magic(a.H[2]); a.mHH = magic(a.H[1]);
+    a.lT1 = ilog2(a.T[1]); a.lT2 = ilog2(a.T[2]);
+    a.swz = strided ? 0 : 1;
     P->grid = dim3(a.nt[0] * a.nt[1] * a.nt[2], a.Cy / (CFG_MT[P->cfg] * 16), a.N * a.ncls);
     P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64;
     if (P->lds < 1024) P->lds = 1024;   // room for the stats reduction

@@ -21,10 +21,10 @@ template <> __device__ __forceinline__ void store_row32<bf16_t>(bf16_t* p, const
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint4 u;
-        u.x = (uint32_t)f32_to_bf16(v[8 * i + 0]) | ((uint32_t)f32_to_bf16(v[8 * i + 1]) << 16);
-        u.y = (uint32_t)f32_to_bf16(v[8 * i + 2]) | ((uint32_t)f32_to_bf16(v[8 * i + 3]) << 16);
-        u.z = (uint32_t)f32_to_bf16(v[8 * i + 4]) | ((uint32_t)f32_to_bf16(v[8 * i + 5]) << 16);
-        u.w = (uint32_t)f32_to_bf16(v[8 * i + 6]) | ((uint32_t)f32_to_bf16(v[8 * i + 7]) << 16);
+        u.x = pack_bf16x2(v[8 * i + 0], v[8 * i + 1]);
+        u.y = pack_bf16x2(v[8 * i + 2], v[8 * i + 3]);
+        u.z = pack_bf16x2(v[8 * i + 4], v[8 * i + 5]);
+        u.w = pack_bf16x2(v[8 * i + 6], v[8 * i + 7]);
         reinterpret_cast<uint4*>(p)[i] = u;
     }
 }

@@ -10,18 +10,19 @@
 // banks); bf16 fragments are fetched with gfx950's transpose read ds_read_b64_tr_b16 (2 per fragment, voxel
 // offset free per lane, so the 27 tap shifts need no shifted copies), fp32 fragments with scalar reads.
 //
-// Workgroup = 4 waves, owns a 32(r) x 32(k) block of dW for ALL taps and loops over a slice of the
-// spatial tiles (TD x TH x 8 lattice points, halo of Q staged once and shared by all taps). Waves split
-// the taps (>= 4 taps) or the contraction steps (< 4 taps). Accumulators stay in registers for the whole
-// slice; the slice result is added to dW (PyTorch layout, fp32) with atomics.
+// Workgroup = 4 waves (one per SIMD, up to 512 registers each), owns a 32(r) x 32(k) block of dW for ALL taps
+// and loops over a slice of the spatial tiles (TD x TH x 8 lattice points, halo of Q staged once and shared by
+// all taps). Waves split the taps (>= 4 taps) or the contraction steps (< 4 taps). Accumulators stay in
+// registers for the whole slice; the slice result is added to dW (PyTorch layout, fp32) with atomics.
+// Software pipeline (bf16): the global loads of tile t+1 are issued into registers BEFORE the MFMA phase of
+// tile t and written to LDS after it, so HBM/L2 latency hides behind the matrix work (the kernel was
+// wait-bound: SQ_WAIT_ANY 52 %, MFMA busy 6.6 % without it, profiles/round1_pmc_*.txt).
 #include "common.h"
 #include "conv_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define WG_MAXT 7    // tap slots per wave
-#define WG_MAXQ 24   // Q halo pieces per thread
-#define WG_MAXP 8    // P tile pieces per thread
 
 struct WgTap { int32_t d[3]; int32_t wt; };
 struct WgArgs {
@@ -36,6 +37,8 @@ struct WgArgs {
     int32_t R, K;
     int64_t sr, sk;
     int32_t ntap, total_tiles;
+    uint32_t mH2, mH1;    // magic multipliers for / H[2], / H[1] (0 = divisor 1)
+    int32_t lTH;          // log2(TH)
     WgTap taps[27];
 };
 
@@ -74,7 +77,7 @@ template <> struct WF<float> {
     }
 };
 
-template <typename T, int KS>
+template <typename T, int KS, int MAXP, int MAXQ, bool PF>
 __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     constexpr int RB = 32 * (int)sizeof(T);      // bytes of one voxel's 32-channel block
     constexpr int PPV = RB / 16;                  // 16-byte pieces per voxel
@@ -93,30 +96,32 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     const int TH = A.TH;
 
     // ---- per-thread staging descriptors (relative to the tile origin; no divisions in the tile loop)
-    int32_t qrel[WG_MAXQ];   // part << 27 | hd << 18 | hh << 9 | hw ; -1 = no piece
-    int32_t qdst[WG_MAXQ];
+    int32_t qrel[MAXQ];   // part << 27 | hd << 18 | hh << 9 | hw ; -1 = no piece
+    int32_t qdst[MAXQ];
 #pragma unroll
-    for (int s = 0; s < WG_MAXQ; ++s) {
+    for (int s = 0; s < MAXQ; ++s) {
         const int pp = tid + s * 256;
         int32_t rel = -1, dst = 0;
         if (pp < NQP) {
             const int hv = pp / PPV, part = pp % PPV;
-            const int hw = hv % H2, row = hv / H2;
-            const int hh = row % H1, hd = row / H1;
+            const int row = A.mH2 ? (int)__umulhi((unsigned)hv, A.mH2) : hv;
+            const int hw = hv - row * H2;
+            const int hd = A.mH1 ? (int)__umulhi((unsigned)row, A.mH1) : row;
+            const int hh = row - hd * H1;
             rel = (part << 27) | (hd << 18) | (hh << 9) | hw;
             dst = row * QROW + hw * RB + part * 16;
         }
         qrel[s] = rel; qdst[s] = dst;
     }
-    int32_t prel[WG_MAXP], pdst[WG_MAXP];
+    int32_t prel[MAXP], pdst[MAXP];
 #pragma unroll
-    for (int s = 0; s < WG_MAXP; ++s) {
+    for (int s = 0; s < MAXP; ++s) {
         const int pp = tid + s * 256;
         int32_t rel = -1, dst = 0;
         if (pp < POINTS * PPV) {
             const int pt = pp / PPV, part = pp % PPV;
             const int tr = pt >> 3, pw = pt & 7;
-            const int pd = tr / TH, ph = tr % TH;
+            const int pd = tr >> A.lTH, ph = tr & (TH - 1);
             rel = (part << 27) | (pd << 18) | (ph << 9) | pw;
             dst = pt * RB + tr * (RB / 2) + part * 16;
         }
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int tr = ks * 4 + q;
-        const int pd = tr / TH, ph = tr % TH;
+        const int pd = tr >> A.lTH, ph = tr & (TH - 1);
         qrow0[ks] = (pd * A.step[0]) * H1 + ph * A.step[1];
     }
     // ---- work split between the waves
@@ -146,7 +151,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     const T* qbase_ptr = reinterpret_cast<const T*>(A.q);
     const int tiles_per_n = A.nt[0] * A.nt[1] * A.nt[2];
 
-    for (int tile = blockIdx.x; tile < A.total_tiles; tile += gridDim.x) {
+    // staging registers: all loads of a tile are UNCONDITIONAL (invalid pieces read a clamped address and are
+    // zeroed at commit) so that they are in flight together; a conditional load per piece would serialise
+    // into one HBM round trip each.
+    u32x4 vp[MAXP], vq[MAXQ];
+    uint32_t okp = 0, okq = 0;
+
+    auto issue = [&](int tile) {
         const int n = tile / tiles_per_n;
         int tt = tile - n * tiles_per_n;
         const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
@@ -154,46 +165,41 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
         const int td_i = tt / A.nt[1];
         const int l0d = td_i * A.TD, l0h = th_i * TH, l0w = tw_i * 8;
         const int q0d = l0d * A.step[0] + A.qbase[0], q0h = l0h * A.step[1] + A.qbase[1], q0w = l0w * A.step[2] + A.qbase[2];
-        __syncthreads();
         const T* pn = pbase + (int64_t)n * A.PL[0] * A.PL[1] * A.PL[2] * A.Cp + r0;
         const T* qn = qbase_ptr + (int64_t)n * A.QD[0] * A.QD[1] * A.QD[2] * A.Cq + k0;
-        // Batches of 8 UNCONDITIONAL 16-byte loads per thread (invalid pieces read a clamped address and are zeroed
-        // afterwards) so that a whole batch is in flight at once; conditional loads would serialise into one HBM
-        // round trip per piece.
-        {
-            u32x4 v[WG_MAXP];
-            bool ok[WG_MAXP];
+        okp = 0; okq = 0;
 #pragma unroll
-            for (int s = 0; s < WG_MAXP; ++s) {
-                const int r = prel[s] < 0 ? 0 : prel[s];
-                const int ld = l0d + ((r >> 18) & 511), lh = l0h + ((r >> 9) & 511), lw = l0w + (r & 511);
-                ok[s] = prel[s] >= 0 && ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2];
-                const int64_t off = ok[s] ? ((int64_t)(ld * A.PL[1] + lh) * A.PL[2] + lw) * A.Cp + (r >> 27) * E16 : 0;
-                v[s] = *reinterpret_cast<const u32x4*>(pn + off);
-            }
-#pragma unroll
-            for (int s = 0; s < WG_MAXP; ++s)
-                if (prel[s] >= 0) *reinterpret_cast<u32x4*>(sp + pdst[s]) = ok[s] ? v[s] : u32x4{0u, 0u, 0u, 0u};
+        for (int s = 0; s < MAXP; ++s) {
+            const int r = prel[s] < 0 ? 0 : prel[s];
+            const int ld = l0d + ((r >> 18) & 511), lh = l0h + ((r >> 9) & 511), lw = l0w + (r & 511);
+            const bool ok = prel[s] >= 0 && ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2];
+            okp |= (uint32_t)ok << s;
+            const int64_t off = ok ? ((int64_t)(ld * A.PL[1] + lh) * A.PL[2] + lw) * A.Cp + (r >> 27) * E16 : 0;
+            vp[s] = *reinterpret_cast<const u32x4*>(pn + off);
         }
 #pragma unroll
-        for (int s0 = 0; s0 < WG_MAXQ; s0 += 8) {
-            if (s0 * 256 >= NQP) break;   // uniform
-            u32x4 v[8];
-            bool ok[8];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int rel = qrel[s0 + b];
-                const int r = rel < 0 ? 0 : rel;
-                const int qd = q0d + ((r >> 18) & 511), qh = q0h + ((r >> 9) & 511), qw = q0w + (r & 511);
-                ok[b] = rel >= 0 && (unsigned)qd < (unsigned)A.QD[0] && (unsigned)qh < (unsigned)A.QD[1] && (unsigned)qw < (unsigned)A.QD[2];
-                const int64_t off = ok[b] ? ((int64_t)(qd * A.QD[1] + qh) * A.QD[2] + qw) * A.Cq + (r >> 27) * E16 : 0;
-                v[b] = *reinterpret_cast<const u32x4*>(qn + off);
-            }
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-                if (qrel[s0 + b] >= 0) *reinterpret_cast<u32x4*>(sq + qdst[s0 + b]) = ok[b] ? v[b] : u32x4{0u, 0u, 0u, 0u};
+        for (int s = 0; s < MAXQ; ++s) {
+            if (s * 256 >= NQP) break;   // uniform
+            const int rel = qrel[s];
+            const int r = rel < 0 ? 0 : rel;
+            const int qd = q0d + ((r >> 18) & 511), qh = q0h + ((r >> 9) & 511), qw = q0w + (r & 511);
+            const bool ok = rel >= 0 && (unsigned)qd < (unsigned)A.QD[0] && (unsigned)qh < (unsigned)A.QD[1] && (unsigned)qw < (unsigned)A.QD[2];
+            okq |= (uint32_t)ok << s;
+            const int64_t off = ok ? ((int64_t)(qd * A.QD[1] + qh) * A.QD[2] + qw) * A.Cq + (r >> 27) * E16 : 0;
+            vq[s] = *reinterpret_cast<const u32x4*>(qn + off);
         }
-        __syncthreads();
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int s = 0; s < MAXP; ++s)
+            if (prel[s] >= 0) *reinterpret_cast<u32x4*>(sp + pdst[s]) = ((okp >> s) & 1u) ? vp[s] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int s = 0; s < MAXQ; ++s) {
+            if (s * 256 >= NQP) break;   // uniform
+            if (qrel[s] >= 0) *reinterpret_cast<u32x4*>(sq + qdst[s]) = ((okq >> s) & 1u) ? vq[s] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (!split_taps && (ks & 3) != wv) continue;
@@ -222,6 +228,28 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
                 }
             }
         }
+    };
+
+    int tile = blockIdx.x;
+    if (PF) {
+        if (tile < A.total_tiles) { issue(tile); commit(); }
+        __syncthreads();
+        for (; tile < A.total_tiles; tile += gridDim.x) {
+            const int next = tile + gridDim.x;
+            if (next < A.total_tiles) issue(next);      // in flight during the MFMA phase
+            compute();
+            __syncthreads();                            // every wave is done reading the tile
+            if (next < A.total_tiles) commit();
+            __syncthreads();
+        }
+    } else {
+        for (; tile < A.total_tiles; tile += gridDim.x) {
+            __syncthreads();
+            issue(tile);
+            commit();
+            __syncthreads();
+            compute();
+        }
     }
     // ---- slice result -> dW (fp32 atomics, PyTorch layout)
 #pragma unroll
@@ -243,15 +271,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     }
 }
 
-template <typename T, int KS>
+template <typename T, int KS, int MAXP, int MAXQ, bool PF>
 static int wg_launch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 2048));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         attr = true;
     }
-    k_wgrad<T, KS><<<grid, 256, lds, st>>>(a);
+    k_wgrad<T, KS, MAXP, MAXQ, PF><<<grid, 256, lds, st>>>(a);
     LAUNCH_CHECK();
     return 0;
 }
@@ -260,7 +288,8 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipS
     WgArgs a;
     memset(&a, 0, sizeof(a));
     const bool tr = c->transposed != 0;
-    const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
+    const bool bf = c->dtype == NNDET_BF16;
+    const int esz = bf ? 2 : 4;
     const int RB = 32 * esz, PPV = RB / 16;
     const int in_sp[3] = {c->in_d, c->in_h, c->in_w}, out_sp[3] = {c->out_d, c->out_h, c->out_w};
     const int64_t T = (int64_t)c->k[0] * c->k[1] * c->k[2];
@@ -286,6 +315,8 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipS
     const bool strided = a.step[0] > 1 || a.step[1] > 1 || a.step[2] > 1;
     const int KS = strided ? 2 : 8;
     const int rows = KS * 4;
+    // Q pieces per thread supported by the instantiation chosen below (registers of the software pipeline)
+    const int maxq = bf ? (strided ? 12 : 10) : (strided ? 24 : 20);
     // tile (TD, TH, 8): minimise padded volume, respect LDS and piece limits
     double best = 1e300; int bTD = 0, bTH = 0;
     for (int td = 1; td <= rows; td *= 2) {
@@ -297,7 +328,7 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipS
             hv *= h[i];
             padded *= (double)ceil_div(a.PL[i], t3[i]) * t3[i];
         }
-        if (hv * PPV > 256 * WG_MAXQ) continue;
+        if (hv * PPV > 256 * maxq) continue;
         const size_t lds = (size_t)(KS * 32) * RB * 17 / 16 + (size_t)h[0] * h[1] * (h[2] * RB + RB / 2);
         if (lds > 150 * 1024) continue;
         const double cost = padded * (1.0 + 0.1 * (double)hv / (KS * 32));
@@ -309,12 +340,15 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipS
     for (int i = 0; i < 3; ++i) { a.H[i] = (t3[i] - 1) * a.step[i] + c->k[i]; a.nt[i] = ceil_div(a.PL[i], t3[i]); }
     if (a.H[0] > 511 || a.H[1] > 511 || a.H[2] > 511) return NNDET_EINVAL;
     a.total_tiles = a.N * a.nt[0] * a.nt[1] * a.nt[2];
+    auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); };
+    a.mH2 = magic(a.H[2]); a.mH1 = magic(a.H[1]);
+    a.lTH = 0; while ((1 << a.lTH) < a.TH) ++a.lTH;
     const size_t lds = (size_t)(KS * 32) * RB + (size_t)(KS * 4) * (RB / 2) + (size_t)a.H[0] * a.H[1] * (a.H[2] * RB + RB / 2) + 64;
     const int rb = a.Cp / 32, kb = a.Cq / 32;
     int S = 1536 / (rb * kb);
     if (S < 1) S = 1;
     if (S > a.total_tiles) S = a.total_tiles;
     dim3 grid(S, rb, kb);
-    if (c->dtype == NNDET_BF16) return KS == 8 ? wg_launch<bf16_t, 8>(a, grid, lds, st) : wg_launch<bf16_t, 2>(a, grid, lds, st);
-    return KS == 8 ? wg_launch<float, 8>(a, grid, lds, st) : wg_launch<float, 2>(a, grid, lds, st);
+    if (bf) return KS == 8 ? wg_launch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_launch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
+    return KS == 8 ? wg_launch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_launch<float, 2, 2, 24, false>(a, grid, lds, st);
 }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_segloss_bwd(const T* __restrict__ logit
     T* o = dlogits + v * c_p;
     constexpr int E = 16 / (int)sizeof(T);
     uint4 first = make_uint4(0u, 0u, 0u, 0u);
-    if (sizeof(T) == 2) first.x = (uint32_t)f32_to_bf16(-d1) | ((uint32_t)f32_to_bf16(d1) << 16);
+    if (sizeof(T) == 2) first.x = pack_bf16x2(-d1, d1);
     else { first.x = __float_as_uint(-d1); first.y = __float_as_uint(d1); }
     reinterpret_cast<uint4*>(o)[0] = first;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
