@@ -22,7 +22,6 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define WG_MAXT 7    // tap slots per wave
 
 struct WgTap { int32_t d[3]; int32_t wt; };
 struct WgArgs {
@@ -77,7 +76,9 @@ template <> struct WF<float> {
     }
 };
 
-template <typename T, int KS, int MAXP, int MAXQ, bool PF>
+// NTS = tap slots per wave (compile time: the MFMA phase is straight-line code, the compiler software-pipelines the
+// LDS transpose reads against the MFMAs); SPLIT = waves split the taps (else: the contraction steps)
+template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT>
 __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     constexpr int RB = 32 * (int)sizeof(T);      // bytes of one voxel's 32-channel block
     constexpr int PPV = RB / 16;                  // 16-byte pieces per voxel
@@ -135,13 +136,26 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
         const int pd = tr >> A.lTH, ph = tr & (TH - 1);
         qrow0[ks] = (pd * A.step[0]) * H1 + ph * A.step[1];
     }
-    // ---- work split between the waves
-    const bool split_taps = A.ntap >= 4;
-    const int nslots = split_taps ? (A.ntap - wv + 3) / 4 : A.ntap;   // taps handled by this wave
-
-    f32x4 acc[WG_MAXT][2][2];
+    // ---- work split between the waves: slot ts of wave wv handles tap (SPLIT ? wv + 4*ts : ts); slots beyond the
+    // tap count recompute tap 0 and are discarded (keeps the MFMA phase branch-free)
+    int tapoff[NTS];      // LDS byte offset of the tap inside the halo tile
+    int tapw[NTS];        // weight tap index, -1 = unused slot
 #pragma unroll
-    for (int t = 0; t < WG_MAXT; ++t)
+    for (int ts = 0; ts < NTS; ++ts) {
+        const int t = SPLIT ? wv + ts * 4 : ts;
+        const bool valid = t < A.ntap;
+        const WgTap& tap = A.taps[valid ? t : 0];
+        tapoff[ts] = (tap.d[0] * H1 + tap.d[1]) * QROW + tap.d[2] * RB;
+        tapw[ts] = valid ? tap.wt : -1;
+    }
+    int qrowb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qrowb[ks] = qrow0[ks] * QROW;
+    const int wstep = A.step[2] * RB;
+
+    f32x4 acc[NTS][2][2];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (!split_taps && (ks & 3) != wv) continue;
+            if (!SPLIT && (ks & 3) != wv) continue;
             // P fragments of this contraction step: point = ks*32 + q*8 + j, channels it*16 + li
             WF<T> pf[2];
             {
@@ -212,20 +226,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
                 pf[1].load(b0 + 16 * (int)sizeof(T), RB, li);
             }
 #pragma unroll
-            for (int ts = 0; ts < WG_MAXT; ++ts) {
-                if (ts < nslots) {
-                    const WgTap& tap = A.taps[split_taps ? wv + ts * 4 : ts];
-                    const int hrow = qrow0[ks] + tap.d[0] * H1 + tap.d[1];
-                    const char* b0 = sq + hrow * QROW + tap.d[2] * RB;
-                    const int wstep = A.step[2] * RB;
-                    WF<T> qf[2];
-                    qf[0].load(b0, wstep, li);
-                    qf[1].load(b0 + 16 * (int)sizeof(T), wstep, li);
+            for (int ts = 0; ts < NTS; ++ts) {
+                const char* b0 = sq + qrowb[ks] + tapoff[ts];
+                WF<T> qf[2];
+                qf[0].load(b0, wstep, li);
+                qf[1].load(b0 + 16 * (int)sizeof(T), wstep, li);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) WF<T>::mma(pf[i], qf[j], acc[ts][i][j]);
-                }
+                    for (int j = 0; j < 2; ++j) WF<T>::mma(pf[i], qf[j], acc[ts][i][j]);
             }
         }
     };
@@ -253,9 +262,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     }
     // ---- slice result -> dW (fp32 atomics, PyTorch layout)
 #pragma unroll
-    for (int ts = 0; ts < WG_MAXT; ++ts) {
-        if (ts < nslots) {
-            const int wt = A.taps[split_taps ? wv + ts * 4 : ts].wt;
+    for (int ts = 0; ts < NTS; ++ts) {
+        if (tapw[ts] >= 0) {
+            const int wt = tapw[ts];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -271,17 +280,33 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     }
 }
 
-template <typename T, int KS, int MAXP, int MAXQ, bool PF>
+template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT>
 static int wg_launch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         attr = true;
     }
-    k_wgrad<T, KS, MAXP, MAXQ, PF><<<grid, 256, lds, st>>>(a);
+    k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT><<<grid, 256, lds, st>>>(a);
     LAUNCH_CHECK();
     return 0;
+}
+
+// tap-slot dispatch: >= 4 taps are split over the 4 waves (slots = ceil(taps / 4) rounded up to an instantiated count),
+// 1-3 taps are processed by every wave (the waves split the contraction steps instead)
+template <typename T, int KS, int MAXP, int MAXQ, bool PF>
+static int wg_dispatch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    if (a.ntap >= 4) {
+        const int need = (a.ntap + 3) / 4;
+        if (need <= 1) return wg_launch<T, KS, MAXP, MAXQ, PF, 1, true>(a, grid, lds, st);
+        if (need <= 2) return wg_launch<T, KS, MAXP, MAXQ, PF, 2, true>(a, grid, lds, st);
+        if (need <= 3) return wg_launch<T, KS, MAXP, MAXQ, PF, 3, true>(a, grid, lds, st);
+        if (need <= 5) return wg_launch<T, KS, MAXP, MAXQ, PF, 5, true>(a, grid, lds, st);
+        return wg_launch<T, KS, MAXP, MAXQ, PF, 7, true>(a, grid, lds, st);
+    }
+    if (a.ntap == 1) return wg_launch<T, KS, MAXP, MAXQ, PF, 1, false>(a, grid, lds, st);
+    return wg_launch<T, KS, MAXP, MAXQ, PF, 3, false>(a, grid, lds, st);
 }
 
 int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipStream_t st) {
@@ -349,6 +374,6 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipS
     if (S < 1) S = 1;
     if (S > a.total_tiles) S = a.total_tiles;
     dim3 grid(S, rb, kb);
-    if (bf) return KS == 8 ? wg_launch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_launch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
-    return KS == 8 ? wg_launch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_launch<float, 2, 2, 24, false>(a, grid, lds, st);
+    if (bf) return KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
+    return KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
 }
