@@ -152,9 +152,10 @@ int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w_packed
 int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w_packed_mode1,
                                void* dx, void* stream);
 /* dw (fp32, PyTorch layout, ACCUMULATED into: zero it first) ; dbias ([cout] fp32, accumulated) may be NULL.
- * NOTE accumulation uses fp32 atomics: the summation order (not the result beyond fp32 round-off) varies run to run. */
+ * Two-stage reduction through `workspace` (nndet_conv3d_wgrad_workspace_bytes(c) bytes): deterministic, no atomics on dw. */
+size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c);
 int nndet_conv3d_backward_weight(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias,
-                                 void* stream);
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d / GroupNorm (+ReLU) on NDHWC -- replaces nn.InstanceNorm3d / nndet GroupNorm + nn.ReLU

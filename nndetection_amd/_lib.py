@@ -50,7 +50,8 @@ SIGNATURES = {
     "nndet_pack_weight": (C.c_int, [_CONVP, _I32, _P, _P, _P]),
     "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
-    "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
+    "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
+    "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_norm_stats": (C.c_int, [_I32, _P, _I32, _I64, _I32, _P, _P]),
     "nndet_norm_apply": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     "nndet_norm_backward": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
@@ -100,6 +101,19 @@ def check(rc: int, what: str):
     if rc != 0:
         kind = {-1: "invalid argument", -2: "workspace too small"}.get(rc, f"hipError {rc}")
         raise NndetError(f"{what} failed: {kind}")
+
+
+_workspaces = {}
+
+
+def workspace(nbytes: int, device) -> "torch.Tensor":
+    """One grow-only scratch buffer per device (kernel launches are serialised on the stream, so it can be shared)."""
+    key = (device.type, device.index)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
 
 
 def call(name: str, *args):

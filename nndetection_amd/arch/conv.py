@@ -142,7 +142,10 @@ class _ConvBlockFn(torch.autograd.Function):
             dx = logical(dx_p, desc.cin)
         dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
         dbias = torch.zeros((cout,), dtype=torch.float32, device=dev) if ctx.has_bias else None
-        L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw), L.ptr(dbias), L.stream())
+        ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
+        ws = L.workspace(ws_bytes, dev)
+        L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw), L.ptr(dbias),
+               L.ptr(ws), ws_bytes, L.stream())
         return dx, dw.to(weight.dtype), dbias, dgamma, dbeta, None
 
 

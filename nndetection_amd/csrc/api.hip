@@ -39,13 +39,18 @@ extern "C" int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, co
     return igemm_run(c, 1, dy, w, nullptr, dx, nullptr, as_stream(stream));
 }
 
+extern "C" size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c) {
+    if (check_conv(c)) return 0;
+    return c->cin_p == 1 ? 256 : wgrad_workspace_bytes(c);
+}
+
 extern "C" int nndet_conv3d_backward_weight(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias,
-                                            void* stream) {
+                                            void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_conv(c);
     if (rc) return rc;
     if (!x || !dy || !dw) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
-    rc = (c->cin_p == 1) ? stem_wgrad(c, x, dy, dw, st) : wgrad_run(c, x, dy, dw, st);
+    rc = (c->cin_p == 1) ? stem_wgrad(c, x, dy, dw, st) : wgrad_run(c, x, dy, dw, workspace, workspace_bytes, st);
     if (rc) return rc;
     if (dbias) {
         const int64_t rows = (int64_t)c->batch * c->out_d * c->out_h * c->out_w;

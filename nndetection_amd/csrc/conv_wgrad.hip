@@ -26,6 +26,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct WgTap { int32_t d[3]; int32_t wt; };
 struct WgArgs {
     const void* p; const void* q; float* dw;
+    float* part;          // partial results [S][rb*kb][ntap][32][32] fp32 (reduced by k_wgrad_reduce)
     int32_t N;
     int32_t PL[3], Cp;
     int32_t QD[3], Cq;
@@ -260,24 +261,44 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
             compute();
         }
     }
-    // ---- slice result -> dW (fp32 atomics, PyTorch layout)
+    // ---- slice result -> partial buffer (plain coalesced stores). Device-scope atomics on dW were the bottleneck of
+    // v1/v2: 1536 workgroups x 27.6 K atomics onto the same 27.6 K addresses ran at ~15 G atomics/s (2.2-2.9 ms per call
+    // independent of the layer's FLOPs); a two-stage reduction costs ~0.1 ms and is deterministic.
+    const int64_t slice = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wv;   // !SPLIT: every wave owns a full partial
+    float* part = A.part + (slice * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)A.ntap * 1024);
 #pragma unroll
     for (int ts = 0; ts < NTS; ++ts) {
         if (tapw[ts] >= 0) {
-            const int wt = tapw[ts];
+            const int t = SPLIT ? wv + ts * 4 : ts;
+            float* pt = part + (int64_t)t * 1024;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int k = k0 + j * 16 + li;
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int r = r0 + i * 16 + q * 4 + rr;
-                        if (r < A.R && k < A.K) atomicAdd(A.dw + r * A.sr + k * A.sk + wt, acc[ts][i][j][rr]);
-                    }
-                }
+                    for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + q * 4 + rr) * 32 + j * 16 + li] = acc[ts][i][j][rr];
         }
     }
+}
+
+// dW[r][k][tap] += sum_s part[s][pair][tap][r%32][k%32]; one thread per (pair, tap, r, k); consecutive threads = consecutive k.
+// With !SPLIT (1-3 taps) every wave holds a partial of every tap: those are summed here too (nsub = 4 sub-slices).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int S, int pairs, int kb, int ntap,
+                                                      int R, int K, int64_t sr, int64_t sk, const int32_t* __restrict__ tapw_dummy,
+                                                      float* __restrict__ dw, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int k = (int)(e & 31), r = (int)((e >> 5) & 31);
+    const int64_t pt = e >> 10;               // pair * ntap + tap
+    const int t = (int)(pt % ntap), pair = (int)(pt / ntap);
+    const int rbi = pair / kb, kbi = pair % kb;
+    const int rg = rbi * 32 + r, kg = kbi * 32 + k;
+    if (rg >= R || kg >= K) return;
+    const int64_t stride = (int64_t)pairs * ntap * 1024;
+    float acc = 0.f;
+    const float* src = part + e;
+    for (int s2 = 0; s2 < S; ++s2) acc += src[(int64_t)s2 * stride];
+    dw[rg * sr + kg * sk + t] += acc;
 }
 
 template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT>
@@ -309,7 +330,25 @@ static int wg_dispatch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     return wg_launch<T, KS, MAXP, MAXQ, PF, 3, false>(a, grid, lds, st);
 }
 
-int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipStream_t st) {
+// number of spatial slices (= workgroups per channel-block pair) for a problem with `pairs` block pairs
+static int wgrad_slices(int pairs, int total_tiles) {
+    int S = 1024 / pairs;
+    if (S < 1) S = 1;
+    if (S > total_tiles) S = total_tiles;
+    return S;
+}
+
+size_t wgrad_workspace_bytes(const NndetConv* c) {
+    const bool tr = c->transposed != 0;
+    const int rb = (tr ? c->cin_p : c->cout_p) / 32, kb = (tr ? c->cout_p : c->cin_p) / 32;
+    const int ntap = c->k[0] * c->k[1] * c->k[2];
+    // upper bound independent of the tile choice: S <= 1024 / pairs (>= 1), x4 sub-slices when the waves split k-steps
+    int S = 1024 / (rb * kb); if (S < 1) S = 1;
+    const int slices = ntap >= 4 ? S : 4 * S;
+    return (size_t)slices * rb * kb * ntap * 1024 * sizeof(float);
+}
+
+int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
     WgArgs a;
     memset(&a, 0, sizeof(a));
     const bool tr = c->transposed != 0;
@@ -370,10 +409,18 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, hipS
     a.lTH = 0; while ((1 << a.lTH) < a.TH) ++a.lTH;
     const size_t lds = (size_t)(KS * 32) * RB + (size_t)(KS * 4) * (RB / 2) + (size_t)a.H[0] * a.H[1] * (a.H[2] * RB + RB / 2) + 64;
     const int rb = a.Cp / 32, kb = a.Cq / 32;
-    int S = 1536 / (rb * kb);
-    if (S < 1) S = 1;
-    if (S > a.total_tiles) S = a.total_tiles;
+    const int S = wgrad_slices(rb * kb, a.total_tiles);
     dim3 grid(S, rb, kb);
-    if (bf) return KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
-    return KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
+    const int slices = (a.ntap >= 4) ? S : 4 * S;
+    const size_t need = (size_t)slices * rb * kb * a.ntap * 1024 * sizeof(float);
+    if (!ws || ws_bytes < need) return NNDET_EWORKSPACE;
+    a.part = reinterpret_cast<float*>(ws);
+    int rc;
+    if (bf) rc = KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
+    else rc = KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
+    if (rc) return rc;
+    const int64_t total = (int64_t)rb * kb * a.ntap * 1024;
+    k_wgrad_reduce<<<(unsigned)ceil_div64(total, 256), 256, 0, st>>>(a.part, slices, rb * kb, kb, a.ntap, a.R, a.K, a.sr, a.sk, nullptr, dw, total);
+    LAUNCH_CHECK();
+    return 0;
 }

@@ -51,7 +51,9 @@ def main():
         st = L.stream()
         f = lambda: L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, L.ptr(y), None, st)
         g = lambda: L.call("nndet_conv3d_backward_data", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx), st)
-        h = lambda: L.call("nndet_conv3d_backward_weight", ctypes.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), None, st)
+        wsb = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+        ws = L.workspace(wsb, x.device)
+        h = lambda: L.call("nndet_conv3d_backward_weight", ctypes.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), None, L.ptr(ws), wsb, st)
         nvox_out = B * d.out_d * d.out_h * d.out_w
         taps = m.k[0] * m.k[1] * m.k[2]
         flops = 2.0 * (B * sp[0] * sp[1] * sp[2] if tr else nvox_out) * taps * cin * cout
