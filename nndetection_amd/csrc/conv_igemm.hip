@@ -90,13 +90,18 @@ struct IgArgs {
     IgTap taps[27];
 };
 
-template <typename T, int MT, int NT, int MAXP>
+// Wave layout inside the workgroup: WR waves along the output rows (channels) x 4/WR waves along the lattice points.
+// A wave owns MT row tiles x NT point tiles of 16. Splitting rows across waves (WR = 2) halves the weight-fragment
+// traffic from L2 (every wave used to stream the weights of ALL rows: 432 KB per workgroup and chunk, the bottleneck of
+// the C >= 64 layers) at the price of twice as many (cheap, conflict-free) LDS activation reads.
+template <typename T, int WR, int MT, int NT, int MAXP>
 __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
+    const int wr = wv % WR, wc = wv / WR;     // row group / point group of this wave
 
     const int cls_i = blockIdx.z % A.ncls;
     const int n = blockIdx.z / A.ncls;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     const int td_i = tt / A.nt[1];
     const int l0d = td_i * A.T[0], l0h = th_i * A.T[1], l0w = tw_i * A.T[2];
     if (l0d >= C.L[0] || l0h >= C.L[1] || l0w >= C.L[2]) return;   // uniform: tile outside this class' lattice
-    const int row0 = blockIdx.y * (MT * 16);
+    const int row0 = blockIdx.y * (WR * MT * 16);
 
     const int HD = A.H[0], HH = A.H[1], HW = A.H[2];
     const int HV4 = HD * HH * HW * 4;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     int pd_[NT], ph_[NT], pw_[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int p = (wv * NT + j) * 16 + li;
+        const int p = (wc * NT + j) * 16 + li;
         const int pw = p & (A.T[2] - 1);
         const int t2 = p >> A.lT2;
         const int ph = t2 & (A.T[1] - 1), pd = t2 >> A.lT1;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + li) * A.Cx + q * EPL;
+    const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + wr * MT * 16 + li) * A.Cx + q * EPL;
     const int nchunk = A.Cx / KC;
     for (int kc = 0; kc < nchunk; ++kc) {
         __syncthreads();
@@ -181,27 +186,25 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
             }
         }
         __syncthreads();
-        // software pipeline over the taps: the fragments of tap tp+1 (weights from L1/L2, activations from LDS)
-        // are in flight while the MFMAs of tap tp issue
-        u32x4 af[MT], bf[NT], afn[MT], bfn[NT];
-        auto load_tap = [&](int tp, u32x4* a_, u32x4* b_) {
+        // software pipeline over the taps: the weight fragments of tap tp+1 (L1/L2 latency) are in flight while the
+        // MFMAs of tap tp issue; the activation fragments (LDS latency) are read at the top of their own tap
+        u32x4 af[MT], afn[MT], bf[NT];
+        auto load_w = [&](int tp, u32x4* a_) {
+            const T* wt = wl + ((int64_t)A.taps[C.tap0 + tp].wt * A.Cy) * A.Cx + kc * KC;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_[i] = *reinterpret_cast<const u32x4*>(wt + (int64_t)i * 16 * A.Cx);
+        };
+        if (C.ntap > 0) load_w(0, afn);
+        for (int tp = 0; tp < C.ntap; ++tp) {
             const IgTap& tap = A.taps[C.tap0 + tp];
             const int trow = tap.d[0] * HH + tap.d[1];
             const int toff = (trow * HW + tap.d[2]) * 64;
             const int flip = (trow & A.swz) << 5;      // row parity of the tap flips the swizzle bit
-            const T* wt = wl + ((int64_t)tap.wt * A.Cy) * A.Cx + kc * KC;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a_[i] = *reinterpret_cast<const u32x4*>(wt + (int64_t)i * 16 * A.Cx);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b_[j] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ flip) + toff));
-        };
-        if (C.ntap > 0) load_tap(0, afn, bfn);
-        for (int tp = 0; tp < C.ntap; ++tp) {
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ flip) + toff));
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[i] = afn[i];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = bfn[j];
-            if (tp + 1 < C.ntap) load_tap(tp + 1, afn, bfn);
+            if (tp + 1 < C.ntap) load_w(tp + 1, afn);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
             T* yo = yb + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * A.Cy;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int r0 = row0 + i * 16 + q * 4;
+                const int r0 = row0 + (wr * MT + i) * 16 + q * 4;
                 float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
                 if (A.bias) { v0 += A.bias[r0]; v1 += A.bias[r0 + 1]; v2 += A.bias[r0 + 2]; v3 += A.bias[r0 + 3]; }
                 store4r<T>(yo + r0, v0, v1, v2, v3);
@@ -241,8 +244,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     if (A.stats) {
         // reduce over the 16 voxel lanes (li), then over the 4 waves through LDS, then one fp64 atomic per row
         __syncthreads();                       // all waves are done reading the halo tile
-        double* red = reinterpret_cast<double*>(smem);   // [MT*16][2]
-        if (tid < MT * 16 * 2) red[tid] = 0.0;
+        double* red = reinterpret_cast<double*>(smem);   // [WR*MT*16][2]
+        if (tid < WR * MT * 16 * 2) red[tid] = 0.0;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -252,12 +255,12 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
                 if (li == 0) {
-                    atomicAdd(&red[(i * 16 + q * 4 + r) * 2 + 0], (double)s);
-                    atomicAdd(&red[(i * 16 + q * 4 + r) * 2 + 1], (double)s2);
+                    atomicAdd(&red[((wr * MT + i) * 16 + q * 4 + r) * 2 + 0], (double)s);
+                    atomicAdd(&red[((wr * MT + i) * 16 + q * 4 + r) * 2 + 1], (double)s2);
                 }
             }
         __syncthreads();
-        if (tid < MT * 16 * 2) {
+        if (tid < WR * MT * 16 * 2) {
             const int rep = (blockIdx.x + blockIdx.z * 7) % NNDET_STATS_REPLICAS;
             double* dst = A.stats + (((int64_t)rep * A.N + n) * A.Cy + row0 + (tid >> 1)) * 2 + (tid & 1);
             atomicAdd(dst, red[tid]);
@@ -268,13 +271,15 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
 // ------------------------------------------------------------------------------------------------ host side
 struct Plan {
     IgArgs a;
-    int cfg;          // 0: (2,8) 1: (4,4) 2: (4,2) 3: (2,2)
+    int cfg;          // index into CFG_*
     dim3 grid;
     size_t lds;
 };
 
-static const int CFG_MT[4] = {2, 4, 4, 2};
-static const int CFG_NT[4] = {8, 4, 2, 2};
+// cfg: 0 unit stride, rows % 64 != 0 : 32 rows x 512 points ; 1 unit stride : 64 rows x 256 points ;
+//      2 strided : 64 rows x 128 points ; 3 strided, rows % 64 != 0 : 32 rows x 128 points      (WR = 2 everywhere)
+static const int CFG_ROWS[4] = {32, 64, 64, 32};
+static const int CFG_PTS[4] = {512, 256, 128, 128};
 
 static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[3], int points, int maxp, int T[3], int H[3]) {
     double best = 1e300;
@@ -385,7 +390,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     const bool strided = a.in_step[0] > 1 || a.in_step[1] > 1 || a.in_step[2] > 1;
     const bool r64 = (a.Cy % 64) == 0;
     P->cfg = strided ? (r64 ? 2 : 3) : (r64 ? 1 : 0);
-    const int points = 4 * CFG_NT[P->cfg] * 16;
+    const int points = CFG_PTS[P->cfg];
     for (int i = 0; i < 3; ++i) if (Lmax[i] <= 0) return NNDET_EINVAL;
     if (!choose_tile(Lmax, a.in_step, span, points, strided ? 24 : 16, a.T, a.H)) return NNDET_EINVAL;
     for (int i = 0; i < 3; ++i) a.nt[i] = ceil_div(Lmax[i], a.T[i]);
@@ -394,7 +399,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     a.mHW = magic(a.H[2]); a.mHH = magic(a.H[1]);
     a.lT1 = ilog2(a.T[1]); a.lT2 = ilog2(a.T[2]);
     a.swz = strided ? 0 : 1;
-    P->grid = dim3(a.nt[0] * a.nt[1] * a.nt[2], a.Cy / (CFG_MT[P->cfg] * 16), a.N * a.ncls);
+    P->grid = dim3(a.nt[0] * a.nt[1] * a.nt[2], a.Cy / CFG_ROWS[P->cfg], a.N * a.ncls);
     P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64;
     if (P->lds < 1024) P->lds = 1024;   // room for the stats reduction
     return 0;
@@ -403,26 +408,26 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
 template <typename T>
 static int launch_cfg(const Plan& P, hipStream_t st) {
     switch (P.cfg) {
-        case 0: k_igemm<T, 2, 8, 16><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 1: k_igemm<T, 4, 4, 16><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 2: k_igemm<T, 4, 2, 24><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        default: k_igemm<T, 2, 2, 24><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 0: k_igemm<T, 2, 1, 16, 16><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 1: k_igemm<T, 2, 2, 8, 16><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 2: k_igemm<T, 2, 2, 4, 24><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        default: k_igemm<T, 2, 1, 4, 24><<<P.grid, 256, P.lds, st>>>(P.a); break;
     }
     LAUNCH_CHECK();
     return 0;
 }
 
-template <typename T, int MT, int NT, int MAXP>
+template <typename T, int WR, int MT, int NT, int MAXP>
 static int set_lds_attr() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, MT, NT, MAXP>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 }
 static int g_attr_done = 0;
 static int ensure_attrs() {
     if (g_attr_done) return 0;
     int rc = 0;
-    rc |= set_lds_attr<bf16_t, 2, 8, 16>(); rc |= set_lds_attr<bf16_t, 4, 4, 16>(); rc |= set_lds_attr<bf16_t, 4, 2, 24>(); rc |= set_lds_attr<bf16_t, 2, 2, 24>();
-    rc |= set_lds_attr<float, 2, 8, 16>(); rc |= set_lds_attr<float, 4, 4, 16>(); rc |= set_lds_attr<float, 4, 2, 24>(); rc |= set_lds_attr<float, 2, 2, 24>();
+    rc |= set_lds_attr<bf16_t, 2, 1, 16, 16>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24>();
+    rc |= set_lds_attr<float, 2, 1, 16, 16>(); rc |= set_lds_attr<float, 2, 2, 8, 16>(); rc |= set_lds_attr<float, 2, 2, 4, 24>(); rc |= set_lds_attr<float, 2, 1, 4, 24>();
     if (rc) return rc;
     g_attr_done = 1;
     return 0;

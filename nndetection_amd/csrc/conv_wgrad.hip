@@ -284,8 +284,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 // dW[r][k][tap] += sum_s part[s][pair][tap][r%32][k%32]; one thread per (pair, tap, r, k); consecutive threads = consecutive k.
 // With !SPLIT (1-3 taps) every wave holds a partial of every tap: those are summed here too (nsub = 4 sub-slices).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int S, int pairs, int kb, int ntap,
-                                                      int R, int K, int64_t sr, int64_t sk, const int32_t* __restrict__ tapw_dummy,
-                                                      float* __restrict__ dw, int64_t total) {
+                                                      int R, int K, int64_t sr, int64_t sk, float* __restrict__ dw, int64_t total) {
+    // grid (ceil(total / 256), ceil(S / 32)): a thread sums 32 slices of one element (coalesced across threads), then
+    // one atomic per thread: total * S / 32 atomics (< 1 M) instead of the 42 M of the atomics-only scheme.
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int k = (int)(e & 31), r = (int)((e >> 5) & 31);
@@ -295,10 +296,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     const int rg = rbi * 32 + r, kg = kbi * 32 + k;
     if (rg >= R || kg >= K) return;
     const int64_t stride = (int64_t)pairs * ntap * 1024;
+    const int s0 = blockIdx.y * 32, s1 = min(S, s0 + 32);
     float acc = 0.f;
-    const float* src = part + e;
-    for (int s2 = 0; s2 < S; ++s2) acc += src[(int64_t)s2 * stride];
-    dw[rg * sr + kg * sk + t] += acc;
+    const float* src = part + e + (int64_t)s0 * stride;
+#pragma unroll 8
+    for (int s2 = s0; s2 < s1; ++s2, src += stride) acc += *src;
+    atomicAdd(&dw[rg * sr + kg * sk + t], acc);
 }
 
 template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT>
@@ -420,7 +423,7 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, void
     else rc = KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
     if (rc) return rc;
     const int64_t total = (int64_t)rb * kb * a.ntap * 1024;
-    k_wgrad_reduce<<<(unsigned)ceil_div64(total, 256), 256, 0, st>>>(a.part, slices, rb * kb, kb, a.ntap, a.R, a.K, a.sr, a.sk, nullptr, dw, total);
+    k_wgrad_reduce<<<dim3((unsigned)ceil_div64(total, 256), ceil_div(slices, 32)), 256, 0, st>>>(a.part, slices, rb * kb, kb, a.ntap, a.R, a.K, a.sr, a.sk, dw, total);
     LAUNCH_CHECK();
     return 0;
 }
