@@ -94,11 +94,6 @@ struct IgArgs {
 // A wave owns MT row tiles x NT point tiles of 16. Splitting rows across waves (WR = 2) halves the weight-fragment
 // traffic from L2 (every wave used to stream the weights of ALL rows: 432 KB per workgroup and chunk, the bottleneck of
 // the C >= 64 layers) at the price of twice as many (cheap, conflict-free) LDS activation reads.
-//
-// Persistent, software-pipelined: a workgroup walks over a strided list of lattice tiles and, inside a tile, over the
-// 64-byte channel chunks. The global loads of the NEXT stage (next chunk, or first chunk of the next tile) are issued into
-// registers before the MFMA phase of the current stage and written to LDS after it (one LDS buffer, two barriers per
-// stage), so HBM / L2 latency and the per-tile address arithmetic hide behind the matrix work.
 template <typename T, int WR, int MT, int NT, int MAXP>
 __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     using M = Mma<T>;
@@ -107,15 +102,47 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
     const int wr = wv % WR, wc = wv / WR;     // row group / point group of this wave
+
+    const int cls_i = blockIdx.z % A.ncls;
+    const int n = blockIdx.z / A.ncls;
+    const IgClass& C = A.cls[cls_i];
+    int tt = blockIdx.x;
+    const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
+    const int th_i = tt % A.nt[1];
+    const int td_i = tt / A.nt[1];
+    const int l0d = td_i * A.T[0], l0h = th_i * A.T[1], l0w = tw_i * A.T[2];
+    if (l0d >= C.L[0] || l0h >= C.L[1] || l0w >= C.L[2]) return;   // uniform: tile outside this class' lattice
     const int row0 = blockIdx.y * (WR * MT * 16);
+
     const int HD = A.H[0], HH = A.H[1], HW = A.H[2];
     const int HV4 = HD * HH * HW * 4;
-    const int nchunk = A.Cx / KC;
-    const int tiles_per_img = A.nt[0] * A.nt[1] * A.nt[2];
-    const int total_tiles = tiles_per_img * A.N * A.ncls;
-    char* const red_lds = smem + HV4 * 16;     // 1 KiB behind the halo tile: statistics reduction scratch
+    const int i0d = l0d * A.in_step[0] + C.in_base[0];
+    const int i0h = l0h * A.in_step[1] + C.in_base[1];
+    const int i0w = l0w * A.in_step[2] + C.in_base[2];
+    const T* xn = reinterpret_cast<const T*>(A.x) + (int64_t)n * A.I[0] * A.I[1] * A.I[2] * A.Cx;
 
-    // ---- tile-independent per-lane constants: LDS byte offsets of this lane's lattice points (tap offset 0)
+    // global element offsets of this thread's halo pieces (identical for every channel chunk)
+    int32_t goff[MAXP];
+    uint32_t swmask = 0;   // bit s: parity of the halo row of piece s (LDS swizzle)
+#pragma unroll
+    for (int s = 0; s < MAXP; ++s) {
+        const int p = tid + s * 256;
+        int32_t o = -1;
+        if (p < HV4) {
+            // no integer division on the GPU: magic-multiplier division by the (runtime) halo dims
+            const int hv = p >> 2, part = p & 3;
+            const int t2 = A.mHW ? (int)__umulhi((unsigned)hv, A.mHW) : hv;
+            const int hw = hv - t2 * HW;
+            const int hd = A.mHH ? (int)__umulhi((unsigned)t2, A.mHH) : t2;
+            const int hh = t2 - hd * HH;
+            swmask |= (uint32_t)(t2 & A.swz) << s;
+            const int id = i0d + hd, ih = i0h + hh, iw = i0w + hw;
+            if ((unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
+                o = ((id * A.I[1] + ih) * A.I[2] + iw) * A.Cx + part * EPL;
+        }
+        goff[s] = o;
+    }
+    // LDS byte offsets of this lane's lattice points (tap offset 0) for its NT B-fragments
     int boff[NT];
     int pd_[NT], ph_[NT], pw_[NT];
 #pragma unroll
@@ -128,95 +155,39 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
         const int brow = (pd * A.in_step[0]) * HH + ph * A.in_step[1];
         boff[j] = ((brow * HW + pw * A.in_step[2]) * 64 + q * 16) ^ ((brow & A.swz) << 5);
     }
-    // halo-relative coordinates of this thread's staging pieces (tile independent): hd << 20 | hh << 10 | hw, -1 = none
-    int32_t hrel[MAXP];
-    uint32_t swmask = 0;   // bit s: parity of the halo row of piece s (LDS swizzle)
-#pragma unroll
-    for (int s = 0; s < MAXP; ++s) {
-        const int p = tid + s * 256;
-        int32_t rel = -1;
-        if (p < HV4) {
-            // no integer division on the GPU: magic-multiplier division by the (runtime) halo dims
-            const int hv = p >> 2;
-            const int t2 = A.mHW ? (int)__umulhi((unsigned)hv, A.mHW) : hv;
-            const int hw = hv - t2 * HW;
-            const int hd = A.mHH ? (int)__umulhi((unsigned)t2, A.mHH) : t2;
-            const int hh = t2 - hd * HH;
-            swmask |= (uint32_t)(t2 & A.swz) << s;
-            rel = (hd << 20) | (hh << 10) | hw;
-        }
-        hrel[s] = rel;
-    }
-    const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + wr * MT * 16 + li) * A.Cx + q * EPL;
-
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- tile bookkeeping (all uniform)
-    struct Tile { int cls, n, l0d, l0h, l0w; };
-    auto decode = [&](int t, Tile& o) -> bool {          // false: tile lies outside the lattice of its class
-        const int img = t / tiles_per_img;
-        int tt = t - img * tiles_per_img;
-        o.cls = img % A.ncls; o.n = img / A.ncls;
-        const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
-        const int th_i = tt % A.nt[1];
-        const int td_i = tt / A.nt[1];
-        o.l0d = td_i * A.T[0]; o.l0h = th_i * A.T[1]; o.l0w = tw_i * A.T[2];
-        const IgClass& C = A.cls[o.cls];
-        return o.l0d < C.L[0] && o.l0h < C.L[1] && o.l0w < C.L[2];
-    };
-    auto next_valid = [&](int t, Tile& o) -> int {        // first valid tile >= t on this workgroup's stride, or -1
-        for (; t < total_tiles; t += gridDim.x)
-            if (decode(t, o)) return t;
-        return -1;
-    };
-
-    // ---- staging of one (tile, chunk) stage
-    u32x4 v[MAXP];
-    int32_t goff[MAXP];     // global element offsets of the pieces of the tile being staged (-1: outside the tensor)
-    auto set_goff = [&](const Tile& t) {
-        const IgClass& C = A.cls[t.cls];
-        const int i0d = t.l0d * A.in_step[0] + C.in_base[0];
-        const int i0h = t.l0h * A.in_step[1] + C.in_base[1];
-        const int i0w = t.l0w * A.in_step[2] + C.in_base[2];
+    const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + wr * MT * 16 + li) * A.Cx + q * EPL;
+    const int nchunk = A.Cx / KC;
+    for (int kc = 0; kc < nchunk; ++kc) {
+        __syncthreads();
+        // Stage the halo in batches of 8 UNCONDITIONAL 16-byte loads per thread (out-of-tensor pieces load a clamped,
+        // valid address and are zeroed afterwards): all loads of a batch are in flight together. A conditional load per
+        // piece makes hipcc branch + wait vmcnt(0) per piece, i.e. 16-24 serial HBM round trips per chunk.
 #pragma unroll
-        for (int s = 0; s < MAXP; ++s) {
-            int32_t o = -1;
-            if (hrel[s] >= 0) {
-                const int id = i0d + (hrel[s] >> 20), ih = i0h + ((hrel[s] >> 10) & 1023), iw = i0w + (hrel[s] & 1023);
-                if ((unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
-                    o = ((id * A.I[1] + ih) * A.I[2] + iw) * A.Cx + ((tid + s * 256) & 3) * EPL;
+        for (int s0 = 0; s0 < MAXP; s0 += 8) {
+            if (s0 * 256 >= HV4) break;   // uniform
+            u32x4 v[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int o = goff[s0 + b];
+                v[b] = *reinterpret_cast<const u32x4*>(xn + (o < 0 ? 0 : o) + kc * KC);
             }
-            goff[s] = o;
-        }
-    };
-    // UNCONDITIONAL loads (out-of-tensor pieces read a clamped valid address and are zeroed at commit): all of them are
-    // in flight together; a conditional load per piece would serialise into one memory round trip each.
-    auto issue = [&](const Tile& t, int kc) {
-        const T* xn = reinterpret_cast<const T*>(A.x) + (int64_t)t.n * A.I[0] * A.I[1] * A.I[2] * A.Cx + kc * KC;
 #pragma unroll
-        for (int s = 0; s < MAXP; ++s) {
-            if (s * 256 >= HV4) break;   // uniform
-            const int o = goff[s];
-            v[s] = *reinterpret_cast<const u32x4*>(xn + (o < 0 ? 0 : o));
+            for (int b = 0; b < 8; ++b) {
+                const int p = tid + (s0 + b) * 256;
+                if (p < HV4)
+                    *reinterpret_cast<u32x4*>(smem + ((p * 16) ^ (((swmask >> (s0 + b)) & 1u) << 5))) =
+                        goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
+            }
         }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int s = 0; s < MAXP; ++s) {
-            if (s * 256 >= HV4) break;   // uniform
-            const int p = tid + s * 256;
-            if (p < HV4)
-                *reinterpret_cast<u32x4*>(smem + ((p * 16) ^ (((swmask >> s) & 1u) << 5))) = goff[s] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[s];
-        }
-    };
-    // ---- MFMA phase of one stage. Software pipeline over the taps: the weight fragments of tap tp+1 (L1/L2 latency) are
-    // in flight while the MFMAs of tap tp issue; the activation fragments (LDS) are read at the top of their own tap.
-    auto compute = [&](const Tile& t, int kc) {
-        const IgClass& C = A.cls[t.cls];
+        __syncthreads();
+        // software pipeline over the taps: the weight fragments of tap tp+1 (L1/L2 latency) are in flight while the
+        // MFMAs of tap tp issue; the activation fragments (LDS latency) are read at the top of their own tap
         u32x4 af[MT], afn[MT], bf[NT];
         auto load_w = [&](int tp, u32x4* a_) {
             const T* wt = wl + ((int64_t)A.taps[C.tap0 + tp].wt * A.Cy) * A.Cx + kc * KC;
@@ -239,95 +210,61 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) M::mma(af[i], bf[j], acc[i][j]);
         }
-    };
-    // ---- epilogue of a finished tile: lane holds rows row0 + (wr*MT+i)*16 + q*4 + {0..3} of voxel (tile j, li)
-    auto epilogue = [&](const Tile& t) {
-        const IgClass& C = A.cls[t.cls];
-        T* yb = reinterpret_cast<T*>(A.y);
-        float ssum[MT][4], ssq[MT][4];
+    }
+
+    // ---------------- epilogue: lane holds rows row0 + i*16 + q*4 + {0..3} of voxel (tile j, li)
+    T* yb = reinterpret_cast<T*>(A.y);
+    float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ld = l0d + pd_[j], lh = l0h + ph_[j], lw = l0w + pw_[j];
+        const bool valid = (ld < C.L[0]) && (lh < C.L[1]) && (lw < C.L[2]);
+        if (valid) {
+            const int od = C.out_off[0] + ld * A.out_step[0];
+            const int oh = C.out_off[1] + lh * A.out_step[1];
+            const int ow = C.out_off[2] + lw * A.out_step[2];
+            T* yo = yb + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * A.Cy;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r0 = row0 + (wr * MT + i) * 16 + q * 4;
+                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                if (A.bias) { v0 += A.bias[r0]; v1 += A.bias[r0 + 1]; v2 += A.bias[r0 + 2]; v3 += A.bias[r0 + 3]; }
+                store4r<T>(yo + r0, v0, v1, v2, v3);
+                if (A.stats) {
+                    ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
+                    ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
+                }
+            }
+        }
+    }
+    if (A.stats) {
+        // reduce over the 16 voxel lanes (li), then over the 4 waves through LDS, then one fp64 atomic per row
+        __syncthreads();                       // all waves are done reading the halo tile
+        double* red = reinterpret_cast<double*>(smem);   // [WR*MT*16][2]
+        if (tid < WR * MT * 16 * 2) red[tid] = 0.0;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[i][r], s2 = ssq[i][r];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int ld = t.l0d + pd_[j], lh = t.l0h + ph_[j], lw = t.l0w + pw_[j];
-            const bool valid = (ld < C.L[0]) && (lh < C.L[1]) && (lw < C.L[2]);
-            if (valid) {
-                const int od = C.out_off[0] + ld * A.out_step[0];
-                const int oh = C.out_off[1] + lh * A.out_step[1];
-                const int ow = C.out_off[2] + lw * A.out_step[2];
-                T* yo = yb + ((((int64_t)t.n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * A.Cy;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int r0 = row0 + (wr * MT + i) * 16 + q * 4;
-                    float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-                    if (A.bias) { v0 += A.bias[r0]; v1 += A.bias[r0 + 1]; v2 += A.bias[r0 + 2]; v3 += A.bias[r0 + 3]; }
-                    store4r<T>(yo + r0, v0, v1, v2, v3);
-                    if (A.stats) {
-                        ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
-                        ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
-                    }
+                for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (li == 0) {
+                    atomicAdd(&red[((wr * MT + i) * 16 + q * 4 + r) * 2 + 0], (double)s);
+                    atomicAdd(&red[((wr * MT + i) * 16 + q * 4 + r) * 2 + 1], (double)s2);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (A.stats) {
-            // reduce over the 16 voxel lanes (li), then over the waves through LDS, then one fp64 atomic per row
-            double* red = reinterpret_cast<double*>(red_lds);   // [WR*MT*16][2], private region behind the halo tile
-            if (tid < WR * MT * 16 * 2) red[tid] = 0.0;
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float s = ssum[i][r], s2 = ssq[i][r];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                    if (li == 0) {
-                        atomicAdd(&red[((wr * MT + i) * 16 + q * 4 + r) * 2 + 0], (double)s);
-                        atomicAdd(&red[((wr * MT + i) * 16 + q * 4 + r) * 2 + 1], (double)s2);
-                    }
-                }
-            __syncthreads();
-            if (tid < WR * MT * 16 * 2) {
-                const int rep = (int)((unsigned)(t.l0w + t.l0h * 3 + t.l0d * 7 + blockIdx.x) % NNDET_STATS_REPLICAS);
-                double* dst = A.stats + (((int64_t)rep * A.N + t.n) * A.Cy + row0 + (tid >> 1)) * 2 + (tid & 1);
-                atomicAdd(dst, red[tid]);
-            }
-        }
-    };
-
-    // ---- the pipeline
-    Tile cur, nxt;
-    int tcur = next_valid(blockIdx.x, cur);
-    if (tcur < 0) return;
-    set_goff(cur);
-    issue(cur, 0);
-    commit();
-    __syncthreads();
-    int kc = 0;
-    while (true) {
-        // what comes after (cur, kc)?
-        int tn = tcur, kn = kc + 1;
-        bool has_next = true;
-        if (kn == nchunk) {
-            kn = 0;
-            tn = next_valid(tcur + gridDim.x, nxt);
-            has_next = tn >= 0;
-            if (has_next) set_goff(nxt);          // goff is only read by issue/commit: safe to overwrite during compute
-        } else {
-            nxt = cur;
-        }
-        if (has_next) issue(nxt, kn);             // in flight during the MFMA phase
-        compute(cur, kc);
-        if (kc == nchunk - 1) epilogue(cur);
-        __syncthreads();                          // every wave is done reading the staged tile
-        if (!has_next) break;
-        commit();
         __syncthreads();
-        cur = nxt; tcur = tn; kc = kn;
+        if (tid < WR * MT * 16 * 2) {
+            const int rep = (blockIdx.x + blockIdx.z * 7) % NNDET_STATS_REPLICAS;
+            double* dst = A.stats + (((int64_t)rep * A.N + n) * A.Cy + row0 + (tid >> 1)) * 2 + (tid & 1);
+            atomicAdd(dst, red[tid]);
+        }
     }
 }
 
@@ -339,8 +276,12 @@ struct Plan {
     size_t lds;
 };
 
-// cfg: 0 unit stride, rows % 64 != 0 : 32 rows x 512 points (WR = 1) ; 1 unit stride : 64 rows x 256 points (WR = 2) ;
-//      2 strided : 64 rows x 128 points (WR = 2) ; 3 strided, rows % 64 != 0 : 32 rows x 128 points (WR = 2)
+// cfg: 0 unit stride, rows % 64 != 0 : 32 rows x 512 points (WR = 1: the 32-row layers are not weight-traffic bound) ;
+//      1 unit stride : 64 rows x 256 points (WR = 2) ; 2 strided : 64 rows x 128 points (WR = 2) ;
+//      3 strided, rows % 64 != 0 : 32 rows x 128 points (WR = 2)
+// A persistent, register-prefetched variant of this kernel (one workgroup per CU, commit 'igemm: persistent
+// software-pipelined kernel') measured 25-50 % SLOWER than two independent workgroups per CU: with one wave per SIMD every
+// L2 / LDS stall of the tap loop is exposed. Two co-resident workgroups hide each other's staging and stalls.
 static const int CFG_ROWS[4] = {32, 64, 64, 32};
 static const int CFG_PTS[4] = {512, 256, 128, 128};
 
@@ -462,13 +403,9 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     a.mHW = magic(a.H[2]); a.mHH = magic(a.H[1]);
     a.lT1 = ilog2(a.T[1]); a.lT2 = ilog2(a.T[2]);
     a.swz = strided ? 0 : 1;
-    const int rowblocks = a.Cy / CFG_ROWS[P->cfg];
-    const int total_tiles = a.nt[0] * a.nt[1] * a.nt[2] * a.N * a.ncls;
-    int G = 1024 / rowblocks;                 // persistent workgroups per row block (~4 per CU over all row blocks)
-    if (G < 1) G = 1;
-    if (G > total_tiles) G = total_tiles;
-    P->grid = dim3(G, rowblocks, 1);
-    P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64 + 1024;   // halo tile + statistics scratch
+    P->grid = dim3(a.nt[0] * a.nt[1] * a.nt[2], a.Cy / CFG_ROWS[P->cfg], a.N * a.ncls);
+    P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64;
+    if (P->lds < 1024) P->lds = 1024;   // room for the stats reduction
     return 0;
 }
 

@@ -74,18 +74,39 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const StemArgs A) {
     store_row32<T>(reinterpret_cast<T*>(A.y) + v * A.Cy + c0, acc);
 }
 
-// persistent grid; block 256: thread = (tap, group of 4 output channels); chunk of 256 voxels staged in LDS
+// persistent grid; block 256: thread = (tap, group of 4 output channels); chunk of 256 voxels staged in LDS.
+// Staging uses UNCONDITIONAL clamped loads (27 input taps + the voxel's 32-channel dY row as 16-byte vectors) so that all
+// loads of a chunk are in flight together; dys rows are padded to 36 floats: conflict-free float4 writes and reads.
+#define STEM_DYS_STRIDE 36
+template <typename T> __device__ __forceinline__ void load_row32(const T* p, float* v);
+template <> __device__ __forceinline__ void load_row32<float>(const float* p, float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float4 f = reinterpret_cast<const float4*>(p)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+}
+template <> __device__ __forceinline__ void load_row32<bf16_t>(const bf16_t* p, float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 u = reinterpret_cast<const uint4*>(p)[i];
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = __uint_as_float(w[k] << 16); v[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_stem_wgrad(const StemArgs A) {
-    __shared__ float xs[27 * 257];       // [tap][voxel], row stride 257: taps land in different banks
-    __shared__ float dys[256 * 32];      // [voxel][32 channels] fp32
+    extern __shared__ __attribute__((aligned(16))) char smem_stem[];
+    float* xs = reinterpret_cast<float*>(smem_stem);                 // [27][257]: taps land in different banks
+    float* dys = xs + 27 * 257 + 1;                                   // [256][36] fp32 (16-byte aligned: 27*257+1 = 6940 floats)
     const int taps = A.k[0] * A.k[1] * A.k[2];
     const int c0 = blockIdx.y * 32;
-    const int tap = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    const int slot = threadIdx.x >> 3, cg = threadIdx.x & 7;          // slot = static (kd, kh, kw) in 3^3
+    const int skd = slot / 9, skh = (slot / 3) % 3, skw = slot % 3;
+    const bool active = slot < 27 && skd < A.k[0] && skh < A.k[1] && skw < A.k[2];
+    const int tap = (skd * A.k[1] + skh) * A.k[2] + skw;              // index into the weight's flattened kernel volume
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int64_t nchunks = (A.total + 255) / 256;
     for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        __syncthreads();
         const int64_t v = ch * 256 + threadIdx.x;
         const bool valid = v < A.total;
         int64_t t2 = valid ? v : 0;
@@ -94,32 +115,41 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemArgs A) {
         const int od = (int)(t2 % A.O[0]);
         const int n = (int)(t2 / A.O[0]);
         const T* xn = reinterpret_cast<const T*>(A.x) + (int64_t)n * A.I[0] * A.I[1] * A.I[2];
-        int t = 0;
-        for (int kd = 0; kd < A.k[0]; ++kd)
-            for (int kh = 0; kh < A.k[1]; ++kh)
-                for (int kw = 0; kw < A.k[2]; ++kw, ++t) {
+        float xv[27];     // static slots (kd, kh, kw) in 3^3; kernels smaller than 3 leave slots inactive (zero)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
                     const int id = od * A.s[0] - A.p[0] + kd, ih = oh * A.s[1] - A.p[1] + kh, iw = ow * A.s[2] - A.p[2] + kw;
-                    float xv = 0.f;
-                    if (valid && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
-                        xv = Elem<T>::ld(xn[((int64_t)id * A.I[1] + ih) * A.I[2] + iw]);
-                    xs[t * 257 + threadIdx.x] = xv;
+                    const bool ok = valid && kd < A.k[0] && kh < A.k[1] && kw < A.k[2] &&
+                                    (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
+                    const float raw = Elem<T>::ld(xn[ok ? ((int64_t)id * A.I[1] + ih) * A.I[2] + iw : 0]);
+                    xv[kd * 9 + kh * 3 + kw] = ok ? raw : 0.f;
                 }
-        const T* dyv = reinterpret_cast<const T*>(A.dy) + v * A.Cy + c0;
-#pragma unroll 8
-        for (int c = 0; c < 32; ++c) dys[threadIdx.x * 32 + c] = valid ? Elem<T>::ld(dyv[c]) : 0.f;
+        float dv[32];
+        load_row32<T>(reinterpret_cast<const T*>(A.dy) + (valid ? v : 0) * A.Cy + c0, dv);
+        __syncthreads();                        // previous chunk's compute is done with the LDS buffers
+#pragma unroll
+        for (int k = 0; k < 27; ++k) xs[k * 257 + threadIdx.x] = xv[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            *reinterpret_cast<float4*>(dys + threadIdx.x * STEM_DYS_STRIDE + 4 * k) =
+                valid ? make_float4(dv[4 * k], dv[4 * k + 1], dv[4 * k + 2], dv[4 * k + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        if (tap < taps) {
-            const float* xr = xs + tap * 257;
+        if (active) {
+            const float* xr = xs + slot * 257;
             const float* dr = dys + cg * 4;
-#pragma unroll 4
+#pragma unroll 8
             for (int i = 0; i < 256; ++i) {
-                const float xv = xr[i];
-                const float4 d = *reinterpret_cast<const float4*>(dr + i * 32);
-                a0 = fmaf(xv, d.x, a0); a1 = fmaf(xv, d.y, a1); a2 = fmaf(xv, d.z, a2); a3 = fmaf(xv, d.w, a3);
+                const float x1 = xr[i];
+                const float4 d = *reinterpret_cast<const float4*>(dr + i * STEM_DYS_STRIDE);
+                a0 = fmaf(x1, d.x, a0); a1 = fmaf(x1, d.y, a1); a2 = fmaf(x1, d.z, a2); a3 = fmaf(x1, d.w, a3);
             }
         }
     }
-    if (tap < taps) {
+    if (active) {
         const int c = c0 + cg * 4;
         if (c + 0 < A.cout) atomicAdd(A.dw + (int64_t)(c + 0) * taps + tap, a0);
         if (c + 1 < A.cout) atomicAdd(A.dw + (int64_t)(c + 1) * taps + tap, a1);
@@ -160,9 +190,16 @@ int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hip
     if (rc) return rc;
     a.x = x; a.dy = dy; a.dw = dw;
     int64_t nchunks = ceil_div64(a.total, 256);
-    dim3 grid((unsigned)(nchunks < 2048 ? nchunks : 2048), c->cout_p / 32);
-    if (c->dtype == NNDET_BF16) k_stem_wgrad<bf16_t><<<grid, 256, 0, st>>>(a);
-    else k_stem_wgrad<float><<<grid, 256, 0, st>>>(a);
+    dim3 grid((unsigned)(nchunks < 1024 ? nchunks : 1024), c->cout_p / 32);
+    const size_t lds = (27 * 257 + 1 + 256 * STEM_DYS_STRIDE) * sizeof(float);   // 64.6 KB
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr = true;
+    }
+    if (c->dtype == NNDET_BF16) k_stem_wgrad<bf16_t><<<grid, 256, lds, st>>>(a);
+    else k_stem_wgrad<float><<<grid, 256, lds, st>>>(a);
     LAUNCH_CHECK();
     return 0;
 }

@@ -94,21 +94,27 @@ def get_params_no_wd_on_norm(model: nn.Module, weight_decay: float) -> List[dict
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
-def configure_optimizer(model: nn.Module, trainer_cfg: dict = None):
-    """SGD(nesterov) + linear warm-up -> poly decay, stepped per iteration (retinaunet/base.py:300-336)."""
+def configure_optimizer(model: nn.Module, trainer_cfg: dict = None, lean: bool = True):
+    """SGD(nesterov) + linear warm-up -> poly decay, stepped per iteration (retinaunet/base.py:300-336).
+    lean=True: the foreach-based implementation of nndetection_amd/optim.py (same arithmetic, far less host time);
+    lean=False: torch.optim.SGD + LambdaLR."""
     cfg = dict(TRAINER_CFG_V001 if trainer_cfg is None else trainer_cfg)
-    opt = torch.optim.SGD(get_params_no_wd_on_norm(model, cfg["weight_decay"]), cfg["initial_lr"],
-                          weight_decay=cfg["weight_decay"], momentum=cfg["sgd_momentum"], nesterov=cfg["sgd_nesterov"])
+    groups = get_params_no_wd_on_norm(model, cfg["weight_decay"])
     total = cfg["max_num_epochs"] * cfg["num_train_batches_per_epoch"]
     warm, warm_lr, lr0, gamma = cfg["warm_iterations"], cfg["warm_lr"], cfg["initial_lr"], cfg["poly_gamma"]
+    if lean:
+        from .optim import SGDNesterov, LinearWarmupPolyLR
+        opt = SGDNesterov(groups, lr0, momentum=cfg["sgd_momentum"], nesterov=cfg["sgd_nesterov"])
+        return opt, LinearWarmupPolyLR(opt, warm, warm_lr, gamma, total)
+    opt = torch.optim.SGD(groups, lr0, weight_decay=cfg["weight_decay"], momentum=cfg["sgd_momentum"], nesterov=cfg["sgd_nesterov"])
 
-    def factor(it: int) -> float:
-        if it < warm:                                     # learning_rate.py:160-171 (linear warm-up from warm_lr)
-            return (warm_lr + (lr0 - warm_lr) * it / warm) / lr0
-        return (1 - (it - warm) / max(1, total - warm)) ** gamma   # poly decay of the remaining iterations
+    def factor(it: int) -> float:                 # it = number of scheduler steps so far; the reference uses k = it + 1
+        k = it + 1
+        if k - 1 < warm:
+            return (warm_lr + (lr0 - warm_lr) * k / warm) / lr0
+        return (1 - (k - warm) / max(1, total - warm)) ** gamma
 
-    sched = torch.optim.lr_scheduler.LambdaLR(opt, factor)
-    return opt, sched
+    return opt, torch.optim.lr_scheduler.LambdaLR(opt, factor)
 
 
 def register_with_nndet():

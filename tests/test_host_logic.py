@@ -74,12 +74,39 @@ def test_optimizer_groups_and_schedule():
     from nndetection_amd.ptmodule import build_model, configure_optimizer
     from nndetection_amd.plans import get_plan
     m = build_model(get_plan("luna160"))
-    opt, sched = configure_optimizer(m)
+    opt, sched = configure_optimizer(m, lean=False)
     no_wd, wd = opt.param_groups
     assert no_wd["weight_decay"] == 0.0 and wd["weight_decay"] == 3e-5
-    assert len(no_wd["params"]) == 2 * 16 and len(no_wd["params"]) + len(wd["params"]) == 92 - 0   # 16 norm modules
+    assert len(no_wd["params"]) == 2 * 16 and len(no_wd["params"]) + len(wd["params"]) == 92     # 16 norm modules
     assert opt.defaults["nesterov"] and opt.defaults["momentum"] == 0.9
-    assert abs(opt.param_groups[0]["lr"] - 1e-6) < 1e-9                                              # warm-up start
+    # reference schedule: lr(k) = warm_lr + (lr0 - warm_lr) * k / 4000 during warm-up, k = _step_count (starts at 1)
+    assert abs(opt.param_groups[0]["lr"] - (1e-6 + (0.01 - 1e-6) / 4000)) < 1e-12
+
+
+def test_lean_optimizer_matches_torch_sgd():
+    """nndetection_amd.optim.SGDNesterov + LinearWarmupPolyLR == torch.optim.SGD + reference schedule, step by step,
+    including parameters without gradient in some steps (unused heads)."""
+    from nndetection_amd.ptmodule import configure_optimizer
+    cfg = {"initial_lr": 0.01, "sgd_momentum": 0.9, "sgd_nesterov": True, "weight_decay": 3e-5, "warm_iterations": 3,
+           "warm_lr": 1e-6, "poly_gamma": 0.9, "max_num_epochs": 1, "num_train_batches_per_epoch": 10}
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(1)
+        return nn.Sequential(nn.Conv3d(2, 4, 3), nn.InstanceNorm3d(4, affine=True), nn.Conv3d(4, 2, 1), nn.Linear(3, 3))
+    a, b = make(), make()
+    oa, sa = configure_optimizer(a, cfg, lean=True)
+    ob, sb = configure_optimizer(b, cfg, lean=False)
+    for it in range(8):
+        x = torch.randn(2, 2, 5, 5, 5)
+        for m, o, s in ((a, oa, sa), (b, ob, sb)):
+            y = m[2](m[1](m[0](x))).sum()
+            if it % 3 != 1:
+                y = y + m[3](torch.ones(3)).sum()       # m[3] has no gradient in some steps
+            y.backward()
+            o.step(); s.step(); o.zero_grad(set_to_none=True)
+        assert abs(oa.param_groups[0]["lr"] - ob.param_groups[0]["lr"]) < 1e-15
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, atol=1e-7, rtol=1e-6), it
 
 
 def _ddp_worker(rank, world, port, q):
