@@ -335,7 +335,7 @@ static int wg_dispatch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
 
 // number of spatial slices (= workgroups per channel-block pair) for a problem with `pairs` block pairs
 static int wgrad_slices(int pairs, int total_tiles) {
-    int S = 1024 / pairs;
+    int S = 512 / pairs;    // ~2 persistent workgroups per CU over all block pairs
     if (S < 1) S = 1;
     if (S > total_tiles) S = total_tiles;
     return S;
@@ -346,7 +346,7 @@ size_t wgrad_workspace_bytes(const NndetConv* c) {
     const int rb = (tr ? c->cin_p : c->cout_p) / 32, kb = (tr ? c->cout_p : c->cin_p) / 32;
     const int ntap = c->k[0] * c->k[1] * c->k[2];
     // upper bound independent of the tile choice: S <= 1024 / pairs (>= 1), x4 sub-slices when the waves split k-steps
-    int S = 1024 / (rb * kb); if (S < 1) S = 1;
+    int S = 512 / (rb * kb); if (S < 1) S = 1;
     const int slices = ntap >= 4 ? S : 4 * S;
     return (size_t)slices * rb * kb * ntap * 1024 * sizeof(float);
 }

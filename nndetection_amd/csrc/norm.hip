@@ -36,13 +36,20 @@ template <> struct Vec16<bf16_t> {
 };
 
 #define ROWS_PER_BLOCK 512    // rows (voxels) handled by one workgroup in the element-wise (apply) kernels
-#define RED_ROWS 4096          // rows per workgroup in the reduction kernels: 8x fewer LDS/global fp64 atomics per byte
+// rows per workgroup in the reduction kernels: as many as possible (fewer LDS / global fp64 atomics per byte) while
+// keeping >= ~1024 workgroups in flight; a fixed 4096 starved the small layers (40 workgroups on 256 CUs)
+static inline int red_rows(int64_t rows_total) {
+    int64_t r = rows_total / 1024;
+    if (r < 256) r = 256;
+    if (r > 4096) r = 4096;
+    return (int)r;
+}
 
 // ------------------------------------------------------------------ statistics: sum / sumsq per (n, channel)
 // grid (ceil(spatial / ROWS_PER_BLOCK), N)
 template <typename T>
 __global__ __launch_bounds__(256) void k_norm_stats(const T* __restrict__ x, int64_t spatial, int c_p, int N,
-                                                    double* __restrict__ stats) {
+                                                    double* __restrict__ stats, int RED_ROWS) {
     constexpr int E = Vec16<T>::E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem);   // [c_p][2]
@@ -79,10 +86,11 @@ __global__ __launch_bounds__(256) void k_norm_stats(const T* __restrict__ x, int
 
 int norm_stats_run(int dtype, const void* x, int batch, int64_t spatial, int c_p, double* stats, hipStream_t st) {
     if (c_p % 32 || c_p > 1024 || batch <= 0 || spatial <= 0) return NNDET_EINVAL;
-    dim3 grid((unsigned)ceil_div64(spatial, RED_ROWS), batch);
+    const int rr = red_rows(spatial * batch);
+    dim3 grid((unsigned)ceil_div64(spatial, rr), batch);
     const size_t lds = (size_t)c_p * 16;
-    if (dtype == NNDET_BF16) k_norm_stats<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)x, spatial, c_p, batch, stats);
-    else k_norm_stats<float><<<grid, 256, lds, st>>>((const float*)x, spatial, c_p, batch, stats);
+    if (dtype == NNDET_BF16) k_norm_stats<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)x, spatial, c_p, batch, stats, rr);
+    else k_norm_stats<float><<<grid, 256, lds, st>>>((const float*)x, spatial, c_p, batch, stats, rr);
     LAUNCH_CHECK();
     return 0;
 }
@@ -186,7 +194,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int64_t spatial, int c, int c_p,
-                                                         int N, int relu, double* __restrict__ red_ws) {
+                                                         int N, int relu, double* __restrict__ red_ws, int RED_ROWS) {
     constexpr int E = Vec16<T>::E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem);
@@ -319,12 +327,13 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
     dim3 grid((unsigned)ceil_div64(spatial, ROWS_PER_BLOCK), batch);
-    dim3 rgrid((unsigned)ceil_div64(spatial, RED_ROWS), batch);
+    const int rr = red_rows(spatial * batch);
+    dim3 rgrid((unsigned)ceil_div64(spatial, rr), batch);
     const size_t lds = (size_t)c_p * 16;
     if (dtype == NNDET_BF16)
-        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws);
+        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr);
     else
-        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws);
+        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr);
     LAUNCH_CHECK();
     k_norm_bwd_finalize<<<batch, 256, lds, st>>>(red_ws, gamma, batch, c, c_p, groups, spatial, dgamma, dbeta);
     LAUNCH_CHECK();
@@ -338,7 +347,7 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
 
 // ------------------------------------------------------------------ column sums (bias gradient): out[c] += sum_rows x[row][c]
 template <typename T>
-__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ x, int64_t rows, int c_p, int c, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ x, int64_t rows, int c_p, int c, float* __restrict__ out, int RED_ROWS) {
     constexpr int E = Vec16<T>::E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);
@@ -367,9 +376,10 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ x, int64_t
 
 int colsum_run(int dtype, const void* x, int64_t rows, int c_p, int c, float* out, hipStream_t st) {
     if (c_p % 32 || c_p > 1024 || rows <= 0) return NNDET_EINVAL;
-    const unsigned nb = (unsigned)ceil_div64(rows, RED_ROWS);
-    if (dtype == NNDET_BF16) k_colsum<bf16_t><<<nb, 256, (size_t)c_p * 4, st>>>((const bf16_t*)x, rows, c_p, c, out);
-    else k_colsum<float><<<nb, 256, (size_t)c_p * 4, st>>>((const float*)x, rows, c_p, c, out);
+    const int rr = red_rows(rows);
+    const unsigned nb = (unsigned)ceil_div64(rows, rr);
+    if (dtype == NNDET_BF16) k_colsum<bf16_t><<<nb, 256, (size_t)c_p * 4, st>>>((const bf16_t*)x, rows, c_p, c, out, rr);
+    else k_colsum<float><<<nb, 256, (size_t)c_p * 4, st>>>((const float*)x, rows, c_p, c, out, rr);
     LAUNCH_CHECK();
     return 0;
 }
