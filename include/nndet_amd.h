@@ -147,6 +147,8 @@ int nndet_pack_weight(const NndetConv* c, int32_t mode, const float* w, void* pa
  * If stats != NULL ([NNDET_STATS_REPLICAS, N, cout_p, 2] fp64, zeroed by the caller) the epilogue accumulates per-(n, channel)
  * sum and sum of squares of the ROUNDED outputs: the InstanceNorm / GroupNorm statistics pass is fused away. */
 int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w_packed_mode0, const float* bias,
+                         const void* residual /* NULL or [N,od,oh,ow,cout_p]: y = conv + bias + residual (UFPN top-down add,
+                                                nndet/arch/decoder/base.py:410) */,
                          void* y, double* stats, void* stream);
 /* dx[N,id,ih,iw,cin_p] = conv^T(dy[N,od,oh,ow,cout_p]) */
 int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w_packed_mode1,

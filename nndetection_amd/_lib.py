@@ -48,7 +48,7 @@ SIGNATURES = {
     "nndet_decode_clip3d_f32": (C.c_int, [_P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P]),
     "nndet_packed_weight_elems": (_SZ, [_CONVP, _I32]),
     "nndet_pack_weight": (C.c_int, [_CONVP, _I32, _P, _P, _P]),
-    "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P]),
+    "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
     "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
     "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -82,7 +82,7 @@ class _ConvBlockFn(torch.autograd.Function):
     """conv (+bias) [-> InstanceNorm/GroupNorm (+ReLU)] as one node."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, mod):
+    def forward(ctx, x, weight, bias, gamma, beta, mod, residual=None):
         x_p, cin = phys(x)
         if cin != mod.in_channels:
             raise L.NndetError(f"expected {mod.in_channels} input channels, got {cin}")
@@ -95,8 +95,15 @@ class _ConvBlockFn(torch.autograd.Function):
         has_norm = gamma is not None
         stats = torch.zeros((L.STATS_REPLICAS, N, cout_p, 2), dtype=torch.float64, device=dev) if has_norm else None
         b_p = _pad1d(bias, cout_p)
-        L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(y), L.ptr(stats), L.stream())
-        ctx.desc, ctx.mod, ctx.has_norm, ctx.has_bias = desc, mod, has_norm, bias is not None
+        r_p = None
+        if residual is not None:
+            if has_norm:
+                raise L.NndetError("a fused residual is only defined for convolutions without norm")
+            r_p, _ = phys(residual, dtype=dt, cp=cout_p)
+            if tuple(r_p.shape) != tuple(y.shape):
+                raise L.NndetError(f"residual shape {tuple(residual.shape)} does not match the conv output")
+        L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats), L.stream())
+        ctx.desc, ctx.mod, ctx.has_norm, ctx.has_bias, ctx.has_res = desc, mod, has_norm, bias is not None, residual is not None
         if has_norm:
             out = torch.empty_like(y)
             mean_rstd = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
@@ -146,7 +153,8 @@ class _ConvBlockFn(torch.autograd.Function):
         ws = L.workspace(ws_bytes, dev)
         L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw), L.ptr(dbias),
                L.ptr(ws), ws_bytes, L.stream())
-        return dx, dw.to(weight.dtype), dbias, dgamma, dbeta, None
+        # d(residual) = grad_out: the same NDHWC buffer is handed to both consumers (no copy, no add kernel)
+        return dx, dw.to(weight.dtype), dbias, dgamma, dbeta, None, (logical(g_p, cout) if ctx.has_res else None)
 
 
 class BaseConvNormAct(nn.Sequential):
@@ -191,10 +199,11 @@ class BaseConvNormAct(nn.Sequential):
         if initializer is not None:
             self.apply(initializer)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """residual (optional, only without norm): returns conv(x) + residual from ONE kernel (epilogue add)."""
         has_norm = self.norm_groups > 0
         return _ConvBlockFn.apply(x, self.conv.weight, self.conv.bias,
-                                  self.norm.weight if has_norm else None, self.norm.bias if has_norm else None, self)
+                                  self.norm.weight if has_norm else None, self.norm.bias if has_norm else None, self, residual)
 
 
 class ConvInstanceRelu(BaseConvNormAct):

@@ -65,11 +65,11 @@ class UFPNModular(nn.Module):
     def forward(self, inp_seq: Sequence[torch.Tensor]) -> List[Optional[torch.Tensor]]:
         fpn = [self.lateral[f"P{l}"](fm) for l, fm in enumerate(inp_seq)]
         xs: List[Optional[torch.Tensor]] = [None] * self.num_level
-        up = None
-        for level in range(self.num_level - 1, -1, -1):
-            x = fpn[level] if up is None else fpn[level] + up
-            if level > 0:
-                up = self.up[f"P{level}"](x)
+        x = fpn[self.num_level - 1]
+        xs[self.num_level - 1] = x
+        for level in range(self.num_level - 2, -1, -1):
+            # x_l = lateral_l + up_{l+1}(x_{l+1})  (decoder/base.py:405-413): the add is the epilogue of the transposed conv
+            x = self.up[f"P{level + 1}"](x, residual=fpn[level])
             xs[level] = x
         outs = []
         for level in range(self.num_level):

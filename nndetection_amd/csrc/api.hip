@@ -14,13 +14,14 @@ static int check_conv(const NndetConv* c) {
     return 0;
 }
 
-extern "C" int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w, const float* bias, void* y,
-                                    double* stats, void* stream) {
+extern "C" int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w, const float* bias, const void* residual,
+                                    void* y, double* stats, void* stream) {
     int rc = check_conv(c);
     if (rc) return rc;
     if (!x || !w || !y) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
     if (c->cin_p == 1) {
+        if (residual) return NNDET_EINVAL;
         rc = stem_forward(c, x, (const float*)w, bias, y, st);
         if (rc) return rc;
         if (stats) {
@@ -29,14 +30,14 @@ extern "C" int nndet_conv3d_forward(const NndetConv* c, const void* x, const voi
         }
         return 0;
     }
-    return igemm_run(c, 0, x, w, bias, y, stats, st);
+    return igemm_run(c, 0, x, w, bias, residual, y, stats, st);
 }
 
 extern "C" int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w, void* dx, void* stream) {
     int rc = check_conv(c);
     if (rc) return rc;
     if (!dy || !w || !dx || c->cin_p == 1) return NNDET_EINVAL;
-    return igemm_run(c, 1, dy, w, nullptr, dx, nullptr, as_stream(stream));
+    return igemm_run(c, 1, dy, w, nullptr, nullptr, dx, nullptr, as_stream(stream));
 }
 
 extern "C" size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c) {

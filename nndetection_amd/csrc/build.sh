@@ -27,5 +27,5 @@ build api.hip
 rc=0
 for p in "${pids[@]}"; do wait $p || rc=1; done
 [ $rc -eq 0 ] || { echo "compile failed"; exit 1; }
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libnndet_amd.so _obj/*.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o libnndet_amd.so _obj/*.o
 echo "built $(pwd)/libnndet_amd.so"

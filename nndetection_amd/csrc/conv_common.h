@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 // fp64 (sum, sumsq) statistics are accumulated into this many replicas to spread atomic contention;
 // consumers (norm_apply) add the replicas up. Layout [NNDET_STATS_REPLICAS][N][C_p][2].
@@ -9,7 +10,7 @@
 
 // conv_igemm.hip
 int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x, const void* w, const float* bias,
-              void* y, double* stats, hipStream_t st);
+              const void* res, void* y, double* stats, hipStream_t st);
 // conv_wgrad.hip
 int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_workspace_bytes(const NndetConv* c);

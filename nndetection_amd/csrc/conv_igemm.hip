@@ -62,6 +62,16 @@ template <> __device__ __forceinline__ void store4r<bf16_t>(bf16_t* p, float& a,
     c = __uint_as_float(v.y << 16); d = __uint_as_float(v.y & 0xffff0000u);
 }
 
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
+    const float4 f = *reinterpret_cast<const float4*>(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+
 // max 16-byte halo pieces per thread per chunk: 16 (halo <= 1024 voxels = 64 KiB) for unit-stride tiles,
 // 24 (<= 1536 voxels = 96 KiB) for the strided configurations (template parameter MAXP)
 
@@ -75,6 +85,7 @@ struct IgTap { int32_t d[3]; int32_t wt; };   // delta - in_base (>= 0), weight 
 
 struct IgArgs {
     const void* x; const void* w; const float* bias; void* y; double* stats;
+    const void* res;      // optional residual, same layout as y: y = conv + bias + res (decoder top-down add fused away)
     int32_t N;
     int32_t I[3], Cx;     // input tensor spatial dims, physical channels (= K)
     int32_t O[3], Cy;     // output tensor spatial dims, physical channels (= rows)
@@ -94,8 +105,9 @@ struct IgArgs {
 // A wave owns MT row tiles x NT point tiles of 16. Splitting rows across waves (WR = 2) halves the weight-fragment
 // traffic from L2 (every wave used to stream the weights of ALL rows: 432 KB per workgroup and chunk, the bottleneck of
 // the C >= 64 layers) at the price of twice as many (cheap, conflict-free) LDS activation reads.
-template <typename T, int WR, int MT, int NT, int MAXP>
-__global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
+// MINW = requested waves per SIMD (= workgroups per CU for 256-thread workgroups): caps the register allocation.
+template <typename T, int WR, int MT, int NT, int MAXP, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -144,14 +156,12 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
     }
     // LDS byte offsets of this lane's lattice points (tap offset 0) for its NT B-fragments
     int boff[NT];
-    int pd_[NT], ph_[NT], pw_[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int p = (wc * NT + j) * 16 + li;
         const int pw = p & (A.T[2] - 1);
         const int t2 = p >> A.lT2;
         const int ph = t2 & (A.T[1] - 1), pd = t2 >> A.lT1;
-        pd_[j] = pd; ph_[j] = ph; pw_[j] = pw;
         const int brow = (pd * A.in_step[0]) * HH + ph * A.in_step[1];
         boff[j] = ((brow * HW + pw * A.in_step[2]) * 64 + q * 16) ^ ((brow & A.swz) << 5);
     }
@@ -221,7 +231,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
         for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int ld = l0d + pd_[j], lh = l0h + ph_[j], lw = l0w + pw_[j];
+        // lattice coordinates of this lane's point (recomputed here instead of living in 3*NT registers through the main loop:
+        // the saved registers buy a third wave per SIMD for latency hiding)
+        const int pp = (wc * NT + j) * 16 + li;
+        const int pt2 = pp >> A.lT2;
+        const int ld = l0d + (pt2 >> A.lT1), lh = l0h + (pt2 & (A.T[1] - 1)), lw = l0w + (pp & (A.T[2] - 1));
         const bool valid = (ld < C.L[0]) && (lh < C.L[1]) && (lw < C.L[2]);
         if (valid) {
             const int od = C.out_off[0] + ld * A.out_step[0];
@@ -233,6 +247,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IgArgs A) {
                 const int r0 = row0 + (wr * MT + i) * 16 + q * 4;
                 float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
                 if (A.bias) { v0 += A.bias[r0]; v1 += A.bias[r0 + 1]; v2 += A.bias[r0 + 2]; v3 += A.bias[r0 + 3]; }
+                if (A.res) {
+                    float r4[4];
+                    load4<T>(reinterpret_cast<const T*>(A.res) + (yo - yb) + r0, r4);
+                    v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+                }
                 store4r<T>(yo + r0, v0, v1, v2, v3);
                 if (A.stats) {
                     ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
@@ -282,8 +301,9 @@ struct Plan {
 // A persistent, register-prefetched variant of this kernel (one workgroup per CU, commit 'igemm: persistent
 // software-pipelined kernel') measured 25-50 % SLOWER than two independent workgroups per CU: with one wave per SIMD every
 // L2 / LDS stall of the tap loop is exposed. Two co-resident workgroups hide each other's staging and stalls.
-static const int CFG_ROWS[4] = {32, 64, 64, 32};
-static const int CFG_PTS[4] = {512, 256, 128, 128};
+//      4 (experimental, NNDET_IGEMM_A256=1): like 0 but 256 points per workgroup, 4 workgroups per CU
+static const int CFG_ROWS[5] = {32, 64, 64, 32, 32};
+static const int CFG_PTS[5] = {512, 256, 128, 128, 256};
 
 static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[3], int points, int maxp, int T[3], int H[3]) {
     double best = 1e300;
@@ -393,7 +413,8 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     }
     const bool strided = a.in_step[0] > 1 || a.in_step[1] > 1 || a.in_step[2] > 1;
     const bool r64 = (a.Cy % 64) == 0;
-    P->cfg = strided ? (r64 ? 2 : 3) : (r64 ? 1 : 0);
+    static const int a256 = getenv("NNDET_IGEMM_A256") ? atoi(getenv("NNDET_IGEMM_A256")) : 0;
+    P->cfg = strided ? (r64 ? 2 : 3) : (r64 ? 1 : (a256 ? 4 : 0));
     const int points = CFG_PTS[P->cfg];
     for (int i = 0; i < 3; ++i) if (Lmax[i] <= 0) return NNDET_EINVAL;
     if (!choose_tile(Lmax, a.in_step, span, points, strided ? 24 : 16, a.T, a.H)) return NNDET_EINVAL;
@@ -412,39 +433,40 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
 template <typename T>
 static int launch_cfg(const Plan& P, hipStream_t st) {
     switch (P.cfg) {
-        case 0: k_igemm<T, 1, 2, 8, 16><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 1: k_igemm<T, 2, 2, 8, 16><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 2: k_igemm<T, 2, 2, 4, 24><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        default: k_igemm<T, 2, 1, 4, 24><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 0: k_igemm<T, 1, 2, 8, 16, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 1: k_igemm<T, 2, 2, 8, 16, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 2: k_igemm<T, 2, 2, 4, 24, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 3: k_igemm<T, 2, 1, 4, 24, 4><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        default: k_igemm<T, 1, 2, 4, 16, 4><<<P.grid, 256, P.lds, st>>>(P.a); break;
     }
     LAUNCH_CHECK();
     return 0;
 }
 
-template <typename T, int WR, int MT, int NT, int MAXP>
+template <typename T, int WR, int MT, int NT, int MAXP, int MINW>
 static int set_lds_attr() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP, MINW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 }
 static int g_attr_done = 0;
 static int ensure_attrs() {
     if (g_attr_done) return 0;
     int rc = 0;
-    rc |= set_lds_attr<bf16_t, 1, 2, 8, 16>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24>();
-    rc |= set_lds_attr<float, 1, 2, 8, 16>(); rc |= set_lds_attr<float, 2, 2, 8, 16>(); rc |= set_lds_attr<float, 2, 2, 4, 24>(); rc |= set_lds_attr<float, 2, 1, 4, 24>();
+    rc |= set_lds_attr<bf16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24, 3>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24, 4>(); rc |= set_lds_attr<bf16_t, 1, 2, 4, 16, 4>();
+    rc |= set_lds_attr<float, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<float, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<float, 2, 2, 4, 24, 3>(); rc |= set_lds_attr<float, 2, 1, 4, 24, 4>(); rc |= set_lds_attr<float, 1, 2, 4, 16, 4>();
     if (rc) return rc;
     g_attr_done = 1;
     return 0;
 }
 
-int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, void* y, double* stats,
-              hipStream_t st) {
+int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y,
+              double* stats, hipStream_t st) {
     Plan P;
     int rc = build_plan(c, kind, &P);
     if (rc) return rc;
     rc = ensure_attrs();
     if (rc) return rc;
-    P.a.x = x; P.a.w = w; P.a.bias = bias; P.a.y = y; P.a.stats = stats;
+    P.a.x = x; P.a.w = w; P.a.bias = bias; P.a.y = y; P.a.stats = stats; P.a.res = res;
     return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t>(P, st) : launch_cfg<float>(P, st);
 }
 

@@ -180,3 +180,26 @@ def test_full_size_layer_against_torch_gpu():
     y2 = m(2.5 * x)
     b = m.conv.bias.view(1, -1, 1, 1, 1)
     assert relerr(y2 - b, 2.5 * (y - b)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_transposed_conv_with_fused_residual(dtype):
+    """decoder top-down step x_l = lateral_l + up(x_{l+1}) (nndet/arch/decoder/base.py:405-413) from one kernel."""
+    m, x, cfg = _mk("up_222", dtype)
+    res = torch.randn(2, 32, 8, 10, 12)
+    rd = lambda t_: t_.detach().to(dtype).float().clone()
+    xr, rr = rd(x).requires_grad_(True), rd(res).requires_grad_(True)
+    w = rd(m.conv.weight).requires_grad_(True); b = m.conv.bias.detach().clone().requires_grad_(True)
+    yref = F.conv_transpose3d(xr, w, b, stride=2) + rr
+    gy = rd(torch.randn_like(yref))
+    yref.backward(gy)
+    m = m.cuda()
+    xg = x.detach().clone().cuda().to(dtype).requires_grad_(True)
+    rg = res.detach().clone().cuda().to(dtype).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    y = m(xg, residual=rg)
+    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    assert relerr(y.float(), yref) <= tol
+    y.backward(gy.cuda().to(dtype))
+    assert relerr(xg.grad.float(), xr.grad) <= tol
+    assert relerr(rg.grad.float(), rr.grad) <= tol
+    assert relerr(m.conv.weight.grad, w.grad) <= tol

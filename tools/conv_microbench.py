@@ -49,7 +49,7 @@ def main():
         dy = torch.randn_like(y); dx = torch.empty_like(x)
         dw = torch.zeros_like(m.conv.weight)
         st = L.stream()
-        f = lambda: L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, L.ptr(y), None, st)
+        f = lambda: L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, None, L.ptr(y), None, st)
         g = lambda: L.call("nndet_conv3d_backward_data", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx), st)
         wsb = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
         ws = L.workspace(wsb, x.device)
