@@ -45,6 +45,7 @@ SIGNATURES = {
     "nndet_anchors3d_grid_f32": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "nndet_atss3d_workspace_bytes": (_SZ, [_I64, _I64, _I32, _I32]),
     "nndet_atss3d_match_f32": (C.c_int, [_P, _I64, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _SZ, _P]),
+    "nndet_atss3d_match_batched_f32": (C.c_int, [_P, _I64, C.POINTER(C.c_int32), _I32, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _SZ, _P]),
     "nndet_decode_clip3d_f32": (C.c_int, [_P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P]),
     "nndet_packed_weight_elems": (_SZ, [_CONVP, _I32]),
     "nndet_pack_weight": (C.c_int, [_CONVP, _I32, _P, _P, _P]),

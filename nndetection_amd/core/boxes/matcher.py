@@ -48,3 +48,29 @@ class ATSSMatcher:
         L.call("nndet_atss3d_match_f32", L.ptr(gt), G, L.ptr(an), M, offs_c, Lv, k, L.ptr(matches), L.ptr(ws), ws_bytes, L.stream())
         mq = self.similarity_fn(gt, an) if self.return_match_quality else an.new_ones(1)
         return mq, matches
+
+    def match_batch(self, boxes: Sequence[Tensor], anchors: Tensor, num_anchors_per_level: Sequence[int],
+                    num_anchors_per_loc: int) -> Tuple[Tensor, Tensor, Sequence[int]]:
+        """All images of a batch against their shared anchors in ONE pass (nndet_atss3d_match_batched_f32).
+        -> (gt_all [G,6] concatenated, matches [B, M] with indices local to the image / -1, offsets [B+1])."""
+        M, B = anchors.shape[0], len(boxes)
+        dev = anchors.device
+        offs_img = [0]
+        for b in boxes:
+            offs_img.append(offs_img[-1] + int(b.shape[0]))
+        G = offs_img[-1]
+        an = anchors.detach().float().contiguous()
+        nz = [b.detach().to(dev, torch.float32).reshape(-1, 6) for b in boxes if b.shape[0] > 0]
+        gt = torch.cat(nz, 0).contiguous() if nz else an.new_zeros((0, 6))
+        Lv = len(num_anchors_per_level)
+        offs = [0]
+        for n in num_anchors_per_level:
+            offs.append(offs[-1] + int(n))
+        assert offs[-1] == M, "num_anchors_per_level does not sum to the number of anchors"
+        k = self.num_candidates * num_anchors_per_loc
+        matches = torch.empty((B, M), dtype=torch.int64, device=dev)
+        ws_bytes = L.load().nndet_atss3d_workspace_bytes(max(G, 1), M, Lv, k)
+        ws = L.workspace(ws_bytes, dev)
+        L.call("nndet_atss3d_match_batched_f32", L.ptr(gt) if G else None, G, (ctypes.c_int32 * (B + 1))(*offs_img), B,
+               L.ptr(an), M, (ctypes.c_int64 * (Lv + 1))(*offs), Lv, k, L.ptr(matches), L.ptr(ws), ws_bytes, L.stream())
+        return gt, matches, offs_img

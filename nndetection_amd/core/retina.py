@@ -65,6 +65,9 @@ class BaseRetinaNet(nn.Module):
         """retina.py:228-290 with the fused ATSS kernel as matcher."""
         labels, matched_gt_boxes = [], []
         npl = None
+        if len(anchors) > 1 and all(a is anchors[0] for a in anchors) and hasattr(self.proposal_matcher, "match_batch") \
+                and len(anchors) <= 64:
+            return self._assign_targets_batched(anchors[0], target_boxes, target_classes)
         for anchors_per_image, gt_boxes, gt_classes in zip(anchors, target_boxes, target_classes):
             if npl is None:
                 npl = self.anchor_generator.get_num_acnhors_per_level()
@@ -86,6 +89,26 @@ class BaseRetinaNet(nn.Module):
             labels.append(labels_per_image)
             matched_gt_boxes.append(matched_gt_boxes_per_image)
         return labels, matched_gt_boxes
+
+    def _assign_targets_batched(self, anchors: Tensor, target_boxes: List[Tensor], target_classes: List[Tensor]):
+        """Same result as the per-image loop above, with one ATSS pass over the shared anchors for the whole batch."""
+        dev, B, M = anchors.device, len(target_boxes), anchors.shape[0]
+        npl = self.anchor_generator.get_num_acnhors_per_level()
+        gt_all, matches, offs = self.proposal_matcher.match_batch(
+            target_boxes, anchors, npl, self.anchor_generator.num_anchors_per_location()[0])
+        if gt_all.shape[0] == 0:
+            z = torch.zeros((B, M), dtype=anchors.dtype, device=dev)
+            return list(z.unbind(0)), [torch.zeros_like(anchors) for _ in range(B)]
+        cls_all = torch.cat([c.to(dev).reshape(-1) for c, b in zip(target_classes, target_boxes) if b.shape[0] > 0], 0)
+        base = torch.tensor(offs[:-1], dtype=torch.int64, device=dev).clamp_(max=gt_all.shape[0] - 1)[:, None]
+        glob = matches.clamp(min=0) + base                                   # [B, M] rows of gt_all
+        boxes = gt_all[glob]                                                 # [B, M, 6]
+        labels = (cls_all[glob].to(anchors.dtype) + 1) * (matches >= 0).to(anchors.dtype)
+        for b in range(B):
+            if offs[b + 1] == offs[b]:                                       # image without objects (retina.py:274-281)
+                boxes[b].zero_()
+                labels[b].zero_()
+        return list(labels.unbind(0)), list(boxes.unbind(0))
 
     # ------------------------------------------------------------------ post-processing (retina.py:161-196,292-379)
     @torch.no_grad()

@@ -16,6 +16,7 @@
 typedef unsigned long long u64;
 #define GT_TILE 16
 #define MAXL 8
+#define MAXB 64
 
 struct AtssArgs {
     int64_t lvl_off[MAXL + 1];   // anchor offsets per level
@@ -23,6 +24,8 @@ struct AtssArgs {
     int32_t k[MAXL];             // candidates per level (clamped)
     int32_t L, G;
     int64_t M;
+    int32_t B;                   // images in the batch (they share the anchors)
+    int32_t img_off[MAXB + 1];   // GT offsets per image into the concatenated GT list
 };
 
 __device__ __forceinline__ float ctr_dist(const float* g, const float* a) {
@@ -80,24 +83,44 @@ __global__ __launch_bounds__(256) void k_atss_hist(AtssArgs A, const float* __re
     }
 }
 
-// one thread per (g, l): choose the digit, update prefix / remaining rank, clear the histogram
-__global__ void k_atss_pick(int GL, u64* __restrict__ prefix, int* __restrict__ krem, unsigned* __restrict__ hist,
-                            int shift) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per (g, l): choose the digit, update prefix / remaining rank, clear the histogram. Lane = 4 consecutive bins;
+// wave-wide inclusive scan with shuffles (the serial 256-bin scan of v1 took 20 us per pass).
+__global__ __launch_bounds__(256) void k_atss_pick(int GL, u64* __restrict__ prefix, int* __restrict__ krem,
+                                                   unsigned* __restrict__ hist, int shift) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= GL) return;
     unsigned* h = hist + (int64_t)i * 256;
-    int rem = krem[i];
-    int b = 0;
-    unsigned cum = 0;
-    for (; b < 256; ++b) {
-        const unsigned c = h[b];
-        if (cum + c >= (unsigned)rem) break;
-        cum += c;
+    const uint4 c = reinterpret_cast<const uint4*>(h)[lane];
+    const unsigned mine = c.x + c.y + c.z + c.w;
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
     }
-    if (b > 255) b = 255;  // cannot happen when k <= level size
-    prefix[i] |= ((u64)b) << shift;
-    krem[i] = rem - (int)cum;
-    for (int q = 0; q < 256; ++q) h[q] = 0;
+    const unsigned rem = (unsigned)krem[i];
+    const unsigned excl = incl - mine;
+    // the lane whose bins contain the rem-th smallest element: excl < rem <= incl
+    const bool owner = (excl < rem) && (rem <= incl);
+    const unsigned long long vote = __ballot(owner);
+    if (vote == 0ULL) {                       // cannot happen when k <= level size; keep the state consistent anyway
+        if (lane == 63) prefix[i] |= ((u64)255) << shift;
+    } else if (owner) {
+        unsigned cum = excl;
+        int b = 0;
+        const unsigned cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            if (cum + cc[k2] >= rem) { b = k2; break; }
+            cum += cc[k2];
+            b = k2 + 1;
+        }
+        if (b > 3) b = 3;
+        prefix[i] |= ((u64)(lane * 4 + b)) << shift;
+        krem[i] = (int)(rem - cum);
+    }
+    reinterpret_cast<uint4*>(h)[lane] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 __global__ void k_atss_init(int G, int L, AtssArgs A, u64* prefix, int* krem) {
@@ -158,7 +181,7 @@ __global__ void k_atss_thr(int G, int ncand, const double* __restrict__ sums, fl
     thr[g] = t;
 }
 
-// per anchor arg-max over the GTs. grid total_blocks, block 256
+// per anchor arg-max over the GTs of ONE image. grid (total_blocks, B), block 256
 __global__ __launch_bounds__(256) void k_atss_assign(AtssArgs A, const float* __restrict__ gt,
                                                      const float* __restrict__ anchors, const u64* __restrict__ kth,
                                                      const float* __restrict__ thr, int64_t* __restrict__ matches) {
@@ -166,6 +189,8 @@ __global__ __launch_bounds__(256) void k_atss_assign(AtssArgs A, const float* __
     __shared__ u64 p_s[GT_TILE];
     __shared__ float t_s[GT_TILE];
     const int l = level_of_block(A, blockIdx.x);
+    const int img = blockIdx.y;
+    const int gbeg = A.img_off[img], gend = A.img_off[img + 1];
     const int64_t a = A.lvl_off[l] + (int64_t)(blockIdx.x - A.blk_off[l]) * 256 + threadIdx.x;
     const bool valid = a < A.lvl_off[l + 1];
     float ab[6] = {0, 0, 0, 0, 0, 0};
@@ -175,8 +200,8 @@ __global__ __launch_bounds__(256) void k_atss_assign(AtssArgs A, const float* __
     }
     float best = -100.f;  // -INF of the reference (atss.py:16)
     int bi = -1;
-    for (int g0 = 0; g0 < A.G; g0 += GT_TILE) {
-        const int ng = min(GT_TILE, A.G - g0);
+    for (int g0 = gbeg; g0 < gend; g0 += GT_TILE) {
+        const int ng = min(GT_TILE, gend - g0);
         __syncthreads();
         if ((int)threadIdx.x < ng * 6) (&g_s[0][0])[threadIdx.x] = gt[g0 * 6 + threadIdx.x];
         if ((int)threadIdx.x < ng) {
@@ -189,12 +214,12 @@ __global__ __launch_bounds__(256) void k_atss_assign(AtssArgs A, const float* __
                 const u64 key = ((u64)__float_as_uint(ctr_dist(g_s[g], ab)) << 32) | (u64)(uint32_t)a;
                 if (key <= p_s[g]) {
                     const float v = iou3(g_s[g], ab);
-                    if (v >= t_s[g] && v > best) { best = v; bi = g0 + g; }
+                    if (v >= t_s[g] && v > best) { best = v; bi = g0 + g - gbeg; }   // index local to the image
                 }
             }
         }
     }
-    if (valid) matches[a] = (int64_t)bi;
+    if (valid) matches[(int64_t)img * A.M + a] = (int64_t)bi;
 }
 
 __global__ void k_fill_i64(int64_t* p, int64_t n, int64_t v) {
@@ -220,16 +245,16 @@ extern "C" size_t nndet_atss3d_workspace_bytes(int64_t G, int64_t M, int32_t L, 
     return w.total;
 }
 
-extern "C" int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* anchors, int64_t M,
-                                      const int64_t* level_offsets_host, int32_t L, int32_t k, int64_t* matches,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const int32_t* img_off_host, int32_t B,
+                                              const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
+                                              int32_t k, int64_t* matches, void* workspace, size_t workspace_bytes, void* stream) {
     hipStream_t st = as_stream(stream);
-    if (G < 0 || M < 0 || L <= 0 || L > MAXL || k <= 0 || !level_offsets_host) return NNDET_EINVAL;
+    if (G < 0 || M < 0 || L <= 0 || L > MAXL || k <= 0 || !level_offsets_host || B <= 0 || B > MAXB || !img_off_host) return NNDET_EINVAL;
     if (M == 0) return 0;
     if (!matches || !anchors) return NNDET_EINVAL;
-    if (M >= (1LL << 32)) return NNDET_EINVAL;
-    if (G == 0) {  // Matcher.__call__ fast path (matcher/base.py:51-56)
-        k_fill_i64<<<(unsigned)ceil_div64(M, 256), 256, 0, st>>>(matches, M, -1);
+    if (M >= (1LL << 32) || img_off_host[0] != 0 || img_off_host[B] != G) return NNDET_EINVAL;
+    if (G == 0) {  // Matcher.__call__ fast path (matcher/base.py:51-56) for every image
+        k_fill_i64<<<(unsigned)ceil_div64(M * B, 256), 256, 0, st>>>(matches, M * B, -1);
         LAUNCH_CHECK();
         return 0;
     }
@@ -239,7 +264,11 @@ extern "C" int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* a
     atss_layout(G, L, (char*)workspace, &w);
     if (w.total > workspace_bytes) return NNDET_EWORKSPACE;
     AtssArgs A;
-    A.L = L; A.G = (int32_t)G; A.M = M;
+    A.L = L; A.G = (int32_t)G; A.M = M; A.B = B;
+    for (int b = 0; b <= B; ++b) {
+        A.img_off[b] = img_off_host[b];
+        if (b && img_off_host[b] < img_off_host[b - 1]) return NNDET_EINVAL;
+    }
     int ncand = 0;
     A.blk_off[0] = 0;
     for (int l = 0; l < L; ++l) {
@@ -265,14 +294,22 @@ extern "C" int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* a
         if (shift < 32 && shift >= idx_bits) continue;
         k_atss_hist<<<grid, 256, 0, st>>>(A, gt, anchors, w.prefix, w.hist, shift);
         LAUNCH_CHECK();
-        k_atss_pick<<<ceil_div(GL, 64), 64, 0, st>>>(GL, w.prefix, w.krem, w.hist, shift);
+        k_atss_pick<<<ceil_div(GL, 4), 256, 0, st>>>(GL, w.prefix, w.krem, w.hist, shift);
         LAUNCH_CHECK();
     }
     k_atss_stats<<<grid, 256, 0, st>>>(A, gt, anchors, w.prefix, w.sums);
     LAUNCH_CHECK();
     k_atss_thr<<<ceil_div((int)G, 64), 64, 0, st>>>((int)G, ncand, w.sums, w.thr);
     LAUNCH_CHECK();
-    k_atss_assign<<<nblk, 256, 0, st>>>(A, gt, anchors, w.prefix, w.thr, matches);
+    k_atss_assign<<<dim3(nblk, B), 256, 0, st>>>(A, gt, anchors, w.prefix, w.thr, matches);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* anchors, int64_t M,
+                                      const int64_t* level_offsets_host, int32_t L, int32_t k, int64_t* matches,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (G < 0 || G > 0x7fffffff) return NNDET_EINVAL;
+    const int32_t off[2] = {0, (int32_t)G};
+    return nndet_atss3d_match_batched_f32(gt, G, off, 1, anchors, M, level_offsets_host, L, k, matches, workspace, workspace_bytes, stream);
 }

@@ -72,8 +72,6 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
     v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
 }
 
-#define IG_ROWPAD 32
-
 // max 16-byte halo pieces per thread per chunk: 16 (halo <= 1024 voxels = 64 KiB) for unit-stride tiles,
 // 24 (<= 1536 voxels = 96 KiB) for the strided configurations (template parameter MAXP)
 
@@ -97,7 +95,7 @@ struct IgArgs {
     int32_t H[3];         // halo dims (max over classes)
     uint32_t mHW, mHH;    // magic multipliers: n / H[2] == umulhi(n, mHW), n / H[1] == umulhi(n, mHH) (0 = divisor 1)
     int32_t lT1, lT2;     // log2 of the (power-of-two) tile dims T[1], T[2]
-    int32_t swz;          // unused (the XOR swizzle was replaced by the 32-byte row-pitch padding IG_ROWPAD)
+    int32_t swz;          // 1: XOR LDS byte-offset bit 5 with the parity of the halo row (conflict-free ds_read_b128 for unit-stride tiles)
     int32_t ncls;
     IgClass cls[8];
     IgTap taps[27];
@@ -130,10 +128,6 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 
     const int HD = A.H[0], HH = A.H[1], HW = A.H[2];
     const int HV4 = HD * HH * HW * 4;
-    // LDS halo tile: [row = hd*HH + hh][hw][64 B]; every row is padded by IG_ROWPAD = 32 B, which rotates odd rows by 8
-    // banks: the 16 lanes of a ds_read_b128 group (8 voxels of one row + 8 of the next) then hit 16 distinct 16-byte slots
-    // (conflict-free; measured SQ_LDS_BANK_CONFLICT 47 % -> 0) with ONE address add per fragment (no XOR swizzle).
-    const int PITCH = HW * 64 + IG_ROWPAD;
     const int i0d = l0d * A.in_step[0] + C.in_base[0];
     const int i0h = l0h * A.in_step[1] + C.in_base[1];
     const int i0w = l0w * A.in_step[2] + C.in_base[2];
@@ -141,6 +135,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 
     // global element offsets of this thread's halo pieces (identical for every channel chunk)
     int32_t goff[MAXP];
+    uint32_t swmask = 0;   // bit s: parity of the halo row of piece s (LDS swizzle)
 #pragma unroll
     for (int s = 0; s < MAXP; ++s) {
         const int p = tid + s * 256;
@@ -152,6 +147,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
             const int hw = hv - t2 * HW;
             const int hd = A.mHH ? (int)__umulhi((unsigned)t2, A.mHH) : t2;
             const int hh = t2 - hd * HH;
+            swmask |= (uint32_t)(t2 & A.swz) << s;
             const int id = i0d + hd, ih = i0h + hh, iw = i0w + hw;
             if ((unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
                 o = ((id * A.I[1] + ih) * A.I[2] + iw) * A.Cx + part * EPL;
@@ -167,7 +163,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
         const int t2 = p >> A.lT2;
         const int ph = t2 & (A.T[1] - 1), pd = t2 >> A.lT1;
         const int brow = (pd * A.in_step[0]) * HH + ph * A.in_step[1];
-        boff[j] = brow * PITCH + pw * A.in_step[2] * 64 + q * 16;
+        boff[j] = ((brow * HW + pw * A.in_step[2]) * 64 + q * 16) ^ ((brow & A.swz) << 5);
     }
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -194,11 +190,9 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int p = tid + (s0 + b) * 256;
-                if (p < HV4) {
-                    const int hv = p >> 2;
-                    const int row = A.mHW ? (int)__umulhi((unsigned)hv, A.mHW) : hv;
-                    *reinterpret_cast<u32x4*>(smem + p * 16 + row * IG_ROWPAD) = goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
-                }
+                if (p < HV4)
+                    *reinterpret_cast<u32x4*>(smem + ((p * 16) ^ (((swmask >> (s0 + b)) & 1u) << 5))) =
+                        goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
             }
         }
         __syncthreads();
@@ -213,9 +207,11 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
         if (C.ntap > 0) load_w(0, afn);
         for (int tp = 0; tp < C.ntap; ++tp) {
             const IgTap& tap = A.taps[C.tap0 + tp];
-            const int toff = (tap.d[0] * HH + tap.d[1]) * PITCH + tap.d[2] * 64;
+            const int trow = tap.d[0] * HH + tap.d[1];
+            const int toff = (trow * HW + tap.d[2]) * 64;
+            const int flip = (trow & A.swz) << 5;      // row parity of the tap flips the swizzle bit
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + (boff[j] + toff));
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ flip) + toff));
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[i] = afn[i];
             if (tp + 1 < C.ntap) load_w(tp + 1, afn);
@@ -427,9 +423,9 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     a.mHW = magic(a.H[2]); a.mHH = magic(a.H[1]);
     a.lT1 = ilog2(a.T[1]); a.lT2 = ilog2(a.T[2]);
-    a.swz = 0;
+    a.swz = strided ? 0 : 1;
     P->grid = dim3(a.nt[0] * a.nt[1] * a.nt[2], a.Cy / CFG_ROWS[P->cfg], a.N * a.ncls);
-    P->lds = (size_t)a.H[0] * a.H[1] * ((size_t)a.H[2] * 64 + IG_ROWPAD);
+    P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64;
     if (P->lds < 1024) P->lds = 1024;   // room for the stats reduction
     return 0;
 }

@@ -89,6 +89,27 @@ def test_atss_random_vs_oracle(G, seed):
     biteq(got, ref, f"atss G={G}")
 
 
+def test_atss_batched_matches_per_image():
+    """One pass for the whole batch (nndet_atss3d_match_batched_f32) == per-image oracle matches, including images
+    without objects at the start / middle / end of the batch and a batch without any object."""
+    from nndetection_amd.core.boxes import ATSSMatcher
+    rng = np.random.default_rng(11)
+    W = [(4, 8, 16), (8, 16, 32), (16, 32, 64)]
+    anchors, npl = bx.anchors_for_image((64, 48, 40), [(16, 12, 10), (8, 6, 5), (4, 3, 3)], W, W, W)
+    m = ATSSMatcher(num_candidates=4, center_in_gt=False)
+    for counts in [(3, 0, 17, 1), (0, 5, 0), (2, 2), (0, 0), (20, 19, 0)]:
+        gts = [rand_boxes(rng, c, extent=(64, 48, 40), smin=4, smax=24) if c else np.zeros((0, 6), np.float32) for c in counts]
+        gt_all, got, offs = m.match_batch([t(x) for x in gts], t(anchors), npl, 27)
+        assert offs == list(np.concatenate([[0], np.cumsum(counts)]))
+        assert gt_all.shape[0] == sum(counts)
+        for b, gt in enumerate(gts):
+            if len(gt):
+                _, ref = bx.atss_match(gt, anchors, npl, 27, 4)
+            else:
+                ref = np.full((anchors.shape[0],), -1, np.int64)
+            biteq(got[b], ref, f"batched atss counts={counts} image {b}")
+
+
 def test_nms_golden(g):
     from nndetection_amd.core.boxes import nms, batched_nms
     for key in ["300_0.6", "1500_0.1", "1500_0.6"]:
