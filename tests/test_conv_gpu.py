@@ -31,7 +31,10 @@ CONVS = [
     ("up_222", 64, 32, 2, 2, 0, True, (4, 5, 6)),               # ConvTranspose k = s
     ("up_221", 128, 128, (2, 2, 1), (2, 2, 1), 0, True, (3, 3, 6)),
     ("stem", 1, 32, 3, 1, 1, False, (9, 10, 12)),
+    ("c32_k3_tiles", 32, 32, 3, 1, 1, False, (17, 16, 9)),      # several (8,8,8) tiles of k_ig3 + ragged edges in every axis
+    ("c64_k3_tiles", 64, 64, 3, 1, 1, False, (9, 17, 16)),      # several (4,8,8) tiles, 2 K-chunks
 ]
+SPEC3 = ["c32_k3", "c64_k3", "c128_k3", "head_cls", "head_reg", "c32_k3_tiles", "c64_k3_tiles"]   # 3x3x3 stride 1
 
 
 def _mk(name, dtype, norm=None, act=False):
@@ -75,8 +78,12 @@ def _ref_forward(m, x, cfg, dtype, norm, act):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("name", [c[0] for c in CONVS])
-def test_conv_fwd_bwd(name, dtype):
+@pytest.mark.parametrize("name,spec", [(c[0], None) for c in CONVS] + [(n, 0) for n in SPEC3] + [(n, 2) for n in SPEC3])
+def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
+    """spec: NNDET_IGEMM_SPEC -- None = the library's own choice, 0 = generic k_igemm only, 2 = force the compile-time-tile
+    kernel k_ig3 for every 3x3x3 stride-1 convolution (forward and backward-data)."""
+    if spec is not None:
+        monkeypatch.setenv("NNDET_IGEMM_SPEC", str(spec))
     m, x, cfg = _mk(name, dtype)
     tol = TOL[dtype]
     xr, w, b, _, _, yref = _ref_forward(m, x, cfg, dtype, None, False)
