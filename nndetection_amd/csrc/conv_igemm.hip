@@ -421,51 +421,48 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
         }
         __syncthreads();
         const int wk = tap0_off + kc * KC * (int)sizeof(T);
-        // Tap order: a, c outer; b in the order 0, 2, 1. Within one (a, c) the fragments of b = 2 are those of b = 0 shifted
-        // by one point row pair (rows 2 jj + b), so the compiler's CSE re-uses 6 of 8 LDS reads. The empty asm makes the lane
-        // bases opaque per (a, c): without it the CSE also spans a (fragments 9 taps apart) and the live ranges spill.
         // Weight fragments are prefetched WD taps ahead into a ring of WD + 1 register sets. hipcc's scheduler sinks such
         // loads down to their first use (then every tap waits a full L2 round trip with vmcnt(0)), so the issue point is
         // pinned with sched_barrier: loads of tap tp + WD, barrier, LDS reads + MFMAs of tap tp.
         constexpr int WD = 2;
         u32x4 af[WD + 1][MT];
-        constexpr int BORD[3] = {0, 2, 1};
+        constexpr int BORD[3] = {0, 1, 2};
         auto tap_off = [&](int tp) { return wk + ((tp / 9 * 3 + BORD[tp % 3]) * 3 + (tp / 3) % 3) * tap_step; };
 #pragma unroll
         for (int t0 = 0; t0 < WD; ++t0)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
                 af[t0][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff[i], tap_off(t0), 0));
-        // Activation fragments: half a tap (NT / 2 point tiles) ahead, double buffered, also pinned: the LDS reads of half-step
-        // h + 1 are issued before the MT * NT / 2 MFMAs of half-step h, which cover their latency.
-        constexpr int NH = NT / 2;
-        u32x4 bf[2][NH];
-        auto lds_half = [&](int h, u32x4* dst) {
-            const int tp = h >> 1, j0 = (h & 1) * NH;
+        // Activation fragments: one step (4 point tiles) ahead, double buffered, also pinned: the LDS reads of step h + 1 are
+        // issued before the MT * 4 MFMAs of step h, which cover their latency.
+        constexpr int SPT = NT / 4, NSTEP = 27 * SPT;
+        u32x4 bf[2][4];
+        auto lds_step = [&](int h, u32x4* dst) {
+            const int tp = h / SPT, j0 = (h % SPT) * 4;
             const int a = tp / 9, c = (tp / 3) % 3, b = BORD[tp % 3];
             const char* sb = smem + ((b & 1) ? sb1off : sb0off);
 #pragma unroll
-            for (int jj = 0; jj < NH; ++jj) {
+            for (int jj = 0; jj < 4; ++jj) {
                 const int j = j0 + jj;
                 dst[jj] = *reinterpret_cast<const u32x4*>(sb + ((((j >> 2) + a) * HH + 2 * (j & 3) + b) * HW + c) * 64);
             }
         };
-        lds_half(0, bf[0]);
+        lds_step(0, bf[0]);
 #pragma unroll
-        for (int h = 0; h < 54; ++h) {
-            const int tp = h >> 1;
-            if ((h & 1) == 0 && tp + WD < 27) {
+        for (int h = 0; h < NSTEP; ++h) {
+            const int tp = h / SPT;
+            if (h % SPT == 0 && tp + WD < 27) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     af[(tp + WD) % (WD + 1)][i] =
                         __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff[i], tap_off(tp + WD), 0));
             }
-            if (h + 1 < 54) lds_half(h + 1, bf[(h + 1) & 1]);
+            if (h + 1 < NSTEP) lds_step(h + 1, bf[(h + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int jj = 0; jj < NH; ++jj) M::mma(af[tp % (WD + 1)][i], bf[h & 1][jj], acc[i][(h & 1) * NH + jj]);
+                for (int jj = 0; jj < 4; ++jj) M::mma(af[tp % (WD + 1)][i], bf[h & 1][jj], acc[i][(h % SPT) * 4 + jj]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -550,9 +547,11 @@ struct Plan {
 // software-pipelined kernel') measured 25-50 % SLOWER than two independent workgroups per CU: with one wave per SIMD every
 // L2 / LDS stall of the tap loop is exposed. Two co-resident workgroups hide each other's staging and stalls.
 //      4 (experimental, NNDET_IGEMM_A256=1): like 0 but 256 points per workgroup, 4 workgroups per CU
-//      5 / 6: k_ig3 (3x3x3 stride 1, compile-time tile) with 32 rows x 512 points / 64 rows x 256 points
-static const int CFG_ROWS[7] = {32, 64, 64, 32, 32, 32, 64};
-static const int CFG_PTS[7] = {512, 256, 128, 128, 256, 512, 256};
+//      5 / 6 / 7: k_ig3 (3x3x3 stride 1, compile-time tile) with 32 rows x 512 points / 64 rows x 256 points / 64 rows x 512
+//      points. The main loop of 7 (NT = 16 point tiles per wave, one weight fragment pair per 32 MFMAs) sustains 1600 TF/s in
+//      tools/probe_loop.hip where the NT = 8 loops stop at ~1000 (the weight buffer loads saturate the vector memory pipe).
+static const int CFG_ROWS[8] = {32, 64, 64, 32, 32, 32, 64, 64};
+static const int CFG_PTS[8] = {512, 256, 128, 128, 256, 512, 256, 512};
 
 static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[3], int points, int maxp, int T[3], int H[3]) {
     double best = 1e300;
@@ -680,14 +679,28 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     const int spec_on = spec_env ? atoi(spec_env) : 1;
     if (spec_on && !strided && !tr && a.ncls == 1 && ntaps == 27 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 &&
         c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1) {
-        const int st[3] = {r64 ? 4 : 8, 8, 8};
+        // 64-row layers: (8,8,8) tiles with NT = 16 (2 workgroups per CU, ~1.6x the main-loop rate) or (4,8,8) tiles with NT = 8
+        // (3 per CU): compare padded work / (rate x occupancy of the last round of workgroups)
+        int st[3] = {8, 8, 8};
+        int spec_cfg = r64 ? 7 : 5;
+        if (r64) {
+            auto cost = [&](int td, double rate, int slots) {
+                const double tiles = (double)ceil_div(Lmax[0], td) * ceil_div(Lmax[1], 8) * ceil_div(Lmax[2], 8);
+                const double wgs = tiles * (a.Cy / 64) * a.N;
+                const double rounds = (double)ceil_div64((int64_t)wgs, slots);
+                return rounds * slots * td / rate;     // ~ time: rounds x per-workgroup work / rate
+            };
+            const char* nt_env = getenv("NNDET_IGEMM_NT");            // 8 / 16: force one variant (tests, experiments)
+            const int force = nt_env ? atoi(nt_env) : 0;
+            if (force == 8 || (force != 16 && cost(4, 1.0, 768) < cost(8, 1.6, 512))) { st[0] = 4; spec_cfg = 6; }
+        }
         double pg = 1.0, ps = 1.0;
         for (int i = 0; i < 3; ++i) { pg *= (double)a.nt[i] * a.T[i]; ps *= (double)ceil_div(Lmax[i], st[i]) * st[i]; }
         const int64_t img_b = (int64_t)a.I[0] * a.I[1] * a.I[2] * a.Cx * (c->dtype == NNDET_BF16 ? 2 : 4);
         const int64_t w_b = (int64_t)27 * a.Cy * a.Cx * (c->dtype == NNDET_BF16 ? 2 : 4);
         const int64_t out_b = (int64_t)a.O[0] * a.O[1] * a.O[2] * a.Cy * (c->dtype == NNDET_BF16 ? 2 : 4);
         if ((ps <= 1.05 * pg || spec_on == 2) && img_b < (1LL << 31) && w_b < (1LL << 31) && out_b < (1LL << 31)) {   // 32-bit buffer offsets
-            P->cfg = r64 ? 6 : 5;
+            P->cfg = spec_cfg;
             for (int i = 0; i < 3; ++i) { a.T[i] = st[i]; a.H[i] = st[i] + 2; a.nt[i] = ceil_div(Lmax[i], st[i]); }
         }
     }
@@ -706,6 +719,7 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
         case 3: k_igemm<T, 2, 1, 4, 24, 4><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 5: k_ig3<T, 1, 2, 8, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 6: k_ig3<T, 2, 2, 8, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 7: k_ig3<T, 2, 2, 16, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
         default: k_igemm<T, 1, 2, 4, 16, 4><<<P.grid, 256, P.lds, st>>>(P.a); break;
     }
     LAUNCH_CHECK();
@@ -728,8 +742,8 @@ static int ensure_attrs() {
     int rc = 0;
     rc |= set_lds_attr<bf16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24, 3>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24, 4>(); rc |= set_lds_attr<bf16_t, 1, 2, 4, 16, 4>();
     rc |= set_lds_attr<float, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<float, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<float, 2, 2, 4, 24, 3>(); rc |= set_lds_attr<float, 2, 1, 4, 24, 4>(); rc |= set_lds_attr<float, 1, 2, 4, 16, 4>();
-    rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>();
-    rc |= set_lds_attr3<float, 1, 2, 8, 2>(); rc |= set_lds_attr3<float, 2, 2, 8, 3>();
+    rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<bf16_t, 2, 2, 16, 2>();
+    rc |= set_lds_attr3<float, 1, 2, 8, 2>(); rc |= set_lds_attr3<float, 2, 2, 8, 3>(); rc |= set_lds_attr3<float, 2, 2, 16, 2>();
     if (rc) return rc;
     g_attr_done = 1;
     return 0;

@@ -78,12 +78,16 @@ def _ref_forward(m, x, cfg, dtype, norm, act):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("name,spec", [(c[0], None) for c in CONVS] + [(n, 0) for n in SPEC3] + [(n, 2) for n in SPEC3])
+@pytest.mark.parametrize("name,spec", [(c[0], "lib") for c in CONVS] + [(n, v) for v in ("generic", "ig3-nt8", "ig3-nt16") for n in SPEC3])
 def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
-    """spec: NNDET_IGEMM_SPEC -- None = the library's own choice, 0 = generic k_igemm only, 2 = force the compile-time-tile
-    kernel k_ig3 for every 3x3x3 stride-1 convolution (forward and backward-data)."""
-    if spec is not None:
-        monkeypatch.setenv("NNDET_IGEMM_SPEC", str(spec))
+    """spec: "lib" = the library's own kernel choice; "generic" = k_igemm only (NNDET_IGEMM_SPEC=0); "ig3-nt8" / "ig3-nt16" =
+    force the compile-time-tile kernel k_ig3 for every 3x3x3 stride-1 convolution (forward and backward-data,
+    NNDET_IGEMM_SPEC=2) with 8 / 16 point tiles per wave for the 64-row layers (NNDET_IGEMM_NT)."""
+    if spec == "generic":
+        monkeypatch.setenv("NNDET_IGEMM_SPEC", "0")
+    elif spec.startswith("ig3"):
+        monkeypatch.setenv("NNDET_IGEMM_SPEC", "2")
+        monkeypatch.setenv("NNDET_IGEMM_NT", spec[6:])
     m, x, cfg = _mk(name, dtype)
     tol = TOL[dtype]
     xr, w, b, _, _, yref = _ref_forward(m, x, cfg, dtype, None, False)
