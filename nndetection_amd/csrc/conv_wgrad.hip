@@ -281,6 +281,177 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3x3, stride 1
+// Specialisation of k_wgrad for the 3x3x3 / stride 1 / pad 1 layers (most of the weight-gradient FLOPs), built like k_ig3:
+//   * compile-time tile 4 x 8 x 8 lattice points (Q halo 6 x 10 x 10), so every LDS transpose read is lane base + wave tap
+//     offset + IMMEDIATE, and the staging descriptors need no registers;
+//   * staging through buffer loads (per-image descriptor, 32-bit offsets, out-of-tensor pieces read as zero by the hardware
+//     bounds check): no 64-bit address arithmetic, no select on the LDS write;
+//   * the fragment reads are software-pipelined two steps (= 8 MFMAs) ahead of their use and pinned with sched_barrier
+//     (hipcc otherwise issues them right before the MFMAs: with the generic kernel's 436 registers = one wave per SIMD every
+//     LDS round trip was exposed, 25 % MFMA utilisation);
+//   * 256 registers per wave -> two workgroups per CU.
+// Work split as in k_wgrad: the 4 waves take taps wv, wv + 4, ... (7 slots, 27 of 28 used), all 8 contraction steps.
+template <typename T, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
+    constexpr int RB = 32 * (int)sizeof(T), PPV = RB / 16;
+    constexpr int KS = 8, NTS = 7, TD = 4, TH = 8, HD = TD + 2, HH = TH + 2, HW = 10;
+    constexpr int PROW = 8 * RB + RB / 2, QROW = HW * RB + RB / 2;     // bytes per row of 8 points / per halo row (with bank padding)
+    constexpr int PBYTES = 32 * PROW;
+    constexpr int QCOLP = HW * PPV, QRPS = 256 / QCOLP, QNROW = HD * HH, QSTEPS = (QNROW + QRPS - 1) / QRPS;   // Q staging: rows per step
+    constexpr int PSTEPS = 256 * PPV / 256;                                                                  // P pieces per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sp = smem;
+    char* const sq = smem + PBYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.y * 32, k0 = blockIdx.z * 32;
+
+    // ---- staging geometry (tile independent)
+    // P: piece s of a thread = point (pd = s / (PPV/4)..) -- with PPV pieces per voxel: pp = tid + s*256, pt = pp / PPV
+    int p_ph[PSTEPS], p_dst[PSTEPS], p_rel[PSTEPS];
+    const int p_part = tid % PPV;
+#pragma unroll
+    for (int s2 = 0; s2 < PSTEPS; ++s2) {
+        const int pt = (tid + s2 * 256) / PPV;            // 0..255
+        const int tr = pt >> 3, pw = pt & 7;
+        p_ph[s2] = ((tr >> 3) << 16) | ((tr & 7) << 8) | pw;                       // pd, ph, pw
+        p_dst[s2] = tr * PROW + pw * RB + p_part * 16;
+        p_rel[s2] = (((tr >> 3) * A.PL[1] + (tr & 7)) * A.PL[2] + pw) * A.Cp * (int)sizeof(T) + p_part * 16;
+    }
+    // Q: thread = column piece (hw, part) of QRPS rows per step
+    const int q_cp = tid % QCOLP, q_r0 = tid / QCOLP;
+    const bool q_active = tid < QRPS * QCOLP;
+    const int q_hw = q_cp / PPV;
+    const int q_dst0 = q_r0 * QROW + q_hw * RB + (q_cp % PPV) * 16;
+    const int q_colb = q_hw * A.Cq * (int)sizeof(T) + (q_cp % PPV) * 16;
+    const int q_rowb = A.QD[2] * A.Cq * (int)sizeof(T);
+
+    // ---- fragment bases: P run of lane group q at contraction step ks = row ks*4 + q; Q halo row of that run at tap (0,0,0)
+    // per-lane part of a fragment address (WF<T>::load is then called with li = 0): bf16 transpose read / fp32 scalar reads
+    const int lanepart = sizeof(T) == 2 ? (li >> 2) * RB + (li & 3) * 8 : li * 4;
+    const char* const p_lane = sp + q * PROW + lanepart;
+    const int q_lane = PBYTES + q * QROW + lanepart;
+    int tapoff[NTS], tapw[NTS];
+#pragma unroll
+    for (int ts = 0; ts < NTS; ++ts) {
+        const int t = wv + ts * 4;
+        const bool valid = t < 27;
+        const int tt = valid ? t : 0;
+        const int a = tt / 9, b = (tt / 3) % 3, c = tt % 3;
+        tapoff[ts] = (a * HH + b) * QROW + c * RB;
+        tapw[ts] = valid ? tt : -1;
+    }
+
+    f32x4 acc[NTS][2][2];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles_per_n = A.nt[0] * A.nt[1] * A.nt[2];
+    const int p_img = A.PL[0] * A.PL[1] * A.PL[2] * A.Cp * (int)sizeof(T), q_img = A.QD[0] * A.QD[1] * A.QD[2] * A.Cq * (int)sizeof(T);
+    u32x4 vp[PSTEPS], vq[QSTEPS];
+
+    auto issue = [&](int tile) {
+        const int n = tile / tiles_per_n;
+        int tt = tile - n * tiles_per_n;
+        const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
+        const int th_i = tt % A.nt[1];
+        const int td_i = tt / A.nt[1];
+        const int l0d = td_i * TD, l0h = th_i * TH, l0w = tw_i * 8;
+        const auto prs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(A.p)) + (int64_t)n * p_img + r0 * (int)sizeof(T), 0, p_img - r0 * (int)sizeof(T), 0x00020000);
+        const auto qrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(A.q)) + (int64_t)n * q_img + k0 * (int)sizeof(T), 0, q_img - k0 * (int)sizeof(T), 0x00020000);
+        const int p_org = ((l0d * A.PL[1] + l0h) * A.PL[2] + l0w) * A.Cp * (int)sizeof(T);
+#pragma unroll
+        for (int s2 = 0; s2 < PSTEPS; ++s2) {
+            const int ld = l0d + (p_ph[s2] >> 16), lh = l0h + ((p_ph[s2] >> 8) & 255), lw = l0w + (p_ph[s2] & 255);
+            const bool ok = ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2];
+            vp[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, ok ? p_rel[s2] : (int)0x80000000, p_org, 0));
+        }
+        const int q0d = l0d - 1, q0h = l0h - 1, qw = l0w - 1 + q_hw;
+        const bool okw = q_active && (unsigned)qw < (unsigned)A.QD[2];
+        const int q_org = (l0w - 1) * A.Cq * (int)sizeof(T);
+#pragma unroll
+        for (int s2 = 0; s2 < QSTEPS; ++s2) {
+            const int r = q_r0 + s2 * QRPS;
+            const int hd = r / HH, hh = r - hd * HH;
+            const int qd = q0d + hd, qh = q0h + hh;
+            const bool ok = okw && (unsigned)qd < (unsigned)A.QD[0] && (unsigned)qh < (unsigned)A.QD[1] && (s2 + 1 < QSTEPS || r < QNROW);
+            vq[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                qrs, ok ? (qd * A.QD[1] + qh) * q_rowb + q_colb + q_org : (int)0x80000000, 0, 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int s2 = 0; s2 < PSTEPS; ++s2) *reinterpret_cast<u32x4*>(sp + p_dst[s2]) = vp[s2];
+        if (q_active) {
+#pragma unroll
+            for (int s2 = 0; s2 < QSTEPS; ++s2)
+                if (s2 + 1 < QSTEPS || q_r0 + s2 * QRPS < QNROW) *reinterpret_cast<u32x4*>(sq + q_dst0 + s2 * (QRPS * QROW)) = vq[s2];
+        }
+    };
+    // pinned software pipeline over the 56 (contraction step, tap slot) pairs
+    auto compute = [&]() {
+        constexpr int U = KS * NTS, QD_ = 2;
+        WF<T> pf[2][2], qf[QD_ + 1][2];
+        auto load_p = [&](int ks, WF<T>* d) {
+            const char* b0 = p_lane + ks * 4 * PROW;
+            d[0].load(b0, RB, 0); d[1].load(b0 + 16 * (int)sizeof(T), RB, 0);
+        };
+        auto load_q = [&](int u, WF<T>* d) {
+            const int ks = u / NTS, ts = u % NTS;
+            const char* b0 = smem + (q_lane + tapoff[ts]) + (((ks >> 1) * HH) + (ks & 1) * 4) * QROW;
+            d[0].load(b0, RB, 0); d[1].load(b0 + 16 * (int)sizeof(T), RB, 0);
+        };
+        load_p(0, pf[0]);
+#pragma unroll
+        for (int u0 = 0; u0 < QD_; ++u0) load_q(u0, qf[u0]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = u / NTS, ts = u % NTS;
+            if (u + QD_ < U) load_q(u + QD_, qf[(u + QD_) % (QD_ + 1)]);
+            if (ts == 0 && ks + 1 < KS) load_p(ks + 1, pf[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) WF<T>::mma(pf[ks & 1][i], qf[u % (QD_ + 1)][j], acc[ts][i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < A.total_tiles) { issue(tile); commit(); }
+    __syncthreads();
+    for (; tile < A.total_tiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < A.total_tiles) issue(next);      // in flight during the MFMA phase
+        compute();
+        __syncthreads();                            // every wave is done reading the tile
+        if (next < A.total_tiles) commit();
+        __syncthreads();
+    }
+    float* part = A.part + ((int64_t)blockIdx.x * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
+#pragma unroll
+    for (int ts = 0; ts < NTS; ++ts) {
+        if (tapw[ts] >= 0) {
+            float* pt = part + (int64_t)tapw[ts] * 1024;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + q * 4 + rr) * 32 + j * 16 + li] = acc[ts][i][j][rr];
+        }
+    }
+}
+
 // dW[r][k][tap] += sum_s part[s][pair][tap][r%32][k%32]; one thread per (pair, tap, r, k); consecutive threads = consecutive k.
 // With !SPLIT (1-3 taps) every wave holds a partial of every tap: those are summed here too (nsub = 4 sub-slices).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int S, int pairs, int kb, int ntap,
@@ -419,6 +590,41 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, void
     if (!ws || ws_bytes < need) return NNDET_EWORKSPACE;
     a.part = reinterpret_cast<float*>(ws);
     int rc;
+    // 3x3x3 / stride 1 / pad 1: compile-time-tile kernel k_wgrad3 unless the fixed (4,8,8) tile pads the volume noticeably
+    // more than the tile found above (NNDET_WGRAD_SPEC: 0 never, 1 default, 2 always)
+    const char* spec_env = getenv("NNDET_WGRAD_SPEC");
+    const int spec_on = spec_env ? atoi(spec_env) : 1;
+    if (spec_on && !tr && !strided && T == 27 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 && c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1) {
+        const int st3[3] = {4, 8, 8};
+        double pg = 1.0, ps = 1.0;
+        for (int i = 0; i < 3; ++i) { pg *= (double)a.nt[i] * t3[i]; ps *= (double)ceil_div(a.PL[i], st3[i]) * st3[i]; }
+        const int64_t pb = (int64_t)a.PL[0] * a.PL[1] * a.PL[2] * a.Cp * esz, qb = (int64_t)a.QD[0] * a.QD[1] * a.QD[2] * a.Cq * esz;
+        if ((ps <= 1.05 * pg || spec_on == 2) && pb < (1LL << 31) && qb < (1LL << 31)) {
+            WgArgs b = a;
+            b.TD = 4; b.TH = 8;
+            for (int i = 0; i < 3; ++i) { b.H[i] = st3[i] + 2; b.nt[i] = ceil_div(a.PL[i], st3[i]); }
+            b.total_tiles = b.N * b.nt[0] * b.nt[1] * b.nt[2];
+            const int S3 = wgrad_slices(rb * kb, b.total_tiles);
+            const size_t need3 = (size_t)S3 * rb * kb * 27 * 1024 * sizeof(float);
+            if (ws_bytes < need3) return NNDET_EWORKSPACE;
+            const size_t lds3 = (size_t)32 * (8 * RB + RB / 2) + (size_t)60 * (10 * RB + RB / 2);
+            dim3 g3(S3, rb, kb);
+            if (bf) {
+                static bool at = false;
+                if (!at) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); at = true; }
+                k_wgrad3<bf16_t, 2><<<g3, 256, lds3, st>>>(b);
+            } else {
+                static bool at = false;
+                if (!at) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); at = true; }
+                k_wgrad3<float, 1><<<g3, 256, lds3, st>>>(b);
+            }
+            LAUNCH_CHECK();
+            const int64_t total3 = (int64_t)rb * kb * 27 * 1024;
+            k_wgrad_reduce<<<dim3((unsigned)ceil_div64(total3, 256), ceil_div(S3, 32)), 256, 0, st>>>(b.part, S3, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, total3);
+            LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (bf) rc = KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
     else rc = KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
     if (rc) return rc;

@@ -85,8 +85,10 @@ def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
     NNDET_IGEMM_SPEC=2) with 8 / 16 point tiles per wave for the 64-row layers (NNDET_IGEMM_NT)."""
     if spec == "generic":
         monkeypatch.setenv("NNDET_IGEMM_SPEC", "0")
+        monkeypatch.setenv("NNDET_WGRAD_SPEC", "0")
     elif spec.startswith("ig3"):
         monkeypatch.setenv("NNDET_IGEMM_SPEC", "2")
+        monkeypatch.setenv("NNDET_WGRAD_SPEC", "2")      # k_wgrad3 (compile-time tile) for the weight gradient
         monkeypatch.setenv("NNDET_IGEMM_NT", spec[6:])
     m, x, cfg = _mk(name, dtype)
     tol = TOL[dtype]
