@@ -115,10 +115,19 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
     const int li = lane & 15, q = lane >> 4;
     const int wr = wv % WR, wc = wv / WR;     // row group / point group of this wave
 
-    const int cls_i = blockIdx.z % A.ncls;
-    const int n = blockIdx.z / A.ncls;
+    // Several classes (parity classes of a strided backward-data / the k^3 positions of a transposed conv) read the SAME
+    // input tile. Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the id is decoded as
+    // (tile / 8, class, tile % 8): the classes of one tile run at the same time on the same XCD and the tile comes from HBM
+    // once instead of once per class.
+    int cls_i = 0, tt = blockIdx.x;
+    const int n = blockIdx.z;
+    if (A.ncls > 1) {
+        const int g = blockIdx.x >> 3;
+        cls_i = g % A.ncls;
+        tt = (g / A.ncls) * 8 + (blockIdx.x & 7);
+        if (tt >= A.nt[0] * A.nt[1] * A.nt[2]) return;   // uniform
+    }
     const IgClass& C = A.cls[cls_i];
-    int tt = blockIdx.x;
     const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
     const int th_i = tt % A.nt[1];
     const int td_i = tt / A.nt[1];
@@ -704,7 +713,8 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
             for (int i = 0; i < 3; ++i) { a.T[i] = st[i]; a.H[i] = st[i] + 2; a.nt[i] = ceil_div(Lmax[i], st[i]); }
         }
     }
-    P->grid = dim3(a.nt[0] * a.nt[1] * a.nt[2], a.Cy / CFG_ROWS[P->cfg], a.N * a.ncls);
+    const int ntiles = a.nt[0] * a.nt[1] * a.nt[2];
+    P->grid = dim3(a.ncls > 1 ? ceil_div(ntiles, 8) * 8 * a.ncls : ntiles, a.Cy / CFG_ROWS[P->cfg], a.N);
     P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64;
     if (P->lds < 1024) P->lds = 1024;   // room for the stats reduction
     return 0;

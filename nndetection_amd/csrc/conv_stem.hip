@@ -158,6 +158,142 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16, 3x3x3, stride 1
+// MFMA formulation of the stem weight gradient: dW[r][tap] = sum_p dY[p][r] * X[p + tap] is a GEMM with M = 32 output
+// channels, N = 27 (padded to 32) taps and K = lattice points once the input patch is expanded ("im2col") into a
+// [point][32 taps] tile -- which is cheap here because the input has ONE channel: the halo of a 4 x 8 x 8 point tile is
+// 600 bf16 values. Both operands are then read with the LDS transpose read exactly like the P / Q tiles of k_wgrad3.
+// Per tile of 256 points: 16 KB of dY (4 buffer loads per thread), 1.2 KB of X, 27 ds_read_u16 + 4 ds_write_b128 per thread
+// for the expansion, 8 MFMAs per wave. The VALU kernel above needed 256 x (ds_read_b32 + ds_read_b128 + 4 FMA) per thread
+// and chunk and was LDS-bound at 0.9 ms (profiles/round1_v6_kernel_stats_by_grid.txt); this one is HBM-bound on dY.
+typedef short st_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) st_s16x4* st_lds_s16x4_ptr;
+typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x4 stem_trfrag(const char* p) {   // 8 points (rows p, p + 4 voxels) of channel li, see WF<bf16_t>
+    const st_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_lds_s16x4_ptr)(p));
+    const st_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_lds_s16x4_ptr)(p + 4 * 64));
+    const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+    return u32x4{ua.x, ua.y, ub.x, ub.y};
+}
+
+__global__ __launch_bounds__(256, 2) void k_stem_wgrad3(const StemArgs A, int nt0, int nt1, int nt2, int total_tiles) {
+    constexpr int PROW = 8 * 64 + 32;                  // bytes per row of 8 points (64 B per point + bank padding)
+    constexpr int TILE = 32 * PROW;                    // 17408
+    __shared__ __attribute__((aligned(16))) char dyt[TILE];
+    __shared__ __attribute__((aligned(16))) char imt[TILE];
+    __shared__ __attribute__((aligned(16))) uint16_t xh[608];
+    __shared__ float red[32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int c0 = blockIdx.y * 32;
+    for (int i = tid; i < 1024; i += 256) red[i] = 0.f;
+
+    // dY staging geometry: piece s of a thread = point (pd = s, ph = tid >> 5, pw = (tid >> 2) & 7), 16-byte part tid & 3
+    const int d_ph = tid >> 5, d_pw = (tid >> 2) & 7;
+    const int d_dst0 = d_ph * PROW + d_pw * 64 + (tid & 3) * 16;
+    const int d_rel = (d_ph * A.O[2] + d_pw) * A.Cy * 2 + (tid & 3) * 16;
+    const int d_slab = A.O[1] * A.O[2] * A.Cy * 2;
+    const int dy_img = A.O[0] * d_slab, x_img = A.I[0] * A.I[1] * A.I[2] * 2;
+    // X halo: values tid, tid + 256, tid + 512 of the 6 x 10 x 10 halo
+    int x_rel[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int i = tid + s * 256;
+        const int hd = i / 100, hh = (i / 10) % 10, hw = i % 10;
+        x_rel[s] = (hd << 16) | (hh << 8) | hw;
+    }
+    // expansion: thread = point tid (pd = tid >> 6, ph = (tid >> 3) & 7, pw = tid & 7)
+    const int e_base = ((tid >> 6) * 10 + ((tid >> 3) & 7)) * 10 + (tid & 7);
+    char* const e_dst = imt + (tid >> 3) * PROW + (tid & 7) * 64;
+    // fragments: wave wv takes the contraction steps 2 wv, 2 wv + 1 (rows of 8 points ks * 4 + q)
+    const int f_lane = q * PROW + (li >> 2) * 64 + (li & 3) * 8;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tiles_per_n = nt0 * nt1 * nt2;
+    u32x4 vd[4];
+    uint16_t vx[3];
+    auto issue = [&](int tile) {
+        const int n = tile / tiles_per_n;
+        int tt = tile - n * tiles_per_n;
+        const int tw_i = tt % nt2; tt /= nt2;
+        const int th_i = tt % nt1;
+        const int td_i = tt / nt1;
+        const int l0d = td_i * 4, l0h = th_i * 8, l0w = tw_i * 8;
+        const auto drs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(A.dy)) + (int64_t)n * dy_img + c0 * 2, 0, dy_img - c0 * 2, 0x00020000);
+        const auto xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (int64_t)n * x_img, 0, x_img, 0x00020000);
+        const int d_org = ((l0d * A.O[1] + l0h) * A.O[2] + l0w) * A.Cy * 2;
+        const bool okhw = (l0h + d_ph < A.O[1]) && (l0w + d_pw < A.O[2]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            vd[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                drs, (okhw && l0d + s < A.O[0]) ? d_rel + s * d_slab : (int)0x80000000, d_org, 0));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int id = l0d - 1 + (x_rel[s] >> 16), ih = l0h - 1 + ((x_rel[s] >> 8) & 255), iw = l0w - 1 + (x_rel[s] & 255);
+            const bool ok = (tid + s * 256 < 600) && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
+            vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, ok ? ((id * A.I[1] + ih) * A.I[2] + iw) * 2 : (int)0x80000000, 0, 0);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < total_tiles) issue(tile);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        __syncthreads();                                   // the MFMA phase of the previous tile is done with the LDS tiles
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(dyt + d_dst0 + s * 8 * PROW) = vd[s];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (tid + s * 256 < 600) xh[tid + s * 256] = vx[s];
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < total_tiles) issue(next);               // in flight during the expansion + MFMA phase
+        uint32_t pk[16];
+#pragma unroll
+        for (int t = 0; t < 32; t += 2) {
+            uint32_t lo = 0, hi = 0;
+            if (t < 27) lo = xh[e_base + (t / 9) * 100 + ((t / 3) % 3) * 10 + t % 3];
+            if (t + 1 < 27) hi = xh[e_base + ((t + 1) / 9) * 100 + (((t + 1) / 3) % 3) * 10 + (t + 1) % 3];
+            pk[t >> 1] = lo | (hi << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(e_dst + k * 16) = u32x4{pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]};
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ks = wv * 2 + kk;
+            u32x4 pf[2], qf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                pf[i] = stem_trfrag(dyt + f_lane + ks * 4 * PROW + i * 32);
+                qf[i] = stem_trfrag(imt + f_lane + ks * 4 * PROW + i * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(st_bf16x8, pf[i]), __builtin_bit_cast(st_bf16x8, qf[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+    // workgroup reduction in LDS, then one atomic per (channel, tap)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) atomicAdd(&red[(i * 16 + q * 4 + rr) * 32 + j * 16 + li], acc[i][j][rr]);
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        const int r = i >> 5, t = i & 31;
+        if (t < 27 && c0 + r < A.cout) atomicAdd(A.dw + (int64_t)(c0 + r) * 27 + t, red[i]);
+    }
+}
+
 static int stem_args(const NndetConv* c, StemArgs* a) {
     if (c->cin_p != 1 || c->cin != 1 || c->transposed || c->cout_p % 32) return NNDET_EINVAL;
     if (c->k[0] * c->k[1] * c->k[2] > 27) return NNDET_EINVAL;
@@ -189,6 +325,18 @@ int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hip
     int rc = stem_args(c, &a);
     if (rc) return rc;
     a.x = x; a.dy = dy; a.dw = dw;
+    const int64_t dyb = (int64_t)a.O[0] * a.O[1] * a.O[2] * a.Cy * 2;
+    if (c->dtype == NNDET_BF16 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1 &&
+        c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1 && dyb < (1LL << 31) && !getenv("NNDET_STEM_VALU")) {
+        const int nt0 = ceil_div(a.O[0], 4), nt1 = ceil_div(a.O[1], 8), nt2 = ceil_div(a.O[2], 8);
+        const int64_t tiles = (int64_t)a.N * nt0 * nt1 * nt2;
+        if (tiles < (1LL << 31)) {
+            dim3 g3((unsigned)(tiles < 512 ? tiles : 512), c->cout_p / 32);
+            k_stem_wgrad3<<<g3, 256, 0, st>>>(a, nt0, nt1, nt2, (int)tiles);
+            LAUNCH_CHECK();
+            return 0;
+        }
+    }
     int64_t nchunks = ceil_div64(a.total, 256);
     dim3 grid((unsigned)(nchunks < 1024 ? nchunks : 1024), c->cout_p / 32);
     const size_t lds = (27 * 257 + 1 + 256 * STEM_DYS_STRIDE) * sizeof(float);   // 64.6 KB

@@ -1,13 +1,14 @@
 #!/usr/bin/env python
 """Per-kernel summary (calls, total, average, share) from a rocprofv3 rocpd SQLite database (ROCm 7.2 default output
-of `rocprofv3 --kernel-trace --stats`). Usage: tools/rocpd_stats.py <results.db> [steps_in_trace] > profiles/<name>.txt"""
+of `rocprofv3 --kernel-trace --stats`). Usage: tools/rocpd_stats.py <results.db> [steps_in_trace] [--by-grid] > profiles/<name>.txt
+--by-grid additionally splits every kernel by its launch grid (= by layer shape) for the kernels matching k_ig / k_wgrad / k_norm."""
 import sqlite3
 import sys
 
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 1.0
     rows = list(db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), "
                            "max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels group by name order by 3 desc"))
     tot = sum(r[2] for r in rows)
@@ -16,6 +17,14 @@ def main():
     print(f"{'total_ms':>10} {'%':>6} {'calls':>6} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'vgpr':>5} {'agpr':>5} {'lds':>7}  kernel")
     for n, c, s, a, mn, mx, vg, ag, lds in rows:
         print(f"{s / 1e6:10.3f} {100 * s / tot:6.2f} {c:6d} {a / 1e3:10.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {vg or 0:5d} {ag or 0:5d} {lds or 0:7d}  {n[:140]}")
+    if "--by-grid" in sys.argv:
+        print("\n# split by launch grid (grid_x/256 workgroups, grid_y, grid_z) -- per step")
+        rows = list(db.execute("select name, grid_x / workgroup_x, grid_y, grid_z, lds_size, count(*), sum(end-start), avg(end-start) from kernels "
+                               "where name like '%k_ig%' or name like '%k_wgrad%' or name like '%k_norm%' or name like '%k_stem%' "
+                               "group by name, grid_x, grid_y, grid_z, lds_size order by 7 desc"))
+        print(f"{'ms/step':>9} {'calls/step':>10} {'avg_us':>9} {'grid':>18} {'lds':>7}  kernel")
+        for n, gx, gy, gz, lds, c, sm, a in rows[:80]:
+            print(f"{sm / 1e6 / steps:9.3f} {c / steps:10.1f} {a / 1e3:9.2f} {f'{gx}x{gy}x{gz}':>18} {lds or 0:7d}  {n[:90]}")
 
 
 if __name__ == "__main__":
