@@ -108,8 +108,9 @@ _workspaces = {}
 
 
 def workspace(nbytes: int, device) -> "torch.Tensor":
-    """One grow-only scratch buffer per device (kernel launches are serialised on the stream, so it can be shared)."""
-    key = (device.type, device.index)
+    """One grow-only scratch buffer per (device, stream): launches on one stream are serialised, so they can share it;
+    branches that run concurrently on side streams (the detection head levels) get their own."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)

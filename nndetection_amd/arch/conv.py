@@ -71,6 +71,19 @@ def _packed(mod, mode: int, weight: torch.Tensor, desc: L.NndetConv, dtype: torc
     return buf
 
 
+def prepack(mod, x: torch.Tensor, modes=(0, 1)) -> None:
+    """Fill the packed-weight cache of conv block `mod` for input `x` on the CURRENT stream. Shared modules that are about
+    to run on several side streams (detection head levels) must be packed before the fork: the cache itself is not
+    stream-aware."""
+    x_p, _ = phys(x)
+    if mod.in_channels == 1:
+        return
+    desc = _desc(x_p, mod.in_channels, mod.out_channels, mod.k, mod.s, mod.p, mod.transposed)
+    desc.cin_p = cpad(mod.in_channels)       # only the channel counts and the kernel enter the packing
+    for mode in modes:
+        _packed(mod, mode, mod.conv.weight, desc, x_p.dtype)
+
+
 def _pad1d(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
     if v is None:
         return None

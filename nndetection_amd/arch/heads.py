@@ -4,6 +4,7 @@
 The conv trunks are ConvGroupRelu blocks (HIP), the GIoU of the sampled positives and the fg-probability
 used by the sampler run in HIP kernels; the remaining arithmetic acts on <= 32*B sampled rows."""
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -127,11 +128,46 @@ class DetectionHeadHNMNative(nn.Module):
         super().__init__()
         self.classifier, self.regressor, self.coder, self.fg_bg_sampler = classifier, regressor, coder, sampler
 
+    # The (classifier, regressor) x level branches are independent until the loss. Run sequentially, the small pyramid levels
+    # leave most of the 256 CUs idle (40 workgroups per conv at 10x10x6) and the 600-workgroup P2 launches have a half-empty
+    # second round; on side streams they fill each other's gaps. Set NNDET_HEAD_STREAMS=0 for the sequential order.
+    multi_stream = os.environ.get("NNDET_HEAD_STREAMS", "1") != "0"
+    _streams: Dict[int, list] = {}
+
+    def _side_streams(self, device, n: int):
+        pool = DetectionHeadHNMNative._streams.setdefault(device.index or 0, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool[:n]
+
     def forward(self, fmaps: List[Tensor]) -> Dict[str, Tensor]:
-        logits, offsets = [], []
-        for level, p in enumerate(fmaps):
-            logits.append(self.classifier(p, level=level))
-            offsets.append(self.regressor(p, level=level))
+        logits, offsets = [None] * len(fmaps), [None] * len(fmaps)
+        if self.multi_stream and fmaps[0].is_cuda and len(fmaps) > 1:
+            from .conv import BaseConvNormAct, prepack
+            main = torch.cuda.current_stream(fmaps[0].device)
+            grad = torch.is_grad_enabled()
+            if grad and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # intended: shared weights, many streams
+            for head in (self.classifier, self.regressor):          # shared weights: pack once, before the fork
+                for m in head.modules():
+                    if isinstance(m, BaseConvNormAct):
+                        prepack(m, fmaps[0], modes=(0, 1) if grad else (0,))
+            streams = self._side_streams(fmaps[0].device, 2 * len(fmaps))
+            for level, p in enumerate(fmaps):
+                for hi, (head, outs) in enumerate(((self.classifier, logits), (self.regressor, offsets))):
+                    s = streams[2 * level + hi]
+                    s.wait_stream(main)
+                    p.record_stream(s)
+                    with torch.cuda.stream(s):
+                        o = head(p, level=level)
+                    o.record_stream(main)
+                    outs[level] = o
+            for s in streams:
+                main.wait_stream(s)
+        else:
+            for level, p in enumerate(fmaps):
+                logits[level] = self.classifier(p, level=level)
+                offsets[level] = self.regressor(p, level=level)
         sdim = fmaps[0].ndim - 2
         return {"box_deltas": torch.cat(offsets, dim=1).reshape(-1, sdim * 2),
                 "box_logits": torch.cat(logits, dim=1).flatten(0, -2)}

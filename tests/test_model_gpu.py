@@ -115,3 +115,35 @@ def test_no_gt_image_and_optimizer_step():
     before = net.encoder.stages[0].convs[0][0].conv.weight.detach().clone()
     opt.step(); sched.step()
     assert not torch.equal(before, net.encoder.stages[0].convs[0][0].conv.weight)
+
+
+def test_head_side_streams_match_sequential(golden_dir):
+    """The (classifier, regressor) x level branches on side streams (default) == the sequential order: identical losses
+    (the same kernels on the same data), gradients up to the summation order of the shared head weights."""
+    from nndetection_amd.arch.heads import DetectionHeadHNMNative
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    x = torch.from_numpy(gn["x"]).cuda()
+    res = {}
+    old = DetectionHeadHNMNative.multi_stream
+    try:
+        for mode in (True, False, True):
+            DetectionHeadHNMNative.multi_stream = mode
+            net.zero_grad(set_to_none=True)
+            torch.manual_seed(5)                       # the sampler's randperm
+            losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+            res.setdefault(mode, []).append(({k: float(v.detach()) for k, v in losses.items()},
+                                             {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        DetectionHeadHNMNative.multi_stream = old
+    (l_ms, g_ms), (l_ms2, g_ms2) = res[True]
+    (l_seq, g_seq), = res[False]
+    assert l_ms == l_seq == l_ms2, (l_ms, l_seq, l_ms2)
+    assert set(g_ms) == set(g_seq)
+    for n in g_seq:
+        d = float((g_ms[n] - g_seq[n]).abs().max()), float((g_ms2[n] - g_seq[n]).abs().max())
+        scale = float(g_seq[n].abs().max()) + 1e-12
+        assert max(d) <= 2e-5 * scale, (n, d, scale)
