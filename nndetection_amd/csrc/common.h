@@ -59,6 +59,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2), so spatially adjacent tiles -- whose halos
+// overlap -- land on different L2s and every halo is fetched from HBM / Infinity Cache again (measured: 1.9x / 2.3x the
+// algorithmic read bytes for k_ig3 / k_wgrad3, profiles/round1_pmc_traffic.json). Remap id b within groups of `group` ids
+// (a multiple of 8, ~ the number of co-resident workgroups) so that the ids of one XCD cover a CONTIGUOUS run of tiles.
+__device__ __forceinline__ int xcd_compact(int b, int total, int group) {
+    const int g0 = (b / group) * group;
+    const int n = min(group, total - g0);
+    if (n & 7) return b;                       // ragged tail: identity
+    const int r = b - g0;
+    return g0 + (r & 7) * (n >> 3) + (r >> 3);
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

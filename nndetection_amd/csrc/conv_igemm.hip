@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
     const int wr = wv % WR, wc = wv / WR;
 
     const int n = blockIdx.z;
-    int tt = blockIdx.x;
+    int tt = xcd_compact(blockIdx.x, gridDim.x, 512);
     const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
     const int th_i = tt % A.nt[1];
     const int td_i = tt / A.nt[1];

@@ -426,15 +426,21 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < A.total_tiles) { issue(tile); commit(); }
+    // round k of the persistent loop covers tiles [k * grid, (k + 1) * grid); within a round the workgroups of one XCD take a
+    // contiguous run of tiles (xcd_compact) so that overlapping halos are shared through that XCD's L2
+    int base = 0;
+    auto tile_of = [&](int b0) { return b0 + xcd_compact(blockIdx.x, min((int)gridDim.x, A.total_tiles - b0), gridDim.x); };
+    int tile = tile_of(0);
+    const bool first_ok = (int)blockIdx.x < A.total_tiles;
+    if (first_ok) { issue(tile); commit(); }
     __syncthreads();
-    for (; tile < A.total_tiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        if (next < A.total_tiles) issue(next);      // in flight during the MFMA phase
+    for (; base + (int)blockIdx.x < A.total_tiles; base += gridDim.x) {
+        const int nb = base + gridDim.x;
+        const bool has_next = nb + (int)blockIdx.x < A.total_tiles;
+        if (has_next) issue(tile_of(nb));           // in flight during the MFMA phase
         compute();
         __syncthreads();                            // every wave is done reading the tile
-        if (next < A.total_tiles) commit();
+        if (has_next) commit();
         __syncthreads();
     }
     float* part = A.part + ((int64_t)blockIdx.x * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
