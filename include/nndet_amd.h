@@ -198,6 +198,19 @@ int nndet_segloss_forward(int32_t dtype, const void* logits, const uint8_t* targ
 int nndet_segloss_backward(int32_t dtype, const void* logits, const uint8_t* target, int64_t nvox, int32_t c_p,
                            const float* coeffs /* device [4]: g_ce, g_tp, g_fp, g_fn */, void* dlogits, void* stream);
 
+/* Fused segmentation HEAD for training: the 1x1x1 output conv of DiCESegmenterFgBg (self.conv_out, 2 classes, bias;
+ * nndet/arch/heads/segmenter.py:160-182) + the loss sums above in ONE pass over the decoder feature map, and its backward
+ * (recomputes the logits, writes dx, accumulates dW / dbias) in one more. The [N, spatial, 32]-padded logits and their
+ * gradient are never written (4 x 629 MB per step at 160x160x96, batch 4). Only c_p == 32 (cin <= 32).
+ *   x [nvox][32] NDHWC (dtype); w [2][cin] fp32 (already rounded to dtype by the caller, like the packed conv weights);
+ *   bias [2] fp32. The logits are rounded to dtype before the loss, as the unfused conv would store them.
+ *   backward: dwb_out [2*cin + 2] fp64 (zeroed): dW[0][:], dW[1][:], dbias[0], dbias[1]; dx [nvox][32] (dtype).
+ * Inference still materialises the logits through nndet_conv3d_forward. */
+int nndet_seghead_forward(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
+                          const uint8_t* target, int64_t nvox, double* sums_out, void* stream);
+int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
+                           const uint8_t* target, int64_t nvox, const float* coeffs, void* dx, double* dwb_out, void* stream);
+
 /* sigmoid + max over classes of the (padded-free) logits [n, C] fp32 -> probs [n] ; used by the hard-negative
  * sampler (DetectionHeadHNM.select_indices, nndet/arch/heads/comb.py:247-276). */
 int nndet_sigmoid_max_f32(const float* logits, int64_t n, int32_t C, float* out, void* stream);

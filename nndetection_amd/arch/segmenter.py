@@ -3,6 +3,7 @@
 loss = alpha * CE + (1 - alpha) * SoftDice(softmax, batch_dice, no background, smooth 1e-5)
 (nndet/losses/segmentation.py:32-151). The per-voxel part of the loss (softmax, CE, tp/fp/fn sums and their
 gradient) is two streaming HIP kernels (csrc/segloss.hip); the scalar algebra on the four sums is autograd."""
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -37,6 +38,41 @@ class _SegSums(torch.autograd.Function):
         return logical(dl, 2), None
 
 
+class _SegHeadFused(torch.autograd.Function):
+    """Training-only fusion of the 1x1x1 output conv with the loss sums (csrc/segloss.hip, nndet_seghead_*): x = finest decoder
+    map [N,C<=32,D,H,W], weight [2,C,1,1,1], bias [2], target uint8 -> fp32 [4] = (sum CE, tp, fp, fn). The padded logits and
+    their gradient never reach HBM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, target_u8):
+        xp, cin = phys(x)
+        if xp.shape[-1] != 32 or weight.shape[0] != 2 or weight.shape[1] != cin:
+            raise L.NndetError("fused segmentation head: needs <= 32 input channels and the 2-class 1x1x1 output conv")
+        nvox = xp.shape[0] * xp.shape[1] * xp.shape[2] * xp.shape[3]
+        w32 = weight.detach().reshape(2, cin).to(xp.dtype).float().contiguous()      # rounded like the packed conv weights
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        sums = torch.zeros((4,), dtype=torch.float64, device=xp.device)
+        L.call("nndet_seghead_forward", L.dtype_code(xp), L.ptr(xp), 32, cin, L.ptr(w32), L.ptr(b32), L.ptr(target_u8), nvox,
+               L.ptr(sums), L.stream())
+        ctx.save_for_backward(xp, w32, target_u8)
+        ctx.b32, ctx.cin, ctx.wshape, ctx.wdtype = b32, cin, tuple(weight.shape), weight.dtype
+        return sums.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, w32, tgt = ctx.saved_tensors
+        cin = ctx.cin
+        nvox = xp.shape[0] * xp.shape[1] * xp.shape[2] * xp.shape[3]
+        coeffs = g.detach().float().contiguous()
+        dx = torch.empty_like(xp)
+        dwb = torch.zeros((2 * cin + 2,), dtype=torch.float64, device=xp.device)
+        L.call("nndet_seghead_backward", L.dtype_code(xp), L.ptr(xp), 32, cin, L.ptr(w32), L.ptr(ctx.b32), L.ptr(tgt), nvox,
+               L.ptr(coeffs), L.ptr(dx), L.ptr(dwb), L.stream())
+        dw = dwb[:2 * cin].float().view(ctx.wshape).to(ctx.wdtype)
+        db = dwb[2 * cin:].float() if ctx.b32 is not None else None
+        return logical(dx, cin), dw, db, None
+
+
 class DiCESegmenterFgBg(nn.Module):
     def __init__(self, conv, seg_classes: int, in_channels: Sequence[int], decoder_levels: Sequence[int],
                  internal_channels: Optional[int] = None, num_internal: int = 0, add_norm: bool = True, add_act: bool = True,
@@ -53,13 +89,19 @@ class DiCESegmenterFgBg(nn.Module):
         self.conv_out = conv(in_channels[0], self.seg_classes, kernel_size=1, padding=0, add_norm=None, add_act=None, bias=True)
         self.conv_intermediate = None
 
-    def forward(self, x: List[Tensor]) -> Dict[str, Tensor]:
+    def forward(self, x: List[Tensor], fused: bool = False) -> Dict[str, Tensor]:
+        """fused=True (training steps that do not need the logits): hand the decoder map to compute_loss, which runs the output
+        conv and the loss in one pass; else the logits as in the reference."""
+        if fused and x[0].is_cuda and self.in_channels[0] <= 32 and os.environ.get("NNDET_SEG_FUSED", "1") != "0":
+            return {"seg_input": x[0]}
         return {"seg_logits": self.conv_out(x[0])}
 
     def compute_loss(self, pred_seg: Dict[str, Tensor], target: Tensor) -> Dict[str, Tensor]:
-        logits = pred_seg["seg_logits"]
         tgt = (target > 0).to(torch.uint8).contiguous()          # segmenter.py:288 binarises in place
-        s = _SegSums.apply(logits, tgt)
+        if "seg_input" in pred_seg:
+            s = _SegHeadFused.apply(pred_seg["seg_input"], self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
+        else:
+            s = _SegSums.apply(pred_seg["seg_logits"], tgt)
         nvox = float(tgt.numel())
         ce = s[0] / nvox                                          # CrossEntropyLoss mean over voxels
         tp, fp, fn = s[1], s[2], s[3]

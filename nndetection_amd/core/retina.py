@@ -39,7 +39,10 @@ class BaseRetinaNet(nn.Module):
         feature_maps_head = [features_maps_all[i] for i in self.decoder_levels]
         pred_detection = self.head(feature_maps_head)
         anchors = self.anchor_generator(inp, feature_maps_head)
-        pred_seg = self.segmenter(features_maps_all) if self.segmenter is not None else None
+        pred_seg = None
+        if self.segmenter is not None:
+            pred_seg = self.segmenter(features_maps_all, fused=True) if getattr(self, "_fuse_seg_head", False) \
+                else self.segmenter(features_maps_all)
         return pred_detection, anchors, pred_seg
 
     # ------------------------------------------------------------------ train step (retina.py:86-159)
@@ -47,7 +50,12 @@ class BaseRetinaNet(nn.Module):
         target_boxes: List[Tensor] = targets["target_boxes"]
         target_classes: List[Tensor] = targets["target_classes"]
         target_seg: Tensor = targets["target_seg"]
-        pred_detection, anchors, pred_seg = self(images)
+        # the segmentation logits are only materialised when a prediction is asked for (evaluation); else conv + loss are fused
+        self._fuse_seg_head = (not evaluation) and torch.is_grad_enabled()
+        try:
+            pred_detection, anchors, pred_seg = self(images)
+        finally:
+            self._fuse_seg_head = False
         labels, matched_gt_boxes = self.assign_targets_to_anchors(anchors, target_boxes, target_classes)
         losses = {}
         head_losses, pos_idx, neg_idx = self.head.compute_loss(pred_detection, labels, matched_gt_boxes, anchors)

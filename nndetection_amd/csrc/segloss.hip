@@ -89,3 +89,162 @@ extern "C" int nndet_segloss_backward(int32_t dtype, const void* logits, const u
     LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ fused head (training)
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); }
+
+// loads the 32-channel row of voxel v as fp32
+template <typename T> __device__ __forceinline__ void ld_row32(const T* p, float* v);
+template <> __device__ __forceinline__ void ld_row32<float>(const float* p, float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float4 f = reinterpret_cast<const float4*>(p)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+}
+template <> __device__ __forceinline__ void ld_row32<bf16_t>(const bf16_t* p, float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 u = reinterpret_cast<const uint4*>(p)[i];
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = __uint_as_float(w[k] << 16); v[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    }
+}
+
+struct SegHeadW { float w0[32], w1[32], b0, b1; };
+
+template <typename T>
+__device__ __forceinline__ float seghead_z(const float* xv, const SegHeadW& W) {
+    float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { l0 = fmaf(W.w0[c], xv[c], l0); l1 = fmaf(W.w1[c], xv[c], l1); }
+    l0 = round_to<T>(l0 + W.b0); l1 = round_to<T>(l1 + W.b1);
+    return l1 - l0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_seghead_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     int cin, const uint8_t* __restrict__ target, int64_t nvox, double* __restrict__ sums) {
+    __shared__ double red[4];
+    __shared__ SegHeadW W;
+    if (threadIdx.x < 4) red[threadIdx.x] = 0.0;
+    if (threadIdx.x < 32) {
+        W.w0[threadIdx.x] = (int)threadIdx.x < cin ? w[threadIdx.x] : 0.f;
+        W.w1[threadIdx.x] = (int)threadIdx.x < cin ? w[cin + threadIdx.x] : 0.f;
+    }
+    if (threadIdx.x == 0) { W.b0 = bias ? bias[0] : 0.f; W.b1 = bias ? bias[1] : 0.f; }
+    __syncthreads();
+    float ce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * 256) {
+        float xv[32];
+        ld_row32<T>(x + v * 32, xv);
+        const float z = seghead_z<T>(xv, W);
+        const bool t = target[v] > 0;
+        const float p1 = 1.f / (1.f + expf(-z));
+        ce += t ? softplus(-z) : softplus(z);
+        if (t) { tp += p1; fn += 1.f - p1; } else { fp += p1; }
+    }
+    double d[4] = {(double)ce, (double)tp, (double)fp, (double)fn};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double s = wave_sum_f64(d[k]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], s);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&sums[threadIdx.x], red[threadIdx.x]);
+}
+
+template <typename T> __device__ __forceinline__ void st_row32(T* p, const float* v);
+template <> __device__ __forceinline__ void st_row32<float>(float* p, const float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+template <> __device__ __forceinline__ void st_row32<bf16_t>(bf16_t* p, const float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint4 u;
+        u.x = pack_bf16x2(v[8 * i + 0], v[8 * i + 1]); u.y = pack_bf16x2(v[8 * i + 2], v[8 * i + 3]);
+        u.z = pack_bf16x2(v[8 * i + 4], v[8 * i + 5]); u.w = pack_bf16x2(v[8 * i + 6], v[8 * i + 7]);
+        reinterpret_cast<uint4*>(p)[i] = u;
+    }
+}
+
+// persistent grid: every thread accumulates sum(d1 * x[c]) for its voxels in registers, block reduction through LDS,
+// one fp64 atomic per (block, channel)
+template <typename T>
+__global__ __launch_bounds__(256) void k_seghead_bwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     int cin, const uint8_t* __restrict__ target, int64_t nvox,
+                                                     const float* __restrict__ coeffs, T* __restrict__ dx, double* __restrict__ dwb) {
+    __shared__ SegHeadW W;
+    __shared__ float red[4][33];
+    if (threadIdx.x < 32) {
+        W.w0[threadIdx.x] = (int)threadIdx.x < cin ? w[threadIdx.x] : 0.f;
+        W.w1[threadIdx.x] = (int)threadIdx.x < cin ? w[cin + threadIdx.x] : 0.f;
+    }
+    if (threadIdx.x == 0) { W.b0 = bias ? bias[0] : 0.f; W.b1 = bias ? bias[1] : 0.f; }
+    __syncthreads();
+    const float g_ce = coeffs[0], g_tp = coeffs[1], g_fp = coeffs[2], g_fn = coeffs[3];
+    float acc[33];
+#pragma unroll
+    for (int c = 0; c < 33; ++c) acc[c] = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * 256) {
+        float xv[32];
+        ld_row32<T>(x + v * 32, xv);
+        const float z = seghead_z<T>(xv, W);
+        const bool t = target[v] > 0;
+        const float p1 = 1.f / (1.f + expf(-z));
+        const float dp = p1 * (1.f - p1);
+        float d1 = g_ce * (p1 - (t ? 1.f : 0.f));
+        d1 += dp * (t ? (g_tp - g_fn) : g_fp);
+        d1 = round_to<T>(d1);                      // the unfused path stores dlogits in T
+        float o[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            acc[c] = fmaf(d1, xv[c], acc[c]);
+            o[c] = fmaf(W.w1[c], d1, W.w0[c] * -d1);
+        }
+        acc[32] += d1;
+        st_row32<T>(dx + v * 32, o);
+    }
+    // reduce 33 values over the block: wave shuffles, then the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 33; ++c) {
+        const float s = wave_sum_f32(acc[c]);
+        if (lane == 0) red[wv][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 33) {
+        const int c = threadIdx.x;
+        const double s = (double)red[0][c] + (double)red[1][c] + (double)red[2][c] + (double)red[3][c];
+        if (c < 32) {
+            if (c < cin) { atomicAdd(&dwb[cin + c], s); atomicAdd(&dwb[c], -s); }     // dW[1][c] = s, dW[0][c] = -s
+        } else {
+            atomicAdd(&dwb[2 * cin + 1], s); atomicAdd(&dwb[2 * cin], -s);
+        }
+    }
+}
+
+extern "C" int nndet_seghead_forward(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
+                                     const uint8_t* target, int64_t nvox, double* sums_out, void* stream) {
+    if (!x || !w || !target || !sums_out || nvox <= 0 || c_p != 32 || cin <= 0 || cin > 32) return NNDET_EINVAL;
+    int64_t nb = ceil_div64(nvox, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    if (dtype == NNDET_BF16) k_seghead_fwd<bf16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const bf16_t*)x, w, bias, cin, target, nvox, sums_out);
+    else k_seghead_fwd<float><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const float*)x, w, bias, cin, target, nvox, sums_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
+                                      const uint8_t* target, int64_t nvox, const float* coeffs, void* dx, double* dwb_out, void* stream) {
+    if (!x || !w || !target || !coeffs || !dx || !dwb_out || nvox <= 0 || c_p != 32 || cin <= 0 || cin > 32) return NNDET_EINVAL;
+    int64_t nb = ceil_div64(nvox, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    if (dtype == NNDET_BF16)
+        k_seghead_bwd<bf16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const bf16_t*)x, w, bias, cin, target, nvox, coeffs, (bf16_t*)dx, dwb_out);
+    else
+        k_seghead_bwd<float><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const float*)x, w, bias, cin, target, nvox, coeffs, (float*)dx, dwb_out);
+    LAUNCH_CHECK();
+    return 0;
+}

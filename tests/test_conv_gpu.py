@@ -216,3 +216,37 @@ def test_transposed_conv_with_fused_residual(dtype):
     assert relerr(xg.grad.float(), xr.grad) <= tol
     assert relerr(rg.grad.float(), rr.grad) <= tol
     assert relerr(m.conv.weight.grad, w.grad) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_fused_seg_head_matches_unfused(dtype):
+    """nndet_seghead_forward / _backward (1x1x1 output conv + loss sums in one pass) == conv (nndet_conv3d_forward) followed by
+    nndet_segloss_*: the four sums, d(input), dW, dbias. fp32: summation order only; bf16: the logits may differ in the last
+    bf16 bit where the fp32 accumulation order of the conv differs."""
+    from nndetection_amd.arch.conv import ConvInstanceRelu, Generator
+    from nndetection_amd.arch.segmenter import DiCESegmenterFgBg
+    torch.manual_seed(3)
+    seg = DiCESegmenterFgBg(Generator(ConvInstanceRelu, 3), seg_classes=1, in_channels=[32], decoder_levels=[0],
+                            dice_kwargs={"batch_dice": True, "smooth_nom": 1e-5, "smooth_denom": 1e-5}).cuda()
+    with torch.no_grad():
+        seg.conv_out.conv.weight.copy_(torch.randn_like(seg.conv_out.conv.weight) * 0.3)
+        seg.conv_out.conv.bias.copy_(torch.tensor([0.2, -0.1]))
+    x0 = (torch.randn(2, 32, 9, 10, 12, device="cuda") * 1.5).to(dtype)
+    target = (torch.rand(2, 9, 10, 12, device="cuda") > 0.7).float()
+    out = {}
+    for fused in (False, True):
+        seg.zero_grad(set_to_none=True)
+        x = x0.detach().clone().requires_grad_(True)
+        pred = seg([x], fused=fused)
+        assert ("seg_input" in pred) == fused
+        losses = seg.compute_loss(pred, target)
+        (losses["seg_ce"] * 1.3 + losses["seg_dice"] * 0.7).backward()
+        torch.cuda.synchronize()
+        out[fused] = (float(losses["seg_ce"].detach()), float(losses["seg_dice"].detach()), x.grad.float().clone(),
+                      seg.conv_out.conv.weight.grad.clone(), seg.conv_out.conv.bias.grad.clone())
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    a, b = out[False], out[True]
+    assert abs(a[0] - b[0]) <= tol * max(1.0, abs(a[0])) and abs(a[1] - b[1]) <= tol, (a[:2], b[:2])
+    for k, name in ((2, "dx"), (3, "dW"), (4, "dbias")):
+        e = relerr(b[k], a[k])
+        assert e <= (5e-5 if dtype == torch.float32 else 4e-2), f"{name} rel err {e:.3e}"

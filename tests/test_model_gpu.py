@@ -46,6 +46,11 @@ def test_tiny_fp32_vs_oracle_and_golden(golden_dir, monkeypatch):
     losses, pred = net.train_step(x.cuda(), _cuda_targets(tg), evaluation=True)
     for k in ("reg", "cls", "seg_ce", "seg_dice"):
         assert abs(losses[k].item() - float(gn[f"loss_{k}"])) < 1e-4, (k, losses[k].item(), float(gn[f"loss_{k}"]))
+    # the training-only path (fused segmentation head, no prediction) must give the same losses as the golden as well
+    losses_t, pred_t = net.train_step(x.cuda(), _cuda_targets(tg), evaluation=False)
+    assert pred_t is None
+    for k in ("reg", "cls", "seg_ce", "seg_dice"):
+        assert abs(losses_t[k].item() - float(gn[f"loss_{k}"])) < 1e-4, (k, losses_t[k].item(), float(gn[f"loss_{k}"]))
     sum(losses.values()).backward()
     torch.cuda.synchronize()
     norms = {k: (p.grad.norm().item() if p.grad is not None else -1.0) for k, p in net.named_parameters()}
