@@ -191,12 +191,13 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "patches/sec (fwd+bwd) 160x160x96 RetinaUNet", "value": round(batch * world * args.steps / dt, 3),
+            "metric": "patches/sec (fwd+bwd) %dx%dx%d RetinaUNet" % tuple(plan["patch_size"]), "value": round(batch * world * args.steps / dt, 3),
             "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: Task016_Luna-like plan (SURVEY 8), RetinaUNetV001 train step "
-                                   "(fwd + ATSS + losses + bwd + SGD), %dx%dx%d patches" % tuple(plan["patch_size"]),
+            "config": {"workload": ("BASELINE.json configs[1]: Task016_Luna-like plan (SURVEY 8)" if args.plan == "luna160" else
+                                    "plan '%s' (not the headline configuration)" % args.plan) +
+                                   ", RetinaUNetV001 train step (fwd + ATSS + losses + bwd + SGD), %dx%dx%d patches" % tuple(plan["patch_size"]),
                        "plan": args.plan, "batch_per_gpu": batch, "global_batch": batch * world,
                        "parallelism": "dp%d" % world, "params": sum(p.numel() for p in net.parameters())},
             "final_loss": round(loss_val, 5), "peak_hbm_gib": round(peak_gb, 2),
