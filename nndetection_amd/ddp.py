@@ -39,7 +39,9 @@ class GradBucket:
 
 
 class GradAllReducer:
-    """Usage:  ddp = GradAllReducer(model);  loss.backward();  ddp.finish();  optimizer.step()"""
+    """Usage:  ddp = GradAllReducer(model);  loss.backward();  ddp.finish();  optimizer.step();  optimizer.zero_grad(set_to_none=True)
+    After finish() every p.grad is a VIEW of its bucket: zero_grad(set_to_none=True) (not in-place zeroing or accumulation over
+    several backward passes) is required before the next backward."""
 
     def __init__(self, model: torch.nn.Module, first_bucket_mb: float = 4.0, bucket_mb: float = 24.0,
                  process_group=None, overlap: bool = True):
@@ -75,11 +77,14 @@ class GradAllReducer:
                 dist.broadcast(t.data, src=0, group=self.pg)
 
     def _launch(self, b: GradBucket):
+        src, dst = [], []
         for p, v in zip(b.params, b.views):
             if p.grad is None:
                 v.zero_()                                # unused on this rank: contributes zeros
             else:
-                v.copy_(p.grad)
+                src.append(p.grad); dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)               # one multi-tensor kernel per bucket instead of one copy per parameter
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _on_grad(self, p):
@@ -102,11 +107,10 @@ class GradAllReducer:
         for b in self.buckets:
             b.work.wait()
             b.flat.mul_(inv)
+            # hand the averaged gradients to the optimizer as views of the bucket (no copy back). They stay valid until the
+            # bucket is refilled by the next backward; the training loop drops them with zero_grad(set_to_none=True).
             for p, v in zip(b.params, b.views):
-                if p.grad is None:
-                    p.grad = v.clone()
-                else:
-                    p.grad.copy_(v)
+                p.grad = v
             b.work = None
             b.pending = len(b.params)
         self._next = 0
