@@ -22,9 +22,10 @@ extern "C" int nndet_conv3d_forward(const NndetConv* c, const void* x, const voi
     hipStream_t st = as_stream(stream);
     if (c->cin_p == 1) {
         if (residual) return NNDET_EINVAL;
-        rc = stem_forward(c, x, (const float*)w, bias, y, st);
+        int stats_done = 0;
+        rc = stem_forward(c, x, (const float*)w, bias, y, stats, &stats_done, st);
         if (rc) return rc;
-        if (stats) {
+        if (stats && !stats_done) {
             const int64_t spatial = (int64_t)c->out_d * c->out_h * c->out_w;
             return norm_stats_run(c->dtype, y, c->batch, spatial, c->cout_p, stats, st);
         }

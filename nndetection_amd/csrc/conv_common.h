@@ -15,7 +15,8 @@ int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x,
 int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 size_t wgrad_workspace_bytes(const NndetConv* c);
 // conv_stem.hip (Cin_p == 1)
-int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const float* bias, void* y, hipStream_t st);
+int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const float* bias, void* y, double* stats, int* stats_done,
+                 hipStream_t st);   // stats_done = 1: the IN statistics were accumulated by the kernel (stats may be NULL)
 int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hipStream_t st);
 // norm.hip
 int colsum_run(int dtype, const void* x, int64_t rows, int c_p, int c, float* out, hipStream_t st);

@@ -294,6 +294,152 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad3(const StemArgs A, int nt
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward on MFMA
+// Same expansion as k_stem_wgrad3: y[p][r] = sum_tap X[p + tap] * W[r][tap] with the [point][32 taps] tile as the B operand
+// (one plain ds_read_b128 per 16 points and K = 32 step) and the 32 x 27 weights as A fragments that live in registers for the
+// whole kernel. The C layout gives every lane 4 consecutive channels of one voxel (8-byte stores) and the InstanceNorm
+// statistics of the rounded outputs are reduced in the epilogue like in k_ig3 (the separate 629 MB statistics pass of the
+// VALU kernel disappears). grid (S, Cout_p / 32, N): a workgroup walks tiles of ONE image so its statistics flush once.
+__device__ __forceinline__ float stem_dpp_row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0, int nt1, int nt2, double* __restrict__ stats) {
+    constexpr int PROW = 8 * 64 + 32;
+    __shared__ __attribute__((aligned(16))) char imt[32 * PROW];
+    __shared__ __attribute__((aligned(16))) uint16_t xh[608];
+    __shared__ double red[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int c0 = blockIdx.y * 32, n = blockIdx.z;
+    if (tid < 64) red[tid] = 0.0;
+    // A fragments: W[c0 + i*16 + li][taps 8q .. 8q+7] rounded to bf16 (taps >= 27 are zero)
+    u32x4 af[2];
+    float bia[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = c0 + i * 16 + li;
+        float wv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = q * 8 + j;
+            wv8[j] = (t < 27 && ch < A.cout) ? A.w[(int64_t)ch * 27 + t] : 0.f;
+        }
+        af[i] = u32x4{pack_bf16x2(wv8[0], wv8[1]), pack_bf16x2(wv8[2], wv8[3]), pack_bf16x2(wv8[4], wv8[5]), pack_bf16x2(wv8[6], wv8[7])};
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int cb = c0 + i * 16 + q * 4 + rr;
+            bia[i][rr] = (A.bias && cb < A.cout) ? A.bias[cb] : 0.f;
+        }
+    }
+    int x_rel[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int i = tid + s * 256;
+        x_rel[s] = ((i / 100) << 16) | (((i / 10) % 10) << 8) | (i % 10);
+    }
+    const int e_base = ((tid >> 6) * 10 + ((tid >> 3) & 7)) * 10 + (tid & 7);
+    char* const e_dst = imt + (tid >> 3) * PROW + (tid & 7) * 64;
+    const int x_img = A.I[0] * A.I[1] * A.I[2] * 2;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (int64_t)n * x_img, 0, x_img, 0x00020000);
+    const int y_img = A.O[0] * A.O[1] * A.O[2] * A.Cy * 2;
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(A.y) + (int64_t)n * y_img + c0 * 2, 0, y_img - c0 * 2, 0x00020000);
+    const int tiles_per_n = nt0 * nt1 * nt2;
+    float ssum[2][4], ssq[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { ssum[i][rr] = 0.f; ssq[i][rr] = 0.f; }
+    uint16_t vx[3];
+    auto issue = [&](int tile, int& l0d, int& l0h, int& l0w) {
+        int tt = tile;
+        const int tw_i = tt % nt2; tt /= nt2;
+        const int th_i = tt % nt1;
+        const int td_i = tt / nt1;
+        l0d = td_i * 4; l0h = th_i * 8; l0w = tw_i * 8;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int id = l0d - 1 + (x_rel[s] >> 16), ih = l0h - 1 + ((x_rel[s] >> 8) & 255), iw = l0w - 1 + (x_rel[s] & 255);
+            const bool ok = (tid + s * 256 < 600) && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
+            vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, ok ? ((id * A.I[1] + ih) * A.I[2] + iw) * 2 : (int)0x80000000, 0, 0);
+        }
+    };
+    int tile = xcd_compact(blockIdx.x, gridDim.x, gridDim.x);     // neighbouring tiles (shared halo rows) on one XCD
+    int l0d = 0, l0h = 0, l0w = 0, n0d, n0h, n0w;
+    if (tile < tiles_per_n) issue(tile, l0d, l0h, l0w);
+    for (; tile < tiles_per_n; tile += gridDim.x) {
+        __syncthreads();                                   // previous tile's MFMA phase is done with imt / xh
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (tid + s * 256 < 600) xh[tid + s * 256] = vx[s];
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < tiles_per_n) issue(next, n0d, n0h, n0w);
+        uint32_t pk[16];
+#pragma unroll
+        for (int t = 0; t < 32; t += 2) {
+            uint32_t lo = 0, hi = 0;
+            if (t < 27) lo = xh[e_base + (t / 9) * 100 + ((t / 3) % 3) * 10 + t % 3];
+            if (t + 1 < 27) hi = xh[e_base + ((t + 1) / 9) * 100 + (((t + 1) / 3) % 3) * 10 + (t + 1) % 3];
+            pk[t >> 1] = lo | (hi << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(e_dst + k * 16) = u32x4{pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]};
+        __syncthreads();
+        u32x4 bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pt = wv * 4 + j;                     // 16 points = rows 2 pt, 2 pt + 1 of the tile
+            bf[j] = *reinterpret_cast<const u32x4*>(imt + (pt * 2 + (li >> 3)) * PROW + (li & 7) * 64 + q * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = (wv * 4 + j) * 16 + li;
+            const int ld = l0d + (p >> 6), lh = l0h + ((p >> 3) & 7), lw = l0w + (p & 7);
+            const bool valid = ld < A.O[0] && lh < A.O[1] && lw < A.O[2];
+            const int vo = valid ? (((ld * A.O[1] + lh) * A.O[2] + lw) * A.Cy + q * 4) * 2 : (int)0x80000000;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 c = f32x4{bia[i][0], bia[i][1], bia[i][2], bia[i][3]};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(st_bf16x8, af[i]), __builtin_bit_cast(st_bf16x8, bf[j]), c, 0, 0, 0);
+                typedef unsigned int v2u_t __attribute__((__vector_size__(8)));
+                v2u_t o;
+                o[0] = pack_bf16x2(c[0], c[1]); o[1] = pack_bf16x2(c[2], c[3]);
+                __builtin_amdgcn_raw_buffer_store_b64(o, yrs, vo + i * 32, 0, 0);
+                if (stats && valid) {
+                    const float r0 = __uint_as_float(o[0] << 16), r1 = __uint_as_float(o[0] & 0xffff0000u);
+                    const float r2 = __uint_as_float(o[1] << 16), r3 = __uint_as_float(o[1] & 0xffff0000u);
+                    ssum[i][0] += r0; ssum[i][1] += r1; ssum[i][2] += r2; ssum[i][3] += r3;
+                    ssq[i][0] += r0 * r0; ssq[i][1] += r1 * r1; ssq[i][2] += r2 * r2; ssq[i][3] += r3 * r3;
+                }
+            }
+        }
+        l0d = n0d; l0h = n0h; l0w = n0w;
+    }
+    if (stats) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float s = stem_dpp_row_sum(ssum[i][rr]), s2 = stem_dpp_row_sum(ssq[i][rr]);
+                if (li == 0) {
+                    atomicAdd(&red[(i * 16 + q * 4 + rr) * 2 + 0], (double)s);
+                    atomicAdd(&red[(i * 16 + q * 4 + rr) * 2 + 1], (double)s2);
+                }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            const int rep = blockIdx.x % NNDET_STATS_REPLICAS;
+            atomicAdd(stats + (((int64_t)rep * A.N + n) * A.Cy + c0 + (tid >> 1)) * 2 + (tid & 1), red[tid]);
+        }
+    }
+}
+
 static int stem_args(const NndetConv* c, StemArgs* a) {
     if (c->cin_p != 1 || c->cin != 1 || c->transposed || c->cout_p % 32) return NNDET_EINVAL;
     if (c->k[0] * c->k[1] * c->k[2] > 27) return NNDET_EINVAL;
@@ -308,11 +454,29 @@ static int stem_args(const NndetConv* c, StemArgs* a) {
     return 0;
 }
 
-int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const float* bias, void* y, hipStream_t st) {
+int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const float* bias, void* y, double* stats, int* stats_done,
+                 hipStream_t st) {
     StemArgs a;
     int rc = stem_args(c, &a);
     if (rc) return rc;
     a.x = x; a.w = w_f32; a.bias = bias; a.y = y;
+    *stats_done = 0;
+    const int64_t yb = (int64_t)a.O[0] * a.O[1] * a.O[2] * a.Cy * 2;
+    if (c->dtype == NNDET_BF16 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1 &&
+        c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1 && yb < (1LL << 31) && !getenv("NNDET_STEM_VALU")) {
+        const int nt0 = ceil_div(a.O[0], 4), nt1 = ceil_div(a.O[1], 8), nt2 = ceil_div(a.O[2], 8);
+        const int64_t tiles = (int64_t)nt0 * nt1 * nt2;
+        if (tiles < (1LL << 30)) {
+            int S = 512 / (a.N * (c->cout_p / 32));
+            if (S < 8) S = 8;
+            S = (S / 8) * 8;
+            if (S > tiles) S = (int)tiles;
+            k_stem_fwd3<<<dim3(S, c->cout_p / 32, a.N), 256, 0, st>>>(a, nt0, nt1, nt2, stats);
+            LAUNCH_CHECK();
+            *stats_done = 1;
+            return 0;
+        }
+    }
     dim3 grid((unsigned)ceil_div64(a.total, 256), c->cout_p / 32);
     if (c->dtype == NNDET_BF16) k_stem_fwd<bf16_t><<<grid, 256, 0, st>>>(a);
     else k_stem_fwd<float><<<grid, 256, 0, st>>>(a);
