@@ -120,5 +120,55 @@ def workspace(nbytes: int, device) -> "torch.Tensor":
     return buf
 
 
+class _ZeroArena:
+    """Zero-initialised scratch for tensors that die inside one forward / backward call (norm statistics and reduction
+    buffers: 2 per normalised conv and step). Bump allocation from one buffer that is re-zeroed with ONE fill per step
+    (`reset()`, called at the start of BaseRetinaNet.forward) instead of one fill kernel per tensor. Memory that was handed
+    out and not yet reset is never handed out again; when the buffer is exhausted (no reset, e.g. a bare conv module in a
+    loop) the caller falls back to torch.zeros, so results never depend on reset() being called."""
+
+    def __init__(self, device, nbytes=64 << 20):
+        self.buf = torch.zeros((nbytes,), dtype=torch.uint8, device=device)
+        self.off = 0
+
+    def take(self, nbytes):
+        start = (self.off + 255) // 256 * 256
+        if start + nbytes > self.buf.numel():
+            return None
+        self.off = start + nbytes
+        return self.buf[start:start + nbytes]
+
+    def reset(self):
+        if self.off:
+            self.buf[:self.off].zero_()
+            self.off = 0
+
+
+_arenas = {}
+
+
+def arena_reset(device):
+    a = _arenas.get((device.type, device.index))
+    if a is not None:
+        a.reset()
+
+
+def arena_zeros(shape, dtype, device):
+    """Zeroed tensor for a temporary that is dead when the current autograd node returns (see _ZeroArena)."""
+    if device.type != "cuda" or os.environ.get("NNDET_NO_ARENA"):
+        return torch.zeros(shape, dtype=dtype, device=device)
+    key = (device.type, device.index)
+    a = _arenas.get(key)
+    if a is None:
+        a = _arenas[key] = _ZeroArena(device)
+    n = 1
+    for s in shape:
+        n *= int(s)
+    raw = a.take(n * torch.empty((), dtype=dtype).element_size())
+    if raw is None:
+        return torch.zeros(shape, dtype=dtype, device=device)
+    return raw.view(dtype).view(shape)
+
+
 def call(name: str, *args):
     check(getattr(load(), name)(*args), name)

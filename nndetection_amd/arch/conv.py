@@ -106,7 +106,7 @@ class _ConvBlockFn(torch.autograd.Function):
         w_arg = weight.detach().float().contiguous() if stem else _packed(mod, 0, weight, desc, dt)
         y = torch.empty((N, desc.out_d, desc.out_h, desc.out_w, cout_p), dtype=dt, device=dev)
         has_norm = gamma is not None
-        stats = torch.zeros((L.STATS_REPLICAS, N, cout_p, 2), dtype=torch.float64, device=dev) if has_norm else None
+        stats = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev) if has_norm else None
         b_p = _pad1d(bias, cout_p)
         r_p = None
         if residual is not None:
@@ -141,12 +141,20 @@ class _ConvBlockFn(torch.autograd.Function):
             x_p, weight = ctx.saved_tensors
         dev, dt = x_p.device, x_p.dtype
         g_p, _ = phys(grad_out, dtype=dt, cp=cout_p)
+        # all parameter gradients of this node (dW, dbias, dgamma, dbeta) are views of ONE zero-filled buffer: one fill kernel
+        # per node instead of up to four
+        nw = weight.numel()
+        gbuf = torch.zeros((nw + (cout if ctx.has_bias else 0) + (2 * cout if ctx.has_norm else 0),), dtype=torch.float32, device=dev)
+        dw = gbuf[:nw].view(weight.shape)
+        off = nw
+        dbias = None
+        if ctx.has_bias:
+            dbias = gbuf[off:off + cout]; off += cout
         dgamma = dbeta = None
         if ctx.has_norm:
             dconv = torch.empty_like(y)
-            dgamma = torch.zeros((cout,), dtype=torch.float32, device=dev)
-            dbeta = torch.zeros((cout,), dtype=torch.float32, device=dev)
-            red = torch.zeros((L.STATS_REPLICAS, N, cout_p, 2), dtype=torch.float64, device=dev)
+            dgamma, dbeta = gbuf[off:off + cout], gbuf[off + cout:off + 2 * cout]
+            red = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev)
             spatial = desc.out_d * desc.out_h * desc.out_w
             L.call("nndet_norm_backward", desc.dtype, L.ptr(y), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,
                    cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.ptr(red), L.stream())
@@ -160,8 +168,6 @@ class _ConvBlockFn(torch.autograd.Function):
             dx_p = torch.empty_like(x_p)
             L.call("nndet_conv3d_backward_data", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.stream())
             dx = logical(dx_p, desc.cin)
-        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
-        dbias = torch.zeros((cout,), dtype=torch.float32, device=dev) if ctx.has_bias else None
         ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
         ws = L.workspace(ws_bytes, dev)
         L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw), L.ptr(dbias),

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from .. import _lib as L
 from . import boxes as box_utils
 from .boxes.coder import decode_clip
 
@@ -35,6 +36,7 @@ class BaseRetinaNet(nn.Module):
 
     # ------------------------------------------------------------------ forward (retina.py:198-226)
     def forward(self, inp: Tensor):
+        L.arena_reset(inp.device)                # one fill for all per-layer statistics buffers of the previous step
         features_maps_all = self.decoder(self.encoder(inp))
         feature_maps_head = [features_maps_all[i] for i in self.decoder_levels]
         pred_detection = self.head(feature_maps_head)
