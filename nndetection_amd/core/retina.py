@@ -34,6 +34,19 @@ class BaseRetinaNet(nn.Module):
                 used.add(0)
             self.decoder.used_levels = used          # out convs nobody reads are not computed
 
+    def never_used_parameters(self) -> List[nn.Parameter]:
+        """Parameters that exist for state-dict parity with the reference but never receive a gradient: the decoder output convs
+        of pyramid levels that neither the detection head nor the segmenter reads (`decoder.out.P1.*` for RetinaUNetV001)."""
+        used = getattr(self.decoder, "used_levels", None)
+        out = getattr(self.decoder, "out", None)
+        if used is None or out is None or not getattr(self.decoder, "skip_unused_out", True):
+            return []
+        res = []
+        for name, mod in out.items():
+            if int(str(name).lstrip("P")) not in used:
+                res.extend(mod.parameters())
+        return res
+
     # ------------------------------------------------------------------ forward (retina.py:198-226)
     def forward(self, inp: Tensor):
         L.arena_reset(inp.device)                # one fill for all per-layer statistics buffers of the previous step

@@ -44,7 +44,11 @@ class GradAllReducer:
     several backward passes) is required before the next backward."""
 
     def __init__(self, model: torch.nn.Module, first_bucket_mb: float = 4.0, bucket_mb: float = 24.0,
-                 process_group=None, overlap: bool = True):
+                 process_group=None, overlap: bool = True, static_unused=None):
+        """static_unused: parameters that NEVER receive a gradient on any rank (default: `model.never_used_parameters()` if the
+        model has it -- for RetinaUNet the `decoder.out.P<l>` convs of levels nobody reads). They are zero-filled and do not
+        count towards bucket readiness; otherwise their bucket -- and, because collectives are issued in order, every later
+        one -- could only be launched from finish(), i.e. without overlapping the backward pass."""
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         params = [p for p in model.parameters() if p.requires_grad]
@@ -59,10 +63,15 @@ class GradAllReducer:
                 self.buckets.append(GradBucket(cur, device)); cur, cur_bytes, limit = [], 0, bucket_mb * 2 ** 20
         if cur:
             self.buckets.append(GradBucket(cur, device))
+        if static_unused is None and hasattr(model, "never_used_parameters"):
+            static_unused = model.never_used_parameters()
+        self._static_unused = {id(p) for p in (static_unused or [])}
         self._where = {}
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
                 self._where[p] = (bi, pi)
+            b.expected = sum(1 for p in b.params if id(p) not in self._static_unused)
+            b.pending = b.expected
         self.overlap = overlap and self.world > 1
         self._next = 0
         self._hooks = []
@@ -89,6 +98,8 @@ class GradAllReducer:
 
     def _on_grad(self, p):
         bi, _ = self._where[p]
+        if id(p) in self._static_unused:
+            raise RuntimeError("a parameter declared as never used received a gradient")
         self.buckets[bi].pending -= 1
         # collectives must be issued in the SAME order on every rank: a bucket is only launched once all
         # earlier buckets are (a bucket holding a parameter that is unused on this rank is launched by finish())
@@ -112,5 +123,5 @@ class GradAllReducer:
             for p, v in zip(b.params, b.views):
                 p.grad = v
             b.work = None
-            b.pending = len(b.params)
+            b.pending = b.expected
         self._next = 0

@@ -156,3 +156,61 @@ def test_grad_allreduce_gloo_world2():
         grads.append([torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in model.parameters()])
     for got, a, b in zip(g0, *grads):
         assert torch.allclose(got, (a + b) / 2, atol=1e-6)
+
+
+def _ddp_static_unused_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from nndetection_amd.ddp import GradAllReducer
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4), nn.Linear(4, 4))    # model[3] is never used
+    unused = list(model[3].parameters())
+    launched = {}
+    for tag, su in (("declared", unused), ("undeclared", [])):
+        ddp = GradAllReducer(model, first_bucket_mb=1e-4, bucket_mb=2e-4, static_unused=su)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(100 + rank)
+        model[2](model[1](model[0](torch.randn(5, 8)))).sum().backward()
+        launched[tag] = (ddp._next, len(ddp.buckets))          # buckets already in flight when backward returns
+        ddp.finish()
+        for h in ddp._hooks:
+            h.remove()
+    q.put((rank, launched, [p.grad.clone() for p in model.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_static_unused_does_not_block_overlap():
+    """A parameter that never gets a gradient (decoder.out.P1 of RetinaUNet) sits in the FIRST bucket (reverse registration
+    order). Undeclared, no bucket can be launched before finish(); declared as static_unused, every bucket is in flight when
+    backward returns, and the unused parameter's gradient is zero on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_static_unused_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    for rank, launched, grads in res:
+        n_decl, nb = launched["declared"]
+        n_undecl, _ = launched["undeclared"]
+        assert nb >= 2
+        assert n_decl == nb, f"rank {rank}: only {n_decl}/{nb} buckets launched during backward"
+        assert n_undecl == 0, "without the declaration the first bucket (and so all of them) waits for finish()"
+        assert float(grads[-1].abs().max()) == 0.0 and float(grads[-2].abs().max()) == 0.0
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.allclose(a, b, atol=1e-6)
+
+
+def test_never_used_parameters_of_retina_unet():
+    from nndetection_amd.plans import get_plan
+    from nndetection_amd.ptmodule import build_model
+    assert build_model(get_plan("tiny")).never_used_parameters() == []      # every level of `tiny` is read by the head / segmenter
+    net = build_model(get_plan("luna160"))                                   # levels (2,3,4,5) + 0: P1 is never read
+    names = {n for n, p in net.named_parameters() if any(p is q for q in net.never_used_parameters())}
+    assert names == {"decoder.out.P1.0.conv.weight", "decoder.out.P1.0.conv.bias"}, names
+    assert names and all(n.startswith("decoder.out.P") for n in names), names
+    used = net.decoder.used_levels
+    assert all(int(n.split(".")[2][1:]) not in used for n in names)
