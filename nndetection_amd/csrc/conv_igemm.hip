@@ -82,6 +82,7 @@ struct IgClass {
     int32_t tap0, ntap;
 };
 struct IgTap { int32_t d[3]; int32_t wt; };   // delta - in_base (>= 0), weight tap index
+struct IgTapX { int32_t toff; int32_t flip; int32_t woff; int32_t pad; };   // LDS byte offset of the tap, swizzle flip (0 / 32), weight byte offset wt * Cy * Cx * sizeof(T)
 
 struct IgArgs {
     const void* x; const void* w; const float* bias; void* y; double* stats;
@@ -95,10 +96,12 @@ struct IgArgs {
     int32_t H[3];         // halo dims (max over classes)
     uint32_t mHW, mHH;    // magic multipliers: n / H[2] == umulhi(n, mHW), n / H[1] == umulhi(n, mHH) (0 = divisor 1)
     int32_t lT1, lT2;     // log2 of the (power-of-two) tile dims T[1], T[2]
+    int32_t wbytes;       // size of the packed weight tensor in bytes (buffer descriptor of the PIPE kernels)
     int32_t swz;          // 1: XOR LDS byte-offset bit 5 with the parity of the halo row (conflict-free ds_read_b128 for unit-stride tiles)
     int32_t ncls;
     IgClass cls[8];
     IgTap taps[27];
+    IgTapX tapx[28];      // per-tap LDS offset / swizzle flip / weight byte offset, precomputed on the host (PIPE kernels)
 };
 
 // Wave layout inside the workgroup: WR waves along the output rows (channels) x 4/WR waves along the lattice points.
@@ -106,7 +109,13 @@ struct IgArgs {
 // traffic from L2 (every wave used to stream the weights of ALL rows: 432 KB per workgroup and chunk, the bottleneck of
 // the C >= 64 layers) at the price of twice as many (cheap, conflict-free) LDS activation reads.
 // MINW = requested waves per SIMD (= workgroups per CU for 256-thread workgroups): caps the register allocation.
-template <typename T, int WR, int MT, int NT, int MAXP, int MINW>
+// PIPE (the strided configurations): the tap loop is software-pipelined and pinned with sched_barrier -- weight fragments by
+// buffer loads two taps ahead (ring of 3, loop unrolled by 3: no register copies), tap descriptors (scalar loads) two taps ahead,
+// the second half of a tap's activation fragments read before the MFMAs of its first half and the first half of the next tap
+// before the MFMAs of the second half. Measured +20 % on the stride-2 forward convs; for 1-tap problems (1x1x1, transposed) the
+// same loop was 25 % slower than the plain one, which is why it is a per-configuration choice
+// (profiles/round1_micro_v8_generic_pinned_rejected.txt).
+template <typename T, int WR, int MT, int NT, int MAXP, int MINW, bool PIPE = false>
 __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
@@ -182,6 +191,78 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 
     const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + wr * MT * 16 + li) * A.Cx + q * EPL;
     const int nchunk = A.Cx / KC;
+    if constexpr (PIPE) {
+        const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.w), 0, A.wbytes, 0x00020000);
+        int voff[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) voff[i] = ((row0 + (wr * MT + i) * 16 + li) * A.Cx + q * EPL) * (int)sizeof(T);
+        const IgTapX* const tx = A.tapx + C.tap0;
+        const int last = C.ntap - 1;
+        constexpr int NH = NT / 2;
+        for (int kc = 0; kc < nchunk; ++kc) {
+            __syncthreads();
+#pragma unroll
+            for (int s0 = 0; s0 < MAXP; s0 += 8) {
+                if (s0 * 256 >= HV4) break;   // uniform
+                u32x4 v[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int o = goff[s0 + b];
+                    v[b] = *reinterpret_cast<const u32x4*>(xn + (o < 0 ? 0 : o) + kc * KC);
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int p = tid + (s0 + b) * 256;
+                    if (p < HV4)
+                        *reinterpret_cast<u32x4*>(smem + ((p * 16) ^ (((swmask >> (s0 + b)) & 1u) << 5))) =
+                            goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
+                }
+            }
+            __syncthreads();
+            if (last < 0) continue;
+            const int kcoff = kc * KC * (int)sizeof(T);
+            IgTapX cur = tx[0], nxt = tx[min(1, last)];
+            u32x4 afr[3][MT], bf0[NH], bf1[NT - NH];
+            auto load_w = [&](const IgTapX& t, u32x4* a_) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a_[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff[i], t.woff + kcoff, 0));
+            };
+            auto lds_h0 = [&](const IgTapX& t) {
+#pragma unroll
+                for (int j = 0; j < NH; ++j) bf0[j] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ t.flip) + t.toff));
+            };
+            auto lds_h1 = [&](const IgTapX& t) {
+#pragma unroll
+                for (int j = NH; j < NT; ++j) bf1[j - NH] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ t.flip) + t.toff));
+            };
+            load_w(cur, afr[0]);
+            load_w(nxt, afr[1]);
+            lds_h0(cur);
+            for (int tp = 0; tp <= last; tp += 3) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (tp + u > last) break;          // uniform
+                    const IgTapX nn = tx[min(tp + u + 2, last)];
+                    load_w(nn, afr[(u + 2) % 3]);      // (clamped: the last taps re-load their own fragments, harmless)
+                    lds_h1(cur);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NH; ++j) M::mma(afr[u][i], bf0[j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds_h0(nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = NH; j < NT; ++j) M::mma(afr[u][i], bf1[j - NH], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nxt; nxt = nn;
+                }
+            }
+        }
+    } else
     for (int kc = 0; kc < nchunk; ++kc) {
         __syncthreads();
         // Stage the halo in batches of 8 UNCONDITIONAL 16-byte loads per thread (out-of-tensor pieces load a clamped,
@@ -681,6 +762,19 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     a.mHW = magic(a.H[2]); a.mHH = magic(a.H[1]);
     a.lT1 = ilog2(a.T[1]); a.lT2 = ilog2(a.T[2]);
     a.swz = strided ? 0 : 1;
+    {
+        const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
+        const int64_t tapb = (int64_t)a.Cy * a.Cx * esz;
+        const int64_t wb = tapb * (c->k[0] * c->k[1] * c->k[2]);
+        if (wb >= (1LL << 31)) return NNDET_EINVAL;
+        a.wbytes = (int32_t)wb;
+        for (int t = 0; t < ntaps; ++t) {
+            const int trow = a.taps[t].d[0] * a.H[1] + a.taps[t].d[1];
+            a.tapx[t].toff = (trow * a.H[2] + a.taps[t].d[2]) * 64;
+            a.tapx[t].flip = (trow & a.swz) << 5;
+            a.tapx[t].woff = (int32_t)(a.taps[t].wt * tapb);
+        }
+    }
     // 3x3x3 / stride 1 / pad 1 (forward or backward-data): compile-time (TD, 8, 8) tile kernel k_ig3, unless the fixed tile
     // pads the volume noticeably more than the tile choose_tile() found
     // NNDET_IGEMM_SPEC: 0 = never, 1 (default) = by the padding rule, 2 = always (tests); read per call so tests can flip it
@@ -725,8 +819,8 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
     switch (P.cfg) {
         case 0: k_igemm<T, 1, 2, 8, 16, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 1: k_igemm<T, 2, 2, 8, 16, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 2: k_igemm<T, 2, 2, 4, 24, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 3: k_igemm<T, 2, 1, 4, 24, 4><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 2: k_igemm<T, 2, 2, 4, 24, 3, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 3: k_igemm<T, 2, 1, 4, 24, 4, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 5: k_ig3<T, 1, 2, 8, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 6: k_ig3<T, 2, 2, 8, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 7: k_ig3<T, 2, 2, 16, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
@@ -736,9 +830,9 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int WR, int MT, int NT, int MAXP, int MINW>
+template <typename T, int WR, int MT, int NT, int MAXP, int MINW, bool PIPE = false>
 static int set_lds_attr() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP, MINW>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP, MINW, PIPE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 }
 template <typename T, int WR, int MT, int NT, int MINW>
@@ -750,8 +844,8 @@ static int g_attr_done = 0;
 static int ensure_attrs() {
     if (g_attr_done) return 0;
     int rc = 0;
-    rc |= set_lds_attr<bf16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24, 3>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24, 4>(); rc |= set_lds_attr<bf16_t, 1, 2, 4, 16, 4>();
-    rc |= set_lds_attr<float, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<float, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<float, 2, 2, 4, 24, 3>(); rc |= set_lds_attr<float, 2, 1, 4, 24, 4>(); rc |= set_lds_attr<float, 1, 2, 4, 16, 4>();
+    rc |= set_lds_attr<bf16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<bf16_t, 1, 2, 4, 16, 4>();
+    rc |= set_lds_attr<float, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<float, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<float, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<float, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<float, 1, 2, 4, 16, 4>();
     rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<bf16_t, 2, 2, 16, 2>();
     rc |= set_lds_attr3<float, 1, 2, 8, 2>(); rc |= set_lds_attr3<float, 2, 2, 8, 3>(); rc |= set_lds_attr3<float, 2, 2, 16, 2>();
     if (rc) return rc;
