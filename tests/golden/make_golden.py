@@ -181,31 +181,14 @@ def build_reference_net(plan):
                          remove_small_boxes=0.01, nms_thresh=0.6)
 
 
-def det_randperm(n, *a, **k):
-    """Deterministic stand-in for torch.randperm in the sampler (identical on every device)."""
-    return torch.arange(n - 1, -1, -1, device=k.get("device", None))
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("_nndet_amd_tests_gpu_util", os.path.join(ROOT, "tests", "gpu_util.py"))
+_gu = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_gu)      # (the reference ships a `tests` package of its own)
+det_randperm, synth_inputs = _gu.det_randperm, _gu.synth_inputs                  # shared with the parity tests; no reference imports
 
 
-def synth_inputs(plan, seed=0):
-    P, B = plan["patch_size"], plan["batch_size"]
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, 1, *P, generator=g)
-    boxes, classes = [], []
-    seg = torch.zeros(B, *P)
-    rng = np.random.default_rng(seed + 1)
-    for b in range(B):
-        n = 2 if b % 2 == 0 else 1
-        c = rng.uniform(0.25, 0.75, (n, 3)) * np.asarray(P) + 0.137
-        s = rng.uniform(5, 11, (n, 3))
-        lo, hi = np.maximum(c - s / 2, 0), np.minimum(c + s / 2, np.asarray(P))
-        bb = np.stack([lo[:, 0], lo[:, 1], hi[:, 0], hi[:, 1], lo[:, 2], hi[:, 2]], 1).astype(np.float32)
-        boxes.append(torch.from_numpy(bb)); classes.append(torch.zeros(n))
-        for q in bb:
-            seg[b, int(q[0]):int(q[2]) + 1, int(q[1]):int(q[3]) + 1, int(q[4]):int(q[5]) + 1] = 1
-    return x, {"target_boxes": boxes, "target_classes": classes, "target_seg": seg}
-
-
-def golden_net(name):
+def golden_net(name, lite=False):
+    """lite: store only scalars / small vectors; the inputs are regenerated from the seed by tests.gpu_util.synth_inputs."""
     plan = get_plan(name)
     ref = build_reference_net(plan)
     ora = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
@@ -225,7 +208,8 @@ def golden_net(name):
         sum(lo.values()).backward()
     finally:
         torch.randperm = orig
-    g = {"x": x.numpy(), "target_seg": tg["target_seg"].numpy().astype(np.uint8)}
+    g = {} if lite else {"x": x.numpy(), "target_seg": tg["target_seg"].numpy().astype(np.uint8)}
+    g["x_checksum"] = np.float64(x.double().sum().item())
     for i, (b, c) in enumerate(zip(tg["target_boxes"], tg["target_classes"])):
         g[f"gt_boxes_{i}"], g[f"gt_classes_{i}"] = b.numpy(), c.numpy()
     print(f"  [{name}] reference losses:", {k: float(v) for k, v in lr.items()})
@@ -258,5 +242,4 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     print("box ops:"); golden_boxes()
     print("network:"); golden_net("tiny")
-    if "--toy64" in sys.argv:
-        golden_net("toy64")
+    golden_net("toy64", lite=True)        # BASELINE.json configs[0]: the reference's own CPU-runnable case

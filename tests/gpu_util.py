@@ -28,3 +28,26 @@ def det_randperm(n, *a, **k):
 def relerr(a, b):
     a = a.detach().double().cpu(); b = b.detach().double().cpu()
     return float((a - b).abs().max() / max(1e-30, b.abs().max()))
+
+
+def synth_inputs(plan, seed=0):
+    """Deterministic synthetic batch of a plan (CPU tensors): image ~ N(0,1) from a seeded generator, 1-2 boxes per image with
+    a consistent instance segmentation. Shared by tests/golden/make_golden.py and the parity tests."""
+    import numpy as np
+    import torch
+    P, B = plan["patch_size"], plan["batch_size"]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 1, *P, generator=g)
+    boxes, classes = [], []
+    seg = torch.zeros(B, *P)
+    rng = np.random.default_rng(seed + 1)
+    for b in range(B):
+        n = 2 if b % 2 == 0 else 1
+        c = rng.uniform(0.25, 0.75, (n, 3)) * np.asarray(P) + 0.137
+        s = rng.uniform(5, 11, (n, 3))
+        lo, hi = np.maximum(c - s / 2, 0), np.minimum(c + s / 2, np.asarray(P))
+        bb = np.stack([lo[:, 0], lo[:, 1], hi[:, 0], hi[:, 1], lo[:, 2], hi[:, 2]], 1).astype(np.float32)
+        boxes.append(torch.from_numpy(bb)); classes.append(torch.zeros(n))
+        for q in bb:
+            seg[b, int(q[0]):int(q[2]) + 1, int(q[1]):int(q[3]) + 1, int(q[4]):int(q[5]) + 1] = 1
+    return x, {"target_boxes": boxes, "target_classes": classes, "target_seg": seg}

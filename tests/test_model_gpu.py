@@ -152,3 +152,34 @@ def test_head_side_streams_match_sequential(golden_dir):
         d = float((g_ms[n] - g_seq[n]).abs().max()), float((g_ms2[n] - g_seq[n]).abs().max())
         scale = float(g_seq[n].abs().max()) + 1e-12
         assert max(d) <= 2e-5 * scale, (n, d, scale)
+
+
+def test_toy64_config0_fp32_vs_reference_golden(golden_dir, monkeypatch):
+    """BASELINE.json configs[0] on the GPU (fp32 kernels): losses within the 1e-4 of north_star, every gradient norm 1e-3 relative,
+    detections (boxes, scores 1e-4; class ids exact) against what the unmodified reference produced on the CPU."""
+    from tests.gpu_util import synth_inputs
+    gn = np.load(os.path.join(golden_dir, "net_toy64_golden.npz"))
+    plan = get_plan("toy64")
+    x, tg = synth_inputs(plan)
+    assert abs(float(x.double().sum()) - float(gn["x_checksum"])) < 1e-6
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    losses, pred = net.train_step(x.cuda(), _cuda_targets(tg), evaluation=True)
+    for k in ("reg", "cls", "seg_ce", "seg_dice"):
+        assert abs(losses[k].item() - float(gn[f"loss_{k}"])) < 1e-4, (k, losses[k].item(), float(gn[f"loss_{k}"]))
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    norms = {k: (p.grad.norm().item() if p.grad is not None else -1.0) for k, p in net.named_parameters()}
+    bad = {}
+    for k, ref in zip(gn["grad_names"], gn["grad_norms"]):
+        k, ref = str(k), float(ref)
+        if abs(norms[k] - ref) > 1e-3 * max(1e-3, abs(ref)):
+            bad[k] = (norms[k], ref)
+    assert not bad, bad
+    for b in range(plan["batch_size"]):
+        pb, ps, pl = pred["pred_boxes"][b].cpu().numpy(), pred["pred_scores"][b].cpu().numpy(), pred["pred_labels"][b].cpu().numpy()
+        assert pb.shape == gn[f"det_boxes_{b}"].shape
+        assert np.allclose(ps, gn[f"det_scores_{b}"], atol=1e-4)
+        assert np.allclose(pb, gn[f"det_boxes_{b}"], atol=1e-4 * 64), float(np.abs(pb - gn[f"det_boxes_{b}"]).max())   # 1e-4 of the patch extent
+        assert np.array_equal(pl, gn[f"det_labels_{b}"])

@@ -105,3 +105,27 @@ def test_network_tiny_against_reference_golden(golden_dir, monkeypatch):
         assert np.allclose(pred["pred_boxes"][b], gn[f"det_boxes_{b}"], atol=1e-4)
         assert np.allclose(pred["pred_scores"][b], gn[f"det_scores_{b}"], atol=1e-5)
         assert np.array_equal(pred["pred_labels"][b], gn[f"det_labels_{b}"])
+
+
+def test_network_toy64_config0_against_reference_golden(golden_dir, monkeypatch):
+    """BASELINE.json configs[0] (64^3 patches, 5 stages, the reference's own CPU-runnable case): the oracle reproduces the losses,
+    all 80 gradient norms and the detections the UNMODIFIED reference produced in the build container. The inputs are regenerated
+    from the seed (tests/gpu_util.synth_inputs) and pinned by a checksum."""
+    from tests.gpu_util import synth_inputs
+    gn = np.load(os.path.join(golden_dir, "net_toy64_golden.npz"))
+    plan = get_plan("toy64")
+    x, tg = synth_inputs(plan)
+    assert abs(float(x.double().sum()) - float(gn["x_checksum"])) < 1e-6, "the seeded input differs from the one the golden was made with"
+    net = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    losses, pred = net.train_step(x, tg, evaluation=True)
+    for k, v in losses.items():
+        assert abs(v.item() - float(gn[f"loss_{k}"])) < 1e-5, k
+    sum(losses.values()).backward()
+    norms = {k: (p.grad.norm().item() if p.grad is not None else -1.0) for k, p in net.named_parameters()}
+    for k, ref in zip(gn["grad_names"], gn["grad_norms"]):
+        assert abs(norms[str(k)] - float(ref)) <= 1e-4 * max(1.0, abs(float(ref))), k
+    for b in range(plan["batch_size"]):
+        assert np.allclose(pred["pred_boxes"][b], gn[f"det_boxes_{b}"], atol=1e-4)
+        assert np.allclose(pred["pred_scores"][b], gn[f"det_scores_{b}"], atol=1e-5)
+        assert np.array_equal(pred["pred_labels"][b], gn[f"det_labels_{b}"])
