@@ -202,12 +202,12 @@ def main():
                        "parallelism": "dp%d" % world, "params": sum(p.numel() for p in net.parameters())},
             "final_loss": round(loss_val, 5), "peak_hbm_gib": round(peak_gb, 2),
         }
-        if not args.no_extras and world == 1:
+        if not args.no_extras:
             del x, tg
             torch.cuda.empty_cache()
-            out["roofline"] = conv_roofline(plan, batch, dtype, device)
+            out["roofline"] = conv_roofline(plan, batch, dtype, device)      # rank 0's GPU; the other ranks are done
             out["nms"] = nms_rate(device)
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and world == 1:                      # the CPU leg only at N = 1 (rank 0)
                 out["cpu_baseline"] = cpu_baseline(plan)
         print(json.dumps(out), flush=True)
     if world > 1:
