@@ -52,9 +52,10 @@ extern "C" int nndet_conv3d_backward_weight(const NndetConv* c, const void* x, c
     if (rc) return rc;
     if (!x || !dy || !dw) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
-    rc = (c->cin_p == 1) ? stem_wgrad(c, x, dy, dw, st) : wgrad_run(c, x, dy, dw, workspace, workspace_bytes, st);
+    int bias_done = 0;
+    rc = (c->cin_p == 1) ? stem_wgrad(c, x, dy, dw, st) : wgrad_run(c, x, dy, dw, dbias, &bias_done, workspace, workspace_bytes, st);
     if (rc) return rc;
-    if (dbias) {
+    if (dbias && !bias_done) {
         const int64_t rows = (int64_t)c->batch * c->out_d * c->out_h * c->out_w;
         rc = colsum_run(c->dtype, dy, rows, c->cout_p, c->cout, dbias, st);
     }

@@ -12,7 +12,8 @@
 int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x, const void* w, const float* bias,
               const void* res, void* y, double* stats, hipStream_t st);
 // conv_wgrad.hip
-int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias, int* bias_done, void* ws, size_t ws_bytes,
+              hipStream_t st);   // bias_done = 1: dbias (may be NULL) was accumulated by the weight-gradient kernel itself
 size_t wgrad_workspace_bytes(const NndetConv* c);
 // conv_stem.hip (Cin_p == 1)
 int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const float* bias, void* y, double* stats, int* stats_done,

@@ -26,6 +26,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct WgTap { int32_t d[3]; int32_t wt; };
 struct WgArgs {
     const void* p; const void* q; float* dw;
+    float* dbias;         // k_wgrad3 only: column sums of P (= dY) accumulated by the otherwise idle 28th tap slot; NULL = off
     float* part;          // partial results [S][rb*kb][ntap][32][32] fp32 (reduced by k_wgrad_reduce)
     int32_t N;
     int32_t PL[3], Cp;
@@ -61,6 +62,7 @@ template <> struct WF<bf16_t> {
         const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
         v = u32x4{ua.x, ua.y, ub.x, ub.y};
     }
+    __device__ __forceinline__ void set_ones() { v = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; }   // bf16 1.0
     __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
     }
@@ -70,6 +72,10 @@ template <> struct WF<float> {
     __device__ __forceinline__ void load(const char* run0, int vstride, int li) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(run0 + j * vstride + li * 4);
+    }
+    __device__ __forceinline__ void set_ones() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 1.f;
     }
     __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) {
 #pragma unroll
@@ -396,6 +402,8 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
                 if (s2 + 1 < QSTEPS || q_r0 + s2 * QRPS < QNROW) *reinterpret_cast<u32x4*>(sq + q_dst0 + s2 * (QRPS * QROW)) = vq[s2];
         }
     };
+    // wave 3's last slot would recompute tap 0 and discard it (27 taps on 28 slots): it accumulates sum_p dY[p][r] instead
+    const bool do_bias = A.dbias != nullptr && blockIdx.z == 0 && wv == 3;
     // pinned software pipeline over the 56 (contraction step, tap slot) pairs
     auto compute = [&]() {
         constexpr int U = KS * NTS, QD_ = 2;
@@ -407,7 +415,11 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
         auto load_q = [&](int u, WF<T>* d) {
             const int ks = u / NTS, ts = u % NTS;
             const char* b0 = smem + (q_lane + tapoff[ts]) + (((ks >> 1) * HH) + (ks & 1) * 4) * QROW;
-            d[0].load(b0, RB, 0); d[1].load(b0 + 16 * (int)sizeof(T), RB, 0);
+            if (ts == NTS - 1 && do_bias) {       // the 28th slot (wave 3): Q = ones -> acc = column sums of P = the bias gradient
+                d[0].set_ones(); d[1].set_ones();
+            } else {
+                d[0].load(b0, RB, 0); d[1].load(b0 + 16 * (int)sizeof(T), RB, 0);
+            }
         };
         load_p(0, pf[0]);
 #pragma unroll
@@ -442,6 +454,15 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
         __syncthreads();                            // every wave is done reading the tile
         if (has_next) commit();
         __syncthreads();
+    }
+    if (do_bias && li == 0) {                // column 0 of the ones-GEMM: rows r0 + i*16 + 4q + rr
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = r0 + i * 16 + q * 4 + rr;
+                if (r < A.R) atomicAdd(A.dbias + r, acc[NTS - 1][i][0][rr]);
+            }
     }
     float* part = A.part + ((int64_t)blockIdx.x * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
 #pragma unroll
@@ -530,9 +551,11 @@ size_t wgrad_workspace_bytes(const NndetConv* c) {
     return (size_t)slices * rb * kb * ntap * 1024 * sizeof(float);
 }
 
-int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias, int* bias_done, void* ws, size_t ws_bytes,
+              hipStream_t st) {
     WgArgs a;
     memset(&a, 0, sizeof(a));
+    *bias_done = 0;
     const bool tr = c->transposed != 0;
     const bool bf = c->dtype == NNDET_BF16;
     const int esz = bf ? 2 : 4;
@@ -610,6 +633,8 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, void
         if ((ps <= 1.05 * pg || spec_on == 2) && pb < (1LL << 31) && qb < (1LL << 31)) {
             WgArgs b = a;
             b.TD = 4; b.TH = 8;
+            b.dbias = dbias;                  // P = dY here (not transposed): the kernel also produces the bias gradient
+            *bias_done = dbias != nullptr;
             for (int i = 0; i < 3; ++i) { b.H[i] = st3[i] + 2; b.nt[i] = ceil_div(a.PL[i], st3[i]); }
             b.total_tiles = b.N * b.nt[0] * b.nt[1] * b.nt[2];
             const int S3 = wgrad_slices(rb * kb, b.total_tiles);
