@@ -93,9 +93,9 @@ int nndet_anchors3d_grid_f32(const float* cell, int32_t A, int32_t sx, int32_t s
  * (the reference's torch.topk leaves ties implementation-defined); positives: IoU >= mean + std
  * (unbiased) over the GT's candidates; an anchor positive for several GTs takes the highest IoU
  * (ties: lowest GT index).
- * G == 0 -> all -1. G <= NNDET_ATSS_MAX_GT.
+ * G == 0 -> all -1. Any G >= 0 is accepted (GTs are processed in tiles of 16); at most NNDET_ATSS_MAX_BATCH images per
+ * batched call.
  * ---------------------------------------------------------------------------------------------- */
-#define NNDET_ATSS_MAX_GT 64
 #define NNDET_ATSS_MAX_BATCH 64
 size_t nndet_atss3d_workspace_bytes(int64_t G, int64_t M, int32_t L, int32_t k);
 int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* anchors, int64_t M,
@@ -115,6 +115,31 @@ int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const int32_t* im
  * ---------------------------------------------------------------------------------------------- */
 int nndet_decode_clip3d_f32(const float* rel, const float* anchors, int64_t n, int64_t n_anchor,
                             float clip_exp, float img_x, float img_y, float img_z, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused post-processing front end (whole batch, no host round trip) -- replaces
+ * DetectionHeadHNM.postprocess_for_inference (decode + sigmoid of ALL anchors, nndet/arch/heads/comb.py:140-158) followed by
+ * BaseRetinaNet.postprocess_detections_single_image (nndet/core/retina.py:332-379: clip, descending sort, top-k, score
+ * threshold, remove_small_boxes, batched_nms, first detections_per_img) and batched_nms' class offsets
+ * (nndet/core/boxes/nms.py:81-106).
+ *   scores [B, M*C]: logits (scores_are_probs == 0: sigmoid is applied, nndet/arch/heads/classifier.py box_logits_to_probs)
+ *                    or probabilities (scores_are_probs != 0);
+ *   deltas [B, M, 6]: regression deltas when anchors != NULL (decoded against anchors [M,6], shared by the images, with
+ *                    clip_exp as nndet_decode_clip3d_f32) or already decoded boxes when anchors == NULL;
+ *   img_* <= 0 disables clipping; topk <= 0 = no top-k (all M*C candidates); K = min(topk, M) candidates survive per image
+ *   ordered by (score descending, flat index a*C + c ascending -- the reference's sort leaves ties implementation-defined);
+ *   use_score_thresh: keep score > score_thresh; use_min_size: keep boxes whose every side >= min_size;
+ *   outputs [B, max_det, ...]: rows >= out_counts[b] are zero boxes / zero scores / label -1. out_labels = flat index % C.
+ * Only the K survivors are decoded; the NMS runs on the already sorted survivors.
+ * workspace: nndet_postprocess3d_workspace_bytes(B, M, C, topk) bytes (0 = invalid arguments).
+ * ---------------------------------------------------------------------------------------------- */
+size_t nndet_postprocess3d_workspace_bytes(int32_t B, int64_t M, int32_t C, int32_t topk);
+int nndet_postprocess3d_f32(const float* scores, int32_t scores_are_probs, const float* deltas, const float* anchors,
+                            int32_t B, int64_t M, int32_t C, float clip_exp, float img_x, float img_y, float img_z,
+                            int32_t topk, float score_thresh, int32_t use_score_thresh, float min_size,
+                            int32_t use_min_size, float nms_thresh, int32_t max_det, float* out_boxes,
+                            float* out_scores, int64_t* out_labels, int64_t* out_counts, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution stack (implicit GEMM on MFMA; NDHWC; fp32 accumulate) -- replaces the

@@ -4,5 +4,6 @@ from .nms import nms, batched_nms  # noqa: F401
 from .anchors import AnchorGenerator3DS, get_anchor_generator  # noqa: F401
 from .matcher import ATSSMatcher  # noqa: F401
 from .sampler import HardNegativeSamplerBatched  # noqa: F401
-from .coder import BoxCoderND, decode_single  # noqa: F401
+from .coder import BoxCoderND, decode_single, BBOX_XFORM_CLIP  # noqa: F401
+from .postprocess import postprocess_batch, postprocess_batch_raw  # noqa: F401
 from .clip import clip_boxes_to_image_  # noqa: F401

@@ -27,14 +27,14 @@ def decode_single(rel_codes: Tensor, boxes: Tensor, weights: Sequence[float] = (
                         pcz - 0.5 * pd, pcz + 0.5 * pd], dim=1)
 
 
-def decode_clip(rel_codes: Tensor, anchors: Tensor, image_shape=None) -> Tensor:
+def decode_clip(rel_codes: Tensor, anchors: Tensor, image_shape=None, bbox_xform_clip: float = BBOX_XFORM_CLIP) -> Tensor:
     """Fused decode (+ clip_boxes_to_image_3d_, clip.py:83-101) of [n,6] deltas against [n_anchor,6] anchors
     (anchor row = i % n_anchor): one pass, 48 B read + 24 B written per box."""
     r = rel_codes.detach().float().contiguous().reshape(-1, 6)
     a = anchors.detach().float().contiguous()
     out = torch.empty_like(r)
     ix, iy, iz = (float(image_shape[0]), float(image_shape[1]), float(image_shape[2])) if image_shape is not None else (0., 0., 0.)
-    L.call("nndet_decode_clip3d_f32", L.ptr(r), L.ptr(a), r.shape[0], a.shape[0], BBOX_XFORM_CLIP, ix, iy, iz, L.ptr(out), L.stream())
+    L.call("nndet_decode_clip3d_f32", L.ptr(r), L.ptr(a), r.shape[0], a.shape[0], float(bbox_xform_clip), ix, iy, iz, L.ptr(out), L.stream())
     return out
 
 
@@ -53,4 +53,4 @@ class BoxCoderND:
         assert isinstance(boxes, (list, tuple))
         same = all(b is boxes[0] for b in boxes)
         anchors = boxes[0] if same else torch.cat(boxes, dim=0)
-        return decode_clip(rel_codes, anchors, None)
+        return decode_clip(rel_codes, anchors, None, self.bbox_xform_clip)

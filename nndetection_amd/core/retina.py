@@ -9,7 +9,6 @@ from torch import Tensor
 
 from .. import _lib as L
 from . import boxes as box_utils
-from .boxes.coder import decode_clip
 
 
 class BaseRetinaNet(nn.Module):
@@ -144,39 +143,35 @@ class BaseRetinaNet(nn.Module):
         return prediction
 
     def postprocess_detections(self, pred_detection: Dict[str, Tensor], anchors: List[Tensor], image_shapes):
-        boxes_per_image = [len(b) for b in anchors]
-        pred = self.head.postprocess_for_inference(pred_detection, anchors)
-        pred_boxes = pred["pred_boxes"].split(boxes_per_image, 0)
-        pred_probs = pred["pred_probs"].split(boxes_per_image, 0)
-        all_boxes, all_probs, all_labels = [], [], []
-        for boxes, probs, image_shape in zip(pred_boxes, pred_probs, image_shapes):
-            b, p, l = self.postprocess_detections_single_image(boxes, probs, image_shape)
-            all_boxes.append(b); all_probs.append(p); all_labels.append(l)
-        return all_boxes, all_probs, all_labels
+        """retina.py:292-330. All images of a batch share the anchors and (patch-based inference) the image shape, so the whole
+        batch goes through ONE fused pass (csrc/postproc.hip): top-k on the logits, decode + clip of the <= topk survivors
+        only, filters, batched NMS, first `detections_per_img` -- one read of the per-image counts at the end."""
+        B = len(anchors)
+        same = all(a is anchors[0] for a in anchors) and all(tuple(sh) == tuple(image_shapes[0]) for sh in image_shapes)
+        if not same:                                   # images with their own anchors / shapes: one fused pass per image
+            per = [len(a) for a in anchors]
+            deltas = pred_detection["box_deltas"].split(per, 0)
+            logits = pred_detection["box_logits"].split(per, 0)
+            res = [self._postprocess_fused(l[None], d[None], a, sh) for l, d, a, sh in zip(logits, deltas, anchors, image_shapes)]
+            return [r[0][0] for r in res], [r[1][0] for r in res], [r[2][0] for r in res]
+        M = anchors[0].shape[0]
+        return self._postprocess_fused(pred_detection["box_logits"].view(B, M, -1), pred_detection["box_deltas"].view(B, M, -1),
+                                       anchors[0], image_shapes[0])
+
+    def _postprocess_fused(self, logits: Tensor, deltas: Tensor, anchors: Tensor, image_shape):
+        return box_utils.postprocess_batch(
+            logits, deltas, anchors, image_shape, self.num_foreground_classes, self.topk_candidates, self.score_thresh,
+            self.remove_small_boxes, self.nms_thresh, self.detections_per_img,
+            bbox_xform_clip=getattr(self.head.coder, "bbox_xform_clip", box_utils.BBOX_XFORM_CLIP))
 
     def postprocess_detections_single_image(self, boxes: Tensor, probs: Tensor, image_shape):
+        """Same contract as retina.py:332-379 (decoded boxes [M, 6] + probabilities [M, C] of ONE image) on the fused kernel."""
         assert boxes.shape[0] == probs.shape[0]
-        boxes = box_utils.clip_boxes_to_image_(boxes, image_shape)
-        probs = probs.flatten()
-        if self.topk_candidates is not None:
-            num_topk = min(self.topk_candidates, boxes.size(0))
-            probs, idx = probs.sort(descending=True)
-            probs, idx = probs[:num_topk], idx[:num_topk]
-        else:
-            idx = torch.arange(probs.numel(), device=probs.device)
-        if self.score_thresh is not None:
-            keep_idxs = probs > self.score_thresh
-            probs, idx = probs[keep_idxs], idx[keep_idxs]
-        anchor_idxs = torch.div(idx, self.num_foreground_classes, rounding_mode="floor")
-        labels = idx % self.num_foreground_classes
-        boxes = boxes[anchor_idxs]
-        if self.remove_small_boxes is not None:
-            keep = box_utils.remove_small_boxes(boxes, min_size=self.remove_small_boxes)
-            boxes, probs, labels = boxes[keep], probs[keep], labels[keep]
-        keep = box_utils.batched_nms(boxes, probs, labels, self.nms_thresh)
-        if self.detections_per_img is not None:
-            keep = keep[:self.detections_per_img]
-        return boxes[keep], probs[keep], labels[keep]
+        b, p, l = box_utils.postprocess_batch(
+            probs.reshape(1, boxes.shape[0], -1), boxes.reshape(1, -1, 6), None, image_shape, self.num_foreground_classes,
+            self.topk_candidates, self.score_thresh, self.remove_small_boxes, self.nms_thresh, self.detections_per_img,
+            scores_are_probs=True)
+        return b[0], p[0], l[0]
 
     @torch.no_grad()
     def inference_step(self, images: Tensor, **kwargs) -> Dict[str, Any]:

@@ -12,8 +12,8 @@
 // Distance: sqrt((dx^2 + dy^2) + dz^2) with centres (hi + lo) / 2, fp32, correctly rounded sqrt
 // (ops.py:262-287,314-327); IoU as box_iou_union_3d (ops.py:131-159). Compile with -ffp-contract=off.
 #include "common.h"
+#include "radix_select.h"
 
-typedef unsigned long long u64;
 #define GT_TILE 16
 #define MAXL 8
 #define MAXB 64
@@ -83,44 +83,13 @@ __global__ __launch_bounds__(256) void k_atss_hist(AtssArgs A, const float* __re
     }
 }
 
-// one WAVE per (g, l): choose the digit, update prefix / remaining rank, clear the histogram. Lane = 4 consecutive bins;
-// wave-wide inclusive scan with shuffles (the serial 256-bin scan of v1 took 20 us per pass).
+// one WAVE per (g, l): choose the digit, update prefix / remaining rank, clear the histogram (radix_select.h; the serial
+// 256-bin scan of v1 took 20 us per pass).
 __global__ __launch_bounds__(256) void k_atss_pick(int GL, u64* __restrict__ prefix, int* __restrict__ krem,
                                                    unsigned* __restrict__ hist, int shift) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
     if (i >= GL) return;
-    unsigned* h = hist + (int64_t)i * 256;
-    const uint4 c = reinterpret_cast<const uint4*>(h)[lane];
-    const unsigned mine = c.x + c.y + c.z + c.w;
-    unsigned incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    const unsigned rem = (unsigned)krem[i];
-    const unsigned excl = incl - mine;
-    // the lane whose bins contain the rem-th smallest element: excl < rem <= incl
-    const bool owner = (excl < rem) && (rem <= incl);
-    const unsigned long long vote = __ballot(owner);
-    if (vote == 0ULL) {                       // cannot happen when k <= level size; keep the state consistent anyway
-        if (lane == 63) prefix[i] |= ((u64)255) << shift;
-    } else if (owner) {
-        unsigned cum = excl;
-        int b = 0;
-        const unsigned cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) {
-            if (cum + cc[k2] >= rem) { b = k2; break; }
-            cum += cc[k2];
-            b = k2 + 1;
-        }
-        if (b > 3) b = 3;
-        prefix[i] |= ((u64)(lane * 4 + b)) << shift;
-        krem[i] = (int)(rem - cum);
-    }
-    reinterpret_cast<uint4*>(h)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    radix_pick_wave(prefix + i, krem + i, hist + (int64_t)i * 256, shift, threadIdx.x & 63);
 }
 
 __global__ void k_atss_init(int G, int L, AtssArgs A, u64* prefix, int* krem) {

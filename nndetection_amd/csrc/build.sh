@@ -9,7 +9,7 @@ pids=()
 build() { # src extra-flags
   local src=$1; shift
   local obj=_obj/${src%.hip}.o
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ conv_common.h -nt "$obj" ] || [ ../../include/nndet_amd.h -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ conv_common.h -nt "$obj" ] || [ radix_select.h -nt "$obj" ] || [ ../../include/nndet_amd.h -nt "$obj" ]; then
     $HIPCC $COMMON "$@" -c "$src" -o "$obj" &
     pids+=($!)
   fi
@@ -18,6 +18,7 @@ build() { # src extra-flags
 build nms3d.hip -ffp-contract=off
 build boxes.hip -ffp-contract=off
 build atss3d.hip -ffp-contract=off
+build postproc.hip -ffp-contract=off
 build conv_igemm.hip
 build conv_wgrad.hip
 build conv_stem.hip

@@ -136,17 +136,23 @@ __global__ __launch_bounds__(256) void k_nms_propagate(const u64* __restrict__ m
 }
 
 // single block of 1024 threads: ordered compaction
+// order == NULL: identity (the caller's boxes already are in score order). n_valid (device, may be NULL): only rows below
+// *n_valid are real boxes, the rest is padding up to the launch capacity (never reported).
 __global__ __launch_bounds__(1024) void k_nms_compact(const u64* __restrict__ keepbits, int col_blocks,
                                                       const int32_t* __restrict__ order, int64_t* __restrict__ keep_out,
-                                                      int64_t* __restrict__ n_keep) {
+                                                      int64_t* __restrict__ n_keep, const int64_t* __restrict__ n_valid) {
     __shared__ int wsum[16];
     __shared__ int running;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) running = 0;
     __syncthreads();
+    const int64_t nv = n_valid ? *n_valid : ((int64_t)col_blocks * 64);
     for (int base = 0; base < col_blocks; base += 1024) {
         const int idx = base + tid;
-        const u64 bits = (idx < col_blocks) ? keepbits[idx] : 0ULL;
+        u64 bits = (idx < col_blocks) ? keepbits[idx] : 0ULL;
+        const int64_t left = nv - (int64_t)idx * 64;
+        if (left <= 0) bits = 0ULL;
+        else if (left < 64) bits &= (1ULL << left) - 1ULL;
         const int cnt = __popcll(bits);
         int incl = cnt;  // inclusive scan inside the wave
 #pragma unroll
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(1024) void k_nms_compact(const u64* __restrict__ ke
         while (b) {
             const int r = __ffsll((long long)b) - 1;
             b &= b - 1;
-            keep_out[pos++] = (int64_t)order[(int64_t)idx * 64 + r];
+            keep_out[pos++] = order ? (int64_t)order[(int64_t)idx * 64 + r] : (int64_t)idx * 64 + r;
         }
         __syncthreads();
         if (tid == 1023) running += woff + incl;
@@ -203,14 +209,19 @@ static int nms_layout(int64_t n, char* base, NmsWs* ws) {
     return 0;
 }
 
+// order == NULL: `boxes` already are in score order (no gather); n_valid: see k_nms_compact
 static int nms_core(const float* boxes, const int32_t* order, int64_t n, float thr, int64_t* keep_out,
-                    int64_t* n_keep_out, NmsWs& ws, hipStream_t st) {
+                    int64_t* n_keep_out, NmsWs& ws, hipStream_t st, const int64_t* n_valid = nullptr) {
     const int cb = (int)ceil_div64(n, 64);
-    k_gather_boxes<<<(unsigned)ceil_div64(n * 6, 256), 256, 0, st>>>(boxes, order, n, ws.sboxes);
-    LAUNCH_CHECK();
+    const float* sboxes = boxes;
+    if (order) {
+        k_gather_boxes<<<(unsigned)ceil_div64(n * 6, 256), 256, 0, st>>>(boxes, order, n, ws.sboxes);
+        LAUNCH_CHECK();
+        sboxes = ws.sboxes;
+    }
     HIP_TRY(hipMemsetAsync(ws.remv, 0, (size_t)cb * 8, st));
     HIP_TRY(hipMemsetAsync(keep_out, 0xFF, (size_t)n * 8, st));
-    k_nms_mask<<<dim3(cb, ceil_div(cb, 4)), 256, 0, st>>>(ws.sboxes, n, thr, ws.mask, cb);
+    k_nms_mask<<<dim3(cb, ceil_div(cb, 4)), 256, 0, st>>>(sboxes, n, thr, ws.mask, cb);
     LAUNCH_CHECK();
     for (int c0 = 0; c0 < cb; c0 += 64) {
         const int c1 = c0 + 64 < cb ? c0 + 64 : cb;
@@ -221,7 +232,7 @@ static int nms_core(const float* boxes, const int32_t* order, int64_t n, float t
             LAUNCH_CHECK();
         }
     }
-    k_nms_compact<<<1, 1024, 0, st>>>(ws.keepbits, cb, order, keep_out, n_keep_out);
+    k_nms_compact<<<1, 1024, 0, st>>>(ws.keepbits, cb, order, keep_out, n_keep_out, n_valid);
     LAUNCH_CHECK();
     return 0;
 }
@@ -263,4 +274,18 @@ extern "C" int nndet_nms3d_sorted_f32(const float* boxes, const int32_t* order, 
     if (rc) return rc;
     if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
     return nms_core(boxes, order, n, thr, keep_out, n_keep_out, ws, st);
+}
+
+// Used by the fused post-processing front end (postproc.hip): boxes [n_cap, 6] already in score order, of which only the
+// first *n_valid_dev (device) are real -- the rest must be all-zero rows (IoU 0 / NaN against everything: they never
+// suppress and are masked out of the result). keep_out [n_cap] / n_keep_out as nndet_nms3d_f32.
+size_t nms_presorted_workspace_bytes(int64_t n_cap) { return nndet_nms3d_workspace_bytes(n_cap); }
+int nms_presorted_run(const float* boxes, int64_t n_cap, const int64_t* n_valid_dev, float thr, int64_t* keep_out,
+                      int64_t* n_keep_out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (n_cap <= 0 || !boxes || !keep_out || !n_keep_out || !workspace) return NNDET_EINVAL;
+    NmsWs ws;
+    int rc = nms_layout(n_cap, (char*)workspace, &ws);
+    if (rc) return rc;
+    if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
+    return nms_core(boxes, nullptr, n_cap, thr, keep_out, n_keep_out, ws, st, n_valid_dev);
 }

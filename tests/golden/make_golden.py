@@ -187,9 +187,12 @@ _gu = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_gu)     
 det_randperm, synth_inputs = _gu.det_randperm, _gu.synth_inputs                  # shared with the parity tests; no reference imports
 
 
-def golden_net(name, lite=False):
-    """lite: store only scalars / small vectors; the inputs are regenerated from the seed by tests.gpu_util.synth_inputs."""
+def golden_net(name, lite=False, batch=None, tag=None):
+    """lite: store only scalars / small vectors; the inputs are regenerated from the seed by tests.gpu_util.synth_inputs.
+    batch: override the plan's batch size (luna160 is generated with ONE patch: the reference needs ~10 GB per patch on CPU)."""
     plan = get_plan(name)
+    if batch is not None:
+        plan["batch_size"] = batch
     ref = build_reference_net(plan)
     ora = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
     assert list(ref.state_dict().keys()) == list(ora.state_dict().keys()), "state-dict keys differ"
@@ -235,11 +238,20 @@ def golden_net(name, lite=False):
     g["pred_seg_sum"] = np.float64(pr["pred_seg"].double().sum().item())
     print(f"  [{name}] oracle == reference: losses 1e-5, all {len(gn_ref)} grad norms 1e-4, detections 1e-4 "
           f"({[len(b) for b in pr['pred_boxes']]} boxes)")
-    np.savez_compressed(os.path.join(OUT, f"net_{name}_golden.npz"), **g)
+    if batch is not None:
+        g["batch"] = np.int64(x.shape[0])
+    np.savez_compressed(os.path.join(OUT, f"net_{tag or name}_golden.npz"), **g)
 
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    print("box ops:"); golden_boxes()
-    print("network:"); golden_net("tiny")
-    golden_net("toy64", lite=True)        # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    which = sys.argv[1:] or ["boxes", "tiny", "toy64", "luna160"]
+    if "boxes" in which:
+        print("box ops:"); golden_boxes()
+    print("network:")
+    if "tiny" in which:
+        golden_net("tiny")
+    if "toy64" in which:
+        golden_net("toy64", lite=True)        # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    if "luna160" in which:
+        golden_net("luna160", lite=True, batch=1)   # BASELINE.json configs[1] (the benchmarked plan), one 160x160x96 patch, fp32
