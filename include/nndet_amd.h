@@ -142,6 +142,24 @@ int nndet_postprocess3d_f32(const float* scores, int32_t scores_are_probs, const
                             size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Device-side target preparation -- replaces FindInstances -> Instances2Boxes -> Instances2Segmentation
+ * (nndet/io/transforms/instances.py:26-41,44-142,207-296), which every training / validation step runs on the GPU before the
+ * network (nndet/ptmodule/retinaunet/base.py:141,163): one pass over the instance volume instead of a Python loop with one
+ * nonzero() / mask per instance.
+ *   inst [B, D*H*W] fp32 instance ids (0 = background; values are truncated to int like `.to(torch.int)`);
+ *   cls_table [B, max_id] int32 (device): class of instance id per image, -1 = id not in the image's instance_mapping;
+ *   seg_out [B, D*H*W] fp32: class + 1 on instance voxels, else 0;
+ *   per image, instances in ascending id order: boxes_out [B, max_id, 6] fp32 = (min0-1, min1-1, max0+1, max1+1, min2-1, max2+1)
+ *   over the voxel coordinates (axis 0, 1, 2 = D, H, W), classes_out [B, max_id] int64, ids_out [B, max_id] int32,
+ *   counts_out [B] int32. ext_ws: [B, max_id, 6] int32 scratch. err_out [1] int32 bit mask: 1 = an id >= max_id occurred,
+ *   2 = an instance has no class (the reference raises KeyError).
+ * ---------------------------------------------------------------------------------------------- */
+int nndet_instances_to_targets_f32(const float* inst, int32_t B, int32_t D, int32_t H, int32_t W,
+                                   const int32_t* cls_table, int32_t max_id, float* seg_out, int32_t* ext_ws,
+                                   float* boxes_out, int64_t* classes_out, int32_t* ids_out, int32_t* counts_out,
+                                   int32_t* err_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Convolution stack (implicit GEMM on MFMA; NDHWC; fp32 accumulate) -- replaces the
  * torch.nn.Conv3d / ConvTranspose3d calls inside ConvInstanceRelu / ConvGroupRelu
  * (nndet/arch/conv.py:54-143,297-348) for the encoder (nndet/arch/encoder/modular.py:110-126),

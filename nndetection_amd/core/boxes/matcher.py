@@ -56,11 +56,11 @@ class ATSSMatcher:
         M, B = anchors.shape[0], len(boxes)
         dev = anchors.device
         offs_img = [0]
-        for b in boxes:
-            offs_img.append(offs_img[-1] + int(b.shape[0]))
+        for b in boxes:                                   # the reference's empty GT is `tensor([[]])` (instances.py:124-125): numel, not shape[0]
+            offs_img.append(offs_img[-1] + int(b.numel() // 6))
         G = offs_img[-1]
         an = anchors.detach().float().contiguous()
-        nz = [b.detach().to(dev, torch.float32).reshape(-1, 6) for b in boxes if b.shape[0] > 0]
+        nz = [b.detach().to(dev, torch.float32).reshape(-1, 6) for b in boxes if b.numel() > 0]
         gt = torch.cat(nz, 0).contiguous() if nz else an.new_zeros((0, 6))
         Lv = len(num_anchors_per_level)
         offs = [0]

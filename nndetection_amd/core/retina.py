@@ -121,7 +121,7 @@ class BaseRetinaNet(nn.Module):
         if gt_all.shape[0] == 0:
             z = torch.zeros((B, M), dtype=anchors.dtype, device=dev)
             return list(z.unbind(0)), [torch.zeros_like(anchors) for _ in range(B)]
-        cls_all = torch.cat([c.to(dev).reshape(-1) for c, b in zip(target_classes, target_boxes) if b.shape[0] > 0], 0)
+        cls_all = torch.cat([c.to(dev).reshape(-1) for c, b in zip(target_classes, target_boxes) if b.numel() > 0], 0)
         base = torch.tensor(offs[:-1], dtype=torch.int64, device=dev).clamp_(max=gt_all.shape[0] - 1)[:, None]
         glob = matches.clamp(min=0) + base                                   # [B, M] rows of gt_all
         boxes = gt_all[glob]                                                 # [B, M, 6]

@@ -19,6 +19,7 @@ build nms3d.hip -ffp-contract=off
 build boxes.hip -ffp-contract=off
 build atss3d.hip -ffp-contract=off
 build postproc.hip -ffp-contract=off
+build targets.hip
 build conv_igemm.hip
 build conv_wgrad.hip
 build conv_stem.hip

@@ -117,26 +117,72 @@ def configure_optimizer(model: nn.Module, trainer_cfg: dict = None, lean: bool =
     return opt, torch.optim.lr_scheduler.LambdaLR(opt, factor)
 
 
+_AMD_CLASS_ATTRS = dict(
+    base_conv_cls=ConvInstanceRelu, head_conv_cls=ConvGroupRelu, block=StackedConvBlock2, encoder_cls=Encoder,
+    decoder_cls=UFPNModular, matcher_cls=ATSSMatcher, head_cls=DetectionHeadHNMNative, head_classifier_cls=BCECLassifier,
+    head_regressor_cls=GIoURegressor, head_sampler_cls=HardNegativeSamplerBatched, segmenter_cls=DiCESegmenterFgBg)
+
+
 def register_with_nndet():
-    """Register the HIP-backed module in nnDetection's MODULE_REGISTRY (requires nnDetection + Lightning)."""
+    """Register the HIP-backed module in nnDetection's MODULE_REGISTRY (requires nnDetection + Lightning to be importable).
+
+    `RetinaUNetV001AMD` subclasses the reference's `RetinaUNetV001` (nndet/ptmodule/retinaunet/v001.py:29-38), so Lightning
+    hooks, evaluators, predictor / ensembler / sweep plumbing are inherited unchanged. It overrides
+      * the component class attributes (retinaunet/base.py:74-85) -- the reference's own `from_config_plan` accepts them too;
+      * `from_config_plan` (base.py:338-466): builds `nndetection_amd.core.retina.BaseRetinaNet`, i.e. also the detector core
+        (batched ATSS assignment, fused post-processing) runs on the HIP kernels; same constructor calls, same state-dict keys;
+      * `training_step` / `validation_step` (base.py:135-180): device-side target preparation instead of `self.pre_trafo`;
+      * `on_fit_start` / `on_after_backward`: the bucketed RCCL gradient all-reduce of nndetection_amd.ddp when the job runs as
+        one process per GPU under torch.distributed (the reference leaves multi-GPU to pl.Trainer, scripts/train.py:265-289).
+    """
     from nndet.ptmodule import MODULE_REGISTRY
     from nndet.ptmodule.retinaunet.v001 import RetinaUNetV001 as _RefV001
 
     class RetinaUNetV001AMD(_RefV001):
-        base_conv_cls = ConvInstanceRelu
-        head_conv_cls = ConvGroupRelu
-        block = StackedConvBlock2
-        encoder_cls = Encoder
-        decoder_cls = UFPNModular
-        matcher_cls = ATSSMatcher
-        head_cls = DetectionHeadHNMNative
-        head_classifier_cls = BCECLassifier
-        head_regressor_cls = GIoURegressor
-        head_sampler_cls = HardNegativeSamplerBatched
-        segmenter_cls = DiCESegmenterFgBg
+        locals().update(_AMD_CLASS_ATTRS)
 
-    MODULE_REGISTRY.register(RetinaUNetV001AMD)
+        @classmethod
+        def from_config_plan(cls, model_cfg: dict, plan_arch: dict, plan_anchors: dict, log_num_anchors: str = None, **kwargs):
+            return RetinaUNetV001.from_config_plan(model_cfg, plan_arch, plan_anchors, log_num_anchors, **kwargs)
+
+        def _prepare(self, batch):
+            from .core.targets import prepare_targets
+            return prepare_targets(batch["data"], batch["target"], batch["instance_mapping"])
+
+        def training_step(self, batch, batch_idx):
+            images, targets = self._prepare(batch)
+            losses, _ = self.model.train_step(images=images, targets=targets, evaluation=False, batch_num=batch_idx)
+            loss = sum(losses.values())
+            return {"loss": loss, **{key: l.detach().item() for key, l in losses.items()}}
+
+        def validation_step(self, batch, batch_idx):
+            with torch.no_grad():
+                images, targets = self._prepare(batch)
+                losses, prediction = self.model.train_step(images=images, targets=targets, evaluation=True, batch_num=batch_idx)
+                loss = sum(losses.values())
+            self.evaluation_step(prediction=prediction, targets=targets)
+            return {"loss": loss.detach().item(), **{key: l.detach().item() for key, l in losses.items()}}
+
+        # ---- data parallel: one process per GPU, gradient all-reduce over RCCL (nndetection_amd/ddp.py)
+        def on_fit_start(self):
+            import torch.distributed as dist
+            self._amd_reducer = None
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from .ddp import GradAllReducer
+                self._amd_reducer = GradAllReducer(self.model)
+            parent = getattr(super(), "on_fit_start", None)
+            return parent() if parent is not None else None
+
+        def on_after_backward(self):
+            red = getattr(self, "_amd_reducer", None)
+            if red is not None:
+                red.finish()
+            parent = getattr(super(), "on_after_backward", None)
+            return parent() if parent is not None else None
+
+    if "RetinaUNetV001AMD" not in MODULE_REGISTRY.mapping:
+        MODULE_REGISTRY.register(RetinaUNetV001AMD)
     import nndet.core.boxes.nms as _ref_nms
     from .core.boxes.nms import nms_gpu
     _ref_nms.nms_gpu = nms_gpu          # the reference resolves this name at call time (nms.py:74-78)
-    return RetinaUNetV001AMD
+    return MODULE_REGISTRY["RetinaUNetV001AMD"]

@@ -299,3 +299,26 @@ def hnm_counts(num_positive: int, num_negative: int, batch_size: int, batch_size
     num_neg = min(num_negative, max(num_neg, min_neg))
     pool = min(num_negative, int(num_neg * pool_size))
     return num_pos, num_neg, pool
+
+
+# --------------------------------------------------------------------------------------
+# target preparation (instances -> boxes / classes / semantic map)
+# --------------------------------------------------------------------------------------
+def instances_to_targets(target, mapping):
+    """One image. FindInstances + instances_to_boxes + get_instance_class_from_properties + instances_to_segmentation,
+    nndet/io/transforms/instances.py:26-41,93-126,166-181,251-296. target [D, H, W] instance ids, mapping {id: class}.
+    -> boxes [n, 6] fp32 (min0-1, min1-1, max0+1, max1+1, min2-1, max2+1), classes [n] int64, ids [n], semantic [D, H, W]."""
+    t = np.asarray(target)
+    ti = t.astype(np.int32)                                  # .to(dtype=torch.int)
+    ids = np.unique(ti)
+    ids = ids[ids > 0]
+    m = {int(k): int(v) for k, v in mapping.items()}
+    boxes, classes = [], []
+    sem = np.zeros_like(t)
+    for i in ids:
+        idx = np.stack(np.nonzero(t == i), 1)
+        mn, mx = idx.min(0), idx.max(0)
+        boxes.append([mn[0] - 1, mn[1] - 1, mx[0] + 1, mx[1] + 1, mn[2] - 1, mx[2] + 1])
+        classes.append(m[int(i)])
+        sem[t == i] = m[int(i)] + 1
+    return (np.asarray(boxes, F32).reshape(-1, 6), np.asarray(classes, np.int64), ids.astype(np.int32), sem)

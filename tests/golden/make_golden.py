@@ -243,9 +243,49 @@ def golden_net(name, lite=False, batch=None, tag=None):
     np.savez_compressed(os.path.join(OUT, f"net_{tag or name}_golden.npz"), **g)
 
 
+def golden_targets():
+    """the three `pre_trafo` transforms of RetinaUNetModule (retinaunet/base.py:108-131) run unmodified on a small
+    synthetic instance volume; the oracle restatement must reproduce them exactly (integer work)."""
+    from oracle.refimport import install_stub_finder
+    install_stub_finder()                                  # nndet.io imports SimpleITK / batchgenerators at module level
+    from nndet.io.transforms import Compose, FindInstances, Instances2Boxes, Instances2Segmentation
+    rng = np.random.default_rng(42)
+    B, D, H, W = 3, 24, 20, 16
+    tgt = np.zeros((B, 1, D, H, W), np.float32)
+    maps = [{"1": 0, "2": 1, "5": 0, "9": 2}, {"3": 1}, {"1": 0, "4": 1, "7": 1}]      # incl. ids that are absent from the patch
+    def blob(b, i, lo, hi):
+        tgt[b, 0, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = i
+    blob(0, 1, (2, 3, 1), (7, 9, 5)); blob(0, 2, (10, 0, 8), (24, 4, 16)); blob(0, 5, (5, 12, 2), (6, 13, 3))
+    blob(0, 2, (0, 18, 0), (2, 20, 2))                     # a second, disconnected part of instance 2 (box spans both)
+    blob(2, 7, (0, 0, 0), (24, 20, 16)); blob(2, 4, (11, 9, 7), (13, 11, 9)); blob(2, 1, (20, 15, 3), (23, 19, 12))
+    noise = rng.integers(0, 40, (D, H, W)) == 0
+    tgt[2, 0][noise] = 4                                   # scattered single voxels of instance 4
+    trafo = Compose(FindInstances(instance_key="target", save_key="present_instances"),
+                    Instances2Boxes(instance_key="target", map_key="instance_mapping", box_key="boxes", class_key="classes",
+                                    present_instances="present_instances"),
+                    Instances2Segmentation(instance_key="target", map_key="instance_mapping", present_instances="present_instances"))
+    with torch.no_grad():
+        out = trafo(data=torch.zeros(B, 1, D, H, W), target=torch.from_numpy(tgt.copy()), instance_mapping=maps)
+    g = {"target": tgt.astype(np.uint8), "maps": np.asarray([repr(m) for m in maps])}
+    for b in range(B):
+        rb, rc = out["boxes"][b].numpy(), out["classes"][b].numpy()
+        ob, oc, oi, osem = bx.instances_to_targets(tgt[b, 0], maps[b])
+        if rb.size == 0:
+            assert ob.shape[0] == 0 and rc.size == 0, "image without instances"
+            rb, rc = np.zeros((0, 6), np.float32), np.zeros((0,), np.int64)
+        eq(ob, rb, f"target boxes image {b}"); eq(oc, rc.astype(np.int64), f"target classes image {b}")
+        eq(oi, out["present_instances"][b].numpy().astype(np.int32), f"present instances image {b}")
+        eq(osem, out["target"][b, 0].numpy(), f"semantic map image {b}")
+        g[f"boxes_{b}"], g[f"classes_{b}"], g[f"ids_{b}"] = rb, rc.astype(np.int64), oi
+        g[f"seg_{b}"] = out["target"][b, 0].numpy().astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "targets_golden.npz"), **g)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["boxes", "tiny", "toy64", "luna160"]
+    which = sys.argv[1:] or ["boxes", "targets", "tiny", "toy64", "luna160"]
+    if "targets" in which:
+        print("target preparation:"); golden_targets()
     if "boxes" in which:
         print("box ops:"); golden_boxes()
     print("network:")

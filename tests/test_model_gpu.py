@@ -1,6 +1,6 @@
 """GPU: the HIP RetinaUNet against the CPU oracle and the reference golden on the `tiny` plan.
 fp32 kernels: losses 1e-4 (north_star tolerance), every parameter gradient norm 1e-3 relative, detections
-(box coords, scores, class ids) 1e-4. bf16 kernels: looser, documented tolerances."""
+(box coords, scores: 1e-4 ABSOLUTE; class ids exact). bf16 kernels: bounds stated in tests/test_parity_full_gpu.py."""
 import os
 
 import numpy as np
@@ -69,7 +69,8 @@ def test_tiny_fp32_vs_oracle_and_golden(golden_dir, monkeypatch):
         assert np.abs(got - ref).max() <= 1e-3 * max(1e-6, np.abs(ref).max()), k
     for b in range(plan["batch_size"]):
         assert pred["pred_boxes"][b].shape == gn[f"det_boxes_{b}"].shape
-        assert np.allclose(pred["pred_boxes"][b].cpu().numpy(), gn[f"det_boxes_{b}"], atol=1e-4 * 32)   # 1e-4 relative to the patch extent
+        err = float(np.abs(pred["pred_boxes"][b].cpu().numpy() - gn[f"det_boxes_{b}"]).max())
+        assert err <= 1e-4, err                                                  # north_star: box coordinates within 1e-4 (absolute)
         assert np.allclose(pred["pred_scores"][b].cpu().numpy(), gn[f"det_scores_{b}"], atol=1e-4)
         assert np.array_equal(pred["pred_labels"][b].cpu().numpy(), gn[f"det_labels_{b}"])
     assert abs(pred["pred_seg"].double().sum().item() - float(gn["pred_seg_sum"])) < 1e-3 * float(gn["pred_seg_sum"])
@@ -97,7 +98,8 @@ def test_inference_step_and_state_dict_roundtrip(golden_dir):
     out = net.inference_step(x.cuda())
     ref = ora.inference_step(x)
     for b in range(x.shape[0]):
-        assert np.allclose(out["pred_boxes"][b].cpu().numpy(), ref["pred_boxes"][b], atol=4e-3)
+        err = float(np.abs(out["pred_boxes"][b].cpu().numpy() - np.asarray(ref["pred_boxes"][b])).max())
+        assert err <= 1e-4, err
         assert np.allclose(out["pred_scores"][b].cpu().numpy(), ref["pred_scores"][b], atol=1e-4)
     sd = {k: v.cpu() for k, v in net.state_dict().items()}
     ora.load_state_dict(sd)                        # keys / shapes load back into the reference-shaped oracle
@@ -181,5 +183,5 @@ def test_toy64_config0_fp32_vs_reference_golden(golden_dir, monkeypatch):
         pb, ps, pl = pred["pred_boxes"][b].cpu().numpy(), pred["pred_scores"][b].cpu().numpy(), pred["pred_labels"][b].cpu().numpy()
         assert pb.shape == gn[f"det_boxes_{b}"].shape
         assert np.allclose(ps, gn[f"det_scores_{b}"], atol=1e-4)
-        assert np.allclose(pb, gn[f"det_boxes_{b}"], atol=1e-4 * 64), float(np.abs(pb - gn[f"det_boxes_{b}"]).max())   # 1e-4 of the patch extent
+        assert np.abs(pb - gn[f"det_boxes_{b}"]).max() <= 1e-4, float(np.abs(pb - gn[f"det_boxes_{b}"]).max())   # 1e-4 absolute
         assert np.array_equal(pl, gn[f"det_labels_{b}"])

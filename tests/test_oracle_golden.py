@@ -129,3 +129,16 @@ def test_network_toy64_config0_against_reference_golden(golden_dir, monkeypatch)
         assert np.allclose(pred["pred_boxes"][b], gn[f"det_boxes_{b}"], atol=1e-4)
         assert np.allclose(pred["pred_scores"][b], gn[f"det_scores_{b}"], atol=1e-5)
         assert np.array_equal(pred["pred_labels"][b], gn[f"det_labels_{b}"])
+
+
+def test_target_preparation_oracle_vs_reference_golden(golden_dir):
+    """the oracle restatement of FindInstances / Instances2Boxes / Instances2Segmentation against what the
+    unmodified reference transforms produced (tests/golden/make_golden.py:golden_targets)."""
+    import ast
+    g = np.load(os.path.join(golden_dir, "targets_golden.npz"))
+    tgt = g["target"].astype(np.float32)
+    maps = [ast.literal_eval(str(m)) for m in g["maps"]]
+    for b in range(tgt.shape[0]):
+        ob, oc, oi, osem = bx.instances_to_targets(tgt[b, 0], maps[b])
+        assert np.array_equal(ob, g[f"boxes_{b}"]) and np.array_equal(oc, g[f"classes_{b}"]) and np.array_equal(oi, g[f"ids_{b}"])
+        assert np.array_equal(osem.astype(np.uint8), g[f"seg_{b}"])
