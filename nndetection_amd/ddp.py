@@ -44,11 +44,13 @@ class GradAllReducer:
     several backward passes) is required before the next backward."""
 
     def __init__(self, model: torch.nn.Module, first_bucket_mb: float = 4.0, bucket_mb: float = 24.0,
-                 process_group=None, overlap: bool = True, static_unused=None):
+                 process_group=None, overlap: bool = True, static_unused=None, force_overlap: bool = False):
         """static_unused: parameters that NEVER receive a gradient on any rank (default: `model.never_used_parameters()` if the
         model has it -- for RetinaUNet the `decoder.out.P<l>` convs of levels nobody reads). They are zero-filled and do not
         count towards bucket readiness; otherwise their bucket -- and, because collectives are issued in order, every later
-        one -- could only be launched from finish(), i.e. without overlapping the backward pass."""
+        one -- could only be launched from finish(), i.e. without overlapping the backward pass.
+        force_overlap: run the hook -> bucket copy -> (all-reduce) -> gradient-view path even at world size 1, so the
+        overlapped path (incl. its stream synchronisation against the multi-stream detection head) is testable on ONE GPU."""
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         params = [p for p in model.parameters() if p.requires_grad]
@@ -72,8 +74,12 @@ class GradAllReducer:
                 self._where[p] = (bi, pi)
             b.expected = sum(1 for p in b.params if id(p) not in self._static_unused)
             b.pending = b.expected
-        self.overlap = overlap and self.world > 1
+        self.force = bool(force_overlap)
+        self.overlap = overlap and (self.world > 1 or self.force)
+        self._cuda = device.type == "cuda"
+        self._events = {}
         self._next = 0
+        self._events.clear()
         self._hooks = []
         if self.overlap:
             for p in params:
@@ -81,11 +87,26 @@ class GradAllReducer:
         self.broadcast_parameters(model)
 
     def broadcast_parameters(self, model):
+        """Rank 0's parameters / buffers to everybody. Written through the tensors themselves under no_grad (NOT `.data`), so
+        `_version` is bumped and the packed-weight caches of the conv blocks (keyed on version + data_ptr) are refreshed."""
         if self.world > 1:
-            for t in list(model.parameters()) + list(model.buffers()):
-                dist.broadcast(t.data, src=0, group=self.pg)
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t, src=0, group=self.pg)
+            for m in model.modules():
+                if hasattr(m, "_pack_cache"):
+                    m._pack_cache.clear()
 
     def _launch(self, b: GradBucket):
+        # Gradients of one bucket are accumulated on DIFFERENT streams (the detection-head branches run on side streams,
+        # arch/heads.py; autograd only joins them at the end of backward): the bucket copy below runs on the stream of whichever
+        # parameter completed the bucket, so it first waits for the event every other parameter recorded in its own hook.
+        if self._cuda:
+            cur = torch.cuda.current_stream()
+            for p in b.params:
+                ev = self._events.pop(p, None)
+                if ev is not None:
+                    cur.wait_event(ev)
         src, dst = [], []
         for p, v in zip(b.params, b.views):
             if p.grad is None:
@@ -94,13 +115,21 @@ class GradAllReducer:
                 src.append(p.grad); dst.append(v)
         if dst:
             torch._foreach_copy_(dst, src)               # one multi-tensor kernel per bucket instead of one copy per parameter
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if self.world > 1:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        elif self._cuda:
+            b.work = torch.cuda.Event()
+            b.work.record()                              # world 1 (force_overlap): finish() still orders against the copy stream
 
     def _on_grad(self, p):
         bi, _ = self._where[p]
         if id(p) in self._static_unused:
             raise RuntimeError("a parameter declared as never used received a gradient")
         self.buckets[bi].pending -= 1
+        if self._cuda:
+            ev = torch.cuda.Event()
+            ev.record()                                  # on the stream this gradient was accumulated on
+            self._events[p] = ev
         # collectives must be issued in the SAME order on every rank: a bucket is only launched once all
         # earlier buckets are (a bucket holding a parameter that is unused on this rank is launched by finish())
         while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
@@ -109,15 +138,19 @@ class GradAllReducer:
 
     def finish(self):
         """Wait for all buckets (launching those whose parameters never produced a gradient) and write the mean back."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         while self._next < len(self.buckets):
             self._launch(self.buckets[self._next])
             self._next += 1
         inv = 1.0 / self.world
         for b in self.buckets:
-            b.work.wait()
-            b.flat.mul_(inv)
+            if self._cuda and isinstance(b.work, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(b.work)
+            elif b.work is not None:
+                b.work.wait()
+            if self.world > 1:
+                b.flat.mul_(inv)
             # hand the averaged gradients to the optimizer as views of the bucket (no copy back). They stay valid until the
             # bucket is refilled by the next backward; the training loop drops them with zero_grad(set_to_none=True).
             for p, v in zip(b.params, b.views):
@@ -125,3 +158,4 @@ class GradAllReducer:
             b.work = None
             b.pending = b.expected
         self._next = 0
+        self._events.clear()

@@ -48,6 +48,37 @@ class SGDNesterov:
                     grads = bufs
             torch._foreach_add_(ps, grads, alpha=-lr)
 
+    # ---- checkpointing, laid out like torch.optim.SGD.state_dict(): {"state": {param index: {"momentum_buffer": t}},
+    # "param_groups": [{"lr", "momentum", "nesterov", "weight_decay", "params": [indices]}]} (indices run over the groups in order),
+    # so a checkpoint written by torch.optim.SGD with the same parameter groups loads here and vice versa.
+    def state_dict(self) -> dict:
+        state, groups, idx = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                if p in self._buf:
+                    state[idx] = {"momentum_buffer": self._buf[p]}
+                ids.append(idx); idx += 1
+            groups.append({"lr": g["lr"], "momentum": self.momentum, "dampening": 0, "nesterov": self.nesterov,
+                           "weight_decay": g["weight_decay"], "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd: dict) -> None:
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has different parameter groups")
+        flat = [p for g in self.param_groups for p in g["params"]]
+        self._buf = {}
+        for k, st in sd["state"].items():
+            buf = st.get("momentum_buffer")
+            if buf is not None:
+                p = flat[int(k)]
+                self._buf[p] = buf.detach().to(device=p.device, dtype=p.dtype).clone()
+        for g, src in zip(self.param_groups, groups):
+            g["lr"], g["weight_decay"] = float(src["lr"]), float(src["weight_decay"])
+        if groups:
+            self.momentum, self.nesterov = float(groups[0]["momentum"]), bool(groups[0]["nesterov"])
+
     def zero_grad(self, set_to_none: bool = True):
         for g in self.param_groups:
             for p in g["params"]:
@@ -74,6 +105,16 @@ class LinearWarmupPolyLR:
 
     def step(self):
         self._step_count += 1
+        lr = self.get_lr()
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+
+    def state_dict(self) -> dict:
+        """`_step_count` / `last_epoch` as torch's _LRScheduler keeps them (last_epoch = _step_count - 1)."""
+        return {"_step_count": self._step_count, "last_epoch": self._step_count - 1, "base_lrs": [self.base_lr]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self._step_count = int(sd["_step_count"])
         lr = self.get_lr()
         for g in self.opt.param_groups:
             g["lr"] = lr

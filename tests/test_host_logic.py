@@ -125,7 +125,10 @@ def _ddp_worker(rank, world, port, q):
     loss = h.sum() if rank == 0 else (model[3](h)).sum()   # rank 0 never uses the last layer: its grads are None there
     loss.backward()
     ddp.finish()
-    q.put((rank, w0, [p.grad.clone() for p in model.parameters()], len(ddp.buckets)))
+    # numpy arrays (pickled by value): torch tensors travel as file descriptors, and the parent's fd-receive raced with this
+    # process exiting under load (ConnectionResetError / FileNotFoundError)
+    q.put((rank, w0.numpy(), [p.grad.detach().numpy().copy() for p in model.parameters()], len(ddp.buckets)))
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -138,6 +141,8 @@ def test_grad_allreduce_gloo_world2():
     [p.start() for p in procs]
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
     [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = [(r, torch.from_numpy(w), [torch.from_numpy(g) for g in gs], nb) for r, w, gs, nb in res]
     (r0, w0a, g0, nb), (r1, w0b, g1, _) = res
     assert torch.equal(w0a, w0b), "parameters were not broadcast from rank 0"
     assert nb >= 2, "expected several buckets"
@@ -177,7 +182,8 @@ def _ddp_static_unused_worker(rank, world, port, q):
         ddp.finish()
         for h in ddp._hooks:
             h.remove()
-    q.put((rank, launched, [p.grad.clone() for p in model.parameters()]))
+    q.put((rank, launched, [p.grad.detach().numpy().copy() for p in model.parameters()]))
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -193,6 +199,8 @@ def test_grad_allreduce_static_unused_does_not_block_overlap():
     [p.start() for p in procs]
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
     [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = [(r, l, [torch.from_numpy(g) for g in gs]) for r, l, gs in res]
     for rank, launched, grads in res:
         n_decl, nb = launched["declared"]
         n_undecl, _ = launched["undeclared"]
@@ -214,3 +222,60 @@ def test_never_used_parameters_of_retina_unet():
     assert names and all(n.startswith("decoder.out.P") for n in names), names
     used = net.decoder.used_levels
     assert all(int(n.split(".")[2][1:]) not in used for n in names)
+
+
+def test_force_overlap_world1_hook_bucket_view_path():
+    """force_overlap=True: the post-accumulate hooks, bucket copies and gradient views run without a process group (what the
+    one-GPU `-m gpu` test uses to exercise the overlapped path against the multi-stream head)."""
+    from nndetection_amd.ddp import GradAllReducer
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4), nn.Linear(4, 4))
+    ref = [None] * 6
+    x = torch.randn(5, 8)
+    model[2](model[1](model[0](x))).sum().backward()
+    ref = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+    ddp = GradAllReducer(model, first_bucket_mb=1e-4, bucket_mb=2e-4, force_overlap=True, static_unused=list(model[3].parameters()))
+    model[2](model[1](model[0](x))).sum().backward()
+    assert ddp._next == len(ddp.buckets) >= 2            # everything was "launched" from the hooks
+    ddp.finish()
+    for p, r in zip(model.parameters(), ref):
+        assert p.grad is not None and p.grad._base is not None       # a view of its bucket
+        assert torch.equal(p.grad, torch.zeros_like(p) if r is None else r)
+
+
+def test_lean_sgd_state_dict_roundtrip_matches_torch_layout():
+    """SGDNesterov / LinearWarmupPolyLR can be checkpointed; the layout is torch.optim.SGD's, so the state
+    loads into a torch.optim.SGD over the same groups and continues identically."""
+    from nndetection_amd.optim import SGDNesterov, LinearWarmupPolyLR
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(1)
+        m = nn.Sequential(nn.Linear(6, 5), nn.GroupNorm(1, 5), nn.Linear(5, 3))
+        groups = [{"params": list(m[1].parameters()), "weight_decay": 0.0},
+                  {"params": list(m[0].parameters()) + list(m[2].parameters()), "weight_decay": 3e-5}]
+        return m, groups
+    def run(m, opt, sched, n, seed):
+        torch.manual_seed(seed)
+        for _ in range(n):
+            m(torch.randn(4, 6)).pow(2).sum().backward()
+            opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
+    m1, g1 = make(); o1 = SGDNesterov(g1, 0.01); s1 = LinearWarmupPolyLR(o1, 5, 1e-6, 0.9, 50)
+    run(m1, o1, s1, 4, 7)
+    import copy
+    sd_o, sd_s, sd_m = copy.deepcopy(o1.state_dict()), s1.state_dict(), {k: v.clone() for k, v in m1.state_dict().items()}   # (like torch, state_dict() holds references)
+    assert set(sd_o) == {"state", "param_groups"} and all("momentum_buffer" in v for v in sd_o["state"].values())
+    run(m1, o1, s1, 3, 8)
+    # resume the lean pair from the checkpoint
+    m2, g2 = make(); m2.load_state_dict(sd_m); o2 = SGDNesterov(g2, 0.01); s2 = LinearWarmupPolyLR(o2, 5, 1e-6, 0.9, 50)
+    o2.load_state_dict(sd_o); s2.load_state_dict(sd_s)
+    run(m2, o2, s2, 3, 8)
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
+    # the same checkpoint loads into torch.optim.SGD (same layout)
+    m3, g3 = make(); m3.load_state_dict(sd_m)
+    o3 = torch.optim.SGD(g3, 0.01, momentum=0.9, nesterov=True)
+    o3.load_state_dict(sd_o)
+    assert len(o3.state) == len(sd_o["state"])
+    lr_now = sd_o["param_groups"][0]["lr"]
+    assert abs(o3.param_groups[0]["lr"] - lr_now) < 1e-15
