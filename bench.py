@@ -110,6 +110,9 @@ def _det_randperm(n, *a, **k):
     return torch.arange(n - 1, -1, -1, device=k.get("device", None))
 
 
+_det_randperm.nndet_reversed_arange = True     # the device sampler then selects what this permutation selects (parity_check)
+
+
 def cpu_baseline(plan, device=None):
     """The CPU oracle (plain PyTorch fp32 restatement of the reference, oracle/retina_torch.py; kind "port") on this host:
     ONE patch forward + ATSS + losses + backward (a bounded sample of the same workload). The thread count is chosen by a

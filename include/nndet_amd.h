@@ -254,6 +254,27 @@ int nndet_seghead_forward(int32_t dtype, const void* x, int32_t c_p, int32_t cin
 int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
                            const uint8_t* target, int64_t nvox, const float* coeffs, void* dx, double* dwb_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Batch-level hard-negative sampling on the device -- replaces DetectionHeadHNM.select_indices (nndet/arch/heads/comb.py:247-276)
+ * + HardNegativeSamplerBatched (nndet/core/boxes/sampler.py:57-98,154-185,237-270): no torch.where / topk / randperm round trips.
+ *   labels [N] fp32 (concatenated over the batch: >= 1 foreground, 0 background, < 0 ignored);
+ *   scores [N, C] logits (scores_are_probs == 0; fg probability = sigmoid(max_c)) or [N] probabilities (!= 0, C == 1);
+ *   pos_cap = int(batch_size_per_image * B * positive_fraction); neg_pos_ratio = |1 - 1 / positive_fraction|;
+ *   num_pos = min(#pos, pos_cap); num_neg = min(#neg, max(int(max(1, num_pos) * neg_pos_ratio), min_neg));
+ *   pool = min(#neg, int(num_neg * pool_size)) highest-probability negatives (ties: lowest index);
+ *   positives = a uniformly random num_pos-subset of the foreground anchors, negatives = a uniformly random num_neg-subset of
+ *   the pool (keys hash(seed, .)); deterministic != 0 selects what randperm(n) := (n-1, ..., 0) selects in the reference (the
+ *   LAST num_pos positives, the num_neg LOWEST-scoring pool members) -- used by the parity tests.
+ *   pos_idx [pos_cap] / neg_idx [nndet_hnm_neg_capacity(...)] int64: anchor indices in ASCENDING order (the reference reads its
+ *   masks back with torch.where), padded with -1; counts [4] int64 = {num_pos, num_neg, #pos, #neg}.
+ * ---------------------------------------------------------------------------------------------- */
+size_t nndet_hnm_sample_workspace_bytes(int32_t pos_cap, double neg_pos_ratio, int32_t min_neg, double pool_size);
+int32_t nndet_hnm_neg_capacity(int32_t pos_cap, double neg_pos_ratio, int32_t min_neg);
+int nndet_hnm_sample_f32(const float* labels, const float* scores, int32_t scores_are_probs, int64_t N, int32_t C,
+                         int32_t pos_cap, double neg_pos_ratio, int32_t min_neg, double pool_size, uint64_t seed,
+                         int32_t deterministic, int64_t* pos_idx, int64_t* neg_idx, int64_t* counts,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* sigmoid + max over classes of the (padded-free) logits [n, C] fp32 -> probs [n] ; used by the hard-negative
  * sampler (DetectionHeadHNM.select_indices, nndet/arch/heads/comb.py:247-276). */
 int nndet_sigmoid_max_f32(const float* logits, int64_t n, int32_t C, float* out, void* stream);

@@ -51,6 +51,10 @@ SIGNATURES = {
     "nndet_postprocess3d_f32": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _I32, _F, _F, _F, _F, _I32, _F, _I32, _F, _I32, _F, _I32,
                                           _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_instances_to_targets_f32": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nndet_hnm_sample_workspace_bytes": (_SZ, [_I32, C.c_double, _I32, C.c_double]),
+    "nndet_hnm_neg_capacity": (_I32, [_I32, C.c_double, _I32]),
+    "nndet_hnm_sample_f32": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, C.c_double, _I32, C.c_double, C.c_uint64, _I32, _P, _P, _P,
+                                       _P, _SZ, _P]),
     "nndet_packed_weight_elems": (_SZ, [_CONVP, _I32]),
     "nndet_pack_weight": (C.c_int, [_CONVP, _I32, _P, _P, _P]),
     "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P]),

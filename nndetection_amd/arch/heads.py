@@ -174,10 +174,12 @@ class DetectionHeadHNMNative(nn.Module):
 
     @torch.no_grad()
     def select_indices(self, target_labels: List[Tensor], boxes_scores: Tensor) -> Tuple[Tensor, Tensor]:
-        """comb.py:247-276; max-over-classes foreground probability from one fused HIP pass."""
-        sc = boxes_scores.detach().float().contiguous()
-        probs = torch.empty((sc.shape[0],), dtype=torch.float32, device=sc.device)
-        L.call("nndet_sigmoid_max_f32", L.ptr(sc), sc.shape[0], sc.shape[1], L.ptr(probs), L.stream())
+        """comb.py:247-276 on the device (csrc/sampler.hip): fg probability, counts, pool top-k and the random picks in one
+        fused op; the only host read is the pair of counts."""
+        labels = target_labels[0] if len(target_labels) == 1 else torch.cat(target_labels, dim=0)
+        if hasattr(self.fg_bg_sampler, "sample_indices"):
+            return self.fg_bg_sampler.sample_indices(labels, boxes_scores, len(target_labels))
+        probs = torch.sigmoid(boxes_scores.detach().float()).max(dim=1)[0]       # a sampler class from elsewhere: mask contract
         pos, neg = self.fg_bg_sampler(target_labels, probs)
         return torch.where(torch.cat(pos, dim=0))[0], torch.where(torch.cat(neg, dim=0))[0]
 

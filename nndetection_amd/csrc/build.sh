@@ -20,6 +20,7 @@ build boxes.hip -ffp-contract=off
 build atss3d.hip -ffp-contract=off
 build postproc.hip -ffp-contract=off
 build targets.hip
+build sampler.hip
 build conv_igemm.hip
 build conv_wgrad.hip
 build conv_stem.hip

@@ -1,0 +1,281 @@
+// Batch-level hard-negative sampling on the device for gfx950 -- replaces DetectionHeadHNM.select_indices +
+// HardNegativeSamplerBatched.__call__ / select_positives / select_negatives (nndet/arch/heads/comb.py:247-276,
+// nndet/core/boxes/sampler.py:57-98,154-185,237-270). The reference does torch.where x3 (one host sync each), a topk over
+// all negatives (4.7 M anchors at batch 4) and two randperm calls whose sizes come back from the device. Here every count
+// stays on the device and the outputs have fixed capacities:
+//   positives : the num_pos anchors with label >= 1 that have the smallest selection keys   (== positive[randperm(n)[:num_pos]])
+//   pool      : the `pool` anchors with label == 0 and the highest foreground probability (ties: lowest index), sorted
+//   negatives : the num_neg pool POSITIONS with the smallest selection keys                 (== pool[randperm(pool)[:num_neg]])
+// Selection key = hash(seed, index) -- a uniformly random subset in random order, the distribution of randperm(n)[:k] -- or,
+// in deterministic mode (parity tests), the reversed index: exactly what randperm := arange(n-1, -1, -1) selects.
+// Both selections are exact radix selects (radix_select.h) over the label / logit arrays; nothing of size N is written.
+#include "common.h"
+#include "radix_select.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+struct SpArgs {
+    const float* labels;   // [N]
+    const float* scores;   // [N, C] logits (is_prob == 0) or [N] probabilities (is_prob == 1, C == 1)
+    int64_t N;
+    int32_t C, is_prob;
+    int32_t P_cap, NEG_cap, POOL_cap, min_neg;
+    double ratio, pool_size;
+    u64 seed;
+    int32_t det;
+};
+// params (device int32[8]): 0 n_pos, 1 n_neg, 2 num_pos, 3 num_neg, 4 pool, 5 cnt_pos, 6 cnt_pool
+
+#define SP_ITEMS 8
+
+__device__ __forceinline__ uint32_t sp_hash(u64 seed, uint32_t i) {
+    u64 x = ((u64)i + seed) * 0x9E3779B97F4A7C15ULL;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+    return (uint32_t)(x >> 32) ^ (uint32_t)x;
+}
+__device__ __forceinline__ u64 sp_key_pos(const SpArgs& A, uint32_t i) {
+    return ((u64)(A.det ? ~i : sp_hash(A.seed, i)) << 32) | (u64)i;
+}
+__device__ __forceinline__ float sp_fgprob(const SpArgs& A, int64_t i) {
+    if (A.is_prob) return A.scores[i];
+    float m = -INFINITY;
+    for (int c = 0; c < A.C; ++c) m = fmaxf(m, A.scores[i * A.C + c]);
+    return 1.f / (1.f + expf(-m));                       // max(sigmoid(x)) == sigmoid(max(x)) (comb.py:262-266)
+}
+__device__ __forceinline__ u64 sp_key_neg(const SpArgs& A, int64_t i) {
+    return ((u64)(~f32_sortable(sp_fgprob(A, i))) << 32) | (u64)(uint32_t)i;
+}
+
+__global__ void k_sp_init(int32_t* params, u64* prefix, unsigned* hist) {
+    const int t = threadIdx.x;
+    if (t < 8) params[t] = 0;
+    if (t < 2) prefix[t] = 0;
+    for (int i = t; i < 512; i += blockDim.x) hist[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_sp_count(SpArgs A, int32_t* params) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256) * SP_ITEMS + threadIdx.x;
+    int np = 0, nn = 0;
+#pragma unroll
+    for (int t = 0; t < SP_ITEMS; ++t) {
+        const int64_t i = i0 + (int64_t)t * 256;
+        if (i < A.N) { const float l = A.labels[i]; np += (l >= 1.f); nn += (l == 0.f); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { np += __shfl_xor(np, o, 64); nn += __shfl_xor(nn, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (np) atomicAdd(&params[0], np);
+        if (nn) atomicAdd(&params[1], nn);
+    }
+}
+
+// sampler.py:154-185,237-262 -- the same integer / double arithmetic as the Python code
+__global__ void k_sp_derive(SpArgs A, int32_t* params, int* krem) {
+    const int n_pos = params[0], n_neg = params[1];
+    const int num_pos = n_pos < A.P_cap ? n_pos : A.P_cap;
+    int num_neg = (int)((double)(num_pos > 1 ? num_pos : 1) * A.ratio);
+    if (num_neg < A.min_neg) num_neg = A.min_neg;
+    if (num_neg > n_neg) num_neg = n_neg;
+    int pool = (int)((double)num_neg * A.pool_size);
+    if (pool > n_neg) pool = n_neg;
+    if (pool > A.POOL_cap) pool = A.POOL_cap;
+    if (num_neg > pool) num_neg = pool;
+    params[2] = num_pos; params[3] = num_neg; params[4] = pool;
+    krem[0] = num_pos; krem[1] = pool;
+}
+
+// two problems in one pass over the anchors: 0 = positives by selection key, 1 = negatives by (probability desc, index)
+__global__ __launch_bounds__(256) void k_sp_hist(SpArgs A, const u64* __restrict__ prefix, unsigned* __restrict__ hist, int shift) {
+    __shared__ unsigned h[2][256];
+    h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
+    __syncthreads();
+    const u64 p0 = prefix[0], p1 = prefix[1];
+    const int64_t i0 = ((int64_t)blockIdx.x * 256) * SP_ITEMS + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < SP_ITEMS; ++t) {
+        const int64_t i = i0 + (int64_t)t * 256;
+        if (i < A.N) {
+            const float l = A.labels[i];
+            if (l >= 1.f) {
+                const u64 key = sp_key_pos(A, (uint32_t)i);
+                if ((shift >= 56) || ((key >> (shift + 8)) == (p0 >> (shift + 8)))) atomicAdd(&h[0][(unsigned)(key >> shift) & 255u], 1u);
+            } else if (l == 0.f) {
+                const u64 key = sp_key_neg(A, i);
+                if ((shift >= 56) || ((key >> (shift + 8)) == (p1 >> (shift + 8)))) atomicAdd(&h[1][(unsigned)(key >> shift) & 255u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned v0 = h[0][threadIdx.x], v1 = h[1][threadIdx.x];
+    if (v0) atomicAdd(&hist[threadIdx.x], v0);
+    if (v1) atomicAdd(&hist[256 + threadIdx.x], v1);
+}
+
+__global__ __launch_bounds__(128) void k_sp_pick(u64* __restrict__ prefix, int* __restrict__ krem, unsigned* __restrict__ hist, int shift) {
+    const int i = threadIdx.x >> 6;
+    radix_pick_wave(prefix + i, krem + i, hist + i * 256, shift, threadIdx.x & 63);
+}
+
+__global__ __launch_bounds__(256) void k_sp_collect(SpArgs A, const u64* __restrict__ kth, int32_t* __restrict__ params,
+                                                    u64* __restrict__ list_pos, u64* __restrict__ list_pool) {
+    const u64 k0 = kth[0], k1 = kth[1];
+    const int num_pos = params[2], pool = params[4];
+    const int64_t i0 = ((int64_t)blockIdx.x * 256) * SP_ITEMS + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < SP_ITEMS; ++t) {
+        const int64_t i = i0 + (int64_t)t * 256;
+        if (i < A.N) {
+            const float l = A.labels[i];
+            if (l >= 1.f && num_pos > 0) {
+                const u64 key = sp_key_pos(A, (uint32_t)i);
+                if (key <= k0) { const int p = atomicAdd(&params[5], 1); if (p < A.P_cap) list_pos[p] = key; }
+            } else if (l == 0.f && pool > 0) {
+                const u64 key = sp_key_neg(A, i);
+                if (key <= k1) { const int p = atomicAdd(&params[6], 1); if (p < A.POOL_cap) list_pool[p] = key; }
+            }
+        }
+    }
+}
+
+__global__ void k_sp_fill(u64* a, int na, u64* b, int nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] = ~0ULL;
+    if (i < nb) b[i] = ~0ULL;
+}
+
+// selection keys over the POSITIONS of the sorted pool (randperm(pool)[:num_neg] of sampler.py:205-207)
+__global__ void k_sp_poolkeys(SpArgs A, const int32_t* __restrict__ params, u64* __restrict__ sel) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= A.POOL_cap) return;
+    const int pool = params[4];
+    sel[j] = j < pool ? (((u64)(A.det ? (uint32_t)(pool - 1 - j) : sp_hash(A.seed ^ 0xA5A5A5A55A5A5A5AULL, (uint32_t)j)) << 32) | (u64)(uint32_t)j) : ~0ULL;
+}
+
+// The reference turns the selections into masks and reads them back with torch.where (comb.py:268-276): the index lists it
+// trains on are in ASCENDING anchor order. k_sp_negidx resolves the chosen pool positions to anchor indices; both lists are
+// then sorted by index (the low 32 bits) and emitted.
+__global__ void k_sp_negidx(SpArgs A, const int32_t* __restrict__ params, const u64* __restrict__ pool_sorted,
+                            const u64* __restrict__ sel_sorted, u64* __restrict__ neg_tmp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.NEG_cap) return;
+    neg_tmp[i] = i < params[3] ? (u64)(uint32_t)pool_sorted[(uint32_t)sel_sorted[i]] : ~0ULL;
+}
+
+__global__ void k_sp_emit(SpArgs A, const int32_t* __restrict__ params, const u64* __restrict__ pos_sorted,
+                          const u64* __restrict__ neg_sorted, int64_t* __restrict__ pos_idx, int64_t* __restrict__ neg_idx,
+                          int64_t* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int num_pos = params[2], num_neg = params[3];
+    if (i < A.P_cap) pos_idx[i] = i < num_pos ? (int64_t)(uint32_t)pos_sorted[i] : -1;
+    if (i < A.NEG_cap) neg_idx[i] = i < num_neg ? (int64_t)(uint32_t)neg_sorted[i] : -1;
+    if (i == 0) { counts[0] = num_pos; counts[1] = num_neg; counts[2] = params[0]; counts[3] = params[1]; }
+}
+
+struct SpWs {
+    int32_t* params; u64* prefix; int* krem; unsigned* hist;
+    u64 *list_pos, *pos_sorted, *list_pool, *pool_sorted, *sel, *sel_sorted, *neg_tmp, *neg_sorted;
+    void* sort_tmp; size_t sort_tmp_bytes; size_t total;
+};
+
+static int sp_layout(int P_cap, int NEG_cap, int POOL_cap, char* base, SpWs* w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    size_t o_pa = take(32), o_pr = take(16), o_kr = take(8), o_h = take(512 * 4);
+    size_t o_lp = take((size_t)P_cap * 8), o_ps = take((size_t)P_cap * 8);
+    size_t o_lq = take((size_t)POOL_cap * 8), o_qs = take((size_t)POOL_cap * 8), o_se = take((size_t)POOL_cap * 8), o_ss = take((size_t)POOL_cap * 8);
+    size_t o_nt = take((size_t)NEG_cap * 8), o_ns = take((size_t)NEG_cap * 8);
+    size_t tmp = 0;
+    const size_t nmax = (size_t)(P_cap > POOL_cap ? P_cap : POOL_cap);
+    hipError_t e = rocprim::radix_sort_keys<rocprim::default_config, const u64*, u64*>(nullptr, tmp, nullptr, nullptr, nmax, 0, 64, (hipStream_t)0, false);
+    if (e != hipSuccess) return (int)e;
+    size_t o_tmp = take(tmp > 0 ? tmp : 256);
+    w->params = (int32_t*)(base + o_pa); w->prefix = (u64*)(base + o_pr); w->krem = (int*)(base + o_kr); w->hist = (unsigned*)(base + o_h);
+    w->list_pos = (u64*)(base + o_lp); w->pos_sorted = (u64*)(base + o_ps); w->list_pool = (u64*)(base + o_lq);
+    w->pool_sorted = (u64*)(base + o_qs); w->sel = (u64*)(base + o_se); w->sel_sorted = (u64*)(base + o_ss);
+    w->neg_tmp = (u64*)(base + o_nt); w->neg_sorted = (u64*)(base + o_ns);
+    w->sort_tmp = base + o_tmp; w->sort_tmp_bytes = tmp; w->total = off;
+    return 0;
+}
+
+static int sp_caps(int32_t pos_cap, double ratio, int32_t min_neg, double pool_size, int* NEG_cap, int* POOL_cap) {
+    if (pos_cap < 0 || ratio < 0 || min_neg < 0 || pool_size < 1.0) return NNDET_EINVAL;
+    int neg = (int)((double)(pos_cap > 1 ? pos_cap : 1) * ratio);
+    if (neg < min_neg) neg = min_neg;
+    if (neg < 1) neg = 1;
+    const double pool = (double)neg * pool_size;
+    if (pool > (double)(1 << 24)) return NNDET_EINVAL;
+    *NEG_cap = neg; *POOL_cap = (int)pool > 0 ? (int)pool : 1;
+    return 0;
+}
+
+extern "C" size_t nndet_hnm_sample_workspace_bytes(int32_t pos_cap, double neg_pos_ratio, int32_t min_neg, double pool_size) {
+    int NEG_cap, POOL_cap;
+    if (sp_caps(pos_cap, neg_pos_ratio, min_neg, pool_size, &NEG_cap, &POOL_cap)) return 0;
+    SpWs w;
+    if (sp_layout(pos_cap > 0 ? pos_cap : 1, NEG_cap, POOL_cap, nullptr, &w)) return 0;
+    return w.total;
+}
+
+extern "C" int32_t nndet_hnm_neg_capacity(int32_t pos_cap, double neg_pos_ratio, int32_t min_neg) {
+    int NEG_cap, POOL_cap;
+    if (sp_caps(pos_cap, neg_pos_ratio, min_neg, 1.0, &NEG_cap, &POOL_cap)) return -1;
+    return NEG_cap;
+}
+
+extern "C" int nndet_hnm_sample_f32(const float* labels, const float* scores, int32_t scores_are_probs, int64_t N, int32_t C,
+                                    int32_t pos_cap, double neg_pos_ratio, int32_t min_neg, double pool_size, uint64_t seed,
+                                    int32_t deterministic, int64_t* pos_idx, int64_t* neg_idx, int64_t* counts,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = as_stream(stream);
+    int NEG_cap, POOL_cap;
+    int rc = sp_caps(pos_cap, neg_pos_ratio, min_neg, pool_size, &NEG_cap, &POOL_cap);
+    if (rc) return rc;
+    if (N <= 0 || N >= (1LL << 32) || C <= 0 || (scores_are_probs && C != 1)) return NNDET_EINVAL;
+    if (!labels || !scores || !pos_idx || !neg_idx || !counts || !workspace) return NNDET_EINVAL;
+    const int P_cap = pos_cap > 0 ? pos_cap : 1;
+    SpWs w;
+    rc = sp_layout(P_cap, NEG_cap, POOL_cap, (char*)workspace, &w);
+    if (rc) return rc;
+    if (w.total > workspace_bytes) return NNDET_EWORKSPACE;
+    SpArgs A;
+    A.labels = labels; A.scores = scores; A.N = N; A.C = C; A.is_prob = scores_are_probs;
+    A.P_cap = pos_cap; A.NEG_cap = NEG_cap; A.POOL_cap = POOL_cap; A.min_neg = min_neg;
+    A.ratio = neg_pos_ratio; A.pool_size = pool_size; A.seed = seed; A.det = deterministic;
+    const unsigned nb = (unsigned)ceil_div64(N, 256 * SP_ITEMS);
+    k_sp_init<<<1, 256, 0, st>>>(w.params, w.prefix, w.hist);
+    LAUNCH_CHECK();
+    k_sp_count<<<nb, 256, 0, st>>>(A, w.params);
+    LAUNCH_CHECK();
+    k_sp_derive<<<1, 1, 0, st>>>(A, w.params, w.krem);
+    LAUNCH_CHECK();
+    int idx_bits = 1;
+    while (((int64_t)1 << idx_bits) < N) ++idx_bits;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (shift < 32 && shift >= idx_bits) continue;
+        k_sp_hist<<<nb, 256, 0, st>>>(A, w.prefix, w.hist, shift);
+        LAUNCH_CHECK();
+        k_sp_pick<<<1, 128, 0, st>>>(w.prefix, w.krem, w.hist, shift);
+        LAUNCH_CHECK();
+    }
+    k_sp_fill<<<ceil_div(P_cap > POOL_cap ? P_cap : POOL_cap, 256), 256, 0, st>>>(w.list_pos, P_cap, w.list_pool, POOL_cap);
+    LAUNCH_CHECK();
+    k_sp_collect<<<nb, 256, 0, st>>>(A, w.prefix, w.params, w.list_pos, w.list_pool);
+    LAUNCH_CHECK();
+    size_t tmp = w.sort_tmp_bytes;
+    // positives: everything collected IS the selection -> sort by anchor index only (low 32 bits; padding sorts last)
+    HIP_TRY((rocprim::radix_sort_keys<rocprim::default_config, const u64*, u64*>(w.sort_tmp, tmp, w.list_pos, w.pos_sorted, (size_t)P_cap, 0, 32, st, false)));
+    tmp = w.sort_tmp_bytes;
+    HIP_TRY((rocprim::radix_sort_keys<rocprim::default_config, const u64*, u64*>(w.sort_tmp, tmp, w.list_pool, w.pool_sorted, (size_t)POOL_cap, 0, 64, st, false)));
+    k_sp_poolkeys<<<ceil_div(POOL_cap, 256), 256, 0, st>>>(A, w.params, w.sel);
+    LAUNCH_CHECK();
+    tmp = w.sort_tmp_bytes;
+    HIP_TRY((rocprim::radix_sort_keys<rocprim::default_config, const u64*, u64*>(w.sort_tmp, tmp, w.sel, w.sel_sorted, (size_t)POOL_cap, 0, 64, st, false)));
+    k_sp_negidx<<<ceil_div(NEG_cap, 256), 256, 0, st>>>(A, w.params, w.pool_sorted, w.sel_sorted, w.neg_tmp);
+    LAUNCH_CHECK();
+    tmp = w.sort_tmp_bytes;
+    HIP_TRY((rocprim::radix_sort_keys<rocprim::default_config, const u64*, u64*>(w.sort_tmp, tmp, w.neg_tmp, w.neg_sorted, (size_t)NEG_cap, 0, 33, st, false)));
+    const int ne = P_cap > NEG_cap ? P_cap : NEG_cap;
+    k_sp_emit<<<ceil_div(ne, 256), 256, 0, st>>>(A, w.params, w.pos_sorted, w.neg_sorted, pos_idx, neg_idx, counts);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -322,3 +322,19 @@ def instances_to_targets(target, mapping):
         classes.append(m[int(i)])
         sem[t == i] = m[int(i)] + 1
     return (np.asarray(boxes, F32).reshape(-1, 6), np.asarray(classes, np.int64), ids.astype(np.int32), sem)
+
+
+def hnm_select_reversed(labels, fg_probs, batch_size: int, batch_size_per_image: int = 32, positive_fraction: float = 0.33,
+                        min_neg: int = 1, pool_size: float = 20):
+    """HardNegativeSamplerBatched.__call__ + DetectionHeadHNM.select_indices (nndet/core/boxes/sampler.py:67-98,187-270,
+    nndet/arch/heads/comb.py:268-276) with torch.randperm(n) := (n-1, ..., 0), the permutation the parity tests patch in.
+    Pool ties (torch.topk leaves them open): lower index first. -> (pos indices, neg indices, pool indices), ascending."""
+    lab, p = _f(labels), _f(fg_probs)
+    positive = np.nonzero(lab >= 1)[0]
+    negative = np.nonzero(lab == 0)[0]
+    num_pos, num_neg, pool = hnm_counts(len(positive), len(negative), batch_size, batch_size_per_image, positive_fraction, min_neg, pool_size)
+    pos = positive[::-1][:num_pos]
+    order = np.argsort(-p[negative], kind="stable")[:pool]
+    pool_idx = negative[order]
+    neg = pool_idx[::-1][:num_neg]
+    return np.sort(pos), np.sort(neg), pool_idx

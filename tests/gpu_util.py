@@ -25,6 +25,9 @@ def det_randperm(n, *a, **k):
     return torch.arange(n - 1, -1, -1, device=k.get("device", None))
 
 
+det_randperm.nndet_reversed_arange = True      # the device sampler (core/boxes/sampler.py) then selects what this permutation selects
+
+
 def relerr(a, b):
     a = a.detach().double().cpu(); b = b.detach().double().cpu()
     return float((a - b).abs().max() / max(1e-30, b.abs().max()))

@@ -50,7 +50,9 @@ def test_fused_postprocess_logits_deltas_anchors():
     W = [(4, 8, 16), (8, 16, 32)]
     anchors, _ = bx.anchors_for_image(shape, [(16, 12, 10), (8, 6, 5)], W, W, W)
     M, C, B = anchors.shape[0], 2, 2
-    logits = (rng.standard_normal((B, M, C)) * 2 - 3).astype(np.float32)
+    # logits on a grid (random order): neighbouring probabilities differ by >> 1 ulp, so the ranking does not depend on whose
+    # exp() rounds which way
+    logits = rng.permutation(np.linspace(-6.0, 2.0, B * M * C)).reshape(B, M, C).astype(np.float32)
     deltas = (rng.standard_normal((B, M, 6)) * 0.3).astype(np.float32)
     deltas[0, 11, 3] = 9.0                                  # exp clamp
     gb, gs, gl = postprocess_batch(t(logits), t(deltas), t(anchors), shape, C, 10000, 0.0, 0.01, 0.6, 100)
