@@ -67,6 +67,9 @@ int nndet_iou3d_pairwise_f32(const float* a, int64_t n, const float* b, int64_t 
                              float* out, void* stream);
 int nndet_giou3d_pairwise_f32(const float* a, int64_t n, const float* b, int64_t m, float eps,
                               float* out, void* stream);
+/* out[i] = max_j IoU(a[i], b[j]) (NaN propagates like torch.max) without the [n, m] matrix: the objective of the planner's
+ * anchor optimisation, box_iou(gt_boxes, anchors).max(dim=1)[0].mean() (nndet/planning/architecture/boxes/base.py:424-484). m >= 1. */
+int nndet_iou3d_rowmax_f32(const float* a, int64_t n, const float* b, int64_t m, float eps, float* out, void* stream);
 /* Element-wise (diagonal) GIoU with gradient w.r.t. `a`: what GIoULoss needs
  * (nndet/losses/regression.py:147-162 takes torch.diag of the [P,P] matrix). */
 int nndet_giou3d_diag_fwd_f32(const float* a, const float* b, int64_t n, float eps, float* out, void* stream);
@@ -140,6 +143,25 @@ int nndet_postprocess3d_f32(const float* scores, int32_t scores_are_probs, const
                             int32_t use_min_size, float nms_thresh, int32_t max_det, float* out_boxes,
                             float* out_scores, int64_t* out_labels, int64_t* out_counts, void* workspace,
                             size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weighted box clustering -- replaces wbc / batched_wbc (nndet/inference/detection/wbc.py:22-160,163-199), the cross-model /
+ * cross-tile consolidation of the ensemblers (nndet/inference/ensembler/detection.py:166-217,476-537). No [N, N] IoU matrix,
+ * no host loop: the cluster heads come from the NMS bit mask + on-device greedy scan (the same recurrence), members are
+ * attached to their FIRST head, one thread per cluster consolidates.
+ *   boxes [n,6], scores [n], weights [n], n_exp_preds [n] fp32; labels [n] int64 or NULL (NULL = one class: `wbc`; else
+ *   clustering per label: `batched_wbc`);
+ *   cluster head order: descending score (ties: lower index); members: IoU(head, box) > iou_thresh among the boxes not yet in a
+ *   cluster; score = sum(iou w s) / (sum(iou w) + max(0, mean(n_exp) - n_found) * mean(iou w) * missing_weight),
+ *   box = sum(box * iou w s) / sum(iou w s), w = weights (* box volume if use_area); clusters with score <= score_thresh are dropped.
+ *   out_boxes [n,6] / out_scores [n] / out_labels [n] int64: clusters in head order; out_count [1] int64 (device).
+ * Sums are fp32 in pool order (the reference's torch.sum order is unspecified: compare at 1e-5 relative).
+ * ---------------------------------------------------------------------------------------------- */
+size_t nndet_wbc3d_workspace_bytes(int64_t n);
+int nndet_wbc3d_f32(const float* boxes, const float* scores, const int64_t* labels, const float* weights,
+                    const float* n_exp_preds, int64_t n, float iou_thresh, float score_thresh, int32_t use_area,
+                    float missing_weight, float* out_boxes, float* out_scores, int64_t* out_labels,
+                    int64_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Device-side target preparation -- replaces FindInstances -> Instances2Boxes -> Instances2Segmentation

@@ -40,6 +40,7 @@ SIGNATURES = {
     "nndet_nms3d_sorted_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
     "nndet_iou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
     "nndet_giou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
+    "nndet_iou3d_rowmax_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
     "nndet_giou3d_diag_fwd_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P]),
     "nndet_giou3d_diag_bwd_f32": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
     "nndet_anchors3d_grid_f32": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
@@ -55,6 +56,8 @@ SIGNATURES = {
     "nndet_hnm_neg_capacity": (_I32, [_I32, C.c_double, _I32]),
     "nndet_hnm_sample_f32": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, C.c_double, _I32, C.c_double, C.c_uint64, _I32, _P, _P, _P,
                                        _P, _SZ, _P]),
+    "nndet_wbc3d_workspace_bytes": (_SZ, [_I64]),
+    "nndet_wbc3d_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _I32, _F, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_packed_weight_elems": (_SZ, [_CONVP, _I32]),
     "nndet_pack_weight": (C.c_int, [_CONVP, _I32, _P, _P, _P]),
     "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P]),

@@ -84,6 +84,44 @@ extern "C" int nndet_iou3d_pairwise_f32(const float* a, int64_t n, const float* 
 extern "C" int nndet_giou3d_pairwise_f32(const float* a, int64_t n, const float* b, int64_t m, float eps, float* out,
                                          void* stream) { return pairwise<true>(a, n, b, m, eps, out, stream); }
 
+// ------------------------------------------------------------------ row maximum of the IoU matrix (anchor search objective)
+// out[i] = max_j IoU(a[i], b[j]) without the [n, m] matrix: the planner's anchor optimisation evaluates
+// box_iou(gt, anchors).max(dim=1)[0].mean() 15 000 times (nndet/planning/architecture/boxes/base.py:424-484).
+// One workgroup per 256 rows; the columns stream through LDS in tiles of 256. NaN handling follows torch.max (NaN propagates).
+__global__ __launch_bounds__(256) void k_iou_rowmax(const float* __restrict__ a, int64_t n, const float* __restrict__ b, int64_t m,
+                                                    float eps, float* __restrict__ out) {
+    __shared__ float tile[256 * 6];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i < n;
+    Box ab = ldbox(a + (ok ? i : 0) * 6);
+    const float va = vol3(ab);
+    float best = -INFINITY;
+    bool nan = false;
+    for (int64_t c0 = 0; c0 < m; c0 += 256) {
+        const int nc = (int)min((int64_t)256, m - c0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nc * 6; k += 256) tile[k] = b[c0 * 6 + k];
+        __syncthreads();
+        for (int j = 0; j < nc; ++j) {
+            Box bb = ldbox(tile + j * 6);
+            float un;
+            const float v = iou_union(ab, va, bb, vol3(bb), eps, &un);
+            nan = nan || (v != v);
+            best = fmaxf(best, v);
+        }
+    }
+    if (ok) out[i] = nan ? __uint_as_float(0x7fc00000u) : best;
+}
+
+extern "C" int nndet_iou3d_rowmax_f32(const float* a, int64_t n, const float* b, int64_t m, float eps, float* out, void* stream) {
+    if (n < 0 || m <= 0) return NNDET_EINVAL;
+    if (n == 0) return 0;
+    if (!a || !b || !out) return NNDET_EINVAL;
+    k_iou_rowmax<<<(unsigned)ceil_div64(n, 256), 256, 0, as_stream(stream)>>>(a, n, b, m, eps, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------ diagonal GIoU (loss) + gradient w.r.t. a
 __global__ void k_giou_diag_fwd(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float eps,
                                 float* __restrict__ out) {

@@ -21,8 +21,10 @@ build atss3d.hip -ffp-contract=off
 build postproc.hip -ffp-contract=off
 build targets.hip
 build sampler.hip
+build wbc3d.hip -ffp-contract=off
 build conv_igemm.hip
 build conv_wgrad.hip
+build conv_pw.hip
 build conv_stem.hip
 build norm.hip
 build segloss.hip

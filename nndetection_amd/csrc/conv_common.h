@@ -11,6 +11,8 @@
 // conv_igemm.hip
 int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x, const void* w, const float* bias,
               const void* res, void* y, double* stats, hipStream_t st);
+// conv_pw.hip: 1x1x1 / kernel == stride transposed convolutions streamed without LDS staging; returns 1 = not covered
+int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, hipStream_t st);
 // conv_wgrad.hip
 int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias, int* bias_done, void* ws, size_t ws_bytes,
               hipStream_t st);   // bias_done = 1: dbias (may be NULL) was accumulated by the weight-gradient kernel itself

@@ -640,8 +640,10 @@ struct Plan {
 //      5 / 6 / 7: k_ig3 (3x3x3 stride 1, compile-time tile) with 32 rows x 512 points / 64 rows x 256 points / 64 rows x 512
 //      points. The main loop of 7 (NT = 16 point tiles per wave, one weight fragment pair per 32 MFMAs) sustains 1600 TF/s in
 //      tools/probe_loop.hip where the NT = 8 loops stop at ~1000 (the weight buffer loads saturate the vector memory pipe).
-static const int CFG_ROWS[8] = {32, 64, 64, 32, 32, 32, 64, 64};
-static const int CFG_PTS[8] = {512, 256, 128, 128, 256, 512, 256, 512};
+//      8 / 9 / 10: strided, 64 points per workgroup (halo 9^3 x 64 B = 46 KB at stride 2 -> 3 workgroups per CU instead of 1 at
+//      the 88 KB of the 128-point tile): 64 rows as 2 x 2 waves (8), 64 rows as 4 row waves x 64 points (9), 32 rows (10)
+static const int CFG_ROWS[11] = {32, 64, 64, 32, 32, 32, 64, 64, 64, 64, 32};
+static const int CFG_PTS[11] = {512, 256, 128, 128, 256, 512, 256, 512, 64, 64, 64};
 
 static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[3], int points, int maxp, int T[3], int H[3]) {
     double best = 1e300;
@@ -752,10 +754,12 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     const bool strided = a.in_step[0] > 1 || a.in_step[1] > 1 || a.in_step[2] > 1;
     const bool r64 = (a.Cy % 64) == 0;
     static const int a256 = getenv("NNDET_IGEMM_A256") ? atoi(getenv("NNDET_IGEMM_A256")) : 0;
-    P->cfg = strided ? (r64 ? 2 : 3) : (r64 ? 1 : (a256 ? 4 : 0));
+    const char* sv_env = getenv("NNDET_IGEMM_STRIDED");            // 0: 128-point tiles, 1: 64 points 2x2 waves, 2: 64 points 4 row waves
+    const int sv = sv_env ? atoi(sv_env) : 0;
+    P->cfg = strided ? (r64 ? (sv == 1 ? 8 : (sv == 2 ? 9 : 2)) : (sv ? 10 : 3)) : (r64 ? 1 : (a256 ? 4 : 0));
     const int points = CFG_PTS[P->cfg];
     for (int i = 0; i < 3; ++i) if (Lmax[i] <= 0) return NNDET_EINVAL;
-    if (!choose_tile(Lmax, a.in_step, span, points, strided ? 24 : 16, a.T, a.H)) return NNDET_EINVAL;
+    if (!choose_tile(Lmax, a.in_step, span, points, strided ? (P->cfg >= 8 ? 16 : 24) : 16, a.T, a.H)) return NNDET_EINVAL;
     for (int i = 0; i < 3; ++i) a.nt[i] = ceil_div(Lmax[i], a.T[i]);
     auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); };
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
@@ -821,6 +825,9 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
         case 1: k_igemm<T, 2, 2, 8, 16, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 2: k_igemm<T, 2, 2, 4, 24, 3, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 3: k_igemm<T, 2, 1, 4, 24, 4, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 8: k_igemm<T, 2, 2, 2, 16, 3, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 9: k_igemm<T, 4, 1, 4, 16, 3, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 10: k_igemm<T, 2, 1, 2, 16, 4, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 5: k_ig3<T, 1, 2, 8, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 6: k_ig3<T, 2, 2, 8, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 7: k_ig3<T, 2, 2, 16, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
@@ -846,6 +853,8 @@ static int ensure_attrs() {
     int rc = 0;
     rc |= set_lds_attr<bf16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<bf16_t, 1, 2, 4, 16, 4>();
     rc |= set_lds_attr<float, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<float, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<float, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<float, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<float, 1, 2, 4, 16, 4>();
+    rc |= set_lds_attr<bf16_t, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<bf16_t, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<bf16_t, 2, 1, 2, 16, 4, true>();
+    rc |= set_lds_attr<float, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<float, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<float, 2, 1, 2, 16, 4, true>();
     rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<bf16_t, 2, 2, 16, 2>();
     rc |= set_lds_attr3<float, 1, 2, 8, 2>(); rc |= set_lds_attr3<float, 2, 2, 8, 3>(); rc |= set_lds_attr3<float, 2, 2, 16, 2>();
     if (rc) return rc;
@@ -855,6 +864,10 @@ static int ensure_attrs() {
 
 int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y,
               double* stats, hipStream_t st) {
+    if (!stats) {                     // pointwise problems (1x1x1, transposed k == s) stream straight from global memory
+        const int prc = pw_run(c, kind, x, w, bias, res, y, st);
+        if (prc != 1) return prc;
+    }
     Plan P;
     int rc = build_plan(c, kind, &P);
     if (rc) return rc;

@@ -1,0 +1,275 @@
+// Pointwise ("no halo") convolutions on MFMA for gfx950: 1x1x1 Conv3d (forward / data gradient) and ConvTranspose3d with
+// kernel == stride (forward = one independent 1x1x1 GEMM per kernel position, data gradient = a gather over the kernel
+// positions). These are the decoder's lateral and top-down convolutions (nndet/arch/decoder/base.py:216-304,391-417), which are
+// HBM-bound streaming operations (16 - 100 FLOP/B) -- the generic implicit-GEMM kernel stages them through LDS with
+// two workgroup barriers per tile and reached 39 % of the HBM roofline at full resolution.
+//
+// Here nothing is staged: a point's 32-channel chunk IS one MFMA B-fragment row (16 bytes per lane, 64 contiguous bytes per
+// point), so every wave streams 16-point tiles straight from global memory into MFMA operands, U tiles in flight per wave, no
+// barrier in the loop. The (small) weight matrices sit in LDS as ready-made A fragments (1 KiB per fragment, lane-contiguous:
+// conflict-free ds_read_b128). Output: 4 consecutive channels per lane (8 bytes bf16 / 16 bytes fp32), + bias + residual.
+//   mode 0 (scatter): loop over the LATTICE points p (1x1x1: every voxel; transposed forward: the input voxels); for each kernel
+//                     position c:  y[S * p + c][r] = sum_k W_c[r][k] x[p][k]  (+ bias[r] + res[S * p + c][r])
+//   mode 1 (gather) : transposed data gradient: dx[p][r] = sum_c sum_k W_c[r][k] dy[S * p + c][k]
+#include "common.h"
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct PwMma;
+template <> struct PwMma<bf16_t> {
+    static constexpr int KC = 32, EPL = 8;
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void store4(bf16_t* p, const f32x4& v) {
+        uint2 u;
+        u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+    __device__ static __forceinline__ f32x4 load4(const bf16_t* p) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    }
+};
+template <> struct PwMma<float> {
+    static constexpr int KC = 16, EPL = 4;
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+    __device__ static __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+};
+
+struct PwArgs {
+    const void* x; const void* w; const float* bias; const void* res; void* y;
+    int64_t npts;             // lattice points over the whole batch (N * L0 * L1 * L2)
+    int32_t L[3], S[3];       // lattice dims per image, stride (= kernel) per axis (1,1,1 for 1x1x1)
+    int32_t Cx, Cy;           // physical channels read per point / written per point
+    int32_t ncls;             // kernel positions S0 * S1 * S2
+    int32_t ntiles;           // ceil(npts / 16)
+    uint32_t mL2, mL1, mL0;   // magic multipliers for / L[2], / L[1], / L[0] (0 = divisor 1)
+};
+
+// strided-tensor point index of lattice point p (decomposed on the fly) and class (c0, c1, c2)
+__device__ __forceinline__ int64_t pw_strided_index(const PwArgs& A, int64_t p, int c0, int c1, int c2) {
+    // p < 2^31 is checked on the host, so the magic-multiplier division applies
+    const unsigned pp = (unsigned)p;
+    const unsigned t1 = A.mL2 ? __umulhi(pp, A.mL2) : pp;
+    const unsigned w = pp - t1 * (unsigned)A.L[2];
+    const unsigned t2 = A.mL1 ? __umulhi(t1, A.mL1) : t1;
+    const unsigned h = t1 - t2 * (unsigned)A.L[1];
+    const unsigned n = A.mL0 ? __umulhi(t2, A.mL0) : t2;
+    const unsigned d = t2 - n * (unsigned)A.L[0];
+    const int64_t O1 = (int64_t)A.L[1] * A.S[1], O2 = (int64_t)A.L[2] * A.S[2], O0 = (int64_t)A.L[0] * A.S[0];
+    return (((int64_t)n * O0 + (d * A.S[0] + c0)) * O1 + (h * A.S[1] + c1)) * O2 + (w * A.S[2] + c2);
+}
+
+// MT row tiles of 16 output channels (Cy = 16 * MT ... or a multiple handled by blockIdx.y), NKC chunks of KC input channels.
+// Weights in LDS: fragment f = (cls * MT + i) * NKC + kc at byte f * 1024 + lane * 16.
+template <typename T, int MT, int NKC, int MODE, int U>
+__global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
+    using M = PwMma<T>;
+    constexpr int KC = M::KC, EPL = M::EPL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.y * (MT * 16);
+    // ---- weights -> LDS fragments (packed layout [cls][rows_p][k_p], rows_p = Cy resp. gather: rows = Cy as well)
+    {
+        const T* wp = reinterpret_cast<const T*>(A.w);
+        const int Kp = (MODE == 0) ? A.Cx : A.Cx;          // contraction length per class = channels read per point
+        const int nfrag = A.ncls * MT * NKC;
+        for (int f = wv; f < nfrag; f += 4) {
+            const int kc = f % NKC, t = f / NKC, i = t % MT, c = t / MT;
+            const T* src = wp + ((int64_t)c * A.Cy + row0 + i * 16 + li) * Kp + kc * KC + q * EPL;
+            *reinterpret_cast<u32x4*>(smem + f * 1024 + lane * 16) = *reinterpret_cast<const u32x4*>(src);
+        }
+    }
+    __syncthreads();
+    const T* xb = reinterpret_cast<const T*>(A.x);
+    T* yb = reinterpret_cast<T*>(A.y);
+    const T* rb = reinterpret_cast<const T*>(A.res);
+    float bia[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bia[i][r] = A.bias ? A.bias[row0 + i * 16 + q * 4 + r] : 0.f;
+    const int wave_global = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    const int S1 = A.S[1], S2 = A.S[2];
+
+    for (int t0 = wave_global * U; t0 < A.ntiles; t0 += nwaves * U) {
+        if constexpr (MODE == 0) {
+            u32x4 b[U][NKC];
+            int64_t pt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t p = (int64_t)(t0 + u) * 16 + li;
+                pt[u] = p < A.npts ? p : -1;
+                const int64_t pc = p < A.npts ? p : 0;       // clamped (valid) address, result discarded
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) b[u][kc] = *reinterpret_cast<const u32x4*>(xb + pc * A.Cx + kc * KC + q * EPL);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u >= A.ntiles) break;               // uniform
+                for (int c = 0; c < A.ncls; ++c) {
+                    f32x4 acc[MT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kc = 0; kc < NKC; ++kc) {
+                            const u32x4 a = *reinterpret_cast<const u32x4*>(smem + ((c * MT + i) * NKC + kc) * 1024 + lane * 16);
+                            M::mma(a, b[u][kc], acc[i]);
+                        }
+                    }
+                    if (pt[u] >= 0) {
+                        int64_t o = pt[u];
+                        if (A.ncls > 1) {
+                            const int c2 = c % S2, ct = c / S2;
+                            o = pw_strided_index(A, pt[u], ct / S1, ct % S1, c2);
+                        }
+                        T* yo = yb + o * A.Cy + row0 + q * 4;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            f32x4 v = acc[i];
+                            v[0] += bia[i][0]; v[1] += bia[i][1]; v[2] += bia[i][2]; v[3] += bia[i][3];
+                            if (rb) {
+                                const f32x4 r4 = M::load4(rb + o * A.Cy + row0 + q * 4 + i * 16);
+                                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+                            }
+                            M::store4(yo + i * 16, v);
+                        }
+                    }
+                }
+            }
+        } else {
+            // gather: all kernel positions of a lattice point contribute to ONE output row block
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u >= A.ntiles) break;               // uniform
+                const int64_t p = (int64_t)(t0 + u) * 16 + li;
+                const bool ok = p < A.npts;
+                const int64_t pc = ok ? p : 0;
+                f32x4 acc[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int c0 = 0; c0 < A.ncls; c0 += 4) {     // 4 kernel positions in flight
+                    u32x4 b[4][NKC];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int c = c0 + cc < A.ncls ? c0 + cc : c0;
+                        const int c2 = c % S2, ct = c / S2;
+                        const int64_t o = pw_strided_index(A, pc, ct / S1, ct % S1, c2);
+#pragma unroll
+                        for (int kc = 0; kc < NKC; ++kc) b[cc][kc] = *reinterpret_cast<const u32x4*>(xb + o * A.Cx + kc * KC + q * EPL);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        if (c0 + cc >= A.ncls) break;        // uniform
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int kc = 0; kc < NKC; ++kc) {
+                                const u32x4 a = *reinterpret_cast<const u32x4*>(smem + (((c0 + cc) * MT + i) * NKC + kc) * 1024 + lane * 16);
+                                M::mma(a, b[cc][kc], acc[i]);
+                            }
+                    }
+                }
+                if (ok) {
+                    T* yo = yb + p * A.Cy + row0 + q * 4;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) M::store4(yo + i * 16, acc[i]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <typename T, int MT, int NKC, int MODE, int U>
+static int pw_launch(const PwArgs& A, int rowblocks, size_t lds, hipStream_t st) {
+    static int attr_done = 0;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw<T, MT, NKC, MODE, U>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_done = 1;
+    }
+    // enough waves to cover the HBM latency-bandwidth product: 8 workgroups (32 waves) per CU at most, fewer for small problems
+    int64_t wgs = ceil_div64(A.ntiles, 4 * U);
+    if (wgs > 256 * 8) wgs = 256 * 8;
+    if (wgs < 1) wgs = 1;
+    k_pw<T, MT, NKC, MODE, U><<<dim3((unsigned)wgs, rowblocks), 256, lds, st>>>(A);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int pw_dispatch(const PwArgs& A, int mt_total, int nkc, int mode, size_t lds_per_rowtile, hipStream_t st) {
+    // row tiles per workgroup: 2 (32 rows) when the weights of more would not fit 64 KiB of LDS or the accumulators many registers
+    const int MT = (mt_total % 4 == 0 && lds_per_rowtile * 4 <= 64 * 1024) ? 4 : 2;
+    const int rowblocks = mt_total / MT;
+    const size_t lds = lds_per_rowtile * MT;
+#define PW_CASE(mt, kc)                                                                                      \
+    if (MT == mt && nkc == kc)                                                                                 \
+        return mode == 0 ? pw_launch<T, mt, kc, 0, 4>(A, rowblocks, lds, st) : pw_launch<T, mt, kc, 1, 2>(A, rowblocks, lds, st);
+    PW_CASE(2, 1) PW_CASE(2, 2) PW_CASE(2, 4) PW_CASE(4, 1) PW_CASE(4, 2) PW_CASE(4, 4) PW_CASE(2, 8) PW_CASE(4, 8)
+#undef PW_CASE
+    return NNDET_EINVAL;
+}
+
+// kind: 0 forward, 1 backward-data. Returns 1 when the problem is not a pointwise one this kernel covers (caller falls back to the
+// implicit-GEMM kernel), 0 on success, else an error.
+int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, hipStream_t st) {
+    static const int enabled = getenv("NNDET_PW") ? atoi(getenv("NNDET_PW")) : 1;
+    if (!enabled) return 1;
+    const bool tr = c->transposed != 0;
+    for (int i = 0; i < 3; ++i) {
+        if (c->p[i] != 0 || c->k[i] != c->s[i]) return 1;
+        if (!tr && c->k[i] != 1) return 1;
+    }
+    const int esz = c->dtype == NNDET_BF16 ? 2 : 4, KC = c->dtype == NNDET_BF16 ? 32 : 16;
+    PwArgs A;
+    memset(&A, 0, sizeof(A));
+    A.x = x; A.w = w; A.bias = bias; A.res = res; A.y = y;
+    const int ncls = c->k[0] * c->k[1] * c->k[2];
+    int mode;
+    if (!tr) {                       // 1x1x1: forward and data gradient are the same streaming GEMM
+        mode = 0;
+        A.L[0] = c->in_d; A.L[1] = c->in_h; A.L[2] = c->in_w;
+        A.S[0] = A.S[1] = A.S[2] = 1;
+        A.Cx = kind == 0 ? c->cin_p : c->cout_p;
+        A.Cy = kind == 0 ? c->cout_p : c->cin_p;
+    } else if (kind == 0) {          // transposed forward: scatter over the kernel positions
+        mode = 0;
+        A.L[0] = c->in_d; A.L[1] = c->in_h; A.L[2] = c->in_w;
+        for (int i = 0; i < 3; ++i) A.S[i] = c->s[i];
+        A.Cx = c->cin_p; A.Cy = c->cout_p;
+    } else {                         // transposed data gradient: gather
+        mode = 1;
+        A.L[0] = c->in_d; A.L[1] = c->in_h; A.L[2] = c->in_w;
+        for (int i = 0; i < 3; ++i) A.S[i] = c->s[i];
+        A.Cx = c->cout_p; A.Cy = c->cin_p;
+        if (bias || res) return 1;
+    }
+    A.ncls = ncls;
+    if (A.Cx % KC != 0 || A.Cy % 32 != 0) return 1;
+    const int nkc = A.Cx / KC, mt_total = A.Cy / 16;
+    if (nkc > 8) return 1;
+    const size_t lds_per_rowtile = (size_t)ncls * nkc * 1024;
+    if (lds_per_rowtile * 2 > 64 * 1024) return 1;      // weights of even a 32-row block do not fit: generic kernel
+    A.npts = (int64_t)c->batch * A.L[0] * A.L[1] * A.L[2];
+    const int64_t nstrided = A.npts * ncls;
+    if (A.npts >= (1LL << 31) || nstrided * (A.Cx > A.Cy ? A.Cx : A.Cy) * esz >= (1LL << 62)) return 1;
+    A.ntiles = (int32_t)ceil_div64(A.npts, 16);
+    auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); };
+    A.mL2 = magic(A.L[2]); A.mL1 = magic(A.L[1]); A.mL0 = magic(A.L[0]);
+    // the magic division n / d == umulhi(n, 2^32 / d + 1) is exact for n * d < 2^32: lattice counts here are < 2^31 / 16 at most
+    if ((uint64_t)A.npts * (uint64_t)(A.L[2] > A.L[1] ? (A.L[2] > A.L[0] ? A.L[2] : A.L[0]) : (A.L[1] > A.L[0] ? A.L[1] : A.L[0])) >= (1ull << 32) && ncls > 1) return 1;
+    return c->dtype == NNDET_BF16 ? pw_dispatch<bf16_t>(A, mt_total, nkc, mode, lds_per_rowtile, st)
+                                  : pw_dispatch<float>(A, mt_total, nkc, mode, lds_per_rowtile, st);
+}

@@ -49,15 +49,20 @@ __global__ void k_gather_boxes(const float* __restrict__ boxes, const int32_t* _
 }
 
 // grid (col_blocks, ceil(col_blocks/4)), block 256 = 4 waves; wave w handles row block 4*by + w.
+// labels (may be NULL): bit only between boxes of the same label (per-class clustering of wbc3d.hip); nan_hits: a NaN IoU sets the
+// bit as well (`!(iou <= thr)`: the box leaves the pool, wbc.py:122,141) -- NMS itself uses `iou > thr` (nms.cu:126).
 __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, int64_t n, float thr,
-                                                  u64* __restrict__ mask, int col_blocks) {
+                                                  u64* __restrict__ mask, int col_blocks,
+                                                  const int32_t* __restrict__ labels = nullptr, int nan_hits = 0) {
     __shared__ float cbox[64 * 6];
+    __shared__ int32_t clab[64];
     const int cb = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int rb = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (cb < (int)blockIdx.y * 4) return;  // the whole block is below the diagonal (uniform exit)
     const int col_size = (int)min((int64_t)64, n - (int64_t)cb * 64);
     for (int i = threadIdx.x; i < col_size * 6; i += 256) cbox[i] = boxes[(int64_t)cb * 64 * 6 + i];
+    if (labels && (int)threadIdx.x < col_size) clab[threadIdx.x] = labels[(int64_t)cb * 64 + threadIdx.x];
     __syncthreads();
     if (rb > cb || rb >= col_blocks) return;
     const int64_t row = (int64_t)rb * 64 + lane;
@@ -67,8 +72,17 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
     for (int k = 0; k < 6; ++k) a[k] = boxes[row * 6 + k];
     u64 t = 0;
     const int start = (rb == cb) ? lane + 1 : 0;
-    for (int j = start; j < col_size; ++j) {
-        if (iou3d(a, cbox + j * 6) > thr) t |= 1ULL << j;
+    if (!labels && !nan_hits) {
+        for (int j = start; j < col_size; ++j) {
+            if (iou3d(a, cbox + j * 6) > thr) t |= 1ULL << j;
+        }
+    } else {
+        const int32_t la = labels ? labels[row] : 0;
+        for (int j = start; j < col_size; ++j) {
+            const float v = iou3d(a, cbox + j * 6);
+            const bool hit = nan_hits ? !(v <= thr) : (v > thr);
+            if (hit && (!labels || clab[j] == la)) t |= 1ULL << j;
+        }
     }
     mask[row * col_blocks + cb] = t;
 }
@@ -288,4 +302,30 @@ int nms_presorted_run(const float* boxes, int64_t n_cap, const int64_t* n_valid_
     if (rc) return rc;
     if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
     return nms_core(boxes, nullptr, n_cap, thr, keep_out, n_keep_out, ws, st, n_valid_dev);
+}
+
+// Mask + greedy scan only (wbc3d.hip): sboxes [n, 6] in descending score order, slabels (may be NULL) their labels. Returns the
+// device pointers of the bit mask [n][ceil(n/64)] and of the head bits (inside `workspace`, valid until it is reused).
+int nms_heads_run(const float* sboxes, const int32_t* slabels, int64_t n, float thr, u64** mask_out, u64** keepbits_out,
+                  void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (n <= 0 || !sboxes || !workspace || !mask_out || !keepbits_out) return NNDET_EINVAL;
+    NmsWs ws;
+    int rc = nms_layout(n, (char*)workspace, &ws);
+    if (rc) return rc;
+    if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
+    const int cb = (int)ceil_div64(n, 64);
+    HIP_TRY(hipMemsetAsync(ws.remv, 0, (size_t)cb * 8, st));
+    k_nms_mask<<<dim3(cb, ceil_div(cb, 4)), 256, 0, st>>>(sboxes, n, thr, ws.mask, cb, slabels, 1);
+    LAUNCH_CHECK();
+    for (int c0 = 0; c0 < cb; c0 += 64) {
+        const int c1 = c0 + 64 < cb ? c0 + 64 : cb;
+        k_nms_scan_super<<<1, 1024, 0, st>>>(ws.mask, n, cb, c0, c1, ws.remv, ws.keepbits);
+        LAUNCH_CHECK();
+        if (c1 < cb) {
+            k_nms_propagate<<<dim3(ceil_div(cb - c1, 256), c1 - c0), 256, 0, st>>>(ws.mask, cb, c0, c1, ws.keepbits, ws.remv);
+            LAUNCH_CHECK();
+        }
+    }
+    *mask_out = ws.mask; *keepbits_out = ws.keepbits;
+    return 0;
 }

@@ -338,3 +338,51 @@ def hnm_select_reversed(labels, fg_probs, batch_size: int, batch_size_per_image:
     pool_idx = negative[order]
     neg = pool_idx[::-1][:num_neg]
     return np.sort(pos), np.sort(neg), pool_idx
+
+
+# --------------------------------------------------------------------------------------
+# weighted box clustering (inference ensembling)
+# --------------------------------------------------------------------------------------
+def wbc(boxes, scores, weights, n_exp_preds, iou_thresh, score_thresh, use_area=True, missing_weight=1.0):
+    """wbc + compute_cluster_consolidation, nndet/inference/detection/wbc.py:94-199, one class. Score ties: lower index first."""
+    b, s, w, ne = _f(boxes).reshape(-1, 6), _f(scores), _f(weights), _f(n_exp_preds)
+    if b.shape[0] == 0:
+        return np.zeros((0, 6), F32), np.zeros((0,), F32)
+    ious = box_iou(b, b)
+    if use_area:
+        w = w * box_area_3d(b)
+    pool = np.argsort(-s, kind="stable")
+    nb, ns = [], []
+    while pool.size > 0:
+        h = pool[0]
+        with np.errstate(invalid="ignore"):
+            row = ious[h][pool]
+            idx = pool[row > F32(iou_thresh)]
+            rest = pool[row <= F32(iou_thresh)]
+        if idx.size:
+            iou_c = ious[h][idx]
+            msw = iou_c * w[idx]
+            ms = msw * s[idx]
+            n_missing = max(F32(0), F32(ne[idx].astype(F32).mean()) - F32(len(idx)))
+            denom = msw.sum(dtype=F32) + F32(n_missing) * F32(msw.mean(dtype=F32)) * F32(missing_weight)
+            sc = ms.sum(dtype=F32) / denom
+            bb = (b[idx] * ms[:, None]).sum(0, dtype=F32) / ms.sum(dtype=F32)
+            if sc > F32(score_thresh):
+                nb.append(bb); ns.append(sc)
+        pool = rest
+    if not nb:
+        return np.zeros((0, 6), F32), np.zeros((0,), F32)
+    return np.stack(nb).astype(F32), np.asarray(ns, F32)
+
+
+def batched_wbc(boxes, scores, labels, weights, iou_thresh, n_exp_preds, score_thresh, use_area=False, missing_weight=1.0):
+    """batched_wbc, wbc.py:22-91: per label (ascending), concatenated."""
+    labels = np.asarray(labels)
+    ob, os_, ol = [], [], []
+    for l in np.unique(labels):
+        m = labels == l
+        bb, ss = wbc(_f(boxes)[m], _f(scores)[m], _f(weights)[m], _f(n_exp_preds)[m], iou_thresh, score_thresh, use_area, missing_weight)
+        ob.append(bb); os_.append(ss); ol.append(np.full((len(ss),), l, F32))
+    if not ob:
+        return np.zeros((0, 6), F32), np.zeros((0,), F32), np.zeros((0,), F32)
+    return np.concatenate(ob), np.concatenate(os_), np.concatenate(ol)

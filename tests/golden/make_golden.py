@@ -281,9 +281,49 @@ def golden_targets():
     np.savez_compressed(os.path.join(OUT, "targets_golden.npz"), **g)
 
 
+def golden_wbc():
+    """the reference's weighted box clustering (nndet/inference/detection/wbc.py, pure torch) on clustered
+    synthetic predictions of 3 "models"; the oracle must agree to 1e-5 (torch's reduction order is its own)."""
+    from oracle.refimport import install_stub_finder
+    install_stub_finder()                                  # nndet.inference imports nndet.io (SimpleITK ...) at package level
+    from nndet.inference.detection.wbc import batched_wbc as ref_batched_wbc, wbc as ref_wbc
+    rng = np.random.default_rng(7)
+    centers = rng.uniform(10, 150, (60, 3)); sizes = rng.uniform(6, 30, (60, 3))
+    boxes, scores, labels, weights, nexp = [], [], [], [], []
+    for c, sz in zip(centers, sizes):
+        lab = int(rng.integers(0, 3))
+        for _ in range(int(rng.integers(1, 7))):                       # 1..6 jittered predictions of the same object
+            cc, ss = c + rng.normal(0, 1.0, 3), sz * rng.uniform(0.9, 1.1, 3)
+            lo, hi = cc - ss / 2, cc + ss / 2
+            boxes.append([lo[0], lo[1], hi[0], hi[1], lo[2], hi[2]]); scores.append(rng.uniform(0.05, 0.99))
+            labels.append(lab); weights.append(rng.uniform(0.2, 1.0)); nexp.append(float(rng.integers(2, 7)))
+    b = np.asarray(boxes, np.float32); s = np.asarray(scores, np.float32); l = np.asarray(labels, np.int64)
+    w = np.asarray(weights, np.float32); ne = np.asarray(nexp, np.float32)
+    g = {"boxes": b, "scores": s, "labels": l, "weights": w, "n_exp": ne}
+    for tag, kw in (("a", dict(iou_thresh=0.3, score_thresh=0.0, use_area=False, missing_weight=1.0)),
+                    ("b", dict(iou_thresh=0.1, score_thresh=0.2, use_area=True, missing_weight=0.5))):
+        rb, rs, rl = ref_batched_wbc(torch.from_numpy(b), torch.from_numpy(s), torch.from_numpy(l), torch.from_numpy(w),
+                                     kw["iou_thresh"], torch.from_numpy(ne), kw["score_thresh"], use_area=kw["use_area"],
+                                     missing_weight=kw["missing_weight"])
+        ob, os_, ol = bx.batched_wbc(b, s, l, w, kw["iou_thresh"], ne, kw["score_thresh"], kw["use_area"], kw["missing_weight"])
+        assert rb.shape == ob.shape, (rb.shape, ob.shape)
+        assert np.allclose(ob, rb.numpy(), rtol=1e-5, atol=1e-5) and np.allclose(os_, rs.numpy(), rtol=1e-5, atol=1e-6)
+        assert np.array_equal(ol, rl.numpy())
+        print(f"  [1e-5] batched_wbc {tag}: {len(b)} predictions -> {len(ob)} clusters")
+        g[f"out_boxes_{tag}"], g[f"out_scores_{tag}"], g[f"out_labels_{tag}"] = rb.numpy(), rs.numpy(), rl.numpy()
+    m = l == 1
+    rb, rs = ref_wbc(torch.from_numpy(b[m]), torch.from_numpy(s[m]), torch.from_numpy(w[m]), torch.from_numpy(ne[m]), 0.2, 0.1)
+    ob, os_ = bx.wbc(b[m], s[m], w[m], ne[m], 0.2, 0.1)
+    assert np.allclose(ob, rb.numpy(), rtol=1e-5, atol=1e-5) and np.allclose(os_, rs.numpy(), rtol=1e-5, atol=1e-6)
+    g["one_boxes"], g["one_scores"] = rb.numpy(), rs.numpy()
+    np.savez_compressed(os.path.join(OUT, "wbc_golden.npz"), **g)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["boxes", "targets", "tiny", "toy64", "luna160"]
+    which = sys.argv[1:] or ["boxes", "targets", "wbc", "tiny", "toy64", "luna160"]
+    if "wbc" in which:
+        print("weighted box clustering:"); golden_wbc()
     if "targets" in which:
         print("target preparation:"); golden_targets()
     if "boxes" in which:

@@ -30,11 +30,15 @@ CONVS = [
     ("seg_out", 32, 2, 1, 1, 0, False, (8, 8, 8)),              # 2 -> 32 padded
     ("up_222", 64, 32, 2, 2, 0, True, (4, 5, 6)),               # ConvTranspose k = s
     ("up_221", 128, 128, (2, 2, 1), (2, 2, 1), 0, True, (3, 3, 6)),
+    ("up_222_c32", 64, 32, 2, 2, 0, True, (5, 7, 9)),           # pointwise kernel, odd dims (ragged 16-point tiles), 8 positions
+    ("lateral_c64", 64, 64, 1, 1, 0, False, (5, 7, 9)),
+    ("lateral_256to128", 256, 128, 1, 1, 0, False, (4, 5, 3)),
     ("stem", 1, 32, 3, 1, 1, False, (9, 10, 12)),
     ("c32_k3_tiles", 32, 32, 3, 1, 1, False, (17, 16, 9)),      # several (8,8,8) tiles of k_ig3 + ragged edges in every axis
     ("c64_k3_tiles", 64, 64, 3, 1, 1, False, (9, 17, 16)),      # several (4,8,8) tiles, 2 K-chunks
 ]
 SPEC3 = ["c32_k3", "c64_k3", "c128_k3", "head_cls", "head_reg", "c32_k3_tiles", "c64_k3_tiles"]   # 3x3x3 stride 1
+STRIDED = ["c32to64_s2", "c32to32_s2", "c64_s221", "up_222", "up_221"]                             # strided gathers (fwd or dgrad)
 
 
 def _mk(name, dtype, norm=None, act=False):
@@ -78,12 +82,15 @@ def _ref_forward(m, x, cfg, dtype, norm, act):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("name,spec", [(c[0], "lib") for c in CONVS] + [(n, v) for v in ("generic", "ig3-nt8", "ig3-nt16") for n in SPEC3])
+@pytest.mark.parametrize("name,spec", [(c[0], "lib") for c in CONVS] + [(n, v) for v in ("generic", "ig3-nt8", "ig3-nt16") for n in SPEC3] +
+                         [(n, v) for v in ("strided-0", "strided-1", "strided-2") for n in STRIDED])
 def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
     """spec: "lib" = the library's own kernel choice; "generic" = k_igemm only (NNDET_IGEMM_SPEC=0); "ig3-nt8" / "ig3-nt16" =
     force the compile-time-tile kernel k_ig3 for every 3x3x3 stride-1 convolution (forward and backward-data,
     NNDET_IGEMM_SPEC=2) with 8 / 16 point tiles per wave for the 64-row layers (NNDET_IGEMM_NT)."""
-    if spec == "generic":
+    if spec.startswith("strided"):                      # tile variants of the strided implicit-GEMM configurations (NNDET_IGEMM_STRIDED)
+        monkeypatch.setenv("NNDET_IGEMM_STRIDED", spec[8:])
+    elif spec == "generic":
         monkeypatch.setenv("NNDET_IGEMM_SPEC", "0")
         monkeypatch.setenv("NNDET_WGRAD_SPEC", "0")
     elif spec.startswith("ig3"):

@@ -142,3 +142,15 @@ def test_target_preparation_oracle_vs_reference_golden(golden_dir):
         ob, oc, oi, osem = bx.instances_to_targets(tgt[b, 0], maps[b])
         assert np.array_equal(ob, g[f"boxes_{b}"]) and np.array_equal(oc, g[f"classes_{b}"]) and np.array_equal(oi, g[f"ids_{b}"])
         assert np.array_equal(osem.astype(np.uint8), g[f"seg_{b}"])
+
+
+def test_wbc_oracle_vs_reference_golden(golden_dir):
+    """the oracle restatement of batched_wbc / wbc against the unmodified reference (make_golden.py:golden_wbc)."""
+    g = np.load(os.path.join(golden_dir, "wbc_golden.npz"))
+    for tag, kw in (("a", dict(iou_thresh=0.3, score_thresh=0.0, use_area=False, missing_weight=1.0)),
+                    ("b", dict(iou_thresh=0.1, score_thresh=0.2, use_area=True, missing_weight=0.5))):
+        ob, os_, ol = bx.batched_wbc(g["boxes"], g["scores"], g["labels"], g["weights"], kw["iou_thresh"], g["n_exp"],
+                                     kw["score_thresh"], kw["use_area"], kw["missing_weight"])
+        assert ob.shape == g[f"out_boxes_{tag}"].shape
+        assert np.allclose(ob, g[f"out_boxes_{tag}"], rtol=1e-5, atol=1e-5) and np.allclose(os_, g[f"out_scores_{tag}"], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(ol, g[f"out_labels_{tag}"])

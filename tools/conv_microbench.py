@@ -22,6 +22,12 @@ SHAPES = {
     "lat_p0_1x1": (32, 32, 1, 1, 0, False, (160, 160, 96), 4),
     "head_reg_out": (128, 162, 3, 1, 1, False, (40, 40, 24), 4),
     "e3_256x256": (256, 256, 3, 1, 1, False, (20, 20, 12), 4),
+    "e2_64to128_s2": (64, 128, 3, 2, 1, False, (80, 80, 48), 4),
+    "e3_128to256_s2": (128, 256, 3, 2, 1, False, (40, 40, 24), 4),
+    "up_p2_128to64": (128, 64, 2, 2, 0, True, (40, 40, 24), 4),
+    "lat_p1_1x1": (64, 64, 1, 1, 0, False, (80, 80, 48), 4),
+    "p3_128x128": (128, 128, 3, 1, 1, False, (20, 20, 12), 4),
+    "p4_128x128": (128, 128, 3, 1, 1, False, (10, 10, 6), 4),
 }
 
 
