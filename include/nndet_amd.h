@@ -214,6 +214,11 @@ typedef struct NndetConv {
 size_t nndet_packed_weight_elems(const NndetConv* c, int32_t mode);
 int nndet_pack_weight(const NndetConv* c, int32_t mode, const float* w, void* packed, void* stream);
 
+/* The same packing for n (convolution, mode) pairs in one or two launches: what a training step does after every optimizer
+ * step for all layers of the model. convs / modes / w / out are HOST arrays of length n (w[i], out[i] device pointers). */
+int nndet_pack_weights_batched(const NndetConv* convs, const int32_t* modes, const float* const* w, void* const* out,
+                               int32_t n, void* stream);
+
 /* y[N,od,oh,ow,cout_p] = conv(x[N,id,ih,iw,cin_p]) + bias ; bias may be NULL ([cout_p] fp32, zero padded).
  * Stem special case cin_p == 1: `w_packed_mode0` is the UNPACKED fp32 weight [cout, 1, kd, kh, kw].
  * If stats != NULL ([NNDET_STATS_REPLICAS, N, cout_p, 2] fp64, zeroed by the caller) the epilogue accumulates per-(n, channel)

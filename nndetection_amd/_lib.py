@@ -60,6 +60,7 @@ SIGNATURES = {
     "nndet_wbc3d_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _I32, _F, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_packed_weight_elems": (_SZ, [_CONVP, _I32]),
     "nndet_pack_weight": (C.c_int, [_CONVP, _I32, _P, _P, _P]),
+    "nndet_pack_weights_batched": (C.c_int, [C.POINTER(NndetConv), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I32, _P]),
     "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
     "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
@@ -179,6 +180,33 @@ def arena_zeros(shape, dtype, device):
     if raw is None:
         return torch.zeros(shape, dtype=dtype, device=device)
     return raw.view(dtype).view(shape)
+
+
+class _GradPool:
+    """One zero-filled fp32 buffer per training step for ALL parameter-gradient accumulators of the convolution nodes (54 fills
+    of a few KB .. 11 MB per step otherwise). A fresh torch tensor per step: the gradients handed to autograd are views of it and
+    keep it alive exactly as long as they live, so nothing depends on when the optimizer drops them."""
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def begin(self, numel: int, device):
+        self.buf = torch.zeros((int(numel),), dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, numel: int, device):
+        b = self.buf
+        start = (self.off + 63) // 64 * 64
+        if b is None or b.device != device or start + numel > b.numel():
+            return torch.zeros((numel,), dtype=torch.float32, device=device)
+        self.off = start + numel
+        return b[start:start + numel]
+
+    def end(self):
+        self.buf, self.off = None, 0
+
+
+grad_pool = _GradPool()
 
 
 def call(name: str, *args):

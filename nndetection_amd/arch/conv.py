@@ -84,6 +84,43 @@ def prepack(mod, x: torch.Tensor, modes=(0, 1)) -> None:
         _packed(mod, mode, mod.conv.weight, desc, x_p.dtype)
 
 
+def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1)) -> int:
+    """Refresh the packed-weight cache of EVERY conv block of `model` whose parameter changed (i.e. after an optimizer step) with
+    one batched launch (nndet_pack_weights_batched) instead of one launch per layer and mode. Returns the number of jobs."""
+    jobs = []
+    for mod in model.modules():
+        if not isinstance(mod, BaseConvNormAct) or mod.in_channels == 1:
+            continue
+        w = mod.conv.weight
+        if not w.is_cuda:
+            return 0
+        ver = (w._version, w.data_ptr())
+        for mode in modes:
+            hit = mod._pack_cache.get((mode, dtype))
+            if hit is not None and hit[0] == ver:
+                continue
+            d = L.NndetConv()
+            d.dtype = L._DT[dtype]
+            d.transposed = int(mod.transposed)
+            d.batch, d.cin, d.cout, d.cin_p, d.cout_p = 1, mod.in_channels, mod.out_channels, cpad(mod.in_channels), cpad(mod.out_channels)
+            d.k = (ctypes.c_int32 * 3)(*mod.k); d.s = (ctypes.c_int32 * 3)(*mod.s); d.p = (ctypes.c_int32 * 3)(*mod.p)
+            n = L.load().nndet_packed_weight_elems(ctypes.byref(d), mode)
+            buf = torch.empty((n,), dtype=dtype, device=w.device)
+            w32 = w.detach().float().contiguous()
+            jobs.append((mod, mode, ver, d, w32, buf))
+    if not jobs:
+        return 0
+    n = len(jobs)
+    convs = (L.NndetConv * n)(*[j[3] for j in jobs])
+    modes_c = (ctypes.c_int32 * n)(*[j[1] for j in jobs])
+    wp = (ctypes.c_void_p * n)(*[j[4].data_ptr() for j in jobs])
+    op = (ctypes.c_void_p * n)(*[j[5].data_ptr() for j in jobs])
+    L.call("nndet_pack_weights_batched", convs, modes_c, wp, op, n, L.stream())
+    for mod, mode, ver, _, _, buf in jobs:
+        mod._pack_cache[(mode, dtype)] = (ver, buf)
+    return n
+
+
 def _pad1d(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
     if v is None:
         return None
@@ -144,7 +181,7 @@ class _ConvBlockFn(torch.autograd.Function):
         # all parameter gradients of this node (dW, dbias, dgamma, dbeta) are views of ONE zero-filled buffer: one fill kernel
         # per node instead of up to four
         nw = weight.numel()
-        gbuf = torch.zeros((nw + (cout if ctx.has_bias else 0) + (2 * cout if ctx.has_norm else 0),), dtype=torch.float32, device=dev)
+        gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0) + (2 * cout if ctx.has_norm else 0), dev)
         dw = gbuf[:nw].view(weight.shape)
         off = nw
         dbias = None

@@ -49,6 +49,15 @@ class BaseRetinaNet(nn.Module):
     # ------------------------------------------------------------------ forward (retina.py:198-226)
     def forward(self, inp: Tensor):
         L.arena_reset(inp.device)                # one fill for all per-layer statistics buffers of the previous step
+        if inp.is_cuda:
+            from ..arch.conv import prepack_all
+            grad = torch.is_grad_enabled()
+            prepack_all(self, inp.dtype if inp.dtype in (torch.float32, torch.bfloat16) else torch.float32,
+                        modes=(0, 1) if grad else (0,))        # all stale packed weights in one launch (after an optimizer step)
+            if grad:                                           # one zero fill for every parameter-gradient accumulator of the step
+                if getattr(self, "_grad_numel", None) is None:
+                    self._grad_numel = sum(p.numel() + 64 for p in self.parameters() if p.requires_grad)
+                L.grad_pool.begin(self._grad_numel, inp.device)
         features_maps_all = self.decoder(self.encoder(inp))
         feature_maps_head = [features_maps_all[i] for i in self.decoder_levels]
         pred_detection = self.head(feature_maps_head)

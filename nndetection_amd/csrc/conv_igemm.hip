@@ -755,7 +755,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     const bool r64 = (a.Cy % 64) == 0;
     static const int a256 = getenv("NNDET_IGEMM_A256") ? atoi(getenv("NNDET_IGEMM_A256")) : 0;
     const char* sv_env = getenv("NNDET_IGEMM_STRIDED");            // 0: 128-point tiles, 1: 64 points 2x2 waves, 2: 64 points 4 row waves
-    const int sv = sv_env ? atoi(sv_env) : 0;
+    const int sv = sv_env ? atoi(sv_env) : 2;                      // measured: profiles/round2_micro_strided_tiles.txt
     P->cfg = strided ? (r64 ? (sv == 1 ? 8 : (sv == 2 ? 9 : 2)) : (sv ? 10 : 3)) : (r64 ? 1 : (a256 ? 4 : 0));
     const int points = CFG_PTS[P->cfg];
     for (int i = 0; i < 3; ++i) if (Lmax[i] <= 0) return NNDET_EINVAL;
@@ -921,5 +921,53 @@ extern "C" int nndet_pack_weight(const NndetConv* c, int32_t mode, const float* 
     else
         k_pack<float><<<nb, 256, 0, as_stream(stream)>>>(w, (float*)packed, R, K, Rp, Kp, taps, sr, sk, total);
     LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ batched weight packing
+// All convolutions of a model re-pack their weights after every optimizer step: 66 tiny launches per step (0.4 ms of GPU time and as
+// much host time). One launch per up to PACK_MAX_JOBS (layer, mode) pairs instead; the job table travels as a kernel argument.
+#define PACK_MAX_JOBS 40
+struct PackJob { const float* w; void* out; int64_t sr, sk, total; int32_t R, K, Rp, Kp, dtype, pad; };
+struct PackJobs { PackJob j[PACK_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void k_pack_batched(const PackJobs J) {
+    const PackJob& job = J.j[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < job.total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % job.Kp);
+        const int64_t t2 = i / job.Kp;
+        const int r = (int)(t2 % job.Rp);
+        const int t = (int)(t2 / job.Rp);
+        float v = 0.f;
+        if (r < job.R && k < job.K) v = job.w[r * job.sr + k * job.sk + t];
+        if (job.dtype == NNDET_BF16) reinterpret_cast<bf16_t*>(job.out)[i] = f32_to_bf16(v);
+        else reinterpret_cast<float*>(job.out)[i] = v;
+    }
+}
+
+extern "C" int nndet_pack_weights_batched(const NndetConv* convs, const int32_t* modes, const float* const* w, void* const* out,
+                                          int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!convs || !modes || !w || !out))) return NNDET_EINVAL;
+    for (int base = 0; base < n; base += PACK_MAX_JOBS) {
+        PackJobs J;
+        memset(&J, 0, sizeof(J));
+        const int cnt = n - base < PACK_MAX_JOBS ? n - base : PACK_MAX_JOBS;
+        int64_t maxtotal = 1;
+        for (int q = 0; q < cnt; ++q) {
+            const NndetConv* c = convs + base + q;
+            const int mode = modes[base + q];
+            if ((mode != 0 && mode != 1) || !w[base + q] || !out[base + q]) return NNDET_EINVAL;
+            int R, K, Rp, Kp, taps; int64_t sr, sk;
+            pack_dims(c, mode, &R, &K, &Rp, &Kp, &taps, &sr, &sk);
+            PackJob& j = J.j[q];
+            j.w = w[base + q]; j.out = out[base + q]; j.sr = sr; j.sk = sk; j.total = (int64_t)taps * Rp * Kp;
+            j.R = R; j.K = K; j.Rp = Rp; j.Kp = Kp; j.dtype = c->dtype;
+            if (j.total > maxtotal) maxtotal = j.total;
+        }
+        int64_t bx = ceil_div64(maxtotal, 256 * 4);
+        if (bx > 1024) bx = 1024;
+        k_pack_batched<<<dim3((unsigned)bx, cnt), 256, 0, as_stream(stream)>>>(J);
+        LAUNCH_CHECK();
+    }
     return 0;
 }
