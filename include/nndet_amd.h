@@ -204,6 +204,14 @@ typedef struct NndetConv {
     int32_t in_d, in_h, in_w;     /* input spatial size (x, y, z of the reference = d, h, w here) */
     int32_t out_d, out_h, out_w;  /* output spatial size */
     int32_t k[3], s[3], p[3];     /* kernel, stride, padding per axis */
+    /* Deferred normalisation of the INPUT (may be NULL): [batch, cin_p, 2] fp32 (scale, shift) per image and channel. The forward
+     * and the weight-gradient kernels then read x as  relu?(x * scale + shift)  while staging it (zero padding stays zero), i.e.
+     * they consume the PRE-norm output of the previous conv + the coefficients of nndet_norm_finalize, and the normalised
+     * activation is never written to HBM (nndet/arch/conv.py:195,271: conv -> norm -> ReLU -> next conv). Arithmetic = the
+     * materialising nndet_norm_apply (fmaf, max, round to dtype), so both routes are bit-identical. Not for transposed convs. */
+    const float* in_affine;
+    int32_t in_relu;
+    int32_t reserved_;
 } NndetConv;
 
 /* pack W (fp32, PyTorch layout) -> [taps][rows_p][k_p] in `dtype`, zero padded.
@@ -245,6 +253,14 @@ int nndet_conv3d_backward_weight(const NndetConv* c, const void* x, const void* 
  * ---------------------------------------------------------------------------------------------- */
 int nndet_norm_stats(int32_t dtype, const void* x, int32_t batch, int64_t spatial, int32_t c_p,
                      double* stats /* zeroed */, void* stream);
+/* Coefficients only: mean_rstd_out [N, C_p, 2] (for backward) and scale_shift_out [N, C_p, 2] = (rstd * gamma, beta - mean * rstd *
+ * gamma) per image and channel (padded channels: 0, 0) -- what NndetConv.in_affine of the CONSUMER convolution takes. */
+int nndet_norm_finalize(const double* stats, const float* gamma, const float* beta, int32_t batch, int64_t spatial, int32_t c,
+                        int32_t c_p, int32_t groups, float eps, float* mean_rstd_out, float* scale_shift_out, void* stream);
+/* y = relu?(x * scale + shift) with scale_shift [N, C_p, 2] from nndet_norm_finalize: materialises a deferred activation (for a
+ * consumer that is not one of the convolution entry points above). */
+int nndet_affine_apply(int32_t dtype, const void* x, const float* scale_shift, int32_t batch, int64_t spatial, int32_t c_p,
+                       int32_t relu, void* y, void* stream);
 /* y = relu?((x - mean) * rstd * gamma + beta); mean_rstd_out [N, C_p, 2] fp32 is written for backward. */
 int nndet_norm_apply(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
                      int32_t batch, int64_t spatial, int32_t c, int32_t c_p, int32_t groups, float eps,

@@ -25,7 +25,8 @@ class NndetConv(C.Structure):
                 ("cin", C.c_int32), ("cout", C.c_int32), ("cin_p", C.c_int32), ("cout_p", C.c_int32),
                 ("in_d", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
                 ("out_d", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32),
-                ("k", C.c_int32 * 3), ("s", C.c_int32 * 3), ("p", C.c_int32 * 3)]
+                ("k", C.c_int32 * 3), ("s", C.c_int32 * 3), ("p", C.c_int32 * 3),
+                ("in_affine", C.c_void_p), ("in_relu", C.c_int32), ("reserved_", C.c_int32)]
 
 
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
@@ -66,6 +67,8 @@ SIGNATURES = {
     "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
     "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_norm_stats": (C.c_int, [_I32, _P, _I32, _I64, _I32, _P, _P]),
+    "nndet_norm_finalize": (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "nndet_affine_apply": (C.c_int, [_I32, _P, _P, _I32, _I64, _I32, _I32, _P, _P]),
     "nndet_norm_apply": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     "nndet_norm_backward": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nndet_segloss_forward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P, _P]),

@@ -27,6 +27,12 @@ class StackedConvBlock2(nn.Module):
             blocks.append(self.build_block(conv, out_channels, out_channels, conv_kernel, 1, padding, **kwargs))
         self.convs = nn.Sequential(*blocks)
         self.out_channels = out_channels
+        # every conv output that is consumed by the NEXT conv of this block only: its norm + ReLU is applied by that consumer while
+        # staging its input (arch/conv.py: deferred normalisation). The block's last output is decided by the encoder.
+        mods = [m for b in blocks for m in b]
+        for m in mods[:-1]:
+            if hasattr(m, "defer_output"):
+                m.defer_output = True
 
     @staticmethod
     def build_block(conv, in_channels, out_channels, kernel_size, stride, padding, **kwargs) -> nn.Module:

@@ -16,6 +16,7 @@ of NDHWC storage whose channel count is padded to a multiple of 32 (`layout.py`)
 PyTorch's layout; they are re-packed (and cast to the activation dtype) once per optimizer step.
 """
 import ctypes
+import os
 from typing import Optional, Sequence, Union
 
 import torch
@@ -24,7 +25,7 @@ import torch.nn as nn
 from .. import _lib as L
 from ..layout import cpad, phys, logical, mark_padded
 
-__all__ = ["Generator", "ConvInstanceRelu", "ConvGroupRelu", "conv_kwargs_helper", "compute_padding_for_kernel"]
+__all__ = ["Generator", "ConvInstanceRelu", "ConvGroupRelu", "conv_kwargs_helper", "compute_padding_for_kernel", "deferred", "materialize"]
 
 
 class Generator:
@@ -128,75 +129,70 @@ def _pad1d(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
     return v.contiguous() if v.numel() == n else torch.nn.functional.pad(v, (0, n - v.numel()))
 
 
-class _ConvBlockFn(torch.autograd.Function):
-    """conv (+bias) [-> InstanceNorm/GroupNorm (+ReLU)] as one node."""
+# Deferred normalisation is implemented and parity-tested on both routes, but OFF by default: every activation element is staged by
+# at least two consumers (forward + weight gradient, each with ~2x halo amplification), so the norm arithmetic is done ~4x instead
+# of once, in staging phases that are VALU / issue-bound rather than HBM-bound. Measured on one MI355X in the same process
+# (profiles/round2_defer_norm_ab.txt): 148.6 / 146.6 patches/s deferred vs 153.1 / 147.8 materialised; peak HBM 4.8 vs 6.5 GiB.
+DEFER_NORM = os.environ.get("NNDET_DEFER_NORM", "0") != "0"
+
+
+def deferred(x: torch.Tensor):
+    """(scale_shift [N, C_p, 2] fp32, relu) if `x` is a DEFERRED activation -- the pre-norm output of a conv block whose
+    InstanceNorm / GroupNorm (+ReLU) is applied by the CONSUMER convolution while it stages its input -- else None."""
+    return getattr(x, "_nndet_deferred", None)
+
+
+class _ConvFn(torch.autograd.Function):
+    """conv (+bias, + fused residual). Input: a plain activation or a deferred one (then `x_ss` = its scale/shift table and the
+    kernels read relu?(x * scale + shift): NndetConv.in_affine). Output: y and -- for blocks with a norm -- the per-(image, channel)
+    sum / sum of squares of y accumulated by the conv epilogue (non-differentiable side output for _NormFn)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, mod, residual=None):
+    def forward(ctx, x, x_ss, x_relu, weight, bias, mod, residual, want_stats):
         x_p, cin = phys(x)
         if cin != mod.in_channels:
             raise L.NndetError(f"expected {mod.in_channels} input channels, got {cin}")
         desc = _desc(x_p, mod.in_channels, mod.out_channels, mod.k, mod.s, mod.p, mod.transposed)
+        if x_ss is not None:
+            if mod.transposed or desc.cin_p == 1 or tuple(x_ss.shape) != (desc.batch, desc.cin_p, 2):
+                raise L.NndetError("deferred input normalisation: unsupported consumer or coefficient table shape")
+            desc.in_affine, desc.in_relu = x_ss.data_ptr(), int(x_relu)
         dev, dt = x_p.device, x_p.dtype
         N, cout, cout_p = desc.batch, desc.cout, desc.cout_p
         stem = desc.cin_p == 1
         w_arg = weight.detach().float().contiguous() if stem else _packed(mod, 0, weight, desc, dt)
         y = torch.empty((N, desc.out_d, desc.out_h, desc.out_w, cout_p), dtype=dt, device=dev)
-        has_norm = gamma is not None
-        stats = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev) if has_norm else None
+        stats = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev) if want_stats else None
         b_p = _pad1d(bias, cout_p)
         r_p = None
         if residual is not None:
-            if has_norm:
+            if want_stats:
                 raise L.NndetError("a fused residual is only defined for convolutions without norm")
             r_p, _ = phys(residual, dtype=dt, cp=cout_p)
             if tuple(r_p.shape) != tuple(y.shape):
                 raise L.NndetError(f"residual shape {tuple(residual.shape)} does not match the conv output")
         L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats), L.stream())
-        ctx.desc, ctx.mod, ctx.has_norm, ctx.has_bias, ctx.has_res = desc, mod, has_norm, bias is not None, residual is not None
-        if has_norm:
-            out = torch.empty_like(y)
-            mean_rstd = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
-            spatial = desc.out_d * desc.out_h * desc.out_w
-            g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-            L.call("nndet_norm_apply", desc.dtype, L.ptr(y), L.ptr(stats), L.ptr(g32), L.ptr(b32), N, spatial, cout, cout_p,
-                   mod.norm_groups, float(mod.norm_eps), int(mod.relu), L.ptr(out), L.ptr(mean_rstd), L.stream())
-            ctx.save_for_backward(x_p, weight, y, mean_rstd, g32, b32)
-        else:
-            out = y
-            ctx.save_for_backward(x_p, weight)
-        res = logical(out, cout)
-        return res
+        ctx.desc, ctx.mod, ctx.has_bias, ctx.has_res = desc, mod, bias is not None, residual is not None
+        ctx.x_ss = x_ss                      # (tiny) keeps the table alive for the weight gradient
+        ctx.save_for_backward(x_p, weight)
+        out = logical(y, cout)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return out, stats
+        return out, None
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _grad_stats=None):
         desc, mod = ctx.desc, ctx.mod
-        N, cout, cout_p = desc.batch, desc.cout, desc.cout_p
-        if ctx.has_norm:
-            x_p, weight, y, mean_rstd, g32, b32 = ctx.saved_tensors
-        else:
-            x_p, weight = ctx.saved_tensors
+        cout, cout_p = desc.cout, desc.cout_p
+        x_p, weight = ctx.saved_tensors
         dev, dt = x_p.device, x_p.dtype
-        g_p, _ = phys(grad_out, dtype=dt, cp=cout_p)
-        # all parameter gradients of this node (dW, dbias, dgamma, dbeta) are views of ONE zero-filled buffer: one fill kernel
-        # per node instead of up to four
+        dconv, _ = phys(grad_out, dtype=dt, cp=cout_p)
+        # dW and dbias of this node are views of the per-step gradient pool (ONE zero fill per step, _lib.grad_pool)
         nw = weight.numel()
-        gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0) + (2 * cout if ctx.has_norm else 0), dev)
+        gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
         dw = gbuf[:nw].view(weight.shape)
-        off = nw
-        dbias = None
-        if ctx.has_bias:
-            dbias = gbuf[off:off + cout]; off += cout
-        dgamma = dbeta = None
-        if ctx.has_norm:
-            dconv = torch.empty_like(y)
-            dgamma, dbeta = gbuf[off:off + cout], gbuf[off + cout:off + 2 * cout]
-            red = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev)
-            spatial = desc.out_d * desc.out_h * desc.out_w
-            L.call("nndet_norm_backward", desc.dtype, L.ptr(y), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,
-                   cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.ptr(red), L.stream())
-        else:
-            dconv = g_p
+        dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
             if desc.cin_p == 1:
@@ -204,13 +200,63 @@ class _ConvBlockFn(torch.autograd.Function):
             w1 = _packed(mod, 1, weight, desc, dt)
             dx_p = torch.empty_like(x_p)
             L.call("nndet_conv3d_backward_data", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.stream())
-            dx = logical(dx_p, desc.cin)
+            dx = logical(dx_p, desc.cin)      # gradient w.r.t. the input AS THE CONV SAW IT (i.e. after a deferred norm + ReLU)
         ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
         ws = L.workspace(ws_bytes, dev)
         L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw), L.ptr(dbias),
                L.ptr(ws), ws_bytes, L.stream())
         # d(residual) = grad_out: the same NDHWC buffer is handed to both consumers (no copy, no add kernel)
-        return dx, dw.to(weight.dtype), dbias, dgamma, dbeta, None, (logical(g_p, cout) if ctx.has_res else None)
+        return dx, None, None, dw.to(weight.dtype), dbias, None, (logical(dconv, cout) if ctx.has_res else None), None
+
+
+class _NormFn(torch.autograd.Function):
+    """InstanceNorm / GroupNorm (+ReLU) of a conv output from the epilogue statistics.
+    materialize=True : writes relu?(norm(y)) (one read + one write of the activation);
+    materialize=False: DEFERRED -- only the coefficients are computed (nndet_norm_finalize); the returned tensor aliases y and is
+                       tagged by the caller; every consumer convolution applies relu?(y * scale + shift) while staging its input,
+                       so the normalised activation never exists in HBM. Backward is the same in both cases: from the gradient
+                       w.r.t. the normalised activation (what the consumers' data gradients deliver) to dy, dgamma, dbeta."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, stats, mod, materialize):
+        y_p, cout = phys(y)
+        N, cout_p = y_p.shape[0], y_p.shape[4]
+        spatial = y_p.shape[1] * y_p.shape[2] * y_p.shape[3]
+        dev = y_p.device
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        mean_rstd = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
+        code = L.dtype_code(y_p)
+        if materialize:
+            out_p = torch.empty_like(y_p)
+            L.call("nndet_norm_apply", code, L.ptr(y_p), L.ptr(stats), L.ptr(g32), L.ptr(b32), N, spatial, cout, cout_p,
+                   mod.norm_groups, float(mod.norm_eps), int(mod.relu), L.ptr(out_p), L.ptr(mean_rstd), L.stream())
+            ss = None
+            out = logical(out_p, cout)
+        else:
+            ss = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
+            L.call("nndet_norm_finalize", L.ptr(stats), L.ptr(g32), L.ptr(b32), N, spatial, cout, cout_p, mod.norm_groups,
+                   float(mod.norm_eps), L.ptr(mean_rstd), L.ptr(ss), L.stream())
+            out = logical(y_p.view(y_p.shape), cout)          # an alias of y's storage (no kernel)
+        ctx.mod, ctx.code, ctx.dims = mod, code, (N, spatial, cout, cout_p)
+        ctx.save_for_backward(y_p, mean_rstd, g32, b32)
+        if ss is not None:
+            ctx.mark_non_differentiable(ss)
+        return out, ss
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_ss=None):
+        mod = ctx.mod
+        N, spatial, cout, cout_p = ctx.dims
+        y_p, mean_rstd, g32, b32 = ctx.saved_tensors
+        dev, dt = y_p.device, y_p.dtype
+        g_p, _ = phys(grad_out, dtype=dt, cp=cout_p)
+        gbuf = L.grad_pool.take(2 * cout, dev)
+        dgamma, dbeta = gbuf[:cout], gbuf[cout:]
+        dconv = torch.empty_like(y_p)
+        red = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev)
+        L.call("nndet_norm_backward", ctx.code, L.ptr(y_p), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,
+               cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.ptr(red), L.stream())
+        return logical(dconv, cout), dgamma, dbeta, None, None, None
 
 
 class BaseConvNormAct(nn.Sequential):
@@ -252,14 +298,56 @@ class BaseConvNormAct(nn.Sequential):
             self.add_module("act", nn.ReLU(inplace=bool(norm is not None) if act_inplace is None else act_inplace))
             self.relu = True
         self._pack_cache = {}
+        self.defer_output = False        # set by our containers: the norm + ReLU of the output is applied by the consumer convs
         if initializer is not None:
             self.apply(initializer)
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """residual (optional, only without norm): returns conv(x) + residual from ONE kernel (epilogue add)."""
+        """residual (optional, only without norm): returns conv(x) + residual from ONE kernel (epilogue add).
+        `x` may be a deferred activation (see `deferred`); with `self.defer_output` (set by OUR containers for outputs that only
+        our own convolutions consume) the result is one: its norm + ReLU is applied by the consumers on load."""
         has_norm = self.norm_groups > 0
-        return _ConvBlockFn.apply(x, self.conv.weight, self.conv.bias,
-                                  self.norm.weight if has_norm else None, self.norm.bias if has_norm else None, self, residual)
+        d = deferred(x)
+        if d is not None and (self.transposed or self.in_channels == 1):
+            x, d = materialize(x), None
+        x_ss, x_relu = d if d is not None else (None, False)
+        y, stats = _ConvFn.apply(x, x_ss, x_relu, self.conv.weight, self.conv.bias, self, residual, has_norm)
+        if not has_norm:
+            return y
+        defer = bool(self.defer_output) and DEFER_NORM and y.is_cuda
+        out, ss = _NormFn.apply(y, self.norm.weight, self.norm.bias, stats, self, not defer)
+        if defer:
+            mark_padded(out)
+            out._nndet_deferred = (ss, self.relu)
+        return out
+
+
+def materialize(x: torch.Tensor) -> torch.Tensor:
+    """A deferred activation as a plain tensor (for a consumer that cannot apply the norm on load): one k_norm_apply pass,
+    differentiable (the gradient flows back into the deferred tensor)."""
+    d = deferred(x)
+    if d is None:
+        return x
+    return _Materialize.apply(x, d[0], d[1])
+
+
+class _Materialize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ss, relu):
+        x_p, c = phys(x)
+        out = torch.empty_like(x_p)
+        N, cp = x_p.shape[0], x_p.shape[4]
+        spatial = x_p.shape[1] * x_p.shape[2] * x_p.shape[3]
+        L.call("nndet_affine_apply", L.dtype_code(x_p), L.ptr(x_p), L.ptr(ss), N, spatial, cp, int(relu), L.ptr(out), L.stream())
+        ctx.save_for_backward(x_p, ss)
+        ctx.relu, ctx.c = relu, c
+        return logical(out, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        # d/d(a) -> d/d(a): the consumers of a deferred tensor hand back the gradient w.r.t. the NORMALISED activation, and so
+        # does this node (the ReLU mask is applied by the producer's norm backward from y itself)
+        return g, None, None
 
 
 class ConvInstanceRelu(BaseConvNormAct):

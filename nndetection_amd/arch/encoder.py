@@ -33,6 +33,7 @@ class Encoder(nn.Module):
             self.out_channels.append(in_channels)
             stages.append(blk)
         self.stages = nn.ModuleList(stages)
+        self.defer_outputs = False       # see set_defer_outputs
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         outputs = []
@@ -41,6 +42,15 @@ class Encoder(nn.Module):
             if sid in self.out_stages:
                 outputs.append(x)
         return outputs
+
+    def set_defer_outputs(self, on: bool) -> None:
+        """Hand the stage outputs on as DEFERRED activations (pre-norm tensor + coefficients, arch/conv.py). Only the detector
+        switches this on, and only when every consumer of the encoder outputs is one of our own convolutions (next stage, decoder
+        laterals); stand-alone the encoder returns ordinary tensors like the reference's."""
+        self.defer_outputs = bool(on)
+        for stage in self.stages:
+            last = [m for m in stage.modules() if hasattr(m, "defer_output")][-1]
+            last.defer_output = bool(on)
 
     def get_channels(self) -> List[int]:
         return [self.out_channels[s] for s in range(self.num_stages) if s in self.out_stages]

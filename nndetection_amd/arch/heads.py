@@ -33,6 +33,9 @@ def _trunk(conv, in_channels, internal_channels, num_convs, **kwargs) -> nn.Sequ
     t.add_module("c_in", conv(in_channels, internal_channels, kernel_size=3, stride=1, padding=1, **kwargs))
     for i in range(num_convs):
         t.add_module(f"c_internal{i}", conv(internal_channels, internal_channels, kernel_size=3, stride=1, padding=1, **kwargs))
+    for m in t:                          # consumed by the next trunk conv / conv_out only: norm + ReLU applied by the consumer on load
+        if hasattr(m, "defer_output"):
+            m.defer_output = True
     return t
 
 

@@ -32,6 +32,9 @@ class BaseRetinaNet(nn.Module):
             if segmenter is not None:
                 used.add(0)
             self.decoder.used_levels = used          # out convs nobody reads are not computed
+        from ..arch.decoder import UFPNModular
+        if isinstance(self.decoder, UFPNModular) and hasattr(self.encoder, "set_defer_outputs"):
+            self.encoder.set_defer_outputs(True)     # the decoder's lateral convs apply the encoder's norm + ReLU on load
 
     def never_used_parameters(self) -> List[nn.Parameter]:
         """Parameters that exist for state-dict parity with the reference but never receive a gradient: the decoder output convs

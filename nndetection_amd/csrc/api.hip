@@ -21,7 +21,7 @@ extern "C" int nndet_conv3d_forward(const NndetConv* c, const void* x, const voi
     if (!x || !w || !y) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
     if (c->cin_p == 1) {
-        if (residual) return NNDET_EINVAL;
+        if (residual || c->in_affine) return NNDET_EINVAL;
         int stats_done = 0;
         rc = stem_forward(c, x, (const float*)w, bias, y, stats, &stats_done, st);
         if (rc) return rc;

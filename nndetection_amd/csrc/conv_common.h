@@ -24,3 +24,45 @@ int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hip
 // norm.hip
 int colsum_run(int dtype, const void* x, int64_t rows, int c_p, int c, float* out, hipStream_t st);
 int norm_stats_run(int dtype, const void* x, int batch, int64_t spatial, int c_p, double* stats, hipStream_t st);
+
+// ---- deferred input normalisation (NndetConv.in_affine): x' = relu?(x * scale + shift) on one 16-byte piece while it is staged.
+// Exactly the arithmetic of k_norm_apply (fmaf, fmaxf, round-to-nearest-even pack), so a consumer that applies the norm on load
+// sees bit-identical activations to one that reads the materialised tensor.
+template <typename T> struct AffinePiece;
+template <> struct AffinePiece<bf16_t> {
+    static constexpr int E = 8;
+    // 20 VALU ops per piece: 8 unpack, 4 v_pk_fma_f32, 4 v_cvt_pk_bf16_f32, 4 v_pk_max_i16 (ReLU on the packed bf16 pair: a
+    // negative bf16 -- incl. -0 -- is a negative int16; rounding is monotone, so relu(round(x)) == round(relu(x)))
+    __device__ static __forceinline__ u32x4 apply(const u32x4 v, const float* sc, const float* sh, int relu) {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2_t x = {__uint_as_float(v[i] << 16), __uint_as_float(v[i] & 0xffff0000u)};
+            const f32x2_t r = __builtin_elementwise_fma(x, f32x2_t{sc[2 * i], sc[2 * i + 1]}, f32x2_t{sh[2 * i], sh[2 * i + 1]});
+            uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
+            if (relu) p = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
+            o[i] = p;
+        }
+        return o;
+    }
+};
+template <> struct AffinePiece<float> {
+    static constexpr int E = 4;
+    __device__ static __forceinline__ u32x4 apply(const u32x4 v, const float* sc, const float* sh, int relu) {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = fmaf(__uint_as_float(v[i]), sc[i], sh[i]);
+            if (relu) x = fmaxf(x, 0.f);
+            o[i] = __float_as_uint(x);
+        }
+        return o;
+    }
+};
+// (scale, shift) pairs of E consecutive channels starting at `ch` of image n: table [N][C_p][2]
+template <int E> __device__ __forceinline__ void load_affine(const float* __restrict__ ss, int n, int C_p, int ch, float* sc, float* sh) {
+    const float2* p = reinterpret_cast<const float2*>(ss) + (int64_t)n * C_p + ch;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const float2 v = p[e]; sc[e] = v.x; sh[e] = v.y; }
+}

@@ -87,6 +87,8 @@ struct IgTapX { int32_t toff; int32_t flip; int32_t woff; int32_t pad; };   // L
 struct IgArgs {
     const void* x; const void* w; const float* bias; void* y; double* stats;
     const void* res;      // optional residual, same layout as y: y = conv + bias + res (decoder top-down add fused away)
+    const float* ss;      // deferred input norm: [N][Cx][2] (scale, shift), NULL = read x as it is (NndetConv.in_affine)
+    int32_t ss_relu;
     int32_t N;
     int32_t I[3], Cx;     // input tensor spatial dims, physical channels (= K)
     int32_t O[3], Cy;     // output tensor spatial dims, physical channels (= rows)
@@ -115,7 +117,7 @@ struct IgArgs {
 // before the MFMAs of the second half. Measured +20 % on the stride-2 forward convs; for 1-tap problems (1x1x1, transposed) the
 // same loop was 25 % slower than the plain one, which is why it is a per-configuration choice
 // (profiles/round1_micro_v8_generic_pinned_rejected.txt).
-template <typename T, int WR, int MT, int NT, int MAXP, int MINW, bool PIPE = false>
+template <typename T, int WR, int MT, int NT, int MAXP, int MINW, bool PIPE = false, bool AFF = false>
 __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
@@ -201,6 +203,9 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
         constexpr int NH = NT / 2;
         for (int kc = 0; kc < nchunk; ++kc) {
             __syncthreads();
+            float asc[EPL], ash[EPL];          // deferred input norm of this thread's 16-byte part of the chunk (AFF variants only)
+            if constexpr (AFF) load_affine<EPL>(A.ss, n, A.Cx, kc * KC + (tid & 3) * EPL, asc, ash);
+            auto aff = [&](const u32x4& v_) { if constexpr (AFF) return AffinePiece<T>::apply(v_, asc, ash, A.ss_relu); else return v_; };
 #pragma unroll
             for (int s0 = 0; s0 < MAXP; s0 += 8) {
                 if (s0 * 256 >= HV4) break;   // uniform
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
                     const int p = tid + (s0 + b) * 256;
                     if (p < HV4)
                         *reinterpret_cast<u32x4*>(smem + ((p * 16) ^ (((swmask >> (s0 + b)) & 1u) << 5))) =
-                            goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
+                            goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : aff(v[b]);
                 }
             }
             __syncthreads();
@@ -265,6 +270,9 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
     } else
     for (int kc = 0; kc < nchunk; ++kc) {
         __syncthreads();
+        float asc[EPL], ash[EPL];              // deferred input norm of this thread's 16-byte part of the chunk (AFF variants only)
+        if constexpr (AFF) load_affine<EPL>(A.ss, n, A.Cx, kc * KC + (tid & 3) * EPL, asc, ash);
+        auto aff = [&](const u32x4& v_) { if constexpr (AFF) return AffinePiece<T>::apply(v_, asc, ash, A.ss_relu); else return v_; };
         // Stage the halo in batches of 8 UNCONDITIONAL 16-byte loads per thread (out-of-tensor pieces load a clamped,
         // valid address and are zeroed afterwards): all loads of a batch are in flight together. A conditional load per
         // piece makes hipcc branch + wait vmcnt(0) per piece, i.e. 16-24 serial HBM round trips per chunk.
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
                 const int p = tid + (s0 + b) * 256;
                 if (p < HV4)
                     *reinterpret_cast<u32x4*>(smem + ((p * 16) ^ (((swmask >> (s0 + b)) & 1u) << 5))) =
-                        goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : v[b];
+                        goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : aff(v[b]);
             }
         }
         __syncthreads();
@@ -424,7 +432,7 @@ __device__ __forceinline__ float dpp_row_sum(float v) {   // sum over the 16 lan
     return v;
 }
 
-template <typename T, int WR, int MT, int NT, int MINW>
+template <typename T, int WR, int MT, int NT, int MINW, bool AFF = false>
 __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
@@ -495,6 +503,8 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
     const int nchunk = A.Cx / KC;
     for (int kc = 0; kc < nchunk; ++kc) {
         __syncthreads();
+        float asc[EPL], ash[EPL];              // deferred input norm: this thread stages part (cp & 3) of every halo voxel (AFF variants)
+        if constexpr (AFF) load_affine<EPL>(A.ss, n, A.Cx, kc * KC + (cp & 3) * EPL, asc, ash);
 #pragma unroll
         for (int s0 = 0; s0 < MAXP; s0 += 8) {
             u32x4 v[8];
@@ -505,8 +515,11 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
             if (st_active) {
 #pragma unroll
                 for (int b = 0; b < 8; ++b)
-                    if (s0 + b < MAXP && (s0 + b + 1 < MAXP || sr0 + (s0 + b) * RPS < NROW))
+                    if (s0 + b < MAXP && (s0 + b + 1 < MAXP || sr0 + (s0 + b) * RPS < NROW)) {
+                        // out-of-tensor pieces (offset >= 2^31: the hardware returned zeros) are the conv padding: they stay zero
+                        if constexpr (AFF) v[b] = goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : AffinePiece<T>::apply(v[b], asc, ash, A.ss_relu);
                         *reinterpret_cast<u32x4*>(smem + st_dst0 + (s0 + b) * (RPS * ROWP * 16)) = v[b];
+                    }
             }
         }
         __syncthreads();
@@ -818,20 +831,20 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     return 0;
 }
 
-template <typename T>
+template <typename T, bool AFF>
 static int launch_cfg(const Plan& P, hipStream_t st) {
     switch (P.cfg) {
-        case 0: k_igemm<T, 1, 2, 8, 16, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 1: k_igemm<T, 2, 2, 8, 16, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 2: k_igemm<T, 2, 2, 4, 24, 3, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 3: k_igemm<T, 2, 1, 4, 24, 4, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 8: k_igemm<T, 2, 2, 2, 16, 3, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 9: k_igemm<T, 4, 1, 4, 16, 3, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 10: k_igemm<T, 2, 1, 2, 16, 4, true><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 5: k_ig3<T, 1, 2, 8, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 6: k_ig3<T, 2, 2, 8, 3><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 7: k_ig3<T, 2, 2, 16, 2><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        default: k_igemm<T, 1, 2, 4, 16, 4><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 0: k_igemm<T, 1, 2, 8, 16, 2, false, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 1: k_igemm<T, 2, 2, 8, 16, 3, false, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 2: k_igemm<T, 2, 2, 4, 24, 3, true, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 3: k_igemm<T, 2, 1, 4, 24, 4, true, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 8: k_igemm<T, 2, 2, 2, 16, 3, true, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 9: k_igemm<T, 4, 1, 4, 16, 3, true, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 10: k_igemm<T, 2, 1, 2, 16, 4, true, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 5: k_ig3<T, 1, 2, 8, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 6: k_ig3<T, 2, 2, 8, 3, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 7: k_ig3<T, 2, 2, 16, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        default: k_igemm<T, 1, 2, 4, 16, 4, false, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
     }
     LAUNCH_CHECK();
     return 0;
@@ -839,13 +852,19 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
 
 template <typename T, int WR, int MT, int NT, int MAXP, int MINW, bool PIPE = false>
 static int set_lds_attr() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP, MINW, PIPE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP, MINW, PIPE, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP, MINW, PIPE, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    return rc;
 }
 template <typename T, int WR, int MT, int NT, int MINW>
 static int set_lds_attr3() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, WR, MT, NT, MINW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, WR, MT, NT, MINW, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, WR, MT, NT, MINW, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    return rc;
 }
 static int g_attr_done = 0;
 static int ensure_attrs() {
@@ -864,7 +883,7 @@ static int ensure_attrs() {
 
 int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y,
               double* stats, hipStream_t st) {
-    if (!stats) {                     // pointwise problems (1x1x1, transposed k == s) stream straight from global memory
+    if (!stats && !(kind == 0 && c->in_affine && c->transposed)) {   // pointwise problems (1x1x1, transposed k == s) stream straight from global memory
         const int prc = pw_run(c, kind, x, w, bias, res, y, st);
         if (prc != 1) return prc;
     }
@@ -874,7 +893,13 @@ int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const 
     rc = ensure_attrs();
     if (rc) return rc;
     P.a.x = x; P.a.w = w; P.a.bias = bias; P.a.y = y; P.a.stats = stats; P.a.res = res;
-    return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t>(P, st) : launch_cfg<float>(P, st);
+    P.a.ss = nullptr; P.a.ss_relu = 0;
+    if (kind == 0 && c->in_affine) {
+        if (c->transposed) return NNDET_EINVAL;
+        P.a.ss = c->in_affine; P.a.ss_relu = c->in_relu;
+    }
+    if (P.a.ss) return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t, true>(P, st) : launch_cfg<float, true>(P, st);
+    return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t, false>(P, st) : launch_cfg<float, false>(P, st);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing

@@ -53,6 +53,9 @@ struct PwArgs {
     int32_t ncls;             // kernel positions S0 * S1 * S2
     int32_t ntiles;           // ceil(npts / 16)
     uint32_t mL2, mL1, mL0;   // magic multipliers for / L[2], / L[1], / L[0] (0 = divisor 1)
+    const float* ss;          // deferred input norm [N][Cx][2] (1x1x1 forward only), NULL = off
+    int32_t ss_relu;
+    int32_t tiles_per_img;    // 16-point tiles per image (ss != NULL requires the image size to be a multiple of 16 points)
 };
 
 // strided-tensor point index of lattice point p (decomposed on the fly) and class (c0, c1, c2)
@@ -102,6 +105,8 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
     const int wave_global = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
     const int S1 = A.S[1], S2 = A.S[2];
 
+    float asc[NKC][EPL], ash[NKC][EPL];      // deferred input norm of this lane's channels (q * EPL .. of every chunk), image ss_n
+    int ss_n = -1;
     for (int t0 = wave_global * U; t0 < A.ntiles; t0 += nwaves * U) {
         if constexpr (MODE == 0) {
             u32x4 b[U][NKC];
@@ -117,6 +122,16 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (t0 + u >= A.ntiles) break;               // uniform
+                if (A.ss) {
+                    const int n_img = (t0 + u) / A.tiles_per_img;        // wave-uniform: a tile never straddles two images
+                    if (n_img != ss_n) {
+                        ss_n = n_img;
+#pragma unroll
+                        for (int kc = 0; kc < NKC; ++kc) load_affine<EPL>(A.ss, n_img, A.Cx, kc * KC + q * EPL, asc[kc], ash[kc]);
+                    }
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) b[u][kc] = AffinePiece<T>::apply(b[u][kc], asc[kc], ash[kc], A.ss_relu);
+                }
                 for (int c = 0; c < A.ncls; ++c) {
                     f32x4 acc[MT];
 #pragma unroll
@@ -257,6 +272,11 @@ int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const flo
         if (bias || res) return 1;
     }
     A.ncls = ncls;
+    if (kind == 0 && c->in_affine) {
+        const int64_t per_img = (int64_t)A.L[0] * A.L[1] * A.L[2];
+        if (tr || per_img % 16 != 0) return 1;            // generic kernel (per-piece image index there)
+        A.ss = c->in_affine; A.ss_relu = c->in_relu; A.tiles_per_img = (int32_t)(per_img / 16);
+    }
     if (A.Cx % KC != 0 || A.Cy % 32 != 0) return 1;
     const int nkc = A.Cx / KC, mt_total = A.Cy / 16;
     if (nkc > 8) return 1;

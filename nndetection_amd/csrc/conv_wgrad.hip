@@ -26,6 +26,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct WgTap { int32_t d[3]; int32_t wt; };
 struct WgArgs {
     const void* p; const void* q; float* dw;
+    const float* qss;     // deferred norm of Q (= X of a Conv3d): [N][Cq][2] (scale, shift), NULL = off (NndetConv.in_affine)
+    int32_t qss_relu;
     float* dbias;         // k_wgrad3 only: column sums of P (= dY) accumulated by the otherwise idle 28th tap slot; NULL = off
     float* part;          // partial results [S][rb*kb][ntap][32][32] fp32 (reduced by k_wgrad_reduce)
     int32_t N;
@@ -85,7 +87,7 @@ template <> struct WF<float> {
 
 // NTS = tap slots per wave (compile time: the MFMA phase is straight-line code, the compiler software-pipelines the
 // LDS transpose reads against the MFMAs); SPLIT = waves split the taps (else: the contraction steps)
-template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT>
+template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT, bool AFF = false>
 __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     constexpr int RB = 32 * (int)sizeof(T);      // bytes of one voxel's 32-channel block
     constexpr int PPV = RB / 16;                  // 16-byte pieces per voxel
@@ -177,9 +179,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     // into one HBM round trip each.
     u32x4 vp[MAXP], vq[MAXQ];
     uint32_t okp = 0, okq = 0;
+    int n_staged = 0;                             // image of the tile whose pieces sit in vq (deferred input norm)
 
     auto issue = [&](int tile) {
         const int n = tile / tiles_per_n;
+        n_staged = n;
         int tt = tile - n * tiles_per_n;
         const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
         const int th_i = tt % A.nt[1];
@@ -214,10 +218,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 #pragma unroll
         for (int s = 0; s < MAXP; ++s)
             if (prel[s] >= 0) *reinterpret_cast<u32x4*>(sp + pdst[s]) = ((okp >> s) & 1u) ? vp[s] : u32x4{0u, 0u, 0u, 0u};
+        float asc[E16], ash[E16];
+        if constexpr (AFF) load_affine<E16>(A.qss, n_staged, A.Cq, k0 + (tid % PPV) * E16, asc, ash);
 #pragma unroll
         for (int s = 0; s < MAXQ; ++s) {
             if (s * 256 >= NQP) break;   // uniform
-            if (qrel[s] >= 0) *reinterpret_cast<u32x4*>(sq + qdst[s]) = ((okq >> s) & 1u) ? vq[s] : u32x4{0u, 0u, 0u, 0u};
+            if (qrel[s] >= 0) {
+                u32x4 v = vq[s];
+                if constexpr (AFF) v = AffinePiece<T>::apply(v, asc, ash, A.qss_relu);
+                *reinterpret_cast<u32x4*>(sq + qdst[s]) = ((okq >> s) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
+            }
         }
     };
     auto compute = [&]() {
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 //     LDS round trip was exposed, 25 % MFMA utilisation);
 //   * 256 registers per wave -> two workgroups per CU.
 // Work split as in k_wgrad: the 4 waves take taps wv, wv + 4, ... (7 slots, 27 of 28 used), all 8 contraction steps.
-template <typename T, int MINW>
+template <typename T, int MINW, bool AFF = false>
 __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
     constexpr int RB = 32 * (int)sizeof(T), PPV = RB / 16;
     constexpr int KS = 8, NTS = 7, TD = 4, TH = 8, HD = TD + 2, HH = TH + 2, HW = 10;
@@ -361,9 +371,12 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
     const int tiles_per_n = A.nt[0] * A.nt[1] * A.nt[2];
     const int p_img = A.PL[0] * A.PL[1] * A.PL[2] * A.Cp * (int)sizeof(T), q_img = A.QD[0] * A.QD[1] * A.QD[2] * A.Cq * (int)sizeof(T);
     u32x4 vp[PSTEPS], vq[QSTEPS];
+    uint32_t okq = 0;                             // deferred input norm: which Q pieces are inside the tensor (padding stays zero)
+    int n_staged = 0;
 
     auto issue = [&](int tile) {
         const int n = tile / tiles_per_n;
+        n_staged = n; okq = 0;
         int tt = tile - n * tiles_per_n;
         const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
         const int th_i = tt % A.nt[1];
@@ -389,6 +402,7 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
             const int hd = r / HH, hh = r - hd * HH;
             const int qd = q0d + hd, qh = q0h + hh;
             const bool ok = okw && (unsigned)qd < (unsigned)A.QD[0] && (unsigned)qh < (unsigned)A.QD[1] && (s2 + 1 < QSTEPS || r < QNROW);
+            if constexpr (AFF) okq |= (uint32_t)ok << s2;
             vq[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 qrs, ok ? (qd * A.QD[1] + qh) * q_rowb + q_colb + q_org : (int)0x80000000, 0, 0));
         }
@@ -397,9 +411,15 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
 #pragma unroll
         for (int s2 = 0; s2 < PSTEPS; ++s2) *reinterpret_cast<u32x4*>(sp + p_dst[s2]) = vp[s2];
         if (q_active) {
+            constexpr int E16 = 16 / (int)sizeof(T);
+            float asc[E16], ash[E16];
+            if constexpr (AFF) load_affine<E16>(A.qss, n_staged, A.Cq, k0 + (q_cp % PPV) * E16, asc, ash);
 #pragma unroll
             for (int s2 = 0; s2 < QSTEPS; ++s2)
-                if (s2 + 1 < QSTEPS || q_r0 + s2 * QRPS < QNROW) *reinterpret_cast<u32x4*>(sq + q_dst0 + s2 * (QRPS * QROW)) = vq[s2];
+                if (s2 + 1 < QSTEPS || q_r0 + s2 * QRPS < QNROW) {
+                    if constexpr (AFF) vq[s2] = ((okq >> s2) & 1u) ? AffinePiece<T>::apply(vq[s2], asc, ash, A.qss_relu) : u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4*>(sq + q_dst0 + s2 * (QRPS * QROW)) = vq[s2];
+                }
         }
     };
     // wave 3's last slot would recompute tap 0 and discard it (27 taps on 28 slots): it accumulates sum_p dY[p][r] instead
@@ -508,11 +528,14 @@ template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT>
 static int wg_launch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         attr = true;
     }
-    k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT><<<grid, 256, lds, st>>>(a);
+    if (a.qss) k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, true><<<grid, 256, lds, st>>>(a);      // deferred input norm applied while staging X
+    else k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, false><<<grid, 256, lds, st>>>(a);
     LAUNCH_CHECK();
     return 0;
 }
@@ -568,7 +591,9 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
         a.p = dy; a.q = x; a.Cp = c->cout_p; a.Cq = c->cin_p; a.R = c->cout; a.K = c->cin;
         a.sr = (int64_t)c->cin * T; a.sk = T;
         for (int i = 0; i < 3; ++i) { a.PL[i] = out_sp[i]; a.QD[i] = in_sp[i]; a.step[i] = c->s[i]; a.qbase[i] = -c->p[i]; }
+        a.qss = c->in_affine; a.qss_relu = c->in_relu;       // deferred input norm: X is read as relu?(x * scale + shift)
     } else {     // P = X, Q = dY ; dW [Cin][Cout][T]
+        if (c->in_affine) return NNDET_EINVAL;
         for (int i = 0; i < 3; ++i) if (c->k[i] != c->s[i] || c->p[i] != 0) return NNDET_EINVAL;
         a.p = x; a.q = dy; a.Cp = c->cin_p; a.Cq = c->cout_p; a.R = c->cin; a.K = c->cout;
         a.sr = (int64_t)c->cout * T; a.sk = T;
@@ -644,12 +669,22 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             dim3 g3(S3, rb, kb);
             if (bf) {
                 static bool at = false;
-                if (!at) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); at = true; }
-                k_wgrad3<bf16_t, 2><<<g3, 256, lds3, st>>>(b);
+                if (!at) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                    at = true;
+                }
+                if (b.qss) k_wgrad3<bf16_t, 2, true><<<g3, 256, lds3, st>>>(b);
+                else k_wgrad3<bf16_t, 2, false><<<g3, 256, lds3, st>>>(b);
             } else {
                 static bool at = false;
-                if (!at) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); at = true; }
-                k_wgrad3<float, 1><<<g3, 256, lds3, st>>>(b);
+                if (!at) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                    at = true;
+                }
+                if (b.qss) k_wgrad3<float, 1, true><<<g3, 256, lds3, st>>>(b);
+                else k_wgrad3<float, 1, false><<<g3, 256, lds3, st>>>(b);
             }
             LAUNCH_CHECK();
             const int64_t total3 = (int64_t)rb * kb * 27 * 1024;

@@ -104,7 +104,8 @@ extern "C" int nndet_norm_stats(int32_t dtype, const void* x, int32_t batch, int
 // ------------------------------------------------------------------ finalize: replicas -> per-channel (mean, rstd) of its group
 // grid N, block 256 (loops channels)
 __global__ void k_norm_finalize(const double* __restrict__ stats, int N, int c, int c_p, int groups, int64_t spatial,
-                                float eps, float* __restrict__ mean_rstd) {
+                                float eps, float* __restrict__ mean_rstd, const float* __restrict__ gamma = nullptr,
+                                const float* __restrict__ beta = nullptr, float* __restrict__ scale_shift = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* ch = reinterpret_cast<double*>(smem);   // [c_p][2]
     const int n = blockIdx.x;
@@ -130,7 +131,24 @@ __global__ void k_norm_finalize(const double* __restrict__ stats, int N, int c, 
         }
         mean_rstd[((int64_t)n * c_p + i) * 2 + 0] = mean;
         mean_rstd[((int64_t)n * c_p + i) * 2 + 1] = rstd;
+        if (scale_shift) {                        // the same two expressions k_norm_apply evaluates per thread
+            float a = 0.f, b = 0.f;
+            if (i < c) { a = rstd * gamma[i]; b = beta[i] - mean * a; }
+            scale_shift[((int64_t)n * c_p + i) * 2 + 0] = a;
+            scale_shift[((int64_t)n * c_p + i) * 2 + 1] = b;
+        }
     }
+}
+
+extern "C" int nndet_norm_finalize(const double* stats, const float* gamma, const float* beta, int32_t batch, int64_t spatial,
+                                   int32_t c, int32_t c_p, int32_t groups, float eps, float* mean_rstd_out, float* scale_shift_out,
+                                   void* stream) {
+    if (!stats || !gamma || !beta || !mean_rstd_out || !scale_shift_out) return NNDET_EINVAL;
+    if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
+    k_norm_finalize<<<batch, 256, (size_t)c_p * 16, as_stream(stream)>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out,
+                                                                        gamma, beta, scale_shift_out);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 // ------------------------------------------------------------------ apply: y = relu?((x - mean) * rstd * gamma + beta)
@@ -158,17 +176,8 @@ __global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, con
     const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
     const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
     const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
-    for (int64_t r = r0 + rr; r < r1; r += rpi) {
-        float v[E];
-        Vec16<T>::ld(x + base + r * c_p, v);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            float o = fmaf(v[e], sc[e], sh[e]);
-            if (relu) o = fmaxf(o, 0.f);
-            v[e] = o;
-        }
-        Vec16<T>::st(y + base + r * c_p, v);
-    }
+    for (int64_t r = r0 + rr; r < r1; r += rpi)      // AffinePiece: the SAME code the convolutions run when they apply the norm on load
+        *reinterpret_cast<u32x4*>(y + base + r * c_p) = AffinePiece<T>::apply(*reinterpret_cast<const u32x4*>(x + base + r * c_p), sc, sh, relu);
 }
 
 extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
@@ -184,6 +193,37 @@ extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stat
         k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (bf16_t*)y);
     else
         k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (float*)y);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ y = relu?(x * scale + shift) from a coefficient table
+// (materialises a deferred activation for a consumer that cannot apply the norm on load; same arithmetic as k_norm_apply)
+template <typename T>
+__global__ __launch_bounds__(256) void k_affine_apply(const T* __restrict__ x, const float* __restrict__ ss, int64_t spatial, int c_p,
+                                                      int relu, T* __restrict__ y) {
+    constexpr int E = Vec16<T>::E;
+    const int ppr = c_p / E, rpi = 256 / ppr;
+    const int n = blockIdx.y;
+    const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+    if (rr >= rpi) return;
+    float sc[E], sh[E];
+    load_affine<E>(ss, n, c_p, cp * E, sc, sh);
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
+    const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
+    for (int64_t r = r0 + rr; r < r1; r += rpi)      // AffinePiece: the SAME code the convolutions run when they apply the norm on load
+        *reinterpret_cast<u32x4*>(y + base + r * c_p) = AffinePiece<T>::apply(*reinterpret_cast<const u32x4*>(x + base + r * c_p), sc, sh, relu);
+}
+
+extern "C" int nndet_affine_apply(int32_t dtype, const void* x, const float* scale_shift, int32_t batch, int64_t spatial, int32_t c_p,
+                                  int32_t relu, void* y, void* stream) {
+    if (!x || !scale_shift || !y || c_p % 32 || c_p > 1024 || batch <= 0) return NNDET_EINVAL;
+    dim3 grid((unsigned)ceil_div64(spatial, ROWS_PER_BLOCK), batch);
+    if (dtype == NNDET_BF16)
+        k_affine_apply<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, scale_shift, spatial, c_p, relu, (bf16_t*)y);
+    else
+        k_affine_apply<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, scale_shift, spatial, c_p, relu, (float*)y);
     LAUNCH_CHECK();
     return 0;
 }

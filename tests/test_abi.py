@@ -41,7 +41,7 @@ def test_identification(lib):
 
 def test_struct_layout_matches_header():
     from nndetection_amd._lib import NndetConv
-    assert ctypes.sizeof(NndetConv) == 4 * (13 + 9)
+    assert ctypes.sizeof(NndetConv) == 4 * (13 + 9) + 8 + 4 + 4      # + in_affine pointer, in_relu, reserved
 
 
 def test_no_cpu_fallback():

@@ -250,3 +250,55 @@ def test_lean_sgd_matches_torch_sgd_on_gpu():
         assert abs(oa.param_groups[0]["lr"] - ob.param_groups[0]["lr"]) < 1e-12
     for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
         assert torch.allclose(pa, pb, atol=1e-7, rtol=1e-6), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_deferred_norm_equals_materialised(golden_dir, monkeypatch, dtype):
+    """with deferred normalisation (default) the consumers apply InstanceNorm / GroupNorm + ReLU while staging
+    their input (NndetConv.in_affine) and `k_norm_apply` never runs; with NNDET_DEFER_NORM=0 every block materialises its
+    activation. Same arithmetic (fmaf, max, one rounding) on both routes -> identical losses; gradients identical up to the
+    summation order of the atomically reduced ones."""
+    import nndetection_amd.arch.conv as C
+    gn, plan, tg = _load(golden_dir)
+    x = torch.from_numpy(gn["x"]).cuda().to(dtype)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(C, "DEFER_NORM", mode)
+        ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+        net = _hip_model(plan, ora)
+        monkeypatch.setattr(torch, "randperm", det_randperm)
+        losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
+                     {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
+        # the deferred route really is deferred: the first encoder conv hands on a tagged tensor
+        with torch.no_grad():
+            y = net.encoder.stages[0].convs[0][0](x)
+        assert (C.deferred(y) is not None) == mode
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    for n, g in res[False][1].items():
+        d = float((res[True][1][n] - g).abs().max())
+        assert d <= 1e-5 * (float(g.abs().max()) + 1e-12), (n, d)
+
+
+def test_materialize_of_deferred_activation():
+    """A deferred activation handed to a consumer that cannot apply the norm on load (here: plain torch code) is materialised by
+    `materialize`; values and gradients equal the non-deferred block."""
+    import nndetection_amd.arch.conv as C
+    from nndetection_amd.arch.conv import ConvInstanceRelu
+    torch.manual_seed(0)
+    m = ConvInstanceRelu(3, 32, 32, 3, padding=1).cuda()
+    x = torch.randn(2, 32, 9, 10, 12, device="cuda")
+    outs = {}
+    for defer in (False, True):
+        m.defer_output = defer
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        assert (C.deferred(y) is not None) == defer
+        y = C.materialize(y)
+        (y * torch.arange(y.numel(), device="cuda").view_as(y).float().cos()).sum().backward()
+        outs[defer] = (y.detach().clone(), xi.grad.clone(), m.conv.weight.grad.clone(), m.norm.weight.grad.clone())
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
