@@ -200,9 +200,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("NNDET_BENCH_FORCE_DIST") == "1"     # exercise the RCCL / bucket path at world size 1 (testing)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -217,7 +219,7 @@ def main():
     torch.manual_seed(0)
     net = build_model(plan).to(device)
     opt, sched = configure_optimizer(net)
-    ddp = GradAllReducer(net) if world > 1 else None
+    ddp = GradAllReducer(net, force_overlap=force_dist) if (world > 1 or force_dist) else None
     x, tg = synth_batch(plan, batch, dtype, device, seed=1000 + rank)
     torch.manual_seed(1234 + rank)
 
@@ -277,7 +279,7 @@ def main():
                 torch.cuda.empty_cache()
                 out["cpu_baseline"], out["parity_check"] = cpu_baseline(plan, device)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -115,7 +115,7 @@ class GradAllReducer:
                 src.append(p.grad); dst.append(v)
         if dst:
             torch._foreach_copy_(dst, src)               # one multi-tensor kernel per bucket instead of one copy per parameter
-        if self.world > 1:
+        if self.world > 1 or (self.force and dist.is_initialized()):
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         elif self._cuda:
             b.work = torch.cuda.Event()

@@ -282,11 +282,12 @@ def test_deferred_norm_equals_materialised(golden_dir, monkeypatch, dtype):
         assert d <= 1e-5 * (float(g.abs().max()) + 1e-12), (n, d)
 
 
-def test_materialize_of_deferred_activation():
+def test_materialize_of_deferred_activation(monkeypatch):
     """A deferred activation handed to a consumer that cannot apply the norm on load (here: plain torch code) is materialised by
     `materialize`; values and gradients equal the non-deferred block."""
     import nndetection_amd.arch.conv as C
     from nndetection_amd.arch.conv import ConvInstanceRelu
+    monkeypatch.setattr(C, "DEFER_NORM", True)
     torch.manual_seed(0)
     m = ConvInstanceRelu(3, 32, 32, 3, padding=1).cuda()
     x = torch.randn(2, 32, 9, 10, 12, device="cuda")
