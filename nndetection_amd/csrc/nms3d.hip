@@ -71,67 +71,121 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
 #pragma unroll
     for (int k = 0; k < 6; ++k) a[k] = boxes[row * 6 + k];
     u64 t = 0;
-    const int start = (rb == cb) ? lane + 1 : 0;
+    // Diagonal tiles carry BOTH directions (bit j of row i for every j != i): the in-wave resolution of k_nms_scan_super needs
+    // the incoming edges of a box (higher-scored boxes of its chunk that overlap it) = the low bits of its own row, because
+    // iou3d(a, b) == iou3d(b, a) bit for bit (min / max / the two additions commute, the products have the same order).
+    const int skip = (rb == cb) ? lane : -1;
     if (!labels && !nan_hits) {
-        for (int j = start; j < col_size; ++j) {
-            if (iou3d(a, cbox + j * 6) > thr) t |= 1ULL << j;
+        for (int j = 0; j < col_size; ++j) {
+            if (j != skip && iou3d(a, cbox + j * 6) > thr) t |= 1ULL << j;
         }
     } else {
         const int32_t la = labels ? labels[row] : 0;
-        for (int j = start; j < col_size; ++j) {
+        for (int j = 0; j < col_size; ++j) {
             const float v = iou3d(a, cbox + j * 6);
             const bool hit = nan_hits ? !(v <= thr) : (v > thr);
-            if (hit && (!labels || clab[j] == la)) t |= 1ULL << j;
+            if (j != skip && hit && (!labels || clab[j] == la)) t |= 1ULL << j;
         }
     }
     mask[row * col_blocks + cb] = t;
 }
 
-// One workgroup of 1024 threads. Chunks [c0, c1) (c1 - c0 <= 64).
+// One workgroup of 1024 threads resolves the chunks [c0, c1) (c1 - c0 <= 64) of a super chunk sequentially.
+// Round 1 fetched the mask rows of the KEPT boxes of a chunk from global memory after its keep bits were known: one exposed L2
+// round trip per chunk, 2.6 us x 64 chunks = 168 us per super chunk = 75 % of the whole NMS at N = 10 000
+// (profiles/round2_nms_kernel_stats.txt). Now the rows of ALL 64 boxes of a chunk (64 rows x <= 64 words of this super chunk =
+// 32 KiB) are prefetched speculatively into a ring of 4 LDS buffers three chunks ahead (global -> registers another three
+// iterations before the LDS write), so the dependent part of an iteration only touches LDS: the 64-row readlane chain on the diagonal word
+// (wave 0), then the OR of the kept rows into the removed-words of the later chunks.
+#define NMS_SCAN_NBUF 4
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)),
+// which would wait for the speculative row loads that are deliberately left in flight across several iterations.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ __launch_bounds__(1024) void k_nms_scan_super(const u64* __restrict__ mask, int64_t n, int col_blocks,
                                                          int c0, int c1, u64* __restrict__ remv,
                                                          u64* __restrict__ keepbits) {
+    extern __shared__ __attribute__((aligned(16))) char nms_smem[];
+    u64* rows = reinterpret_cast<u64*>(nms_smem);                    // [NMS_SCAN_NBUF][64 rows][64 words]
     __shared__ u64 remv_l[64];
     __shared__ u64 keep_l;
     const int tid = threadIdx.x;
-    if (tid < c1 - c0) remv_l[tid] = remv[c0 + tid];
-    __syncthreads();
-    for (int c = c0; c < c1; ++c) {
-        if (tid < 64) {
-            const int64_t row = (int64_t)c * 64 + tid;
-            u64 d = (row < n) ? mask[row * col_blocks + c] : 0ULL;
-            const uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
-            u64 rem = remv_l[c - c0];
-            const int valid = (int)min((int64_t)64, n - (int64_t)c * 64);
-            u64 keep = 0;
+    const int nc = c1 - c0;
+    if (tid < nc) remv_l[tid] = remv[c0 + tid];
+    // thread -> (row r of the chunk, words jj, jj + 16, jj + 32, jj + 48 of the super chunk)
+    const int r = tid >> 4, jj = tid & 15;
+    u64 reg[3][4];                                // global -> register loads run THREE chunks ahead of their LDS write
+    auto issue = [&](int ci, u64* dst) {          // chunk index ci relative to c0; words before the diagonal are never written by k_nms_mask
+        const int64_t row = (int64_t)(c0 + ci) * 64 + r;
+        const bool okr = ci < nc && row < n;
 #pragma unroll
-            for (int r = 0; r < 64; ++r) {
-                const uint32_t lo = __builtin_amdgcn_readlane(dlo, r);
-                const uint32_t hi = __builtin_amdgcn_readlane(dhi, r);
-                if (r < valid && !((rem >> r) & 1ULL)) {
-                    keep |= 1ULL << r;
-                    rem |= ((u64)hi << 32) | lo;
-                }
+        for (int k = 0; k < 4; ++k) {
+            const int j = jj + 16 * k;
+            dst[k] = (okr && j >= ci && j < nc) ? mask[row * col_blocks + c0 + j] : 0ULL;
+        }
+    };
+    auto commit = [&](int ci, const u64* src) {
+        u64* b = rows + (size_t)(ci % NMS_SCAN_NBUF) * 4096 + r * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[jj + 16 * k] = src[k];
+    };
+    // prologue: chunks 0, 1, 2 into the ring, chunks 3, 4, 5 in flight (chunk k travels through reg[k % 3])
+    issue(0, reg[0]); issue(1, reg[1]); issue(2, reg[2]);
+    commit(0, reg[0]); commit(1, reg[1]); commit(2, reg[2]);
+    issue(3, reg[0]); issue(4, reg[1]); issue(5, reg[2]);
+    __syncthreads();
+    auto step = [&](int ci, u64* rg) {
+        const u64* buf = rows + (size_t)(ci % NMS_SCAN_NBUF) * 4096;
+        if (tid < 64) {
+            // Greedy NMS inside the chunk = the lexicographically first maximal independent set of its 64 x 64 overlap graph.
+            // Instead of walking the 64 boxes one by one (2.6 us per chunk in round 1), every lane decides its own box as soon
+            // as all higher-scored overlapping boxes of the chunk are decided: kept if none of them is kept, suppressed if one
+            // is. A round is two ballots; the number of rounds is the longest dependency chain (1-4 for detector outputs, 64
+            // at worst -- identical result either way).
+            const u64 d = buf[tid * 64 + ci];                       // row tid of the diagonal tile: all overlaps inside the chunk
+            const u64 in = d & ((1ULL << tid) - 1ULL);              // higher-scored boxes of the chunk that overlap this one
+            const int valid = (int)min((int64_t)64, n - (int64_t)(c0 + ci) * 64);
+            const u64 vmask = valid >= 64 ? ~0ULL : ((1ULL << valid) - 1ULL);
+            u64 S = remv_l[ci] | ~vmask;                            // suppressed from outside (earlier chunks) or beyond n
+            u64 K = 0;
+            for (int round = 0; round < 64; ++round) {
+                const u64 U = ~(K | S);
+                if (U == 0) break;                                  // uniform
+                const bool und = (U >> tid) & 1ULL;
+                const bool now_s = und && (in & K) != 0ULL;
+                const bool now_k = und && !now_s && (in & U) == 0ULL;
+                S |= __ballot(now_s);
+                K |= __ballot(now_k);
             }
             if (tid == 0) {
-                keepbits[c] = keep;
-                keep_l = keep;
+                keepbits[c0 + ci] = K;
+                keep_l = K;
             }
         }
-        __syncthreads();
+        lds_barrier();
         const u64 keep = keep_l;
-        // OR the kept rows of chunk c into the removed-words of the later chunks of this super chunk
-        {
-            const int r = tid >> 4, jj = tid & 15;
-            if ((keep >> r) & 1ULL) {
-                const int64_t row = (int64_t)c * 64 + r;
-                for (int j = c + 1 + jj; j < c1; j += 16) {
-                    u64 v = mask[row * col_blocks + j];
-                    if (v) atomicOr(&remv_l[j - c0], v);
+        // OR the kept rows of this chunk into the removed-words of the later chunks of the super chunk (LDS only)
+        if ((keep >> r) & 1ULL) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = jj + 16 * k;
+                if (j > ci && j < nc) {
+                    const u64 v = buf[r * 64 + j];
+                    if (v) atomicOr(&remv_l[j], v);
                 }
             }
         }
-        __syncthreads();
+        // ring maintenance: the registers issued three iterations ago (chunk ci + 3) go to the slot chunk ci - 1 used; the loads of
+        // chunk ci + 6 start in the same registers
+        commit(ci + 3, rg);
+        lds_barrier();
+        issue(ci + 6, rg);
+    };
+    // unrolled by 3 so that every register set is addressed statically: the wait before a commit is then vmcnt(8) (the two
+    // younger sets stay in flight) instead of a full drain
+    for (int ci = 0; ci < nc; ci += 3) {
+        step(ci, reg[0]);
+        if (ci + 1 < nc) step(ci + 1, reg[1]);
+        if (ci + 2 < nc) step(ci + 2, reg[2]);
     }
 }
 
@@ -192,6 +246,17 @@ __global__ __launch_bounds__(1024) void k_nms_compact(const u64* __restrict__ ke
     if (tid == 0) *n_keep = running;
 }
 
+static const size_t NMS_SCAN_LDS = (size_t)NMS_SCAN_NBUF * 64 * 64 * 8;
+static int nms_scan_attr() {
+    static int done = 0;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nms_scan_super), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NMS_SCAN_LDS);
+        if (e != hipSuccess) return (int)e;
+        done = 1;
+    }
+    return 0;
+}
+
 struct NmsWs {
     float* sboxes;
     float* keys_out;
@@ -227,6 +292,7 @@ static int nms_layout(int64_t n, char* base, NmsWs* ws) {
 static int nms_core(const float* boxes, const int32_t* order, int64_t n, float thr, int64_t* keep_out,
                     int64_t* n_keep_out, NmsWs& ws, hipStream_t st, const int64_t* n_valid = nullptr) {
     const int cb = (int)ceil_div64(n, 64);
+    { const int arc = nms_scan_attr(); if (arc) return arc; }
     const float* sboxes = boxes;
     if (order) {
         k_gather_boxes<<<(unsigned)ceil_div64(n * 6, 256), 256, 0, st>>>(boxes, order, n, ws.sboxes);
@@ -239,7 +305,7 @@ static int nms_core(const float* boxes, const int32_t* order, int64_t n, float t
     LAUNCH_CHECK();
     for (int c0 = 0; c0 < cb; c0 += 64) {
         const int c1 = c0 + 64 < cb ? c0 + 64 : cb;
-        k_nms_scan_super<<<1, 1024, 0, st>>>(ws.mask, n, cb, c0, c1, ws.remv, ws.keepbits);
+        k_nms_scan_super<<<1, 1024, NMS_SCAN_LDS, st>>>(ws.mask, n, cb, c0, c1, ws.remv, ws.keepbits);
         LAUNCH_CHECK();
         if (c1 < cb) {
             k_nms_propagate<<<dim3(ceil_div(cb - c1, 256), c1 - c0), 256, 0, st>>>(ws.mask, cb, c0, c1, ws.keepbits, ws.remv);
@@ -314,12 +380,13 @@ int nms_heads_run(const float* sboxes, const int32_t* slabels, int64_t n, float 
     if (rc) return rc;
     if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
     const int cb = (int)ceil_div64(n, 64);
+    { const int arc = nms_scan_attr(); if (arc) return arc; }
     HIP_TRY(hipMemsetAsync(ws.remv, 0, (size_t)cb * 8, st));
     k_nms_mask<<<dim3(cb, ceil_div(cb, 4)), 256, 0, st>>>(sboxes, n, thr, ws.mask, cb, slabels, 1);
     LAUNCH_CHECK();
     for (int c0 = 0; c0 < cb; c0 += 64) {
         const int c1 = c0 + 64 < cb ? c0 + 64 : cb;
-        k_nms_scan_super<<<1, 1024, 0, st>>>(ws.mask, n, cb, c0, c1, ws.remv, ws.keepbits);
+        k_nms_scan_super<<<1, 1024, NMS_SCAN_LDS, st>>>(ws.mask, n, cb, c0, c1, ws.remv, ws.keepbits);
         LAUNCH_CHECK();
         if (c1 < cb) {
             k_nms_propagate<<<dim3(ceil_div(cb - c1, 256), c1 - c0), 256, 0, st>>>(ws.mask, cb, c0, c1, ws.keepbits, ws.remv);

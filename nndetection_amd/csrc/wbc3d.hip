@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void k_wbc_assign(const u64* __restrict__ mask
     const int rb = (int)(i >> 6);
     for (int cb = rb + lane; cb < col_blocks; cb += 64) {
         u64 w = mask[i * col_blocks + cb];
+        if (cb == rb) w &= ~((2ULL << (i & 63)) - 1ULL);   // diagonal tiles carry both directions: only LOWER-scored boxes can join
         while (w) {
             const int b = __ffsll((long long)w) - 1;
             w &= w - 1;

@@ -81,7 +81,9 @@ class MemoryEstimatorDetection:
         device = torch.device("cuda", self.gpu_id)
         loss = opt = inp = block = None
         try:
+            torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats(device)
+            alloc0 = torch.cuda.memory_allocated(device)
             network = network.to(device)
             empty_mem = torch.cuda.memory_reserved(device)
             opt = optimizer_cls(network.parameters())
@@ -99,12 +101,19 @@ class MemoryEstimatorDetection:
                                                       for _ in range(self.batch_size)],
                                    "target_seg": torch.zeros((self.batch_size, *shape[1:]), device=device, dtype=torch.float)}}
                 fixed_mem = torch.cuda.memory_reserved(device)
+                alloc_fixed = torch.cuda.memory_allocated(device)
                 loss_dict, _ = network.train_step(images=inp["images"], targets=inp["targets"], evaluation=False, batch_num=0)
                 loss = sum(loss_dict.values())
                 loss.backward()
                 opt.step()
             torch.cuda.synchronize(device)
             dyn_mem = torch.cuda.memory_reserved(device)
+            # The reference measures the caching allocator's RESERVED bytes in a fresh process. In a process whose allocator
+            # already holds free blocks (tests, notebooks) reserved memory does not grow; the peak of ALLOCATED bytes is the lower
+            # bound that is always valid, so report the larger of the two views.
+            fixed = max(fixed_mem - empty_mem, alloc_fixed - alloc0)
+            dynamic = max(dyn_mem - fixed_mem, torch.cuda.max_memory_allocated(device) - alloc_fixed)
+            empty_mem, fixed_mem, dyn_mem = 0, fixed, fixed + dynamic
         except Exception as e:                                  # out of memory: report "does not fit" like the reference
             self.last_error = e
             empty_mem, fixed_mem, dyn_mem = 0, float("Inf"), float("Inf")
