@@ -238,6 +238,12 @@ int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w_packed
 /* dx[N,id,ih,iw,cin_p] = conv^T(dy[N,od,oh,ow,cout_p]) */
 int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w_packed_mode1,
                                void* dx, void* stream);
+/* Data gradient that also accumulates the bias gradient dbias[cout] += sum over voxels of dy (fp32, zero it first): the pointwise
+ * kernels (1x1x1 convolutions, transposed k == s) read every dy element exactly once anyway, which saves the separate
+ * column-sum pass over dy (629 MB at full resolution). nndet_conv3d_dgrad_fuses_bias() tells whether a problem is covered;
+ * the caller then passes dbias = NULL to nndet_conv3d_backward_weight. */
+int32_t nndet_conv3d_dgrad_fuses_bias(const NndetConv* c);
+int nndet_conv3d_backward_data_bias(const NndetConv* c, const void* dy, const void* w_packed_mode1, void* dx, float* dbias, void* stream);
 /* dw (fp32, PyTorch layout, ACCUMULATED into: zero it first) ; dbias ([cout] fp32, accumulated) may be NULL.
  * Two-stage reduction through `workspace` (nndet_conv3d_wgrad_workspace_bytes(c) bytes): deterministic, no atomics on dw. */
 size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c);

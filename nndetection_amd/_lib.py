@@ -64,6 +64,8 @@ SIGNATURES = {
     "nndet_pack_weights_batched": (C.c_int, [C.POINTER(NndetConv), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I32, _P]),
     "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
+    "nndet_conv3d_dgrad_fuses_bias": (_I32, [_CONVP]),
+    "nndet_conv3d_backward_data_bias": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
     "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
     "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_norm_stats": (C.c_int, [_I32, _P, _I32, _I64, _I32, _P, _P]),

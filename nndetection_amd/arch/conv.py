@@ -194,17 +194,23 @@ class _ConvFn(torch.autograd.Function):
         dw = gbuf[:nw].view(weight.shape)
         dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
         dx = None
+        bias_from_dgrad = False
         if ctx.needs_input_grad[0]:
             if desc.cin_p == 1:
                 raise L.NndetError("gradient w.r.t. the 1-channel input image is not implemented (never needed in training)")
             w1 = _packed(mod, 1, weight, desc, dt)
             dx_p = torch.empty_like(x_p)
-            L.call("nndet_conv3d_backward_data", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.stream())
+            if dbias is not None and L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)):
+                # pointwise kernels read every dy element once: the bias gradient comes out of the same pass
+                L.call("nndet_conv3d_backward_data_bias", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.ptr(dbias), L.stream())
+                bias_from_dgrad = True
+            else:
+                L.call("nndet_conv3d_backward_data", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.stream())
             dx = logical(dx_p, desc.cin)      # gradient w.r.t. the input AS THE CONV SAW IT (i.e. after a deferred norm + ReLU)
         ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
         ws = L.workspace(ws_bytes, dev)
-        L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw), L.ptr(dbias),
-               L.ptr(ws), ws_bytes, L.stream())
+        L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw),
+               None if bias_from_dgrad else L.ptr(dbias), L.ptr(ws), ws_bytes, L.stream())
         # d(residual) = grad_out: the same NDHWC buffer is handed to both consumers (no copy, no add kernel)
         return dx, None, None, dw.to(weight.dtype), dbias, None, (logical(dconv, cout) if ctx.has_res else None), None
 

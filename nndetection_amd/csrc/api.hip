@@ -41,6 +41,20 @@ extern "C" int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, co
     return igemm_run(c, 1, dy, w, nullptr, nullptr, dx, nullptr, as_stream(stream));
 }
 
+extern "C" int32_t nndet_conv3d_dgrad_fuses_bias(const NndetConv* c) {
+    if (check_conv(c) || c->cin_p == 1) return 0;
+    static const int on = getenv("NNDET_PW_BIAS") ? atoi(getenv("NNDET_PW_BIAS")) : 1;
+    return on && pw_covers(c, 1) ? 1 : 0;
+}
+
+extern "C" int nndet_conv3d_backward_data_bias(const NndetConv* c, const void* dy, const void* w, void* dx, float* dbias, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!dy || !w || !dx || !dbias || c->cin_p == 1) return NNDET_EINVAL;
+    if (!nndet_conv3d_dgrad_fuses_bias(c)) return NNDET_EINVAL;
+    return igemm_run(c, 1, dy, w, nullptr, nullptr, dx, nullptr, as_stream(stream), dbias);
+}
+
 extern "C" size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c) {
     if (check_conv(c)) return 0;
     return c->cin_p == 1 ? 256 : wgrad_workspace_bytes(c);

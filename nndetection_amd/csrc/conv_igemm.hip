@@ -882,11 +882,12 @@ static int ensure_attrs() {
 }
 
 int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y,
-              double* stats, hipStream_t st) {
+              double* stats, hipStream_t st, float* dbias) {
     if (!stats && !(kind == 0 && c->in_affine && c->transposed)) {   // pointwise problems (1x1x1, transposed k == s) stream straight from global memory
-        const int prc = pw_run(c, kind, x, w, bias, res, y, st);
+        const int prc = pw_run(c, kind, x, w, bias, res, y, st, dbias);
         if (prc != 1) return prc;
     }
+    if (dbias) return NNDET_EINVAL;     // only the pointwise data-gradient kernels fuse the bias gradient (nndet_conv3d_dgrad_fuses_bias)
     Plan P;
     int rc = build_plan(c, kind, &P);
     if (rc) return rc;

@@ -45,6 +45,27 @@ template <> struct PwMma<float> {
     __device__ static __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 };
 
+// column sums of the streamed operand (fused bias gradient): add the EPL channel values of one fragment to per-lane sums
+template <typename T> __device__ __forceinline__ void pw_accum(const u32x4& v, float* acc, float w);
+template <> __device__ __forceinline__ void pw_accum<bf16_t>(const u32x4& v, float* acc, float w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[2 * i] += w * __uint_as_float(v[i] << 16);
+        acc[2 * i + 1] += w * __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+template <> __device__ __forceinline__ void pw_accum<float>(const u32x4& v, float* acc, float w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += w * __uint_as_float(v[i]);
+}
+__device__ __forceinline__ float pw_row_sum(float v) {   // sum over the 16 lanes of a DPP row (= the 16 points of a tile)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
 struct PwArgs {
     const void* x; const void* w; const float* bias; const void* res; void* y;
     int64_t npts;             // lattice points over the whole batch (N * L0 * L1 * L2)
@@ -53,6 +74,8 @@ struct PwArgs {
     int32_t ncls;             // kernel positions S0 * S1 * S2
     int32_t ntiles;           // ceil(npts / 16)
     uint32_t mL2, mL1, mL0;   // magic multipliers for / L[2], / L[1], / L[0] (0 = divisor 1)
+    float* dbias;             // data-gradient launches: also accumulate sum_points x[p][k] (= the bias gradient: x is dY there), NULL = off
+    int32_t nbias;            // logical channel count of dbias
     const float* ss;          // deferred input norm [N][Cx][2] (1x1x1 forward only), NULL = off
     int32_t ss_relu;
     int32_t tiles_per_img;    // 16-point tiles per image (ss != NULL requires the image size to be a multiple of 16 points)
@@ -105,6 +128,12 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
     const int wave_global = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
     const int S1 = A.S[1], S2 = A.S[2];
 
+    float bsum[NKC][EPL];                    // fused bias gradient: this lane's channel sums over its points
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) bsum[kc][e] = 0.f;
+    const bool do_bias = A.dbias != nullptr && blockIdx.y == 0;
     float asc[NKC][EPL], ash[NKC][EPL];      // deferred input norm of this lane's channels (q * EPL .. of every chunk), image ss_n
     int ss_n = -1;
     for (int t0 = wave_global * U; t0 < A.ntiles; t0 += nwaves * U) {
@@ -122,6 +151,11 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (t0 + u >= A.ntiles) break;               // uniform
+                if (do_bias) {
+                    const float wv_ = pt[u] >= 0 ? 1.f : 0.f;
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) pw_accum<T>(b[u][kc], bsum[kc], wv_);
+                }
                 if (A.ss) {
                     const int n_img = (t0 + u) / A.tiles_per_img;        // wave-uniform: a tile never straddles two images
                     if (n_img != ss_n) {
@@ -187,6 +221,10 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
                         if (c0 + cc >= A.ncls) break;        // uniform
+                        if (do_bias) {
+#pragma unroll
+                            for (int kc = 0; kc < NKC; ++kc) pw_accum<T>(b[cc][kc], bsum[kc], ok ? 1.f : 0.f);
+                        }
 #pragma unroll
                         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -203,6 +241,21 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
                 }
             }
         }
+    }
+    if (A.dbias != nullptr && blockIdx.y == 0) {       // (uniform per workgroup) waves -> LDS -> ONE atomic per channel and workgroup
+        __shared__ float bred[NKC * KC];
+        for (int i = tid; i < NKC * KC; i += 256) bred[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const float v = pw_row_sum(bsum[kc][e]);
+                if (li == 0) atomicAdd(&bred[kc * KC + q * EPL + e], v);
+            }
+        __syncthreads();
+        for (int i = tid; i < NKC * KC; i += 256)
+            if (i < A.nbias && bred[i] != 0.f) atomicAdd(A.dbias + i, bred[i]);
     }
 }
 
@@ -239,7 +292,10 @@ static int pw_dispatch(const PwArgs& A, int mt_total, int nkc, int mode, size_t 
 
 // kind: 0 forward, 1 backward-data. Returns 1 when the problem is not a pointwise one this kernel covers (caller falls back to the
 // implicit-GEMM kernel), 0 on success, else an error.
-int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, hipStream_t st) {
+// dbias (kind 1 only, may be NULL): the data-gradient launch also accumulates the bias gradient (column sums of dY)
+static int pw_plan(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, float* dbias,
+                   PwArgs* out, int* mt_total_o, int* nkc_o, int* mode_o, size_t* lds_o) {
+    PwArgs& A = *out;
     static const int enabled = getenv("NNDET_PW") ? atoi(getenv("NNDET_PW")) : 1;
     if (!enabled) return 1;
     const bool tr = c->transposed != 0;
@@ -248,7 +304,6 @@ int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const flo
         if (!tr && c->k[i] != 1) return 1;
     }
     const int esz = c->dtype == NNDET_BF16 ? 2 : 4, KC = c->dtype == NNDET_BF16 ? 32 : 16;
-    PwArgs A;
     memset(&A, 0, sizeof(A));
     A.x = x; A.w = w; A.bias = bias; A.res = res; A.y = y;
     const int ncls = c->k[0] * c->k[1] * c->k[2];
@@ -272,6 +327,7 @@ int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const flo
         if (bias || res) return 1;
     }
     A.ncls = ncls;
+    if (kind == 1 && dbias) { A.dbias = dbias; A.nbias = c->cout; }
     if (kind == 0 && c->in_affine) {
         const int64_t per_img = (int64_t)A.L[0] * A.L[1] * A.L[2];
         if (tr || per_img % 16 != 0) return 1;            // generic kernel (per-piece image index there)
@@ -290,6 +346,23 @@ int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const flo
     A.mL2 = magic(A.L[2]); A.mL1 = magic(A.L[1]); A.mL0 = magic(A.L[0]);
     // the magic division n / d == umulhi(n, 2^32 / d + 1) is exact for n * d < 2^32: lattice counts here are < 2^31 / 16 at most
     if ((uint64_t)A.npts * (uint64_t)(A.L[2] > A.L[1] ? (A.L[2] > A.L[0] ? A.L[2] : A.L[0]) : (A.L[1] > A.L[0] ? A.L[1] : A.L[0])) >= (1ull << 32) && ncls > 1) return 1;
-    return c->dtype == NNDET_BF16 ? pw_dispatch<bf16_t>(A, mt_total, nkc, mode, lds_per_rowtile, st)
-                                  : pw_dispatch<float>(A, mt_total, nkc, mode, lds_per_rowtile, st);
+    *mt_total_o = mt_total; *nkc_o = nkc; *mode_o = mode; *lds_o = lds_per_rowtile;
+    return 0;
+}
+
+int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, hipStream_t st,
+           float* dbias) {
+    PwArgs A;
+    int mt_total, nkc, mode;
+    size_t lds;
+    const int rc = pw_plan(c, kind, x, w, bias, res, y, dbias, &A, &mt_total, &nkc, &mode, &lds);
+    if (rc) return rc;
+    return c->dtype == NNDET_BF16 ? pw_dispatch<bf16_t>(A, mt_total, nkc, mode, lds, st) : pw_dispatch<float>(A, mt_total, nkc, mode, lds, st);
+}
+
+int pw_covers(const NndetConv* c, int kind) {
+    PwArgs A;
+    int mt_total, nkc, mode;
+    size_t lds;
+    return pw_plan(c, kind, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &A, &mt_total, &nkc, &mode, &lds) == 0;
 }

@@ -34,6 +34,29 @@ __device__ __forceinline__ float iou3d(const float* a, const float* b) {
     return inter / (sa + sb - inter);
 }
 
+// iou3d(a, b) > thr without the IEEE division in all but ~1e-6 of the cases, and with EXACTLY its result in all of them:
+// inter / un > thr is decided by comparing inter with un * thr * (1 +- 1e-6) -- the two products are rounded (relative error
+// 6e-8 each), far inside the 1e-6 margin, while RN(inter / un) can only differ from inter / un by 6e-8 relative, so outside the
+// band the rounded quotient is on the same side of thr as the exact one. Inside the band, and for NaN / inf / negative volumes
+// (both comparisons false), the division itself decides. The mask kernel was issue-stalled on the dependent division sequence
+// for 64 % of its wave cycles (profiles/round2_nms_pmc.txt).
+__device__ __forceinline__ bool iou3d_gt(const float* a, const float* b, float thr, float thr_hi, float thr_lo) {
+    float bottom = fmaxf(a[0], b[0]), top = fminf(a[2], b[2]);
+    float left = fmaxf(a[1], b[1]), right = fminf(a[3], b[3]);
+    float front = fmaxf(a[4], b[4]), back = fminf(a[5], b[5]);
+    float width = fmaxf(right - left, 0.f), height = fmaxf(top - bottom, 0.f);
+    float depth = fmaxf(back - front, 0.f);
+    float inter = width * height * depth;
+    float sa = (a[2] - a[0]) * (a[3] - a[1]) * (a[5] - a[4]);
+    float sb = (b[2] - b[0]) * (b[3] - b[1]) * (b[5] - b[4]);
+    const float un = sa + sb - inter;
+    if (un > 1e-30f && thr > 0.f) {                  // the bounds below assume positive, normal operands
+        if (inter > un * thr_hi) return true;
+        if (inter < un * thr_lo) return false;
+    }
+    return inter / un > thr;
+}
+
 __global__ void k_iota(int32_t* v, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (int32_t)i;
@@ -76,8 +99,9 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
     // iou3d(a, b) == iou3d(b, a) bit for bit (min / max / the two additions commute, the products have the same order).
     const int skip = (rb == cb) ? lane : -1;
     if (!labels && !nan_hits) {
+        const float thr_hi = (float)((double)thr * (1.0 + 1e-6)), thr_lo = (float)((double)thr * (1.0 - 1e-6));
         for (int j = 0; j < col_size; ++j) {
-            if (j != skip && iou3d(a, cbox + j * 6) > thr) t |= 1ULL << j;
+            if (j != skip && iou3d_gt(a, cbox + j * 6, thr, thr_hi, thr_lo)) t |= 1ULL << j;
         }
     } else {
         const int32_t la = labels ? labels[row] : 0;
