@@ -99,7 +99,10 @@ struct IgArgs {
     uint32_t mHW, mHH;    // magic multipliers: n / H[2] == umulhi(n, mHW), n / H[1] == umulhi(n, mHH) (0 = divisor 1)
     int32_t lT1, lT2;     // log2 of the (power-of-two) tile dims T[1], T[2]
     int32_t wbytes;       // size of the packed weight tensor in bytes (buffer descriptor of the PIPE kernels)
-    int32_t swz;          // 1: XOR LDS byte-offset bit 5 with the parity of the halo row (conflict-free ds_read_b128 for unit-stride tiles)
+    int32_t swz;          // 1: XOR LDS byte-offset bit 5 with bit `swzsh` of the halo row index (conflict-free ds_read_b128)
+    int32_t swzsh;        // 0 for unit-stride tiles (row parity); 1 when the fragment's rows are 2 apart (stride 2 along H)
+    int32_t deint, HWE;   // stride 2 along W: a halo row is stored de-interleaved, even w first (HWE of them), then odd w, so that the
+                          // 16 points of a fragment (w, w+2, ...) are 64 bytes apart instead of 128 (PIPE kernels)
     int32_t ncls;
     IgClass cls[8];
     IgTap taps[27];
@@ -155,11 +158,13 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 
     // global element offsets of this thread's halo pieces (identical for every channel chunk)
     int32_t goff[MAXP];
+    int32_t pofs[PIPE ? MAXP : 1];   // PIPE kernels: LDS byte offset of piece s (de-interleaved / swizzled layout); else p * 16 ^ swizzle
     uint32_t swmask = 0;   // bit s: parity of the halo row of piece s (LDS swizzle)
 #pragma unroll
     for (int s = 0; s < MAXP; ++s) {
         const int p = tid + s * 256;
         int32_t o = -1;
+        if constexpr (PIPE) pofs[s] = p * 16;
         if (p < HV4) {
             // no integer division on the GPU: magic-multiplier division by the (runtime) halo dims
             const int hv = p >> 2, part = p & 3;
@@ -167,7 +172,11 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
             const int hw = hv - t2 * HW;
             const int hd = A.mHH ? (int)__umulhi((unsigned)t2, A.mHH) : t2;
             const int hh = t2 - hd * HH;
-            swmask |= (uint32_t)(t2 & A.swz) << s;
+            swmask |= (uint32_t)((t2 >> A.swzsh) & A.swz) << s;
+            if constexpr (PIPE) {
+                const int hwp = A.deint ? (hw & 1) * A.HWE + (hw >> 1) : hw;
+                pofs[s] = (((t2 * HW + hwp) * 4 + part) * 16) ^ ((((t2 >> A.swzsh) & A.swz)) << 5);
+            }
             const int id = i0d + hd, ih = i0h + hh, iw = i0w + hw;
             if ((unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2])
                 o = ((id * A.I[1] + ih) * A.I[2] + iw) * A.Cx + part * EPL;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
         const int t2 = p >> A.lT2;
         const int ph = t2 & (A.T[1] - 1), pd = t2 >> A.lT1;
         const int brow = (pd * A.in_step[0]) * HH + ph * A.in_step[1];
-        boff[j] = ((brow * HW + pw * A.in_step[2]) * 64 + q * 16) ^ ((brow & A.swz) << 5);
+        boff[j] = ((brow * HW + pw * (A.deint ? 1 : A.in_step[2])) * 64 + q * 16) ^ (((brow >> A.swzsh) & A.swz) << 5);
     }
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -219,8 +228,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
                 for (int b = 0; b < 8; ++b) {
                     const int p = tid + (s0 + b) * 256;
                     if (p < HV4)
-                        *reinterpret_cast<u32x4*>(smem + ((p * 16) ^ (((swmask >> (s0 + b)) & 1u) << 5))) =
-                            goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : aff(v[b]);
+                        *reinterpret_cast<u32x4*>(smem + pofs[s0 + b]) = goff[s0 + b] < 0 ? u32x4{0u, 0u, 0u, 0u} : aff(v[b]);
                 }
             }
             __syncthreads();
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
             const IgTap& tap = A.taps[C.tap0 + tp];
             const int trow = tap.d[0] * HH + tap.d[1];
             const int toff = (trow * HW + tap.d[2]) * 64;
-            const int flip = (trow & A.swz) << 5;      // row parity of the tap flips the swizzle bit
+            const int flip = ((trow >> A.swzsh) & A.swz) << 5;      // row parity of the tap flips the swizzle bit
 #pragma unroll
             for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ flip) + toff));
 #pragma unroll
@@ -778,7 +786,17 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     a.mHW = magic(a.H[2]); a.mHH = magic(a.H[1]);
     a.lT1 = ilog2(a.T[1]); a.lT2 = ilog2(a.T[2]);
+    // LDS layout. Unit-stride tiles: XOR bit 5 with the row parity. Strided tiles (PIPE kernels): when the stride along H is 2 the
+    // rows of a fragment are 2 apart -> swizzle on bit 1 of the row index (valid because the tile origin row is even: in_step[0] * H1
+    // * pd + 2 * ph); when the stride along W is 2 the rows are stored de-interleaved. PMC before: 71 % of the LDS cycles of the
+    // stride-2 forward kernel were bank conflicts (profiles/round2_pmc_e1_32to64_s2.txt).
     a.swz = strided ? 0 : 1;
+    a.swzsh = 0; a.deint = 0; a.HWE = 0;
+    static const int lds_v2 = getenv("NNDET_IGEMM_LDSV2") ? atoi(getenv("NNDET_IGEMM_LDSV2")) : 1;
+    if (strided && lds_v2) {
+        if (a.in_step[1] == 2 && ((a.in_step[0] * a.H[1]) % 2 == 0 || a.in_step[0] % 2 == 0)) { a.swz = 1; a.swzsh = 1; }
+        if (a.in_step[2] == 2) { a.deint = 1; a.HWE = (a.H[2] + 1) / 2; }
+    }
     {
         const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
         const int64_t tapb = (int64_t)a.Cy * a.Cx * esz;
@@ -787,8 +805,9 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
         a.wbytes = (int32_t)wb;
         for (int t = 0; t < ntaps; ++t) {
             const int trow = a.taps[t].d[0] * a.H[1] + a.taps[t].d[1];
-            a.tapx[t].toff = (trow * a.H[2] + a.taps[t].d[2]) * 64;
-            a.tapx[t].flip = (trow & a.swz) << 5;
+            const int tw = a.taps[t].d[2];
+            a.tapx[t].toff = (trow * a.H[2] + (a.deint ? (tw & 1) * a.HWE + (tw >> 1) : tw)) * 64;
+            a.tapx[t].flip = ((trow >> a.swzsh) & a.swz) << 5;
             a.tapx[t].woff = (int32_t)(a.taps[t].wt * tapb);
         }
     }
