@@ -46,7 +46,8 @@ def _mk(name, dtype, norm=None, act=False):
     cfg = {c[0]: c for c in CONVS}[name]
     _, cin, cout, k, s, p, tr, sp = cfg
     cls = ConvGroupRelu if norm == "group" else ConvInstanceRelu
-    torch.manual_seed(hash(name) % 1000)
+    import zlib
+    torch.manual_seed(zlib.crc32(name.encode()) % 1000)      # (hash(str) is randomised per process: runs were not reproducible)
     m = cls(3, cin, cout, k, stride=s, padding=p, transposed=tr, add_norm=norm is not None, add_act=act)
     with torch.no_grad():
         for pname, prm in m.named_parameters():
