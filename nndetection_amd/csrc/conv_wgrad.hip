@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 //     LDS round trip was exposed, 25 % MFMA utilisation);
 //   * 256 registers per wave -> two workgroups per CU.
 // Work split as in k_wgrad: the 4 waves take taps wv, wv + 4, ... (7 slots, 27 of 28 used), all 8 contraction steps.
-template <typename T, int MINW, bool AFF = false>
+template <typename T, int MINW, bool AFF = false, int QDEPTH = 2>
 __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
     constexpr int RB = 32 * (int)sizeof(T), PPV = RB / 16;
     constexpr int KS = 8, NTS = 7, TD = 4, TH = 8, HD = TD + 2, HH = TH + 2, HW = 10;
@@ -326,16 +326,17 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
 
     // ---- staging geometry (tile independent)
     // P: piece s of a thread = point (pd = s / (PPV/4)..) -- with PPV pieces per voxel: pp = tid + s*256, pt = pp / PPV
-    int p_ph[PSTEPS], p_dst[PSTEPS], p_rel[PSTEPS];
+    // P piece s2 of a thread = point pt = tid / PPV + s2 * (256 / PPV): row tr = pt >> 3 = tr0 + s2 * TRSTEP, pw = pt & 7. Nothing of
+    // this is kept in per-piece register arrays (round 1 did: p_ph / p_dst / p_rel = 12 VGPRs, and the bf16 kernel -- capped at 256
+    // registers for two workgroups per CU -- spilled 13 of them to scratch; the scratch RELOADS sat between the staging loads of
+    // issue(), and since scratch shares the vector-memory counter each forced s_waitcnt vmcnt(0): the four P loads of every tile
+    // were serialised into four memory round trips).
     const int p_part = tid % PPV;
-#pragma unroll
-    for (int s2 = 0; s2 < PSTEPS; ++s2) {
-        const int pt = (tid + s2 * 256) / PPV;            // 0..255
-        const int tr = pt >> 3, pw = pt & 7;
-        p_ph[s2] = ((tr >> 3) << 16) | ((tr & 7) << 8) | pw;                       // pd, ph, pw
-        p_dst[s2] = tr * PROW + pw * RB + p_part * 16;
-        p_rel[s2] = (((tr >> 3) * A.PL[1] + (tr & 7)) * A.PL[2] + pw) * A.Cp * (int)sizeof(T) + p_part * 16;
-    }
+    constexpr int TRSTEP = 256 / PPV / 8;
+    const int p_tr0 = (tid / PPV) >> 3, p_pw = (tid / PPV) & 7;
+    const int p_dst0 = p_tr0 * PROW + p_pw * RB + p_part * 16;                      // + s2 * TRSTEP * PROW
+    const int p_rowb = A.PL[2] * A.Cp * (int)sizeof(T), p_slab = A.PL[1] * p_rowb;  // bytes per lattice row / slice
+    const int p_col = p_pw * A.Cp * (int)sizeof(T) + p_part * 16;
     // Q: thread = column piece (hw, part) of QRPS rows per step
     const int q_cp = tid % QCOLP, q_r0 = tid / QCOLP;
     const bool q_active = tid < QRPS * QCOLP;
@@ -356,8 +357,8 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
         const bool valid = t < 27;
         const int tt = valid ? t : 0;
         const int a = tt / 9, b = (tt / 3) % 3, c = tt % 3;
-        tapoff[ts] = (a * HH + b) * QROW + c * RB;
-        tapw[ts] = valid ? tt : -1;
+        tapoff[ts] = __builtin_amdgcn_readfirstlane((a * HH + b) * QROW + c * RB);      // wave-uniform: keep them in SGPRs
+        tapw[ts] = __builtin_amdgcn_readfirstlane(valid ? tt : -1);
     }
 
     f32x4 acc[NTS][2][2];
@@ -389,9 +390,11 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
         const int p_org = ((l0d * A.PL[1] + l0h) * A.PL[2] + l0w) * A.Cp * (int)sizeof(T);
 #pragma unroll
         for (int s2 = 0; s2 < PSTEPS; ++s2) {
-            const int ld = l0d + (p_ph[s2] >> 16), lh = l0h + ((p_ph[s2] >> 8) & 255), lw = l0w + (p_ph[s2] & 255);
+            const int tr = p_tr0 + s2 * TRSTEP;
+            const int pd = tr >> 3, ph = tr & 7;
+            const int ld = l0d + pd, lh = l0h + ph, lw = l0w + p_pw;
             const bool ok = ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2];
-            vp[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, ok ? p_rel[s2] : (int)0x80000000, p_org, 0));
+            vp[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, ok ? pd * p_slab + ph * p_rowb + p_col : (int)0x80000000, p_org, 0));
         }
         const int q0d = l0d - 1, q0h = l0h - 1, qw = l0w - 1 + q_hw;
         const bool okw = q_active && (unsigned)qw < (unsigned)A.QD[2];
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int s2 = 0; s2 < PSTEPS; ++s2) *reinterpret_cast<u32x4*>(sp + p_dst[s2]) = vp[s2];
+        for (int s2 = 0; s2 < PSTEPS; ++s2) *reinterpret_cast<u32x4*>(sp + p_dst0 + s2 * (TRSTEP * PROW)) = vp[s2];
         if (q_active) {
             constexpr int E16 = 16 / (int)sizeof(T);
             float asc[E16], ash[E16];
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
     const bool do_bias = A.dbias != nullptr && blockIdx.z == 0 && wv == 3;
     // pinned software pipeline over the 56 (contraction step, tap slot) pairs
     auto compute = [&]() {
-        constexpr int U = KS * NTS, QD_ = 2;
+        constexpr int U = KS * NTS, QD_ = QDEPTH;   // LDS fragment prefetch distance (steps of 4 MFMAs)
         WF<T> pf[2][2], qf[QD_ + 1][2];
         auto load_p = [&](int ks, WF<T>* d) {
             const char* b0 = p_lane + ks * 4 * PROW;
@@ -670,12 +673,17 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             if (bf) {
                 static bool at = false;
                 if (!at) {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
                     at = true;
                 }
-                if (b.qss) k_wgrad3<bf16_t, 2, true><<<g3, 256, lds3, st>>>(b);
-                else k_wgrad3<bf16_t, 2, false><<<g3, 256, lds3, st>>>(b);
+                // QDEPTH 1: 248 registers, no spill. With depth 2 the kernel needs > 256 registers at two workgroups per CU and the
+                // spill reloads (scratch shares vmcnt) serialise the staging loads of every tile (profiles/round2_wgrad3_spill.txt)
+                static const int qd = getenv("NNDET_WGRAD3_QD") ? atoi(getenv("NNDET_WGRAD3_QD")) : 1;
+                if (b.qss) k_wgrad3<bf16_t, 2, true, 1><<<g3, 256, lds3, st>>>(b);
+                else if (qd == 2) k_wgrad3<bf16_t, 2, false, 2><<<g3, 256, lds3, st>>>(b);
+                else k_wgrad3<bf16_t, 2, false, 1><<<g3, 256, lds3, st>>>(b);
             } else {
                 static bool at = false;
                 if (!at) {
