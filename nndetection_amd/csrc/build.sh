@@ -22,7 +22,8 @@ build postproc.hip -ffp-contract=off
 build targets.hip
 build sampler.hip
 build wbc3d.hip -ffp-contract=off
-build conv_igemm.hip
+# k_ig3r is one fully unrolled 432-MFMA tile body: beyond the default size limit of '#pragma unroll'
+build conv_igemm.hip -mllvm -pragma-unroll-threshold=1000000
 build conv_wgrad.hip
 build conv_pw.hip
 build conv_stem.hip

@@ -643,6 +643,252 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3x3, stride 1, 32 -> 32 channels
+// k_ig3r: persistent kernel for the full-resolution 32 -> 32 layers (bf16), the layer shape with the most FLOPs of the network.
+// k_ig3 tops out at ~0.9 PFLOP/s there: with only 2 row tiles to amortise a weight fragment over, the 2 weight buffer loads per 16
+// MFMAs saturate the vector-memory pipe (tools/probe_loop.hip: 1.0 PF with them, 1.6 PF without). Here
+//   * ALL weights live in registers: 27 taps x 2 row tiles x 4 VGPRs = 216 registers per lane (one wave per SIMD, 512-register
+//     budget); a workgroup loads them once and then walks over ~75 tiles of 8x8x8 outputs;
+//   * the halo of the NEXT tile goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds; no staging registers, no ds_write
+//     pass; lanes whose voxel is outside the tensor use an out-of-range offset and the hardware writes the zero padding:
+//     tools/probe_ldsdma.hip) into the second 64 KB buffer while the MFMAs of the current tile run; one barrier per tile;
+//   * the MFMA order is point-group major (d-plane 0 of the wave: 27 taps, then d-plane 1), so the 8 accumulators of a finished
+//     plane are free while the other plane computes: the epilogue (bias, bf16 pack, store, norm statistics) of one plane is cut
+//     into single-instruction micro-ops and issued one per MFMA slot under the MFMAs of the next plane / next tile;
+//   * the statistics stay in registers across the tiles of an image (one DPP reduction + 64 fp64 atomics per wave and image).
+// Every MFMA slot is pinned with sched_barrier: with one wave per SIMD nothing else hides a badly placed instruction.
+struct Ig3rArgs {
+    const void* x; const void* w; const float* bias; void* y; double* stats;
+    int32_t N, D, H, W;          // spatial dims of input == output, all multiples of 8
+    int32_t nt1, nt2, ntiles;    // tiles along H, W; tiles per image
+    uint32_t m_tiles, m_hw, m_w; // magic multipliers for / ntiles, / (nt1 * nt2), / nt2 (0 = divisor 1)
+    int32_t rev;                 // backward-data: the tap at halo offset idx is weight tap 26 - idx
+    int32_t total, per_xcd;      // N * ntiles; tiles per XCD (workgroup ids go round-robin over the 8 XCDs)
+};
+
+__device__ __forceinline__ uint32_t mdiv(uint32_t n, uint32_t m) { return m ? __umulhi(n, m) : n; }
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, int voff, uint32_t lds_dst) {
+    // M0 is written in the same statement that reads it (the compiler does not preserve it around asm); hipcc does not count this
+    // load: its completion is waited for by hand (vmcnt(0) before the tile barrier)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
+    constexpr int HH = 10, HW = 10, BUF = 65536, NPIECE = 16;
+    constexpr int NM = STATS ? 19 : 7;                       // epilogue micro-ops per accumulator fragment
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, stride = gridDim.x >> 3;
+    int g = xcd * A.per_xcd + slot;
+    const int g_end = min((xcd + 1) * A.per_xcd, A.total);
+    if (g >= g_end) return;                                   // uniform
+    const int rowb = A.W * 64, slab = A.H * rowb, img_bytes = A.D * slab;        // < 2^31 (checked on the host)
+
+    // ---- staging: wave wv moves pieces wv * 16 .. wv * 16 + 15 (1 KB each) of the 10x10x10 halo; LDS granule G = piece * 64 + lane
+    // holds halo row G / 40, voxel (G % 40) / 4, 16-byte part ((G % 4) ^ (row parity << 1)) (the XOR swizzle of k_ig3, applied to the
+    // SOURCE address because the LDS-DMA destination is lane-linear)
+    int rel[NPIECE];
+    uint32_t bsel[NPIECE];
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) {
+        const int G = (wv * NPIECE + p) * 64 + lane;
+        const int row = G / 40, col = G - row * 40;
+        const int hd = row / HH, hh = row - hd * HH, hw = col >> 2, part = (col & 3) ^ ((row & 1) << 1);
+        rel[p] = (hd * A.H + hh) * rowb + hw * 64 + part * 16;
+        bsel[p] = G < 4000 ? (1u << hd) | (1u << (10 + hh)) | (1u << (20 + hw)) : 0x80000000u;
+    }
+    // scalars of a tile: image, byte offset of the halo origin in the input image, of the tile origin in the output image, validity
+    // mask (bit hd | bit 10 + hh | bit 20 + hw set = that halo plane / row / column lies inside the tensor)
+    auto decode = [&](int gg, int& n, int& tin, int& tout, uint32_t& M) {
+        n = (int)mdiv((uint32_t)gg, A.m_tiles);
+        const int t = gg - n * A.ntiles;
+        const int td = (int)mdiv((uint32_t)t, A.m_hw);
+        const int r = t - td * A.nt1 * A.nt2;
+        const int th = (int)mdiv((uint32_t)r, A.m_w);
+        const int tw = r - th * A.nt2;
+        const int l0d = td * 8, l0h = th * 8, l0w = tw * 8;
+        tin = ((l0d - 1) * A.H + (l0h - 1)) * rowb + (l0w - 1) * 64;
+        tout = (l0d * A.H + l0h) * rowb + l0w * 64;
+        const uint32_t dm = 0x3ffu & ~(l0d == 0 ? 1u : 0u) & ~(l0d + 8 == A.D ? 0x200u : 0u);
+        const uint32_t hm = 0x3ffu & ~(l0h == 0 ? 1u : 0u) & ~(l0h + 8 == A.H ? 0x200u : 0u);
+        const uint32_t wm = 0x3ffu & ~(l0w == 0 ? 1u : 0u) & ~(l0w + 8 == A.W ? 0x200u : 0u);
+        M = dm | (hm << 10) | (wm << 20);
+    };
+    auto x_rsrc = [&](int n) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (int64_t)n * img_bytes, 0, img_bytes, 0x00020000);
+    };
+    auto y_rsrc = [&](int n, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(A.y) + (int64_t)n * img_bytes, 0, live ? img_bytes : 0, 0x00020000);
+    };
+
+    // ---- weights -> registers
+    u32x4 wr[27][2];
+    {
+        const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.w), 0, 27 * 2048, 0x00020000);
+#pragma unroll
+        for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+            {   // step tp visits halo offset (a, b, c) = (tp / 9, tp % 3, (tp / 3) % 3): the tap order of k_ig3, so both kernels add
+                // the 27 x 32 products of an output in the same order and give bit-identical results
+                const int widx = ((tp / 9) * 3 + tp % 3) * 3 + (tp / 3) % 3;
+                wr[tp][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, ((i * 16 + li) * 32 + q * 8) * 2, (A.rev ? 26 - widx : widx) * 2048, 0));
+            }
+    }
+    float bia[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bia[i][r] = A.bias ? A.bias[i * 16 + q * 4 + r] : 0.f;
+
+    // ---- first tile: stage into buffer 0
+    int n_cur, tin_cur, tout_cur; uint32_t M_cur;
+    decode(g, n_cur, tin_cur, tout_cur, M_cur);
+    {
+        const auto xrs = x_rsrc(n_cur);
+#pragma unroll
+        for (int p = 0; p < NPIECE; ++p) {
+            const int vo = (M_cur & bsel[p]) == bsel[p] ? tin_cur + rel[p] : (int)0x80000000;
+            lds_dma16(xrs, vo, (uint32_t)((wv * NPIECE + p) * 1024));
+        }
+    }
+    // fragment addresses: the two swizzle phases of this lane's base (see k_ig3); ^= BUF switches the halo buffer
+    const int par = (li >> 3) & 1;
+    const int lanevox = (wv * 2 * HH + (li >> 3)) * HW + (li & 7);
+    int sb0 = lanevox * 64 + ((q ^ (par << 1)) << 4);
+    int sb1 = lanevox * 64 + ((q ^ (par << 1) ^ 2) << 4);
+    auto lds_frag = [&](int gph, int tp, int jj) {
+        const int a = tp / 9, b = tp % 3, c = (tp / 3) % 3;
+        return *reinterpret_cast<const u32x4*>(smem + ((b & 1) ? sb1 : sb0) + (((gph + a) * HH + 2 * jj + b) * HW + c) * 64);
+    };
+    const int vlane = ((li >> 3) * A.W + (li & 7)) * 64 + q * 8;       // this lane's 4 channels of fragment row i = 0, point li
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssum[2][4], ssq[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+    auto flush = [&](int n) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = dpp_row_sum(ssum[i][r]), s2 = dpp_row_sum(ssq[i][r]);
+                if (li == 0) {
+                    const int rep = (blockIdx.x * 4 + wv) % NNDET_STATS_REPLICAS;
+                    double* dst = A.stats + (((int64_t)rep * A.N + n) * 32 + i * 16 + q * 4 + r) * 2;
+                    atomicAdd(dst, (double)s);
+                    atomicAdd(dst + 1, (double)s2);
+                }
+                ssum[i][r] = 0.f; ssq[i][r] = 0.f;
+            }
+    };
+    // epilogue micro-op m of fragment (i, j): the values pass through ev / epk between slots
+    float ev[4];
+    v2u_t epk;
+    auto epi = [&](int i, int j, int m, __amdgpu_buffer_rsrc_t yrs, int soff) {
+        if (m < 4) ev[m] = acc[i][j][m] + bia[i][m];
+        else if (m == 4) epk[0] = pack_bf16x2(ev[0], ev[1]);
+        else if (m == 5) epk[1] = pack_bf16x2(ev[2], ev[3]);
+        else if (m == 6) __builtin_amdgcn_raw_buffer_store_b64(epk, yrs, vlane + i * 32, soff, 0);
+        else if (m < 11) { const int r = m - 7; ev[r] = __uint_as_float((r & 1) ? (epk[r >> 1] & 0xffff0000u) : (epk[r >> 1] << 16)); }
+        else if (m < 15) ssum[i][m - 11] += ev[m - 11];
+        else ssq[i][m - 15] = fmaf(ev[m - 15], ev[m - 15], ssq[i][m - 15]);
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    u32x4 bf[2][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) bf[0][jj] = lds_frag(0, 0, jj);
+
+    bool first = true;
+    int cur_buf = 0;                                                    // LDS byte offset of the halo buffer being read (scalar twin of sb0 & BUF)
+    int stat_n = n_cur;
+    int n_prev = n_cur, tout_prev = 0;
+    for (;;) {
+        const int g_next = g + stride;
+        const bool has_next = g_next < g_end;
+        int n_next, tin_next, tout_next; uint32_t M_next;
+        decode(has_next ? g_next : g, n_next, tin_next, tout_next, M_next);
+        if (!has_next) M_next = 0;                                      // every piece out of range: the DMA writes zeros nobody reads
+        const auto xrs = x_rsrc(n_next);
+        const uint32_t dma_dst = (uint32_t)((cur_buf ^ BUF) + wv * NPIECE * 1024);
+        int dma_vo = 0;
+#pragma unroll
+        for (int gph = 0; gph < 2; ++gph) {
+            // the plane whose epilogue runs under this phase: plane 1 of the previous tile (phase 0) / plane 0 of this tile (phase 1)
+            const auto yrs = gph == 0 ? y_rsrc(n_prev, !first) : y_rsrc(n_cur, true);
+            const int ebase = (gph == 0 ? tout_prev : tout_cur) + (wv * 2 + (gph ^ 1)) * slab;
+            if (gph == 1 && STATS) {
+                if (first) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+                } else if (stat_n != n_cur) flush(stat_n);
+                stat_n = n_cur;
+            }
+#pragma unroll
+            for (int tp = 0; tp < 27; ++tp) {
+                const int h = gph * 27 + tp;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int i = s >> 2, jj = s & 3;
+                    if (tp == 0) acc[i][gph * 4 + jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    Mma<bf16_t>::mma(wr[tp][i], bf[h & 1][jj], acc[i][gph * 4 + jj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // fillers of this MFMA slot
+                    if (s < 4) {
+                        if (h == 53) {
+                            if (s == 0) {
+                                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                                sb0 ^= BUF; sb1 ^= BUF; cur_buf ^= BUF;
+                            }
+                            bf[0][s] = lds_frag(0, 0, s);
+                        } else {
+                            bf[(h + 1) & 1][s] = lds_frag(tp == 26 ? 1 : gph, tp == 26 ? 0 : tp + 1, s);
+                        }
+                    }
+                    const int e = tp * 8 + s - 8;                       // epilogue micro-op of this slot
+                    if (e >= 0 && e < 8 * NM) {
+                        const int f = e / NM, m = e % NM;
+                        epi(f >> 2, (gph ^ 1) * 4 + (f & 3), m, yrs, ebase + 2 * (f & 3) * rowb);
+                    }
+                    if (gph == 0 && tp >= 1 && tp <= NPIECE) {          // LDS-DMA of the next tile: one piece per step
+                        const int p = tp - 1;
+                        if (s == 5) dma_vo = (M_next & bsel[p]) == bsel[p] ? tin_next + rel[p] : (int)0x80000000;
+                        if (s == 6) lds_dma16(xrs, dma_vo, dma_dst + p * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        first = false;
+        n_prev = n_cur; tout_prev = tout_cur;
+        n_cur = n_next; tout_cur = tout_next;
+        if (!has_next) break;
+        g = g_next;
+    }
+    // plane 1 of the last tile
+    {
+        const auto yrs = y_rsrc(n_prev, true);
+        const int ebase = tout_prev + (wv * 2 + 1) * slab;
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int m = 0; m < NM; ++m) epi(f >> 2, 4 + (f & 3), m, yrs, ebase + 2 * (f & 3) * rowb);
+        if (STATS) flush(stat_n);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct Plan {
     IgArgs a;
@@ -900,6 +1146,48 @@ static int ensure_attrs() {
     return 0;
 }
 
+// persistent register-weight kernel: bf16, 32 -> 32 (padded) channels, every dim a multiple of the 8x8x8 tile, enough tiles to
+// amortise the 55 KB weight load per workgroup. NNDET_IG3R=0 disables it (read per call so tests can flip it).
+static bool ig3r_applicable(const NndetConv* c, const Plan& P) {
+    const char* e = getenv("NNDET_IG3R");
+    if (e && atoi(e) == 0) return false;
+    const IgArgs& a = P.a;
+    if (c->dtype != NNDET_BF16 || P.cfg != 5 || a.Cx != 32 || a.Cy != 32) return false;
+    for (int i = 0; i < 3; ++i) if (a.I[i] != a.O[i] || (a.I[i] % 8) != 0) return false;
+    const int64_t total = (int64_t)a.N * (a.I[0] / 8) * (a.I[1] / 8) * (a.I[2] / 8);
+    const int64_t min_tiles = (e && atoi(e) == 2) ? 1 : 2048;           // 2 = always (tests)
+    return total >= min_tiles && total < (1 << 24);
+}
+static int ig3r_launch(const Plan& P, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) return (int)hipErrorInvalidValue;
+        n_cu = v & ~7;
+        int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3r<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3r<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+        if (rc) { n_cu = 0; return rc; }
+    }
+    const IgArgs& a = P.a;
+    auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); };
+    Ig3rArgs r;
+    memset(&r, 0, sizeof(r));
+    r.x = a.x; r.w = a.w; r.bias = a.bias; r.y = a.y; r.stats = a.stats;
+    r.N = a.N; r.D = a.I[0]; r.H = a.I[1]; r.W = a.I[2];
+    r.nt1 = r.H / 8; r.nt2 = r.W / 8; r.ntiles = (r.D / 8) * r.nt1 * r.nt2;
+    r.m_tiles = magic(r.ntiles); r.m_hw = magic(r.nt1 * r.nt2); r.m_w = magic(r.nt2);
+    r.rev = a.taps[0].d[0] != 0;
+    r.total = r.N * r.ntiles;
+    r.per_xcd = ceil_div(r.total, 8);
+    int grid = n_cu;
+    const char* ge = getenv("NNDET_IG3R_GRID");                        // tests: few workgroups -> many tiles (and images) per workgroup
+    if (ge && atoi(ge) >= 8) grid = atoi(ge) & ~7;
+    while (grid > 8 && (grid / 8) > r.per_xcd) grid -= 8;
+    if (r.stats) k_ig3r<true><<<grid, 256, 2 * 65536, st>>>(r); else k_ig3r<false><<<grid, 256, 2 * 65536, st>>>(r);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y,
               double* stats, hipStream_t st, float* dbias) {
     if (!stats && !(kind == 0 && c->in_affine && c->transposed)) {   // pointwise problems (1x1x1, transposed k == s) stream straight from global memory
@@ -918,6 +1206,7 @@ int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const 
         if (c->transposed) return NNDET_EINVAL;
         P.a.ss = c->in_affine; P.a.ss_relu = c->in_relu;
     }
+    if (!P.a.ss && !res && ig3r_applicable(c, P)) return ig3r_launch(P, st);
     if (P.a.ss) return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t, true>(P, st) : launch_cfg<float, true>(P, st);
     return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t, false>(P, st) : launch_cfg<float, false>(P, st);
 }

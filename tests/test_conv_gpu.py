@@ -188,6 +188,57 @@ def test_segloss(dtype):
     assert torch.allclose(pr.sum(1).cpu(), torch.ones(2, 8, 9, 10), atol=1e-5)
 
 
+@pytest.mark.parametrize("grid", ["8", "16", "0"], ids=["grid8", "grid16", "gridall"])
+@pytest.mark.parametrize("norm", [None, "instance"], ids=["bias", "instnorm"])
+def test_ig3r_persistent_32to32(norm, grid, monkeypatch):
+    """k_ig3r (persistent, register-resident weights, LDS-DMA staging; bf16 32 -> 32 with every dim a multiple of 8): forward
+    with bias / with the fused InstanceNorm statistics + ReLU, data gradient (mirrored taps), weight gradient of the block.
+    NNDET_IG3R=2 forces the kernel for small problems; NNDET_IG3R_GRID=8/16 makes every workgroup walk over 6-12 tiles that
+    span both images (tile pipeline, buffer toggling, statistics flush at the image change); grid 0 = one tile per workgroup."""
+    monkeypatch.setenv("NNDET_IG3R", "2")
+    if grid != "0":
+        monkeypatch.setenv("NNDET_IG3R_GRID", grid)
+    from nndetection_amd.arch.conv import ConvInstanceRelu
+    dtype = torch.bfloat16
+    torch.manual_seed(5)
+    m = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=norm is not None, add_act=norm is not None)
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.randn_like(m.conv.weight) / 29.4)
+        if m.conv.bias is not None:
+            m.conv.bias.copy_(torch.randn_like(m.conv.bias) * 0.3)
+        if norm is not None:
+            m.norm.weight.copy_(1.0 + 0.3 * torch.randn_like(m.norm.weight))
+            m.norm.bias.copy_(0.3 * torch.randn_like(m.norm.bias))
+    x = torch.randn(2, 32, 16, 24, 32)
+    cfg = ("c32r", 32, 32, 3, 1, 1, False, (16, 24, 32))
+    xr, w, b, g, be, yref = _ref_forward(m, x, cfg, dtype, norm, norm is not None)
+    gy = torch.randn_like(yref).to(dtype).float()
+    yref.backward(gy)
+    outs = []
+    for ig3r in ("2", "0"):                              # the persistent kernel, then k_ig3 on the same inputs
+        monkeypatch.setenv("NNDET_IG3R", ig3r)
+        mg = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=norm is not None, add_act=norm is not None)
+        mg.load_state_dict(m.state_dict())
+        mg = mg.cuda()
+        xg = x.detach().clone().cuda().to(dtype).requires_grad_(True)
+        y = mg(xg)
+        y.backward(gy.cuda().to(dtype))
+        torch.cuda.synchronize()
+        outs.append((y.float().cpu(), xg.grad.float().cpu(), mg.conv.weight.grad.cpu()))
+    tol = TOL[dtype]
+    y, dx, dw = outs[0]
+    assert relerr(y, yref) <= (2e-2 if norm else tol["fwd"])
+    assert relerr(dx, xr.grad) <= (2e-2 if norm else tol["dx"])
+    assert relerr(dw, w.grad) <= (2e-2 if norm else tol["dw"])
+    # against k_ig3: same products, same fp32 accumulation order per output -> identical conv outputs; the statistics are summed in
+    # a different order (fp32 partial sums per lane), so the normalised block may differ by an output ulp
+    y0, dx0, dw0 = outs[1]
+    if norm is None:
+        assert torch.equal(y, y0) and torch.equal(dx, dx0)
+    else:
+        assert relerr(y, y0) <= 8e-3 and relerr(dx, dx0) <= 8e-3
+
+
 def test_full_size_layer_against_torch_gpu():
     """Full-resolution layer shapes of BASELINE config 2 (too slow for the CPU oracle at batch 4): compare against
     PyTorch's own GPU conv (MIOpen) in fp32 on a 1-patch slice, plus linearity as a size-independent property."""
