@@ -673,6 +673,21 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, int voff, u
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst) : "memory");
 }
 
+#ifndef IG3R_PD
+#define IG3R_PD 2
+#endif
+#ifndef IG3R_DPH
+#define IG3R_DPH 0      // phase (d-plane) whose MFMAs cover the LDS-DMA issue
+#define IG3R_DS0 9      // first step (after the stores of the previous plane: measured 3 % faster than from step 1)
+#define IG3R_PPS 1      // pieces per step
+#define IG3R_SL0 6      // MFMA slot of the first piece of a step
+#endif
+#ifndef IG3R_SKEW
+#define IG3R_SKEW 0
+#endif
+#ifndef IG3R_DBG
+#define IG3R_DBG 0      // timing experiments only (wrong results): 1 no LDS-DMA in the loop, 2 no epilogue, 4 no tile barrier
+#endif
 template <bool STATS>
 __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
     constexpr int HH = 10, HW = 10, BUF = 65536, NPIECE = 16;
@@ -805,9 +820,14 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
     };
 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    u32x4 bf[2][4];
+    // activation fragments: read PD steps (of 8 MFMAs) ahead into a ring of PD + 1 register sets (54 steps per tile: 54 % (PD + 1) == 0)
+    constexpr int PD = IG3R_PD, RING = PD + 1;
+    static_assert(54 % RING == 0, "ring phase must repeat per tile");
+    u32x4 bf[RING][4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) bf[0][jj] = lds_frag(0, 0, jj);
+    for (int hh = 0; hh < PD; ++hh)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bf[hh][jj] = lds_frag(0, hh, jj);
 
     bool first = true;
     int cur_buf = 0;                                                    // LDS byte offset of the halo buffer being read (scalar twin of sb0 & BUF)
@@ -842,30 +862,44 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const int i = s >> 2, jj = s & 3;
-                    if (tp == 0) acc[i][gph * 4 + jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    Mma<bf16_t>::mma(wr[tp][i], bf[h & 1][jj], acc[i][gph * 4 + jj]);
+                    // weights as AGPR operands (asm: the builtin form keeps them in VGPRs, i.e. 262 v_accvgpr_read + 104 s_nop per tile
+                    // for the 60+ registers that do not fit); first tap: C = inline 0. Hazards: B comes from ds_read (counted wait by
+                    // the compiler), an accumulator is next read >= 8 MFMA slots after its last MFMA
+                    if (tp == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[i][gph * 4 + jj]) : "a"(wr[tp][i]), "v"(bf[h % RING][jj]));
+                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][gph * 4 + jj]) : "a"(wr[tp][i]), "v"(bf[h % RING][jj]));
                     __builtin_amdgcn_sched_barrier(0);
                     // fillers of this MFMA slot
                     if (s < 4) {
-                        if (h == 53) {
-                            if (s == 0) {
-                                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        const int hn = h + PD;                          // the step whose fragments are read now
+                        if (hn >= 54) {                                 // = step hn - 54 of the next tile, from the other halo buffer
+                            if (hn == 54 && s == 0) {
+                                if (!(IG3R_DBG & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                                 sb0 ^= BUF; sb1 ^= BUF; cur_buf ^= BUF;
+#if IG3R_SKEW
+                                // the barrier releases the four waves in the same cycle and their LDS-DMA pieces would collide in the
+                                // address path step after step: delay wave w by w * IG3R_SKEW * 8 cycles once per tile
+                                for (int k = 0; k < wv * IG3R_SKEW; ++k) asm volatile("s_nop 7");
+#endif
                             }
-                            bf[0][s] = lds_frag(0, 0, s);
+                            bf[hn % RING][s] = lds_frag(0, hn - 54, s);
                         } else {
-                            bf[(h + 1) & 1][s] = lds_frag(tp == 26 ? 1 : gph, tp == 26 ? 0 : tp + 1, s);
+                            bf[hn % RING][s] = lds_frag(hn / 27, hn % 27, s);
                         }
                     }
                     const int e = tp * 8 + s - 8;                       // epilogue micro-op of this slot
-                    if (e >= 0 && e < 8 * NM) {
+                    if (e >= 0 && e < 8 * NM && !(IG3R_DBG & 2)) {
                         const int f = e / NM, m = e % NM;
                         epi(f >> 2, (gph ^ 1) * 4 + (f & 3), m, yrs, ebase + 2 * (f & 3) * rowb);
                     }
-                    if (gph == 0 && tp >= 1 && tp <= NPIECE) {          // LDS-DMA of the next tile: one piece per step
-                        const int p = tp - 1;
-                        if (s == 5) dma_vo = (M_next & bsel[p]) == bsel[p] ? tin_next + rel[p] : (int)0x80000000;
-                        if (s == 6) lds_dma16(xrs, dma_vo, dma_dst + p * 1024);
+                    // LDS-DMA of the next tile: IG3R_PPS pieces per step from step IG3R_DS0 of phase IG3R_DPH on; the offset is computed one
+                    // slot before the issue slot
+                    if (gph == IG3R_DPH && tp >= IG3R_DS0 && tp < IG3R_DS0 + NPIECE / IG3R_PPS && !(IG3R_DBG & 1)) {
+#pragma unroll
+                        for (int k = 0; k < IG3R_PPS; ++k) {
+                            const int p = (tp - IG3R_DS0) * IG3R_PPS + k, sl = IG3R_SL0 + k * (IG3R_PPS > 2 ? 1 : 2);
+                            if (s == sl - 1) dma_vo = (M_next & bsel[p]) == bsel[p] ? tin_next + rel[p] : (int)0x80000000;
+                            if (s == sl) lds_dma16(xrs, dma_vo, dma_dst + p * 1024);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

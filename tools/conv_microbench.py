@@ -43,7 +43,8 @@ def timeit(fn, iters):
 
 def main():
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(SHAPES)
-    iters = 5
+    iters = int(os.environ.get("MICRO_ITERS", "5"))
+    order = os.environ.get("MICRO_ORDER", "fwd,dgrad,wgrad").split(",")     # e.g. dgrad,fwd,dgrad: clocks depend on what ran just before
     dt = torch.bfloat16
     for name in names:
         cin, cout, k, s, p, tr, sp, B = SHAPES[name]
@@ -65,8 +66,9 @@ def main():
         flops = 2.0 * (B * sp[0] * sp[1] * sp[2] if tr else nvox_out) * taps * cin * cout
         byts = 2.0 * (x.numel() + y.numel())
         res = []
-        for nm, fn in (("fwd", f), ("dgrad", g), ("wgrad", h)):
-            ms = timeit(fn, iters)
+        fns = {"fwd": f, "dgrad": g, "wgrad": h}
+        for nm in order:
+            ms = timeit(fns[nm], iters)
             res.append(f"{nm} {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF/s {byts / ms / 1e6:7.0f} GB/s")
         print(f"{name:16s} {flops / 1e9:7.1f} GF {byts / 1e6:7.0f} MB | " + " | ".join(res), flush=True)
 
