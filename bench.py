@@ -78,11 +78,14 @@ def conv_roofline(plan, batch, dtype, device, iters=10):
         tj = os.path.join(pdir, name)
         if os.path.isfile(tj) and batch == 4 and tuple(P) == (160, 160, 96) and dtype == torch.bfloat16:
             with open(tj) as f:
-                traffic = int(json.load(f)["k_ig3_cfgA_e0"]["hbm_bytes"])
+                tr = json.load(f)
+                key = "k_ig3r_e0" if os.environ.get("NNDET_IG3R", "1") != "0" and "k_ig3r_e0" in tr else "k_ig3_cfgA_e0"
+                traffic = int(tr[key]["hbm_bytes"])
             break
     # 432 FLOP per algorithmic byte is above the MFMA/HBM ridge (2500 TF/s / 8 TB/s = 312): the kernel is priced against the
     # dense bf16 MFMA peak; the HBM view (algorithmic bytes / time) is reported next to it
-    return {"bound": "mfma", "kernel": "k_ig3<bf16,WR=1,MT=2,NT=8> conv3d 3x3x3 32->32 @%dx%dx%d, batch %d (forward)" % (*P, batch),
+    kname = "k_ig3r<bf16> (persistent, weights in registers)" if os.environ.get("NNDET_IG3R", "1") != "0" else "k_ig3<bf16,WR=1,MT=2,NT=8>"
+    return {"bound": "mfma", "kernel": kname + " conv3d 3x3x3 32->32 @%dx%dx%d, batch %d (forward)" % (*P, batch),
             "achieved": round(tfs, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tfs / 2500.0, 4),
             "traffic": traffic, "algorithmic_flops_per_launch": int(flops), "algorithmic_bytes_per_launch": int(alg_bytes),
             "ms_per_launch": round(float(ms), 4), "algorithmic_GBs": round(gbs, 1), "hbm_frac_of_8TBs": round(gbs / 8000.0, 4),
