@@ -186,9 +186,26 @@ class DetectionHeadHNMNative(nn.Module):
         pos, neg = self.fg_bg_sampler(target_labels, probs)
         return torch.where(torch.cat(pos, dim=0))[0], torch.where(torch.cat(neg, dim=0))[0]
 
+    # The sampler's counts are the only data-dependent sizes of a training step. Reading them (select_indices) blocks the host
+    # until the whole forward pass has drained, and everything after it -- loss, backward of the heads, i.e. hundreds of small
+    # launches -- is then issued into an empty queue. The sync-free path keeps the fixed-capacity, -1 padded index lists of the
+    # device sampler and masks the padding out of the two reductions instead (same sums, same divisors; summation order aside).
+    # NNDET_SYNCFREE_LOSS=0, a patched / overridden select_indices, a foreign sampler or reduction=None select the compact path.
+    sync_free = os.environ.get("NNDET_SYNCFREE_LOSS", "1") != "0"
+    _unit_box: Dict[torch.device, Tensor] = {}
+
+    def _use_sync_free(self) -> bool:
+        return (self.sync_free and "select_indices" not in self.__dict__
+                and type(self).select_indices is DetectionHeadHNMNative.select_indices
+                and hasattr(self.fg_bg_sampler, "sample_device")
+                and type(self.classifier) is BCECLassifier and self.classifier.reduction in ("mean", "sum")
+                and type(self.regressor) is GIoURegressor and self.regressor.reduction in ("mean", "sum"))
+
     def compute_loss(self, prediction: Dict[str, Tensor], target_labels: List[Tensor], matched_gt_boxes: List[Tensor],
                      anchors: List[Tensor]):
         box_logits, box_deltas = prediction["box_logits"], prediction["box_deltas"]
+        if box_logits.is_cuda and self._use_sync_free():
+            return self._compute_loss_sync_free(box_logits, box_deltas, target_labels, matched_gt_boxes, anchors)
         losses = {}
         sampled_pos_inds, sampled_neg_inds = self.select_indices(target_labels, box_logits)
         sampled_inds = torch.cat([sampled_pos_inds, sampled_neg_inds], dim=0)
@@ -207,6 +224,48 @@ class DetectionHeadHNMNative(nn.Module):
             losses["reg"] = self.regressor.compute_loss(pred_boxes_sampled, target_boxes_sampled) / max(1, sampled_pos_inds.numel())
         losses["cls"] = self.classifier.compute_loss(box_logits[sampled_inds], labels[sampled_inds])
         return losses, sampled_pos_inds, sampled_neg_inds
+
+    def _compute_loss_sync_free(self, box_logits: Tensor, box_deltas: Tensor, target_labels: List[Tensor], matched_gt_boxes,
+                                anchors: List[Tensor]):
+        """comb.py:351-405 without a host read. Returns the PADDED index lists (-1 = unused slot) in place of the compact ones.
+        With no positive anchor the reference leaves "reg" out of the dict; here it is an exact 0 (the total is the same)."""
+        labels = target_labels[0] if len(target_labels) == 1 else torch.cat(target_labels, dim=0)
+        pos, neg, counts = self.fg_bg_sampler.sample_device(labels, box_logits, len(target_labels))
+        n_pos, n_neg = counts[0], counts[1]
+        pos_ok, neg_ok = pos >= 0, neg >= 0
+        pos_c, neg_c = pos.clamp(min=0), neg.clamp(min=0)
+        m = anchors[0].shape[0]
+        if all(a is anchors[0] for a in anchors):
+            anchors_pos = anchors[0][pos_c % m]
+        else:
+            anchors_pos = torch.cat(anchors, dim=0)[pos_c]
+        if isinstance(matched_gt_boxes, (list, tuple)):
+            matched_gt_boxes = matched_gt_boxes[0] if len(matched_gt_boxes) == 1 else torch.cat(matched_gt_boxes, dim=0)
+        pred = self.coder.decode_single(box_deltas[pos_c], anchors_pos)
+        tgt = matched_gt_boxes[pos_c]
+        # unused slots point at anchor 0, whose target may be the all-zero box of a background anchor (GIoU 0/0): give them a
+        # harmless pair; torch.where also keeps their (zero) gradient away from row 0 of box_deltas
+        unit = self._unit_box.get(pred.device)
+        if unit is None:                                            # built once per device (a host -> device copy blocks the host)
+            unit = self._unit_box[pred.device] = torch.tensor([0., 0., 1., 1., 0., 1.], device=pred.device)
+        pred = torch.where(pos_ok[:, None], pred.float(), unit)
+        tgt = torch.where(pos_ok[:, None], tgt.float(), unit)
+        g = giou_diag(pred, tgt, eps=self.regressor.eps)
+        g_sum = torch.where(pos_ok, g, torch.zeros_like(g)).sum()
+        n_pos_f = n_pos.clamp(min=1).to(g_sum.dtype)
+        red = g_sum if self.regressor.reduction == "sum" else g_sum / n_pos_f
+        losses = {"reg": self.regressor.loss_weight * -1 * red / n_pos_f}
+        idx = torch.cat([pos_c, neg_c], dim=0)
+        ok = torch.cat([pos_ok, neg_ok], dim=0)
+        lab = torch.where(ok, labels[idx], torch.zeros((), dtype=labels.dtype, device=labels.device))
+        nc = self.classifier.num_classes
+        onehot = F.one_hot(lab.long(), nc + 1)[:, 1:].float()
+        bce = F.binary_cross_entropy_with_logits(box_logits[idx], onehot, reduction="none")
+        b_sum = torch.where(ok[:, None], bce, torch.zeros_like(bce)).sum()
+        if self.classifier.reduction == "mean":
+            b_sum = b_sum / ((n_pos + n_neg).clamp(min=1) * nc).to(b_sum.dtype)
+        losses["cls"] = self.classifier.loss_weight * b_sum
+        return losses, pos, neg
 
     def postprocess_for_inference(self, prediction: Dict[str, Tensor], anchors: List[Tensor]) -> Dict[str, Tensor]:
         return {"pred_boxes": self.coder.decode(prediction["box_deltas"], anchors),

@@ -134,7 +134,11 @@ class BaseRetinaNet(nn.Module):
             z = torch.zeros((B, M), dtype=anchors.dtype, device=dev)
             return list(z.unbind(0)), [torch.zeros_like(anchors) for _ in range(B)]
         cls_all = torch.cat([c.to(dev).reshape(-1) for c, b in zip(target_classes, target_boxes) if b.numel() > 0], 0)
-        base = torch.tensor(offs[:-1], dtype=torch.int64, device=dev).clamp_(max=gt_all.shape[0] - 1)[:, None]
+        # (pinned + non_blocking: torch.tensor(..., device=dev) copies through the stream and blocks the host until the forward pass
+        # in front of it has drained)
+        last = gt_all.shape[0] - 1
+        base = torch.tensor([min(o, last) for o in offs[:-1]], dtype=torch.int64)
+        base = (base.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else base.to(dev))[:, None]
         glob = matches.clamp(min=0) + base                                   # [B, M] rows of gt_all
         boxes = gt_all[glob]                                                 # [B, M, 6]
         labels = (cls_all[glob].to(anchors.dtype) + 1) * (matches >= 0).to(anchors.dtype)

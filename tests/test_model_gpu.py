@@ -105,9 +105,14 @@ def test_inference_step_and_state_dict_roundtrip(golden_dir):
     ora.load_state_dict(sd)                        # keys / shapes load back into the reference-shaped oracle
 
 
-def test_no_gt_image_and_optimizer_step():
-    """A batch without any GT (all anchors background, no 'reg' loss: comb.py:397-401) and one SGD step."""
+@pytest.mark.parametrize("sync_free", [False, True], ids=["compact", "syncfree"])
+def test_no_gt_image_and_optimizer_step(sync_free, monkeypatch):
+    """A batch without any GT (all anchors background, no 'reg' loss: comb.py:397-401) and one SGD step. The compact loss path
+    reproduces the reference's dict (no "reg" key, regressor gradients None = the DDP zero-fill case); the default
+    sync-free path cannot know the count on the host: "reg" is an exact 0 and the regressor gradients are zeros."""
     from nndetection_amd.ptmodule import build_model, configure_optimizer
+    from nndetection_amd.arch.heads import DetectionHeadHNMNative
+    monkeypatch.setattr(DetectionHeadHNMNative, "sync_free", sync_free)
     plan = get_plan("tiny")
     torch.manual_seed(0)
     net = build_model(plan).cuda()
@@ -116,9 +121,13 @@ def test_no_gt_image_and_optimizer_step():
     tg = {"target_boxes": [torch.zeros(0, 6, device="cuda")] * 2, "target_classes": [torch.zeros(0, device="cuda")] * 2,
           "target_seg": torch.zeros(2, *plan["patch_size"], device="cuda")}
     losses, _ = net.train_step(x, tg, evaluation=False)
-    assert "reg" not in losses and set(losses) == {"cls", "seg_ce", "seg_dice"}
+    if sync_free:
+        assert set(losses) == {"reg", "cls", "seg_ce", "seg_dice"} and float(losses["reg"].detach()) == 0.0
+    else:
+        assert "reg" not in losses and set(losses) == {"cls", "seg_ce", "seg_dice"}
     sum(losses.values()).backward()
-    assert net.head.regressor.conv_out.conv.weight.grad is None      # the DDP zero-fill case
+    g = net.head.regressor.conv_out.conv.weight.grad
+    assert (g is not None and not g.any()) if sync_free else g is None
     before = net.encoder.stages[0].convs[0][0].conv.weight.detach().clone()
     opt.step(); sched.step()
     assert not torch.equal(before, net.encoder.stages[0].convs[0][0].conv.weight)

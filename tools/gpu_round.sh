@@ -14,7 +14,7 @@ for s in $STAGES; do
     model) timeout 900 python -m pytest tests/test_model_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_model.txt 2>&1; tail -30 gpurun_out/t_model.txt;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.txt 2>&1; tail -5 gpurun_out/smoke.txt;;
     bench) timeout 1200 python bench.py ${BENCH_ARGS:---steps 30 --warmup 5} > gpurun_out/bench.txt 2>&1; tail -5 gpurun_out/bench.txt;;
-    prof)  rm -rf gpurun_out/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-extras > $OLDPWD/gpurun_out/prof.txt 2>&1); db=$(find gpurun_out/prof -name "*_results.db" | head -1); [ -n "$db" ] && python tools/rocpd_stats.py "$db" 3 --by-grid > gpurun_out/kernel_stats.txt && head -22 gpurun_out/kernel_stats.txt | cut -c1-170; rm -rf gpurun_out/prof gpurun_out/prof_old; true;;
+    prof)  rm -rf gpurun_out/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -- python $OLDPWD/bench.py --steps 3 --warmup 2 --no-extras > $OLDPWD/gpurun_out/prof.txt 2>&1); db=$(find gpurun_out/prof -name "*_results.db" | head -1); [ -n "$db" ] && python tools/rocpd_stats.py "$db" 5 --by-grid --timeline gpurun_out/timeline.txt > gpurun_out/kernel_stats.txt && head -22 gpurun_out/kernel_stats.txt | cut -c1-170; rm -rf gpurun_out/prof gpurun_out/prof_old; true;;
     micro) timeout 600 python tools/conv_microbench.py $MICRO > gpurun_out/micro.txt 2>&1; cat gpurun_out/micro.txt;;
     pmc)   rm -rf gpurun_out/pmc; for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_MFMA"; do
              tag=$(echo $pass | cut -d' ' -f1); (cd /tmp && timeout 300 rocprofv3 --pmc $pass -d $OLDPWD/gpurun_out/pmc/$tag -- python $OLDPWD/tools/conv_microbench.py ${MICRO:-e0_32x32_full} > $OLDPWD/gpurun_out/pmc_$tag.txt 2>&1); done

@@ -27,5 +27,44 @@ def main():
             print(f"{sm / 1e6 / steps:9.3f} {c / steps:10.1f} {a / 1e3:9.2f} {f'{gx}x{gy}x{gz}':>18} {lds or 0:7d}  {n[:90]}")
 
 
+def timeline(path, steps, out):
+    """--timeline <file>: kernels of the LAST step of the trace in start order (start offset, duration, queue, grid, name) plus the
+    union-busy time and the time with >= 2 kernels in flight (the detection-head levels run on side streams)."""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = list(db.execute(f"select start, end, name, grid_x / workgroup_x, grid_y, grid_z, {qcol} from kernels order by start"))
+    # one step = from one launch of the stem forward kernel (first kernel of a forward pass) to the next
+    marks = [i for i, r in enumerate(rows) if "k_stem_fwd" in r[2]]
+    if len(marks) >= 2:
+        rows = rows[marks[-2]:marks[-1]]
+    per = len(rows)
+    t0 = rows[0][0]
+    ev = sorted([(r[0], 1) for r in rows] + [(r[1], -1) for r in rows])
+    busy = multi = 0
+    depth = 0
+    last = ev[0][0]
+    for t, d in ev:
+        if depth >= 1: busy += t - last
+        if depth >= 2: multi += t - last
+        depth += d
+        last = t
+    with open(out, "w") as f:
+        f.write(f"# one step (stem forward to the next stem forward): {per} kernels, span {(max(r[1] for r in rows) - t0) / 1e6:.3f} ms, GPU busy (union) {busy / 1e6:.3f} ms, "
+                f">= 2 kernels in flight {multi / 1e6:.3f} ms, sum of durations {sum(r[1] - r[0] for r in rows) / 1e6:.3f} ms\n")
+        gaps = []
+        cur_end = rows[0][1]
+        for st, en, *_ in rows[1:]:
+            if st > cur_end: gaps.append(st - cur_end)
+            cur_end = max(cur_end, en)
+        f.write(f"# idle gaps: {len(gaps)} totalling {sum(gaps) / 1e6:.3f} ms; > 20 us: {sum(1 for g in gaps if g > 20000)} totalling {sum(g for g in gaps if g > 20000) / 1e6:.3f} ms\n")
+        f.write("# start_us   dur_us  queue  grid  kernel\n")
+        for st, en, name, gx, gy, gz, q in rows:
+            f.write(f"{(st - t0) / 1e3:10.1f} {(en - st) / 1e3:8.1f} {q!s:>5} {f'{gx}x{gy}x{gz}':>14}  {name[:70]}\n")
+
+
 if __name__ == "__main__":
+    if "--timeline" in sys.argv:
+        i = sys.argv.index("--timeline")
+        timeline(sys.argv[1], float(sys.argv[2]), sys.argv[i + 1])
     main()
