@@ -49,3 +49,11 @@ for _ in range(n):
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 print(f"wall per step {wall / n * 1e3:.2f} ms, host time inside step() {host / n * 1e3:.2f} ms (includes the time the host is blocked in synchronizing calls)")
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    torch.cuda.synchronize()
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(3):
+        step()
+    pr.disable(); torch.cuda.synchronize()
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
