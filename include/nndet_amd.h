@@ -328,6 +328,33 @@ int nndet_hnm_sample_f32(const float* labels, const float* scores, int32_t score
  * sampler (DetectionHeadHNM.select_indices, nndet/arch/heads/comb.py:247-276). */
 int nndet_sigmoid_max_f32(const float* logits, int64_t n, int32_t C, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Detection-head output gather -- replaces, for all pyramid levels of one head branch in ONE pass, the
+ * `permute(0, 2, 3, 4, 1).contiguous().view(N, -1, last)` of the classifier / regressor outputs
+ * (nndet/arch/heads/classifier.py:176-181, regressor.py:165-172), the level-specific `Scale` of the regressor
+ * (regressor.py:163-164, nndet/arch/layers/scale.py:21-43) and the `torch.cat(levels, dim=1)` of
+ * DetectionHead.forward (nndet/arch/heads/comb.py:107-108).
+ *   y[l]     : conv_out of level l, NDHWC [N, points[l], cout_p] (dtype), channels padded to cout_p (multiple of 32);
+ *   scale[l] : device pointer to the level's scalar (fp32) or NULL;  out : fp32 [N, sum_l points[l], cout] (row = position,
+ *              i.e. [N, sum_l points[l] * A, last] for cout = A * last), level blocks in order inside every image.
+ * Backward: grad_out (same shape as out) -> dy[l] (padded NDHWC gradient of conv_out, zeros in the padding) and, where dscale[l] is
+ * not NULL, dscale[l] += sum(grad_out_l * y_l) (fp32 atomics; the caller zeroes it).
+ * ---------------------------------------------------------------------------------------------- */
+#define NNDET_HEAD_MAX_LEVELS 8
+typedef struct NndetHeadLevels {
+    int32_t nlev;
+    int32_t reserved_;
+    const void* y[NNDET_HEAD_MAX_LEVELS];
+    void* dy[NNDET_HEAD_MAX_LEVELS];            /* backward only */
+    const float* scale[NNDET_HEAD_MAX_LEVELS];
+    float* dscale[NNDET_HEAD_MAX_LEVELS];       /* backward only */
+    int64_t points[NNDET_HEAD_MAX_LEVELS];
+} NndetHeadLevels;
+int nndet_head_gather_f32(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t cout, int32_t cout_p, float* out,
+                          void* stream);
+int nndet_head_gather_backward(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t cout, int32_t cout_p,
+                               const float* grad_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,16 @@ class NndetConv(C.Structure):
                 ("in_affine", C.c_void_p), ("in_relu", C.c_int32), ("reserved_", C.c_int32)]
 
 
+HEAD_MAX_LEVELS = 8
+
+
+class NndetHeadLevels(C.Structure):
+    _fields_ = [("nlev", C.c_int32), ("reserved_", C.c_int32),
+                ("y", C.c_void_p * HEAD_MAX_LEVELS), ("dy", C.c_void_p * HEAD_MAX_LEVELS),
+                ("scale", C.c_void_p * HEAD_MAX_LEVELS), ("dscale", C.c_void_p * HEAD_MAX_LEVELS),
+                ("points", C.c_int64 * HEAD_MAX_LEVELS)]
+
+
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _CONVP = C.POINTER(NndetConv)
 
@@ -55,6 +65,8 @@ SIGNATURES = {
     "nndet_instances_to_targets_f32": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_hnm_sample_workspace_bytes": (_SZ, [_I32, C.c_double, _I32, C.c_double]),
     "nndet_hnm_neg_capacity": (_I32, [_I32, C.c_double, _I32]),
+    "nndet_head_gather_f32": (C.c_int, [_I32, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, _P, _P]),
+    "nndet_head_gather_backward": (C.c_int, [_I32, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, _P, _P]),
     "nndet_hnm_sample_f32": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, C.c_double, _I32, C.c_double, C.c_uint64, _I32, _P, _P, _P,
                                        _P, _SZ, _P]),
     "nndet_wbc3d_workspace_bytes": (_SZ, [_I64]),

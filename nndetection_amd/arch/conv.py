@@ -72,6 +72,20 @@ def _packed(mod, mode: int, weight: torch.Tensor, desc: L.NndetConv, dtype: torc
     return buf
 
 
+def _padded_bias(mod, bias: Optional[torch.Tensor], cout_p: int) -> Optional[torch.Tensor]:
+    """fp32 bias padded to the physical channel count. The padded copy (zeros + copy = 2 tiny launches) is made once per parameter
+    version on the stream that first needs it (prepack / prepack_all: before the head forks its side streams), not once per call."""
+    if bias is None:
+        return None
+    if bias.numel() == cout_p and bias.dtype == torch.float32:
+        return bias.detach()
+    key, ver = ("bias", cout_p), (bias._version, bias.data_ptr())
+    hit = mod._pack_cache.get(key)
+    if hit is None or hit[0] != ver:
+        hit = mod._pack_cache[key] = (ver, _pad1d(bias, cout_p))
+    return hit[1]
+
+
 def prepack(mod, x: torch.Tensor, modes=(0, 1)) -> None:
     """Fill the packed-weight cache of conv block `mod` for input `x` on the CURRENT stream. Shared modules that are about
     to run on several side streams (detection head levels) must be packed before the fork: the cache itself is not
@@ -83,6 +97,7 @@ def prepack(mod, x: torch.Tensor, modes=(0, 1)) -> None:
     desc.cin_p = cpad(mod.in_channels)       # only the channel counts and the kernel enter the packing
     for mode in modes:
         _packed(mod, mode, mod.conv.weight, desc, x_p.dtype)
+    _padded_bias(mod, mod.conv.bias, cpad(mod.out_channels))
 
 
 def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1)) -> int:
@@ -95,6 +110,7 @@ def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1)) -> int:
         w = mod.conv.weight
         if not w.is_cuda:
             return 0
+        _padded_bias(mod, mod.conv.bias, cpad(mod.out_channels))
         ver = (w._version, w.data_ptr())
         for mode in modes:
             hit = mod._pack_cache.get((mode, dtype))
@@ -163,7 +179,7 @@ class _ConvFn(torch.autograd.Function):
         w_arg = weight.detach().float().contiguous() if stem else _packed(mod, 0, weight, desc, dt)
         y = torch.empty((N, desc.out_d, desc.out_h, desc.out_w, cout_p), dtype=dt, device=dev)
         stats = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev) if want_stats else None
-        b_p = _pad1d(bias, cout_p)
+        b_p = _padded_bias(mod, bias, cout_p)
         r_p = None
         if residual is not None:
             if want_stats:

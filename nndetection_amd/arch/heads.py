@@ -15,6 +15,8 @@ from torch import Tensor
 from .. import _lib as L
 from ..core.boxes.ops import giou_diag
 from ..core.boxes.coder import decode_clip
+from ..layout import phys, logical
+import ctypes
 
 CONV_TYPES = (nn.Conv2d, nn.Conv3d)
 
@@ -45,6 +47,47 @@ def _flatten_head(x: Tensor, last: int) -> Tensor:
     return x.permute(0, 2, 3, 4, 1).contiguous().view(n, -1, last).float()
 
 
+class _HeadGatherFn(torch.autograd.Function):
+    """All pyramid levels of one head branch -> fp32 [N, sum_l positions_l, cout] in one launch (csrc/headio.hip): the
+    permute/contiguous/view of classifier.py:176-181 / regressor.py:165-172, the per-level Scale (regressor.py:163-164) and the
+    torch.cat over the levels (comb.py:107-108). args = n_scales scalar parameters followed by the per-level conv outputs."""
+
+    @staticmethod
+    def forward(ctx, cout: int, n_scales: int, *args):
+        scales, xs = args[:n_scales], args[n_scales:]
+        ys = [phys(x)[0] for x in xs]
+        N, cout_p = ys[0].shape[0], ys[0].shape[4]
+        pts = [y.shape[1] * y.shape[2] * y.shape[3] for y in ys]
+        sc = [s.detach().float().contiguous() for s in scales]
+        out = torch.empty((N, sum(pts), cout), dtype=torch.float32, device=ys[0].device)
+        lv = L.NndetHeadLevels()
+        lv.nlev = len(ys)
+        for l, y in enumerate(ys):
+            lv.y[l], lv.points[l] = y.data_ptr(), pts[l]
+            lv.scale[l] = sc[l].data_ptr() if n_scales else None
+        L.call("nndet_head_gather_f32", L.dtype_code(ys[0]), ctypes.byref(lv), N, cout, cout_p, L.ptr(out), L.stream())
+        ctx.cout, ctx.n_scales, ctx.pts = cout, n_scales, pts
+        ctx.save_for_backward(*ys, *sc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nl = len(ctx.pts)
+        ys, sc = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]
+        N, cout_p = ys[0].shape[0], ys[0].shape[4]
+        g = g.contiguous().float()
+        dys = [torch.empty_like(y) for y in ys]
+        dsc = torch.zeros((max(ctx.n_scales, 1),), dtype=torch.float32, device=g.device)
+        lv = L.NndetHeadLevels()
+        lv.nlev = nl
+        for l, y in enumerate(ys):
+            lv.y[l], lv.dy[l], lv.points[l] = y.data_ptr(), dys[l].data_ptr(), ctx.pts[l]
+            if ctx.n_scales:
+                lv.scale[l], lv.dscale[l] = sc[l].data_ptr(), dsc.data_ptr() + 4 * l
+        L.call("nndet_head_gather_backward", L.dtype_code(ys[0]), ctypes.byref(lv), N, ctx.cout, cout_p, L.ptr(g), L.stream())
+        return (None, None) + tuple(dsc[l].reshape(()) for l in range(ctx.n_scales)) + tuple(logical(d, ctx.cout) for d in dys)
+
+
 class BCECLassifier(nn.Module):
     def __init__(self, conv, in_channels: int, internal_channels: int, num_classes: int, anchors_per_pos: int,
                  num_levels: int, num_convs: int = 3, add_norm: bool = True, prior_prob: Optional[float] = None,
@@ -64,6 +107,10 @@ class BCECLassifier(nn.Module):
 
     def forward(self, x: Tensor, level: int, **kwargs) -> Tensor:
         return _flatten_head(self.conv_out(self.conv_internal(x)), self.num_classes)
+
+    def forward_raw(self, x: Tensor) -> Tensor:
+        """conv output of one level before the flatten; DetectionHeadHNMNative gathers all levels in one pass (_HeadGatherFn)"""
+        return self.conv_out(self.conv_internal(x))
 
     def compute_loss(self, pred_logits: Tensor, targets: Tensor, **kwargs) -> Tensor:
         """BCEWithLogitsLossOneHot (nndet/losses/classification.py:137-181): one-hot without the background column."""
@@ -109,6 +156,10 @@ class GIoURegressor(nn.Module):
             bb = self.scales[level](bb)          # a scalar multiply commutes with the permute/view of regressor.py:165-172
         return bb
 
+    def forward_raw(self, x: Tensor) -> Tensor:
+        """conv output of one level before Scale and flatten (both applied by _HeadGatherFn)"""
+        return self.conv_out(self.conv_internal(x))
+
     def compute_loss(self, pred_boxes: Tensor, target_boxes: Tensor, **kwargs) -> Tensor:
         """GIoULoss (nndet/losses/regression.py:118-162): -sum(diag(GIoU(pred, target, eps=1e-7)))."""
         g = giou_diag(pred_boxes, target_boxes, eps=self.eps)
@@ -143,8 +194,14 @@ class DetectionHeadHNMNative(nn.Module):
             pool.append(torch.cuda.Stream(device=device))
         return pool[:n]
 
+    gather_levels = os.environ.get("NNDET_HEAD_GATHER", "1") != "0"      # one flatten + Scale + cat launch per branch (csrc/headio.hip)
+
     def forward(self, fmaps: List[Tensor]) -> Dict[str, Tensor]:
         logits, offsets = [None] * len(fmaps), [None] * len(fmaps)
+        fused = (self.gather_levels and fmaps[0].is_cuda and len(fmaps) <= L.HEAD_MAX_LEVELS
+                 and type(self.classifier) is BCECLassifier and type(self.regressor) is GIoURegressor)
+        run_cls = (lambda p, level: self.classifier.forward_raw(p)) if fused else (lambda p, level: self.classifier(p, level=level))
+        run_reg = (lambda p, level: self.regressor.forward_raw(p)) if fused else (lambda p, level: self.regressor(p, level=level))
         if self.multi_stream and fmaps[0].is_cuda and len(fmaps) > 1:
             from .conv import BaseConvNormAct, prepack
             main = torch.cuda.current_stream(fmaps[0].device)
@@ -157,21 +214,27 @@ class DetectionHeadHNMNative(nn.Module):
                         prepack(m, fmaps[0], modes=(0, 1) if grad else (0,))
             streams = self._side_streams(fmaps[0].device, 2 * len(fmaps))
             for level, p in enumerate(fmaps):
-                for hi, (head, outs) in enumerate(((self.classifier, logits), (self.regressor, offsets))):
+                for hi, (run, outs) in enumerate(((run_cls, logits), (run_reg, offsets))):
                     s = streams[2 * level + hi]
                     s.wait_stream(main)
                     p.record_stream(s)
                     with torch.cuda.stream(s):
-                        o = head(p, level=level)
+                        o = run(p, level)
                     o.record_stream(main)
                     outs[level] = o
             for s in streams:
                 main.wait_stream(s)
         else:
             for level, p in enumerate(fmaps):
-                logits[level] = self.classifier(p, level=level)
-                offsets[level] = self.regressor(p, level=level)
+                logits[level] = run_cls(p, level)
+                offsets[level] = run_reg(p, level)
         sdim = fmaps[0].ndim - 2
+        if fused:
+            nc, a = self.classifier.num_classes, self.classifier.anchors_per_pos
+            scales = [sc.scale for sc in self.regressor.scales[:len(fmaps)]] if self.regressor.learn_scale else []
+            box_logits = _HeadGatherFn.apply(nc * a, 0, *logits).view(-1, nc)
+            box_deltas = _HeadGatherFn.apply(self.regressor.anchors_per_pos * sdim * 2, len(scales), *scales, *offsets).view(-1, sdim * 2)
+            return {"box_deltas": box_deltas, "box_logits": box_logits}
         return {"box_deltas": torch.cat(offsets, dim=1).reshape(-1, sdim * 2),
                 "box_logits": torch.cat(logits, dim=1).flatten(0, -2)}
 

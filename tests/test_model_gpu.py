@@ -165,6 +165,46 @@ def test_head_side_streams_match_sequential(golden_dir):
         assert max(d) <= 2e-5 * scale, (n, d, scale)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_head_gather_matches_per_level_flatten(golden_dir, dtype):
+    """One gather launch per head branch (csrc/headio.hip: flatten + Scale + cat of all levels, forward and backward) == the
+    reference's per-level permute / contiguous / view / Scale / cat chain in torch: identical predictions and losses (the same
+    values are copied), gradients equal up to the order of the d(scale) sum."""
+    from nndetection_amd.arch.heads import DetectionHeadHNMNative
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    with torch.no_grad():
+        for i, sc in enumerate(net.head.regressor.scales):
+            sc.scale.fill_(1.0 + 0.25 * i)              # the golden weights leave every Scale at 1
+    x = torch.from_numpy(gn["x"]).cuda().to(dtype)
+    res = {}
+    old = DetectionHeadHNMNative.gather_levels
+    try:
+        for mode in (True, False):
+            DetectionHeadHNMNative.gather_levels = mode
+            net.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            with torch.no_grad():
+                pred, _, _ = net(x)
+            losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+            res[mode] = (pred, {k: float(v.detach()) for k, v in losses.items()},
+                         {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        DetectionHeadHNMNative.gather_levels = old
+    (p1, l1, g1), (p0, l0, g0) = res[True], res[False]
+    assert p1["box_logits"].dtype == torch.float32 and p1["box_logits"].shape == p0["box_logits"].shape
+    assert torch.equal(p1["box_logits"], p0["box_logits"]) and torch.equal(p1["box_deltas"], p0["box_deltas"])
+    assert l1 == l0, (l1, l0)
+    assert set(g1) == set(g0) and any("scales" in n for n in g1)
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-12
+        tol = 2e-5 if dtype == torch.float32 else 2e-3      # bf16: dY of conv_out is rounded once (gather) instead of after the Scale mul
+        assert float((g1[n] - g0[n]).abs().max()) <= tol * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
+
+
 def test_toy64_config0_fp32_vs_reference_golden(golden_dir, monkeypatch):
     """BASELINE.json configs[0] on the GPU (fp32 kernels): losses within the 1e-4 of north_star, every gradient norm 1e-3 relative,
     detections (boxes, scores 1e-4; class ids exact) against what the unmodified reference produced on the CPU."""
