@@ -1058,8 +1058,18 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     const char* sv_env = getenv("NNDET_IGEMM_STRIDED");            // 0: 128-point tiles, 1: 64 points 2x2 waves, 2: 64 points 4 row waves
     const int sv = sv_env ? atoi(sv_env) : 2;                      // measured: profiles/round2_micro_strided_tiles.txt
     P->cfg = strided ? (r64 ? (sv == 1 ? 8 : (sv == 2 ? 9 : 2)) : (sv ? 10 : 3)) : (r64 ? 1 : (a256 ? 4 : 0));
-    const int points = CFG_PTS[P->cfg];
     for (int i = 0; i < 3; ++i) if (Lmax[i] <= 0) return NNDET_EINVAL;
+    // Small pyramid levels: with 256 / 512-point tiles a level of 150 ... 4800 positions gives 8 ... 200 workgroups for 256 CUs and
+    // every one of them walks serially through 27 taps x all K chunks of a mostly padded tile. Below `small_wg` workgroups the
+    // 64-point tiles are used instead (4 - 8x as many workgroups, each with 1/4 - 1/8 of the serial work): latency, not throughput.
+    static const int small_wg = getenv("NNDET_IGEMM_SMALLWG") ? atoi(getenv("NNDET_IGEMM_SMALLWG")) : 200;   // measured: 40 -> 160 workgroups halves the kernel, 200 -> 800 gains nothing
+    bool small = false;
+    if (!strided && small_wg > 0) {
+        const int64_t lat = (int64_t)Lmax[0] * Lmax[1] * Lmax[2];
+        const int64_t wgs = ceil_div64(lat, CFG_PTS[P->cfg]) * (a.Cy / CFG_ROWS[P->cfg]) * a.N * a.ncls;
+        if (wgs < small_wg) { small = true; P->cfg = r64 ? 9 : 10; }
+    }
+    const int points = CFG_PTS[P->cfg];
     if (!choose_tile(Lmax, a.in_step, span, points, strided ? (P->cfg >= 8 ? 16 : 24) : 16, a.T, a.H)) return NNDET_EINVAL;
     for (int i = 0; i < 3; ++i) a.nt[i] = ceil_div(Lmax[i], a.T[i]);
     auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); };
@@ -1096,7 +1106,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     // NNDET_IGEMM_SPEC: 0 = never, 1 (default) = by the padding rule, 2 = always (tests); read per call so tests can flip it
     const char* spec_env = getenv("NNDET_IGEMM_SPEC");
     const int spec_on = spec_env ? atoi(spec_env) : 1;
-    if (spec_on && !strided && !tr && a.ncls == 1 && ntaps == 27 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 &&
+    if (spec_on && !small && !strided && !tr && a.ncls == 1 && ntaps == 27 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 &&
         c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1) {
         // 64-row layers: (8,8,8) tiles with NT = 16 (2 workgroups per CU, ~1.6x the main-loop rate) or (4,8,8) tiles with NT = 8
         // (3 per CU): compare padded work / (rate x occupancy of the last round of workgroups)

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_model_gpu.py tests/test_abi.py tests/test_parity_full_gpu.py -q -p no:cacheprovider --tb=short 2>&1 | tail -12
-for v in 1 0 1 0; do echo -n "HEAD_GATHER=$v "; NNDET_HEAD_GATHER=$v python bench.py --steps 60 --warmup 10 --no-extras 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"])"; done
+NNDET_IGEMM_SMALLWG=100000000 timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -p no:cacheprovider --tb=line -k "lib or norm_relu" 2>&1 | tail -8
+for v in 0 100000; do echo "== SMALLWG=$v"; NNDET_IGEMM_SMALLWG=$v MICRO_ITERS=20 timeout 300 python tools/conv_microbench.py p2_128x128 p3_128x128 p4_128x128 e3_256x256 2>&1 | grep -v "Warn\|amdgpu" | sed 's/| wgrad.*//'; done
+for v in 0 300 700 0 300 700; do echo -n "SMALLWG=$v "; NNDET_IGEMM_SMALLWG=$v python bench.py --steps 60 --warmup 10 --no-extras 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"])"; done
