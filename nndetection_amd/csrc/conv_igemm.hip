@@ -682,6 +682,9 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, int voff, u
 #define IG3R_PPS 1      // pieces per step
 #define IG3R_SL0 6      // MFMA slot of the first piece of a step
 #endif
+#ifndef IG3R_SPLIT
+#define IG3R_SPLIT 0
+#endif
 #ifndef IG3R_SKEW
 #define IG3R_SKEW 0
 #endif
@@ -893,6 +896,13 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
                     }
                     // LDS-DMA of the next tile: IG3R_PPS pieces per step from step IG3R_DS0 of phase IG3R_DPH on; the offset is computed one
                     // slot before the issue slot
+#if IG3R_SPLIT
+                    if (tp >= IG3R_DS0 && tp < IG3R_DS0 + NPIECE / 2 && !(IG3R_DBG & 1)) {      // 8 pieces under each plane
+                        const int p = gph * (NPIECE / 2) + tp - IG3R_DS0;
+                        if (s == IG3R_SL0 - 1) dma_vo = (M_next & bsel[p]) == bsel[p] ? tin_next + rel[p] : (int)0x80000000;
+                        if (s == IG3R_SL0) lds_dma16(xrs, dma_vo, dma_dst + p * 1024);
+                    }
+#else
                     if (gph == IG3R_DPH && tp >= IG3R_DS0 && tp < IG3R_DS0 + NPIECE / IG3R_PPS && !(IG3R_DBG & 1)) {
 #pragma unroll
                         for (int k = 0; k < IG3R_PPS; ++k) {
@@ -901,6 +911,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
                             if (s == sl) lds_dma16(xrs, dma_vo, dma_dst + p * 1024);
                         }
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

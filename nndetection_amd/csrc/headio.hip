@@ -4,7 +4,7 @@
 // The conv output is NDHWC with the channels padded to 32: the permuted view IS the buffer, minus the padding. One launch reads the
 // padded bf16 / fp32 rows of every level and writes fp32 [N, sum_l points_l * A, last] (+ scale); the backward launch reads the
 // gradient of that tensor and writes the padded NDHWC gradients of the levels (zeros in the padding) and d(scale_l) = sum(g * y).
-// HBM-bound element-wise work: 16-byte loads of the padded rows, coalesced 4-byte stores of the compact rows.
+// HBM-bound element-wise work: consecutive lanes read consecutive channels of the padded rows and write consecutive floats.
 #include "common.h"
 #include <string.h>
 
