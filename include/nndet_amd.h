@@ -272,7 +272,8 @@ int nndet_norm_apply(int32_t dtype, const void* x, const double* stats, const fl
                      int32_t batch, int64_t spatial, int32_t c, int32_t c_p, int32_t groups, float eps,
                      int32_t relu, void* y, float* mean_rstd_out, void* stream);
 /* backward of y = relu?(norm(x)): dx, and dgamma / dbeta ([c] fp32, accumulated -> zero first).
- * red_ws: [N, C_p, 2] fp64 scratch (zeroed). */
+ * red_ws: fp64 scratch, zeroed: [NNDET_STATS_REPLICAS, N, C_p, 2] partial sums followed by N more doubles (the tickets by which the
+ * last workgroup of an image finishes the reduction inside the first pass). */
 int nndet_norm_backward(int32_t dtype, const void* x, const void* dy, const float* mean_rstd,
                         const float* gamma, const float* beta, int32_t batch, int64_t spatial, int32_t c,
                         int32_t c_p, int32_t groups, int32_t relu, void* dx, float* dgamma, float* dbeta,

@@ -125,7 +125,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter costs ~0.3 us; torch.cuda.current_stream()
+    builds a Stream object: ~10 us, at ~290 calls per training step)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -275,7 +275,7 @@ class _NormFn(torch.autograd.Function):
         gbuf = L.grad_pool.take(2 * cout, dev)
         dgamma, dbeta = gbuf[:cout], gbuf[cout:]
         dconv = torch.empty_like(y_p)
-        red = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev)
+        red = L.arena_zeros((L.STATS_REPLICAS * N * cout_p * 2 + N,), torch.float64, dev)     # replica sums + N ticket slots
         L.call("nndet_norm_backward", ctx.code, L.ptr(y_p), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,
                cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.ptr(red), L.stream())
         return logical(dconv, cout), dgamma, dbeta, None, None, None

@@ -234,7 +234,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int64_t spatial, int c, int c_p,
-                                                         int N, int relu, double* __restrict__ red_ws, int RED_ROWS) {
+                                                         int N, int relu, double* __restrict__ red_ws, int RED_ROWS, int groups,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
     constexpr int E = Vec16<T>::E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem);
@@ -280,23 +281,31 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
     const int rep = blockIdx.x % NNDET_STATS_REPLICAS;
     double* dst = red_ws + ((int64_t)rep * N + n) * c_p * 2;
     for (int i = threadIdx.x; i < c_p * 2; i += 256) atomicAdd(&dst[i], red[i]);
-}
-
-// pass 2 (grid N): dgamma/dbeta and the per-channel group coefficients (s1/m, s2/m) written over replica 0
-__global__ void k_norm_bwd_finalize(double* __restrict__ red_ws, const float* __restrict__ gamma, int N, int c, int c_p,
-                                    int groups, int64_t spatial, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* ch = reinterpret_cast<double*>(smem);   // [c_p][2]
-    const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < c_p * 2; i += blockDim.x) {
+    // ---- the LAST workgroup of image n finishes the reduction (was a separate 4-workgroup launch, k_norm_bwd_finalize, between the
+    // two passes: 84 launches per training step). Ticket counters live behind the replicas in red_ws (zeroed with them). Ordering:
+    // everything this workgroup publishes are agent-scope atomic RMWs, performed at the coherence point once vmcnt reaches 0; only
+    // then is the ticket drawn. No release fence: it would write back the whole L2 (buffer_wbl2) once per workgroup -- measured
+    // +1.2 ms per training step -- and there are no plain stores to publish. The last arriver acquires and reads the replica sums
+    // with agent-scope atomic loads.
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(red_ws + (int64_t)NNDET_STATS_REPLICAS * N * c_p * 2);
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ticket[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double* ch = red;                               // [c_p][2]
+    for (int i = threadIdx.x; i < c_p * 2; i += 256) {
         double v = 0.0;
-        for (int r = 0; r < NNDET_STATS_REPLICAS; ++r) v += red_ws[(((int64_t)r * N + n) * c_p) * 2 + i];
+        for (int r = 0; r < NNDET_STATS_REPLICAS; ++r)
+            v += __hip_atomic_load(&red_ws[(((int64_t)r * N + n) * c_p) * 2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ch[i] = v;
     }
     __syncthreads();
     const int cpg = c / groups;
     float* coef = reinterpret_cast<float*>(red_ws + ((int64_t)n * c_p) * 2);   // replica 0, this n: [c_p][2] fp32 (first half)
-    for (int i = threadIdx.x; i < c_p; i += blockDim.x) {
+    for (int i = threadIdx.x; i < c_p; i += 256) {
         float c1 = 0.f, c2 = 0.f;
         if (i < c) {
             atomicAdd(&dbeta[i], (float)ch[i * 2]);
@@ -311,11 +320,13 @@ __global__ void k_norm_bwd_finalize(double* __restrict__ red_ws, const float* __
             const double m = (double)cpg * (double)spatial;
             c1 = (float)(s1 / m); c2 = (float)(s2 / m);
         }
-        // all reads of this n's slices happened before the __syncthreads above
+        // every read of this n's replica slices happened before the __syncthreads above; the coefficients are read by the NEXT kernel
         coef[i * 2 + 0] = c1;
         coef[i * 2 + 1] = c2;
     }
 }
+
+// (pass 2, dgamma / dbeta and the per-channel group coefficients (s1/m, s2/m) written over replica 0, is the tail of pass 1)
 
 // pass 3: dx = rstd * (g * gamma - s1/m - xhat * s2/m)
 template <typename T>
@@ -371,11 +382,9 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     dim3 rgrid((unsigned)ceil_div64(spatial, rr), batch);
     const size_t lds = (size_t)c_p * 16;
     if (dtype == NNDET_BF16)
-        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr);
+        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta);
     else
-        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr);
-    LAUNCH_CHECK();
-    k_norm_bwd_finalize<<<batch, 256, lds, st>>>(red_ws, gamma, batch, c, c_p, groups, spatial, dgamma, dbeta);
+        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
         k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx);
