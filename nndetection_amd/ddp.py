@@ -36,6 +36,7 @@ class GradBucket:
             off += p.numel()
         self.pending = len(params)
         self.work = None
+        self.streams = set()            # raw handles of the streams that accumulated a gradient of this bucket in this backward
 
 
 class GradAllReducer:
@@ -77,9 +78,11 @@ class GradAllReducer:
         self.force = bool(force_overlap)
         self.overlap = overlap and (self.world > 1 or self.force)
         self._cuda = device.type == "cuda"
-        self._events = {}
         self._next = 0
-        self._events.clear()
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._dev_index = device.index if device.index is not None else (torch.cuda.current_device() if self._cuda else 0)
+        self._stream_objs = {}          # raw stream handle -> torch.cuda.Stream
+        self._event_pool, self._used_events = [], []
         self._hooks = []
         if self.overlap:
             for p in params:
@@ -99,14 +102,19 @@ class GradAllReducer:
 
     def _launch(self, b: GradBucket):
         # Gradients of one bucket are accumulated on DIFFERENT streams (the detection-head branches run on side streams,
-        # arch/heads.py; autograd only joins them at the end of backward): the bucket copy below runs on the stream of whichever
-        # parameter completed the bucket, so it first waits for the event every other parameter recorded in its own hook.
+        # arch/heads.py; autograd only joins them at the end of backward). The bucket copy below runs on the stream of whichever
+        # parameter completed the bucket: it first waits for every other stream that contributed. All contributions are already
+        # enqueued (every hook of the bucket has fired), so ONE event per contributing stream, recorded now, covers them -- the hooks
+        # themselves only note a raw stream handle (an event per parameter cost ~15 us x 92 hooks inside the autograd thread).
         if self._cuda:
             cur = torch.cuda.current_stream()
-            for p in b.params:
-                ev = self._events.pop(p, None)
-                if ev is not None:
+            for sid in b.streams:
+                if sid != cur.cuda_stream:
+                    ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
+                    ev.record(self._stream_objs[sid])
                     cur.wait_event(ev)
+                    self._used_events.append(ev)
+            b.streams.clear()
         src, dst = [], []
         for p, v in zip(b.params, b.views):
             if p.grad is None:
@@ -125,11 +133,13 @@ class GradAllReducer:
         bi, _ = self._where[p]
         if id(p) in self._static_unused:
             raise RuntimeError("a parameter declared as never used received a gradient")
-        self.buckets[bi].pending -= 1
+        b = self.buckets[bi]
+        b.pending -= 1
         if self._cuda:
-            ev = torch.cuda.Event()
-            ev.record()                                  # on the stream this gradient was accumulated on
-            self._events[p] = ev
+            sid = self._raw_stream(self._dev_index) if self._raw_stream is not None else torch.cuda.current_stream().cuda_stream
+            if sid not in self._stream_objs:
+                self._stream_objs[sid] = torch.cuda.current_stream()     # the stream this gradient was accumulated on
+            b.streams.add(sid)
         # collectives must be issued in the SAME order on every rank: a bucket is only launched once all
         # earlier buckets are (a bucket holding a parameter that is unused on this rank is launched by finish())
         while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
@@ -158,4 +168,5 @@ class GradAllReducer:
             b.work = None
             b.pending = b.expected
         self._next = 0
-        self._events.clear()
+        self._event_pool.extend(self._used_events)       # every wait on them has been enqueued: safe to re-record next step
+        self._used_events.clear()
