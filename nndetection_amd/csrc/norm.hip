@@ -35,12 +35,22 @@ template <> struct Vec16<bf16_t> {
     }
 };
 
-#define ROWS_PER_BLOCK 512    // rows (voxels) handled by one workgroup in the element-wise (apply) kernels
+#define ROWS_PER_BLOCK 512    // max rows (voxels) handled by one workgroup in the element-wise (apply) kernels
+// rows per workgroup of the element-wise kernels: 512 for the big layers; the pyramid levels P3-P5 (150 ... 4800 rows per image) got
+// 1-10 workgroups per image of 32 dependent load -> store iterations each (24-33 us for 0.6-5 MB): aim at >= ~1024 workgroups
+static inline int apply_rows(int64_t rows_total, int c_p, int esz) {
+    const int rpi = 256 / (c_p * esz / 16);          // rows covered by one iteration of the workgroup
+    int64_t r = rows_total / 1024;
+    if (r > ROWS_PER_BLOCK) r = ROWS_PER_BLOCK;
+    const int lo = rpi > 0 ? 2 * rpi : 32;
+    if (r < lo) r = lo;
+    return (int)((r + 31) / 32 * 32);
+}
 // rows per workgroup in the reduction kernels: as many as possible (fewer LDS / global fp64 atomics per byte) while
 // keeping >= ~1024 workgroups in flight; a fixed 4096 starved the small layers (40 workgroups on 256 CUs)
 static inline int red_rows(int64_t rows_total) {
     int64_t r = rows_total / 1024;
-    if (r < 256) r = 256;
+    if (r < 64) r = 64;        // (256 before: 1-19 workgroups per image on the small pyramid levels, 18-45 us per launch)
     if (r > 4096) r = 4096;
     return (int)r;
 }
@@ -155,7 +165,7 @@ extern "C" int nndet_norm_finalize(const double* stats, const float* gamma, cons
 template <typename T>
 __global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, const float* __restrict__ mean_rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    int64_t spatial, int c, int c_p, int relu, T* __restrict__ y) {
+                                                    int64_t spatial, int c, int c_p, int relu, T* __restrict__ y, int RPB) {
     constexpr int E = Vec16<T>::E;
     const int ppr = c_p / E, rpi = 256 / ppr;
     const int n = blockIdx.y;
@@ -173,8 +183,8 @@ __global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, con
         }
         sc[e] = a; sh[e] = b;
     }
-    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-    const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
+    const int64_t r0 = (int64_t)blockIdx.x * RPB;
+    const int64_t r1 = min(r0 + RPB, spatial);
     const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
     for (int64_t r = r0 + rr; r < r1; r += rpi)      // AffinePiece: the SAME code the convolutions run when they apply the norm on load
         *reinterpret_cast<u32x4*>(y + base + r * c_p) = AffinePiece<T>::apply(*reinterpret_cast<const u32x4*>(x + base + r * c_p), sc, sh, relu);
@@ -188,11 +198,12 @@ extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stat
     hipStream_t st = as_stream(stream);
     k_norm_finalize<<<batch, 256, (size_t)c_p * 16, st>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out);
     LAUNCH_CHECK();
-    dim3 grid((unsigned)ceil_div64(spatial, ROWS_PER_BLOCK), batch);
+    const int rpb = apply_rows(spatial * batch, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
     if (dtype == NNDET_BF16)
-        k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (bf16_t*)y);
+        k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (bf16_t*)y, rpb);
     else
-        k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (float*)y);
+        k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (float*)y, rpb);
     LAUNCH_CHECK();
     return 0;
 }
@@ -201,7 +212,7 @@ extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stat
 // (materialises a deferred activation for a consumer that cannot apply the norm on load; same arithmetic as k_norm_apply)
 template <typename T>
 __global__ __launch_bounds__(256) void k_affine_apply(const T* __restrict__ x, const float* __restrict__ ss, int64_t spatial, int c_p,
-                                                      int relu, T* __restrict__ y) {
+                                                      int relu, T* __restrict__ y, int RPB) {
     constexpr int E = Vec16<T>::E;
     const int ppr = c_p / E, rpi = 256 / ppr;
     const int n = blockIdx.y;
@@ -209,8 +220,8 @@ __global__ __launch_bounds__(256) void k_affine_apply(const T* __restrict__ x, c
     if (rr >= rpi) return;
     float sc[E], sh[E];
     load_affine<E>(ss, n, c_p, cp * E, sc, sh);
-    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-    const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
+    const int64_t r0 = (int64_t)blockIdx.x * RPB;
+    const int64_t r1 = min(r0 + RPB, spatial);
     const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
     for (int64_t r = r0 + rr; r < r1; r += rpi)      // AffinePiece: the SAME code the convolutions run when they apply the norm on load
         *reinterpret_cast<u32x4*>(y + base + r * c_p) = AffinePiece<T>::apply(*reinterpret_cast<const u32x4*>(x + base + r * c_p), sc, sh, relu);
@@ -219,11 +230,12 @@ __global__ __launch_bounds__(256) void k_affine_apply(const T* __restrict__ x, c
 extern "C" int nndet_affine_apply(int32_t dtype, const void* x, const float* scale_shift, int32_t batch, int64_t spatial, int32_t c_p,
                                   int32_t relu, void* y, void* stream) {
     if (!x || !scale_shift || !y || c_p % 32 || c_p > 1024 || batch <= 0) return NNDET_EINVAL;
-    dim3 grid((unsigned)ceil_div64(spatial, ROWS_PER_BLOCK), batch);
+    const int rpb = apply_rows(spatial * batch, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
     if (dtype == NNDET_BF16)
-        k_affine_apply<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, scale_shift, spatial, c_p, relu, (bf16_t*)y);
+        k_affine_apply<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, scale_shift, spatial, c_p, relu, (bf16_t*)y, rpb);
     else
-        k_affine_apply<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, scale_shift, spatial, c_p, relu, (float*)y);
+        k_affine_apply<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, scale_shift, spatial, c_p, relu, (float*)y, rpb);
     LAUNCH_CHECK();
     return 0;
 }
@@ -333,7 +345,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy,
                                                         const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const double* __restrict__ red_ws,
-                                                        int64_t spatial, int c, int c_p, int relu, T* __restrict__ dx) {
+                                                        int64_t spatial, int c, int c_p, int relu, T* __restrict__ dx, int RPB) {
     constexpr int E = Vec16<T>::E;
     const int ppr = c_p / E, rpi = 256 / ppr;
     const int n = blockIdx.y;
@@ -353,8 +365,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const T* __restrict__ x,
         k1[e] = ok ? coef[ci * 2] : 0.f;
         k2[e] = ok ? coef[ci * 2 + 1] : 0.f;
     }
-    const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-    const int64_t r1 = min(r0 + ROWS_PER_BLOCK, spatial);
+    const int64_t r0 = (int64_t)blockIdx.x * RPB;
+    const int64_t r1 = min(r0 + RPB, spatial);
     const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
     for (int64_t r = r0 + rr; r < r1; r += rpi) {
         float xv[E], gv[E];
@@ -377,7 +389,8 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     if (!x || !dy || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red_ws) return NNDET_EINVAL;
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
-    dim3 grid((unsigned)ceil_div64(spatial, ROWS_PER_BLOCK), batch);
+    const int rpb = apply_rows(spatial * batch, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
     const int rr = red_rows(spatial * batch);
     dim3 rgrid((unsigned)ceil_div64(spatial, rr), batch);
     const size_t lds = (size_t)c_p * 16;
@@ -387,9 +400,9 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
         k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
-        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx);
+        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx, rpb);
     else
-        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (float*)dx);
+        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (float*)dx, rpb);
     LAUNCH_CHECK();
     return 0;
 }
