@@ -244,6 +244,12 @@ int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w
  * the caller then passes dbias = NULL to nndet_conv3d_backward_weight. */
 int32_t nndet_conv3d_dgrad_fuses_bias(const NndetConv* c);
 int nndet_conv3d_backward_data_bias(const NndetConv* c, const void* dy, const void* w_packed_mode1, void* dx, float* dbias, void* stream);
+/* dx += conv^T(dy): the data gradient ADDED to what dx already holds -- the gradient an earlier consumer of the same activation
+ * wrote (an encoder stage output feeds the next stage and the decoder lateral; autograd would add the two gradients in a third pass:
+ * two reads + one write of the activation size). dbias as in nndet_conv3d_backward_data_bias, or NULL. Transposed convolutions are
+ * not covered (NNDET_EINVAL). */
+int nndet_conv3d_backward_data_acc(const NndetConv* c, const void* dy, const void* w_packed_mode1, void* dx_inout, float* dbias,
+                                   void* stream);
 /* dw (fp32, PyTorch layout, ACCUMULATED into: zero it first) ; dbias ([cout] fp32, accumulated) may be NULL.
  * Two-stage reduction through `workspace` (nndet_conv3d_wgrad_workspace_bytes(c) bytes): deterministic, no atomics on dw. */
 size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c);

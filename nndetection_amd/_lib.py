@@ -78,6 +78,7 @@ SIGNATURES = {
     "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
     "nndet_conv3d_dgrad_fuses_bias": (_I32, [_CONVP]),
     "nndet_conv3d_backward_data_bias": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
+    "nndet_conv3d_backward_data_acc": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
     "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
     "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_norm_stats": (C.c_int, [_I32, _P, _I32, _I64, _I32, _P, _P]),

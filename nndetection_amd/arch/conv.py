@@ -189,6 +189,7 @@ class _ConvFn(torch.autograd.Function):
                 raise L.NndetError(f"residual shape {tuple(residual.shape)} does not match the conv output")
         L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats), L.stream())
         ctx.desc, ctx.mod, ctx.has_bias, ctx.has_res = desc, mod, bias is not None, residual is not None
+        ctx.gacc = None if mod.transposed else getattr(x, "_nndet_gacc", None)   # fused accumulation of the input gradient (encoder.py)
         ctx.x_ss = x_ss                      # (tiny) keeps the table alive for the weight gradient
         ctx.save_for_backward(x_p, weight)
         out = logical(y, cout)
@@ -215,14 +216,29 @@ class _ConvFn(torch.autograd.Function):
             if desc.cin_p == 1:
                 raise L.NndetError("gradient w.r.t. the 1-channel input image is not implemented (never needed in training)")
             w1 = _packed(mod, 1, weight, desc, dt)
-            dx_p = torch.empty_like(x_p)
-            if dbias is not None and L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)):
+            gacc = ctx.gacc
+            fuses_bias = dbias is not None and bool(L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)))
+            if gacc is not None and gacc["buf"] is not None and gacc["buf"].shape == x_p.shape and gacc["buf"].dtype == dt:
+                # second consumer of this activation: add into the gradient the first consumer wrote and hand autograd nothing
+                L.call("nndet_conv3d_backward_data_acc", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(gacc["buf"]),
+                       L.ptr(dbias) if fuses_bias else None, L.stream())
+                gacc["buf"] = None
+                bias_from_dgrad = fuses_bias
+                dx_p = None
+            else:
+                dx_p = torch.empty_like(x_p)
+            if dx_p is None:
+                pass
+            elif dbias is not None and L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)):
                 # pointwise kernels read every dy element once: the bias gradient comes out of the same pass
                 L.call("nndet_conv3d_backward_data_bias", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.ptr(dbias), L.stream())
                 bias_from_dgrad = True
             else:
                 L.call("nndet_conv3d_backward_data", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.stream())
-            dx = logical(dx_p, desc.cin)      # gradient w.r.t. the input AS THE CONV SAW IT (i.e. after a deferred norm + ReLU)
+            if dx_p is not None:
+                dx = logical(dx_p, desc.cin)  # gradient w.r.t. the input AS THE CONV SAW IT (i.e. after a deferred norm + ReLU)
+                if gacc is not None:
+                    gacc["buf"] = dx_p        # first consumer: the second one adds into this buffer (same stream: encoder / decoder)
         ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
         ws = L.workspace(ws_bytes, dev)
         L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw),

@@ -3,6 +3,7 @@
 `inference_step(images)`, `forward(inp)`, loss keys (reg, cls, seg_ce, seg_dice) and prediction keys."""
 from typing import Any, Dict, List, Optional, Tuple
 
+import os
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -35,6 +36,8 @@ class BaseRetinaNet(nn.Module):
         from ..arch.decoder import UFPNModular
         if isinstance(self.decoder, UFPNModular) and hasattr(self.encoder, "set_defer_outputs"):
             self.encoder.set_defer_outputs(True)     # the decoder's lateral convs apply the encoder's norm + ReLU on load
+            if hasattr(self.encoder, "set_fuse_grad_accum"):
+                self.encoder.set_fuse_grad_accum(os.environ.get("NNDET_FUSE_GRAD_ACC", "1") != "0")
 
     def never_used_parameters(self) -> List[nn.Parameter]:
         """Parameters that exist for state-dict parity with the reference but never receive a gradient: the decoder output convs

@@ -55,6 +55,15 @@ extern "C" int nndet_conv3d_backward_data_bias(const NndetConv* c, const void* d
     return igemm_run(c, 1, dy, w, nullptr, nullptr, dx, nullptr, as_stream(stream), dbias);
 }
 
+extern "C" int nndet_conv3d_backward_data_acc(const NndetConv* c, const void* dy, const void* w, void* dx, float* dbias, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!dy || !w || !dx || c->cin_p == 1 || c->transposed) return NNDET_EINVAL;
+    if (dbias && !nndet_conv3d_dgrad_fuses_bias(c)) return NNDET_EINVAL;
+    // every kernel reads `res` at exactly the element it then writes: in place is safe (residual == output buffer)
+    return igemm_run(c, 1, dy, w, nullptr, dx, dx, nullptr, as_stream(stream), dbias);
+}
+
 extern "C" size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c) {
     if (check_conv(c)) return 0;
     return c->cin_p == 1 ? 256 : wgrad_workspace_bytes(c);

@@ -205,6 +205,39 @@ def test_head_gather_matches_per_level_flatten(golden_dir, dtype):
         assert float((g1[n] - g0[n]).abs().max()) <= tol * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_fused_input_gradient_accumulation(golden_dir, dtype, monkeypatch):
+    """Encoder stage outputs feed the next stage and the decoder lateral. With set_fuse_grad_accum the second data gradient is added
+    into the first one's buffer (nndet_conv3d_backward_data_acc) instead of autograd adding two tensors: same gradients (fp32: the
+    same single rounding of a + b; bf16: one rounding less), and the accumulate entry point really is the one that runs."""
+    from nndetection_amd import _lib as L
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    x = torch.from_numpy(gn["x"]).cuda().to(dtype)
+    calls = []
+    orig_call = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), orig_call(name, *a))[1])
+    res = {}
+    for mode in (True, False):
+        net.encoder.set_fuse_grad_accum(mode)
+        net.zero_grad(set_to_none=True)
+        calls.clear()
+        torch.manual_seed(5)
+        losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        res[mode] = ({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None},
+                     calls.count("nndet_conv3d_backward_data_acc"))
+    (g1, n1), (g0, n0) = res[True], res[False]
+    assert n0 == 0 and n1 == net.encoder.num_stages - 1, (n0, n1)
+    assert set(g1) == set(g0)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2      # bf16: the sum is rounded once instead of twice; dgamma / dbeta are cancelling sums
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-12
+        assert float((g1[n] - g0[n]).abs().max()) <= tol * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
+
+
 def test_toy64_config0_fp32_vs_reference_golden(golden_dir, monkeypatch):
     """BASELINE.json configs[0] on the GPU (fp32 kernels): losses within the 1e-4 of north_star, every gradient norm 1e-3 relative,
     detections (boxes, scores 1e-4; class ids exact) against what the unmodified reference produced on the CPU."""

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --tb=short -k "norm or tiny or deferred or materialize" 2>&1 | tail -4
-for i in 1 2; do python bench.py --steps 60 --warmup 10 --no-extras 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"])"; done
+timeout 900 python -m pytest tests/test_model_gpu.py tests/test_parity_full_gpu.py -m gpu -q -p no:cacheprovider --tb=short 2>&1 | tail -6
+for v in 1 0 1 0; do echo -n "FUSE_GRAD_ACC=$v "; NNDET_FUSE_GRAD_ACC=$v python bench.py --steps 60 --warmup 10 --no-extras 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"])"; done
