@@ -26,6 +26,7 @@ build wbc3d.hip -ffp-contract=off
 build conv_igemm.hip -mllvm -pragma-unroll-threshold=1000000
 build conv_wgrad.hip
 build conv_pw.hip
+build conv_dgs.hip
 build conv_stem.hip
 build norm.hip
 build segloss.hip

@@ -15,6 +15,9 @@ int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x,
 int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, hipStream_t st,
            float* dbias = nullptr);
 int pw_covers(const NndetConv* c, int kind);   // 1 if pw_run would take this problem (so a fused dbias is available for kind 1)
+// conv_dgs.hip: data gradient of the strided 3x3x3 convolutions, all parity classes from one staged halo; returns 1 = not covered
+int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st);
+int dgs_covers(const NndetConv* c);
 // conv_wgrad.hip
 int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias, int* bias_done, void* ws, size_t ws_bytes,
               hipStream_t st);   // bias_done = 1: dbias (may be NULL) was accumulated by the weight-gradient kernel itself

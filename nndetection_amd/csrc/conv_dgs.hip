@@ -1,0 +1,305 @@
+// Data gradient of the STRIDED 3x3x3 / pad 1 convolutions (encoder stage transitions, stride 2 per axis or (2, 2, 1)) for gfx950.
+//
+// k_igemm computes a strided data gradient by output-parity classes (no zero-tap work): class c = (cd, ch, cw) owns the outputs
+// o = s * i + c and only the taps t with (c + p - t) % s == 0, reading dY at i + (c + p - t) / s. It runs ONE class per
+// workgroup: the up-to-8 classes of a tile each stage the SAME dY halo into LDS, and with 1-8 taps per class the kernel is
+// almost pure staging: 19 200 workgroups x 93 KB = 1.8 GB through the load -> ds_write path for 136 GFLOP (32 <- 64 channels at
+// 160^3: 0.49 ms, 279 TFLOP/s).
+// Here a workgroup stages the halo of its lattice tile ONCE, for all channel chunks, and then walks over the classes:
+// per class zero 32-64 accumulators, run that class' taps x chunks out of LDS, store the class' outputs (stride-s scatter).
+//   lattice tile 4 x 8 x 8 points (x classes = up to 8 x 16 x 16 outputs), one d-plane per wave, 4 point tiles of 16 per wave;
+//   halo = tile + (hi - lo) per axis (stride 2: deltas {0, 1} -> +1; stride 1: {-1, 0, 1} -> +2), chunk-major [chunk][voxel][64 B]
+//   with the row-parity XOR swizzle of k_igemm (conflict-free ds_read_b128 for unit-stride points);
+//   MFMA operands as everywhere: A = packed mode-1 weights [tap][cin_p rows][cout_p k] from global memory (one fragment per
+//   row tile, tap and chunk, prefetched one (tap, chunk) step ahead), B = dY fragments from LDS.
+// Optional residual (dx += ...: the fused gradient accumulation of nndet_conv3d_backward_data_acc), read at the element it writes.
+#include "common.h"
+#include "conv_common.h"
+
+typedef __bf16 dgs_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct DgMma;
+template <> struct DgMma<bf16_t> {
+    static constexpr int KC = 32, EPL = 8;
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dgs_bf16x8, a), __builtin_bit_cast(dgs_bf16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+        uint2 v; v.x = pack_bf16x2(a, b); v.y = pack_bf16x2(c, d);
+        *reinterpret_cast<uint2*>(p) = v;
+    }
+    __device__ static __forceinline__ void load4(const bf16_t* p, float* v) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+};
+template <> struct DgMma<float> {
+    static constexpr int KC = 16, EPL = 4;
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+    __device__ static __forceinline__ void load4(const float* p, float* v) {
+        const float4 f = *reinterpret_cast<const float4*>(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    }
+};
+
+struct DgsClass { int32_t c[3]; int32_t L[3]; int32_t tap0, ntap; };
+struct DgsTap { int32_t toff; int32_t flip; int32_t wt; int32_t pad; };   // LDS byte offset of the delta inside a chunk image, swizzle flip, weight tap
+struct DgsArgs {
+    const void* dy; const void* w; const void* res; void* dx;
+    int32_t N, K, R;            // dY channels (= cout_p, the contraction), dx channels (= cin_p, the rows)
+    int32_t O[3], I[3];         // dY spatial dims (conv output), dx spatial dims (conv input)
+    int32_t s[3], lo[3];        // stride, smallest delta per axis
+    int32_t H[3], nt[3];        // halo dims, lattice tiles per axis
+    uint32_t mHW, mHH, mHV4;    // magic multipliers for / H[2], / H[1], / (halo voxels * 4)
+    int32_t chb;                // bytes of one chunk image in LDS (halo voxels * 64)
+    int32_t ncls;
+    DgsClass cls[8];
+    DgsTap taps[27];
+};
+
+#define DGS_TD 4
+#define DGS_TH 8
+#define DGS_TW 8
+template <typename T, int MT, int MAXP, int G>
+__global__ __launch_bounds__(256, MT == 2 ? 3 : 1) void k_dgs(const DgsArgs A) {
+    using M = DgMma<T>;
+    constexpr int KC = M::KC, EPL = M::EPL, NT = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int n = blockIdx.z;
+    int tt = xcd_compact(blockIdx.x, gridDim.x, 768);
+    const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
+    const int th_i = tt % A.nt[1];
+    const int td_i = tt / A.nt[1];
+    const int l0d = td_i * DGS_TD, l0h = th_i * DGS_TH, l0w = tw_i * DGS_TW;
+    const int row0 = blockIdx.y * (MT * 16);
+    const int HH = A.H[1], HW = A.H[2];
+    const int HV4 = A.H[0] * HH * HW * 4;
+    const int nchunk = A.K / KC;
+
+    // ---- stage the dY halo of the lattice tile, every chunk (the only staging of this workgroup)
+    {
+        const T* dyn = reinterpret_cast<const T*>(A.dy) + (int64_t)n * A.O[0] * A.O[1] * A.O[2] * A.K;
+        const int total = HV4 * nchunk;
+        const int i0d = l0d + A.lo[0], i0h = l0h + A.lo[1], i0w = l0w + A.lo[2];
+#pragma unroll
+        for (int s0 = 0; s0 < MAXP; s0 += 8) {
+            if (s0 * 256 >= total) break;      // uniform
+            u32x4 v[8];
+            int dst[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int p = tid + (s0 + b) * 256;
+                const int kc = (int)__umulhi((unsigned)p, A.mHV4);
+                const int pi = p - kc * HV4;
+                const int hv = pi >> 2, part = pi & 3;
+                const int t2 = A.mHW ? (int)__umulhi((unsigned)hv, A.mHW) : hv;
+                const int hw = hv - t2 * HW;
+                const int hd = A.mHH ? (int)__umulhi((unsigned)t2, A.mHH) : t2;
+                const int hh = t2 - hd * HH;
+                const int id = i0d + hd, ih = i0h + hh, iw = i0w + hw;
+                const bool ok = p < total && (unsigned)id < (unsigned)A.O[0] && (unsigned)ih < (unsigned)A.O[1] && (unsigned)iw < (unsigned)A.O[2];
+                const int64_t o = ok ? ((int64_t)(id * A.O[1] + ih) * A.O[2] + iw) * A.K + kc * KC + part * EPL : 0;
+                v[b] = *reinterpret_cast<const u32x4*>(dyn + o);          // unconditional (clamped) load: all 8 in flight together
+                if (!ok) v[b] = u32x4{0u, 0u, 0u, 0u};
+                dst[b] = p < total ? kc * A.chb + ((pi * 16) ^ ((t2 & 1) << 5)) : -1;
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (dst[b] >= 0) *reinterpret_cast<u32x4*>(smem + dst[b]) = v[b];
+        }
+    }
+    // LDS byte offsets of this lane's lattice points at delta == lo (tap offset 0), chunk 0
+    int boff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ph = 2 * j + (li >> 3), pw = li & 7;
+        const int brow = wv * HH + ph;
+        boff[j] = ((brow * HW + pw) * 64 + q * 16) ^ ((brow & 1) << 5);
+    }
+    const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + li) * A.K + q * EPL;
+    T* dxn = reinterpret_cast<T*>(A.dx) + (int64_t)n * A.I[0] * A.I[1] * A.I[2] * A.R;
+    const T* rsn = A.res ? reinterpret_cast<const T*>(A.res) + (int64_t)n * A.I[0] * A.I[1] * A.I[2] * A.R : nullptr;
+    __syncthreads();
+
+    // Classes come in groups of G consecutive ones (G = 2: the two W parities of one (cd, ch)): their outputs interleave voxel by
+    // voxel along W, i.e. the two classes fill the two halves of every 128-byte line. Stored one class at a time the half lines sit
+    // in L2 until the other class of the workgroup is done (microseconds later, 12 MB of half-written lines in flight per XCD against
+    // 4 MB of L2); the group keeps both accumulator sets and stores the two halves back to back.
+    for (int cg = 0; cg < A.ncls; cg += G) {
+        f32x4 acc[G][MT][NT];
+        bool live[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const DgsClass& C = A.cls[cg + g];
+            live[g] = !(l0d >= C.L[0] || l0h >= C.L[1] || l0w >= C.L[2]);      // uniform: the tile lies outside this class' lattice
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!live[g]) continue;
+            const int nstep = C.ntap * nchunk;                                   // (tap, chunk) steps, chunk fastest
+            u32x4 af[MT], afn[MT];
+            auto load_w = [&](int st, u32x4* a_) {
+                const int tp = st / nchunk, kc = st - tp * nchunk;
+                const T* wt = wl + ((int64_t)A.taps[C.tap0 + tp].wt * A.R) * A.K + kc * KC;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a_[i] = *reinterpret_cast<const u32x4*>(wt + (int64_t)i * 16 * A.K);
+            };
+            if (nstep > 0) load_w(0, afn);
+            for (int st = 0; st < nstep; ++st) {
+                const int tp = st / nchunk, kc = st - tp * nchunk;
+                const DgsTap tap = A.taps[C.tap0 + tp];
+                const char* base = smem + kc * A.chb + tap.toff;
+                u32x4 bf[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4*>(base + (boff[j] ^ tap.flip));
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = afn[i];
+                if (st + 1 < nstep) load_w(st + 1, afn);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) M::mma(af[i], bf[j], acc[g][i][j]);
+            }
+        }
+        // ---- the group's outputs: o = s * i + c
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int ld = l0d + wv, lh = l0h + 2 * j + (li >> 3), lw = l0w + (li & 7);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const DgsClass& C = A.cls[cg + g];
+                if (live[g] && ld < C.L[0] && lh < C.L[1] && lw < C.L[2]) {
+                    const int od = ld * A.s[0] + C.c[0], oh = lh * A.s[1] + C.c[1], ow = lw * A.s[2] + C.c[2];
+                    const int64_t eo = (((int64_t)od * A.I[1] + oh) * A.I[2] + ow) * A.R + row0 + q * 4;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        float v0 = acc[g][i][j][0], v1 = acc[g][i][j][1], v2 = acc[g][i][j][2], v3 = acc[g][i][j][3];
+                        if (rsn) {
+                            float r4[4];
+                            M::load4(rsn + eo + i * 16, r4);
+                            v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+                        }
+                        M::store4(dxn + eo + i * 16, v0, v1, v2, v3);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static uint32_t dgs_magic(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); }
+
+int dgs_covers(const NndetConv* c) {
+    static const int on = getenv("NNDET_DGS") ? atoi(getenv("NNDET_DGS")) : 1;
+    if (!on || c->transposed || c->cin_p == 1) return 0;
+    bool strided = false;
+    for (int i = 0; i < 3; ++i) {
+        if (c->k[i] != 3 || c->p[i] != 1 || (c->s[i] != 1 && c->s[i] != 2)) return 0;
+        strided |= c->s[i] == 2;
+    }
+    if (!strided) return 0;
+    const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
+    const int kcb = c->dtype == NNDET_BF16 ? 32 : 16;
+    int hv = 1;
+    const int T[3] = {DGS_TD, DGS_TH, DGS_TW};
+    for (int i = 0; i < 3; ++i) hv *= T[i] + (c->s[i] == 2 ? 1 : 2);
+    const int64_t lds = (int64_t)hv * 64 * (c->cout_p / kcb);
+    // every chunk of the halo must be resident; above 64 KB only one workgroup fits a CU and nothing hides its serial class walk
+    // (measured 64 <- 128 channels, 104 KB: 0.228 ms against 0.165 ms for k_igemm)
+    if (c->cout_p % kcb || lds > 64 * 1024) return 0;
+    if ((int64_t)hv * 4 * (c->cout_p / kcb) > 256 * 32) return 0;          // <= 32 staged pieces per thread
+    const int64_t dyb = (int64_t)c->out_d * c->out_h * c->out_w * c->cout_p * esz, dxb = (int64_t)c->in_d * c->in_h * c->in_w * c->cin_p * esz;
+    return dyb < (1LL << 31) && dxb < (1LL << 31) ? 1 : 0;
+}
+
+template <typename T, int MT, int MAXP, int G>
+static int dgs_launch(const DgsArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgs<T, MT, MAXP, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        attr = true;
+    }
+    k_dgs<T, MT, MAXP, G><<<grid, 256, lds, st>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// returns 1 = not covered (the caller falls back to k_igemm)
+int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st) {
+    if (!dgs_covers(c)) return 1;
+    DgsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = dy; a.w = w; a.res = res; a.dx = dx;
+    a.N = c->batch; a.K = c->cout_p; a.R = c->cin_p;
+    const int osp[3] = {c->out_d, c->out_h, c->out_w}, isp[3] = {c->in_d, c->in_h, c->in_w};
+    const int T[3] = {DGS_TD, DGS_TH, DGS_TW};
+    int Lmax[3], hi[3];
+    // per axis and class parity: the (tap, delta) pairs with (c + p - t) % s == 0, delta = (c + p - t) / s
+    int ntp[3][2], tl[3][2][3], dl[3][2][3];
+    for (int i = 0; i < 3; ++i) {
+        a.O[i] = osp[i]; a.I[i] = isp[i]; a.s[i] = c->s[i];
+        if (osp[i] != (isp[i] + 2 - 3) / c->s[i] + 1) return NNDET_EINVAL;
+        int lo = 1 << 30; hi[i] = -(1 << 30);
+        for (int cc = 0; cc < c->s[i]; ++cc) {
+            ntp[i][cc] = 0;
+            for (int t = 0; t < 3; ++t) {
+                const int num = cc + 1 - t;
+                if (((num % c->s[i]) + c->s[i]) % c->s[i] != 0) continue;
+                const int d = num >= 0 ? num / c->s[i] : -((-num) / c->s[i]);
+                tl[i][cc][ntp[i][cc]] = t; dl[i][cc][ntp[i][cc]] = d; ++ntp[i][cc];
+                if (d < lo) lo = d;
+                if (d > hi[i]) hi[i] = d;
+            }
+        }
+        a.lo[i] = lo;
+        a.H[i] = T[i] + hi[i] - lo;
+        Lmax[i] = (isp[i] + c->s[i] - 1) / c->s[i];       // lattice of class 0 (the largest)
+        a.nt[i] = ceil_div(Lmax[i], T[i]);
+    }
+    const int hv = a.H[0] * a.H[1] * a.H[2];
+    a.mHW = dgs_magic(a.H[2]); a.mHH = dgs_magic(a.H[1]); a.mHV4 = dgs_magic(hv * 4);
+    a.chb = hv * 64;
+    int ncls = 0, ntaps = 0;
+    for (int cd = 0; cd < c->s[0]; ++cd) for (int ch = 0; ch < c->s[1]; ++ch) for (int cw = 0; cw < c->s[2]; ++cw) {
+        DgsClass& C = a.cls[ncls++];
+        const int cc[3] = {cd, ch, cw};
+        for (int i = 0; i < 3; ++i) { C.c[i] = cc[i]; C.L[i] = isp[i] > cc[i] ? (isp[i] - cc[i] + c->s[i] - 1) / c->s[i] : 0; }
+        C.tap0 = ntaps;
+        for (int x = 0; x < ntp[0][cd]; ++x) for (int y = 0; y < ntp[1][ch]; ++y) for (int z = 0; z < ntp[2][cw]; ++z) {
+            if (ntaps >= 27) return NNDET_EINVAL;
+            DgsTap& t = a.taps[ntaps++];
+            const int dd = dl[0][cd][x] - a.lo[0], dh = dl[1][ch][y] - a.lo[1], dw = dl[2][cw][z] - a.lo[2];
+            const int trow = dd * a.H[1] + dh;
+            t.toff = (trow * a.H[2] + dw) * 64;
+            t.flip = (trow & 1) << 5;
+            t.wt = (tl[0][cd][x] * 3 + tl[1][ch][y]) * 3 + tl[2][cw][z];
+        }
+        C.ntap = ntaps - C.tap0;
+    }
+    a.ncls = ncls;
+    const int kcb = c->dtype == NNDET_BF16 ? 32 : 16;
+    const int nchunk = a.K / kcb;
+    const size_t lds = (size_t)a.chb * nchunk;
+    const int pieces = ceil_div(hv * 4 * nchunk, 256);
+    const int mt = (a.R % 64 == 0 && lds > 70 * 1024) ? 4 : 2;     // one workgroup per CU anyway: 64 rows per workgroup halve the staging
+    const dim3 grid(a.nt[0] * a.nt[1] * a.nt[2], a.R / (mt * 16), a.N);
+    const bool bf = c->dtype == NNDET_BF16;
+    const bool g2 = c->s[2] == 2;          // classes are enumerated with the W parity fastest: (2k, 2k + 1) differ in cw only
+#define DGS_GO(MT_, MP_) (g2 ? (bf ? dgs_launch<bf16_t, MT_, MP_, 2>(a, grid, lds, st) : dgs_launch<float, MT_, MP_, 2>(a, grid, lds, st)) \
+                             : (bf ? dgs_launch<bf16_t, MT_, MP_, 1>(a, grid, lds, st) : dgs_launch<float, MT_, MP_, 1>(a, grid, lds, st)))
+    if (pieces <= 16) return mt == 2 ? DGS_GO(2, 16) : DGS_GO(4, 16);
+    return mt == 2 ? DGS_GO(2, 32) : DGS_GO(4, 32);
+#undef DGS_GO
+}

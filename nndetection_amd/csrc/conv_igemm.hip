@@ -694,7 +694,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, int voff, u
 template <bool STATS>
 __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
     constexpr int HH = 10, HW = 10, BUF = 65536, NPIECE = 16;
-    constexpr int NM = STATS ? 19 : 7;                       // epilogue micro-ops per accumulator fragment
+    constexpr int NM = STATS ? 39 : 15;                      // epilogue micro-ops per point tile (= the two row-tile accumulators of 16 points)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -782,7 +782,10 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
         const int a = tp / 9, b = tp % 3, c = (tp / 3) % 3;
         return *reinterpret_cast<const u32x4*>(smem + ((b & 1) ? sb1 : sb0) + (((gph + a) * HH + 2 * jj + b) * HW + c) * 64);
     };
-    const int vlane = ((li >> 3) * A.W + (li & 7)) * 64 + q * 8;       // this lane's 4 channels of fragment row i = 0, point li
+    // One 16-byte store per lane and point tile instead of two 8-byte ones (the epilogue is store-ISSUE bound): v_permlane16_swap
+    // exchanges the packed row-tile-0 values of the odd lane rows with the row-tile-1 values of the even ones, after which lane row q
+    // holds 8 CONSECUTIVE channels of its point: q = 0: 0-7, 1: 16-23, 2: 8-15, 3: 24-31 (tools/probe_permlane.hip)
+    const int vlane = ((li >> 3) * A.W + (li & 7)) * 64 + ((q >> 1) * 8 + (q & 1) * 16) * 2;
 
     f32x4 acc[2][8];
 #pragma unroll
@@ -810,16 +813,21 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
             }
     };
     // epilogue micro-op m of fragment (i, j): the values pass through ev / epk between slots
-    float ev[4];
-    v2u_t epk;
-    auto epi = [&](int i, int j, int m, __amdgpu_buffer_rsrc_t yrs, int soff) {
-        if (m < 4) ev[m] = acc[i][j][m] + bia[i][m];
-        else if (m == 4) epk[0] = pack_bf16x2(ev[0], ev[1]);
-        else if (m == 5) epk[1] = pack_bf16x2(ev[2], ev[3]);
-        else if (m == 6) __builtin_amdgcn_raw_buffer_store_b64(epk, yrs, vlane + i * 32, soff, 0);
-        else if (m < 11) { const int r = m - 7; ev[r] = __uint_as_float((r & 1) ? (epk[r >> 1] & 0xffff0000u) : (epk[r >> 1] << 16)); }
-        else if (m < 15) ssum[i][m - 11] += ev[m - 11];
-        else ssq[i][m - 15] = fmaf(ev[m - 15], ev[m - 15], ssq[i][m - 15]);
+    float ev[2][4];
+    uint32_t epk[2][2];
+    v4u_t est;
+    auto epi = [&](int j, int m, __amdgpu_buffer_rsrc_t yrs, int soff) {
+        if (m < 8) ev[m >> 2][m & 3] = acc[m >> 2][j][m & 3] + bia[m >> 2][m & 3];
+        else if (m < 12) { const int i = (m - 8) >> 1, h = (m - 8) & 1; epk[i][h] = pack_bf16x2(ev[i][2 * h], ev[i][2 * h + 1]); }
+        else if (m < 14) {
+            const int h = m - 12;
+            const v2u_t r = __builtin_amdgcn_permlane16_swap(epk[0][h], epk[1][h], false, false);
+            est[h] = r[0]; est[2 + h] = r[1];
+        }
+        else if (m == 14) __builtin_amdgcn_raw_buffer_store_b128(est, yrs, vlane, soff, 0);
+        else if (m < 23) { const int i = (m - 15) >> 2, r = (m - 15) & 3; ev[i][r] = __uint_as_float((r & 1) ? (epk[i][r >> 1] & 0xffff0000u) : (epk[i][r >> 1] << 16)); }
+        else if (m < 31) { const int i = (m - 23) >> 2, r = (m - 23) & 3; ssum[i][r] += ev[i][r]; }
+        else { const int i = (m - 31) >> 2, r = (m - 31) & 3; ssq[i][r] = fmaf(ev[i][r], ev[i][r], ssq[i][r]); }
     };
 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -890,9 +898,9 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
                         }
                     }
                     const int e = tp * 8 + s - 8;                       // epilogue micro-op of this slot
-                    if (e >= 0 && e < 8 * NM && !(IG3R_DBG & 2)) {
+                    if (e >= 0 && e < 4 * NM && !(IG3R_DBG & 2)) {
                         const int f = e / NM, m = e % NM;
-                        epi(f >> 2, (gph ^ 1) * 4 + (f & 3), m, yrs, ebase + 2 * (f & 3) * rowb);
+                        epi((gph ^ 1) * 4 + f, m, yrs, ebase + 2 * f * rowb);
                     }
                     // LDS-DMA of the next tile: IG3R_PPS pieces per step from step IG3R_DS0 of phase IG3R_DPH on; the offset is computed one
                     // slot before the issue slot
@@ -927,9 +935,9 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
         const auto yrs = y_rsrc(n_prev, true);
         const int ebase = tout_prev + (wv * 2 + 1) * slab;
 #pragma unroll
-        for (int f = 0; f < 8; ++f)
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int m = 0; m < NM; ++m) epi(f >> 2, 4 + (f & 3), m, yrs, ebase + 2 * (f & 3) * rowb);
+            for (int m = 0; m < NM; ++m) epi(4 + f, m, yrs, ebase + 2 * f * rowb);
         if (STATS) flush(stat_n);
     }
 }
@@ -1250,6 +1258,10 @@ int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const 
         if (prc != 1) return prc;
     }
     if (dbias) return NNDET_EINVAL;     // only the pointwise data-gradient kernels fuse the bias gradient (nndet_conv3d_dgrad_fuses_bias)
+    if (kind == 1 && !bias && !stats) {                                 // strided 3x3x3 data gradient: every parity class from ONE staged halo
+        const int drc = dgs_run(c, x, w, res, y, st);
+        if (drc != 1) return drc;
+    }
     Plan P;
     int rc = build_plan(c, kind, &P);
     if (rc) return rc;
