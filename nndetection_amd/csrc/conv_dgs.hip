@@ -179,7 +179,31 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 1) void k_dgs(const DgsArgs A) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const DgsClass& C = A.cls[cg + g];
-                if (live[g] && ld < C.L[0] && lh < C.L[1] && lw < C.L[2]) {
+                const bool pv = live[g] && ld < C.L[0] && lh < C.L[1] && lw < C.L[2];
+                if constexpr (sizeof(T) == 2) {
+                    // bf16: row tiles in pairs, ONE 16-byte store per lane and pair (v_permlane16_swap: lane row q ends up with 8 consecutive
+                    // channels, q = 0: 0-7, 1: 16-23, 2: 8-15, 3: 24-31; the partner lane (q ^ 1, same li) is the same point -> same pv)
+                    typedef unsigned int dgs_v2u __attribute__((ext_vector_type(2)));
+                    const int od = ld * A.s[0] + C.c[0], oh = lh * A.s[1] + C.c[1], ow = lw * A.s[2] + C.c[2];
+                    const int64_t vo = pv ? (((int64_t)od * A.I[1] + oh) * A.I[2] + ow) * A.R + row0 : 0;
+#pragma unroll
+                    for (int i = 0; i < MT; i += 2) {
+                        uint32_t pk[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            float v0 = acc[g][i + h][j][0], v1 = acc[g][i + h][j][1], v2 = acc[g][i + h][j][2], v3 = acc[g][i + h][j][3];
+                            if (rsn && pv) {
+                                float r4[4];
+                                M::load4(rsn + vo + q * 4 + (i + h) * 16, r4);
+                                v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+                            }
+                            pk[h][0] = pack_bf16x2(v0, v1); pk[h][1] = pack_bf16x2(v2, v3);
+                        }
+                        const dgs_v2u s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const dgs_v2u s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        if (pv) *reinterpret_cast<u32x4*>(dxn + vo + i * 16 + (q >> 1) * 8 + (q & 1) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    }
+                } else if (pv) {
                     const int od = ld * A.s[0] + C.c[0], oh = lh * A.s[1] + C.c[1], ow = lw * A.s[2] + C.c[2];
                     const int64_t eo = (((int64_t)od * A.I[1] + oh) * A.I[2] + ow) * A.R + row0 + q * 4;
 #pragma unroll

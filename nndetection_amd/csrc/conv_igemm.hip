@@ -27,6 +27,8 @@
 #include "conv_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int v2u_t __attribute__((__vector_size__(8)));
+typedef unsigned int v4u_t __attribute__((__vector_size__(16)));
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -343,11 +345,35 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
         const int pt2 = pp >> A.lT2;
         const int ld = l0d + (pt2 >> A.lT1), lh = l0h + (pt2 & (A.T[1] - 1)), lw = l0w + (pp & (A.T[2] - 1));
         const bool valid = (ld < C.L[0]) && (lh < C.L[1]) && (lw < C.L[2]);
-        if (valid) {
-            const int od = C.out_off[0] + ld * A.out_step[0];
-            const int oh = C.out_off[1] + lh * A.out_step[1];
-            const int ow = C.out_off[2] + lw * A.out_step[2];
-            T* yo = yb + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * A.Cy;
+        const int od = C.out_off[0] + ld * A.out_step[0];
+        const int oh = C.out_off[1] + lh * A.out_step[1];
+        const int ow = C.out_off[2] + lw * A.out_step[2];
+        T* yo = yb + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * A.Cy;
+        if constexpr (sizeof(T) == 2 && MT == 2) {
+            // one 16-byte store per lane instead of two 8-byte ones: see k_ig3 (v_permlane16_swap; partner lane = same point)
+            uint32_t pk[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r0 = row0 + (wr * MT + i) * 16 + q * 4;
+                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                if (A.bias) { v0 += A.bias[r0]; v1 += A.bias[r0 + 1]; v2 += A.bias[r0 + 2]; v3 += A.bias[r0 + 3]; }
+                if (A.res && valid) {
+                    float r4[4];
+                    load4<T>(reinterpret_cast<const T*>(A.res) + (yo - yb) + r0, r4);
+                    v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+                }
+                pk[i][0] = pack_bf16x2(v0, v1); pk[i][1] = pack_bf16x2(v2, v3);
+                if (A.stats && valid) {
+                    v0 = __uint_as_float(pk[i][0] << 16); v1 = __uint_as_float(pk[i][0] & 0xffff0000u);
+                    v2 = __uint_as_float(pk[i][1] << 16); v3 = __uint_as_float(pk[i][1] & 0xffff0000u);
+                    ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
+                    ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
+                }
+            }
+            const v2u_t s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const v2u_t s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            if (valid) *reinterpret_cast<u32x4*>(yo + row0 + wr * MT * 16 + (q >> 1) * 8 + (q & 1) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        } else if (valid) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int r0 = row0 + (wr * MT + i) * 16 + q * 4;
@@ -405,8 +431,6 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 //   * the InstanceNorm / GroupNorm statistics are reduced over the 16 voxel lanes with DPP adds instead of ds_bpermute.
 // Tile <-> lane mapping: point p = (wc * NT + j) * 16 + li, pw = li & 7, ph = 2 * (j & 3) + (li >> 3),
 // pd = wc * NT / 4 + (j >> 2).
-typedef unsigned int v2u_t __attribute__((__vector_size__(8)));
-typedef unsigned int v4u_t __attribute__((__vector_size__(16)));
 // 4 consecutive channels through a buffer descriptor (voffset = lane byte offset, soffset = scalar byte offset); the store
 // returns the values as stored (rounded to T) like store4r
 template <typename T, typename R> __device__ __forceinline__ void buf_store4r(R rs, int vo, int so, float& a, float& b, float& c, float& d);
@@ -602,7 +626,34 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
         const int ld = ld0 + (j >> 2), lh = lh0 + 2 * (j & 3);
         const bool valid = (ld < A.O[0]) && (lh < A.O[1]) && (lw < A.O[2]);
         const int so = (j >> 2) * oslab + 2 * (j & 3) * orow;
-        if (valid) {
+        if constexpr (sizeof(T) == 2 && MT == 2) {
+            // bf16, two row tiles per wave: ONE 16-byte store per lane instead of two 8-byte ones (the epilogue is store-issue bound).
+            // v_permlane16_swap exchanges the packed row-tile-0 values of the odd lane rows with the row-tile-1 values of the even
+            // ones; lane row q then holds 8 consecutive channels: q = 0: 0-7, 1: 16-23, 2: 8-15, 3: 24-31 (tools/probe_permlane.hip).
+            // The partner lane (q ^ 1, same li) belongs to the same point, so `valid` is the same for both.
+            uint32_t pk[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v0 = acc[i][j][0] + bia[i][0], v1 = acc[i][j][1] + bia[i][1], v2 = acc[i][j][2] + bia[i][2], v3 = acc[i][j][3] + bia[i][3];
+                if (A.res) {
+                    float r4[4];
+                    buf_load4<T>(rrs, valid ? vb + i * 16 * (int)sizeof(T) : (int)0x80000000, so, r4);
+                    v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+                }
+                pk[i][0] = pack_bf16x2(v0, v1); pk[i][1] = pack_bf16x2(v2, v3);
+                if (A.stats && valid) {
+                    v0 = __uint_as_float(pk[i][0] << 16); v1 = __uint_as_float(pk[i][0] & 0xffff0000u);
+                    v2 = __uint_as_float(pk[i][1] << 16); v3 = __uint_as_float(pk[i][1] & 0xffff0000u);
+                    ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
+                    ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
+                }
+            }
+            const v2u_t s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const v2u_t s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            const v4u_t st16 = {s0[0], s1[0], s0[1], s1[1]};
+            const int vb16 = vb + (((q >> 1) * 8 + (q & 1) * 16) - q * 4) * (int)sizeof(T);
+            __builtin_amdgcn_raw_buffer_store_b128(st16, yrs, valid ? vb16 : (int)0x80000000, so, 0);      // out-of-range offsets are dropped
+        } else if (valid) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 float v0 = acc[i][j][0] + bia[i][0], v1 = acc[i][j][1] + bia[i][1], v2 = acc[i][j][2] + bia[i][2], v3 = acc[i][j][3] + bia[i][3];

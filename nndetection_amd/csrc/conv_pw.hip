@@ -177,12 +177,35 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
                             M::mma(a, b[u][kc], acc[i]);
                         }
                     }
-                    if (pt[u] >= 0) {
-                        int64_t o = pt[u];
-                        if (A.ncls > 1) {
-                            const int c2 = c % S2, ct = c / S2;
-                            o = pw_strided_index(A, pt[u], ct / S1, ct % S1, c2);
+                    const bool pv = pt[u] >= 0;
+                    int64_t o = pv ? pt[u] : 0;
+                    if (A.ncls > 1) {
+                        const int c2 = c % S2, ct = c / S2;
+                        o = pw_strided_index(A, o, ct / S1, ct % S1, c2);
+                    }
+                    if constexpr (sizeof(T) == 2 && MT % 2 == 0) {
+                        // bf16, row tiles in pairs: ONE 16-byte store per lane and pair instead of two 8-byte ones (v_permlane16_swap: lane
+                        // row q ends up with 8 consecutive channels, q = 0: 0-7, 1: 16-23, 2: 8-15, 3: 24-31; the partner lane (q ^ 1,
+                        // same li) holds the same point, so it shares `pv`)
+                        typedef unsigned int pw_v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int i = 0; i < MT; i += 2) {
+                            uint32_t pk[2][2];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                f32x4 v = acc[i + h];
+                                v[0] += bia[i + h][0]; v[1] += bia[i + h][1]; v[2] += bia[i + h][2]; v[3] += bia[i + h][3];
+                                if (rb && pv) {
+                                    const f32x4 r4 = M::load4(rb + o * A.Cy + row0 + q * 4 + (i + h) * 16);
+                                    v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+                                }
+                                pk[h][0] = pack_bf16x2(v[0], v[1]); pk[h][1] = pack_bf16x2(v[2], v[3]);
+                            }
+                            const pw_v2u s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                            const pw_v2u s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                            if (pv) *reinterpret_cast<u32x4*>(yb + o * A.Cy + row0 + i * 16 + (q >> 1) * 8 + (q & 1) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                         }
+                    } else if (pv) {
                         T* yo = yb + o * A.Cy + row0 + q * 4;
 #pragma unroll
                         for (int i = 0; i < MT; ++i) {
@@ -234,7 +257,15 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
                             }
                     }
                 }
-                if (ok) {
+                if constexpr (sizeof(T) == 2 && MT % 2 == 0) {      // paired 16-byte stores (see the scatter branch)
+                    typedef unsigned int pw_v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int i = 0; i < MT; i += 2) {
+                        const pw_v2u s0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[i][0], acc[i][1]), pack_bf16x2(acc[i + 1][0], acc[i + 1][1]), false, false);
+                        const pw_v2u s1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[i][2], acc[i][3]), pack_bf16x2(acc[i + 1][2], acc[i + 1][3]), false, false);
+                        if (ok) *reinterpret_cast<u32x4*>(yb + p * A.Cy + row0 + i * 16 + (q >> 1) * 8 + (q & 1) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    }
+                } else if (ok) {
                     T* yo = yb + p * A.Cy + row0 + q * 4;
 #pragma unroll
                     for (int i = 0; i < MT; ++i) M::store4(yo + i * 16, acc[i]);
