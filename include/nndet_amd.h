@@ -257,6 +257,41 @@ int nndet_conv3d_backward_weight(const NndetConv* c, const void* x, const void* 
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * RAGGED batches ("items"): feature maps of DIFFERENT spatial sizes that share the channel count and go through the SAME layer --
+ * the pyramid levels P2..P5 through the shared detection-head trunks (nndet/arch/heads/classifier.py:160-181, regressor.py:153-173,
+ * comb.py:85-109 loop over the levels and call the same convs once per level). One launch covers every (level, image) pair:
+ * the small levels (75 .. 4800 positions per image) ride along in the half-empty last round of workgroups of the largest level
+ * instead of costing a latency-bound launch each, and the weight gradient of the shared parameters is summed over the levels inside
+ * the kernel instead of by 3 extra additions per parameter.
+ *   storage: ONE [rows, C_p] buffer; item i is the NDHWC volume dims[i] = (D, H, W) starting at voxel row row_off[i]
+ *   (row_off[i] * C_p * sizeof(dtype) must be a multiple of 16; items must not overlap; every item < 2^31 bytes).
+ * Only the 3x3x3 / stride 1 / padding 1 Conv3d is covered (what the head trunks are); NndetConv.batch / in_* / out_* are ignored,
+ * in_affine must be NULL. Per-item statistics use the item index where the uniform entry points use the image index:
+ * stats [NNDET_STATS_REPLICAS, n_items, cout_p, 2], mean_rstd [n_items, C_p, 2].
+ * ---------------------------------------------------------------------------------------------- */
+#define NNDET_MAX_ITEMS 32
+typedef struct NndetItems {
+    int32_t n_items, reserved_;
+    int32_t dims[NNDET_MAX_ITEMS][3];
+    int64_t row_off[NNDET_MAX_ITEMS];
+} NndetItems;
+int nndet_conv3d_forward_items(const NndetConv* c, const NndetItems* items, const void* x, const void* w_packed_mode0,
+                               const float* bias, void* y, double* stats, void* stream);
+int nndet_conv3d_backward_data_items(const NndetConv* c, const NndetItems* items, const void* dy, const void* w_packed_mode1,
+                                     void* dx, void* stream);
+/* dw / dbias accumulate the sum over ALL items; workspace: nndet_conv3d_wgrad_workspace_bytes(c) */
+int nndet_conv3d_backward_weight_items(const NndetConv* c, const NndetItems* items, const void* x, const void* dy, float* dw,
+                                       float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+/* nndet_norm_apply / nndet_norm_backward per item (statistics over the item's own voxels); red_ws as in nndet_norm_backward with
+ * N = n_items */
+int nndet_norm_apply_items(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
+                           const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, float eps, int32_t relu, void* y,
+                           float* mean_rstd_out, void* stream);
+int nndet_norm_backward_items(int32_t dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma,
+                              const float* beta, const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, int32_t relu,
+                              void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d / GroupNorm (+ReLU) on NDHWC -- replaces nn.InstanceNorm3d / nndet GroupNorm + nn.ReLU
  * inside ConvInstanceRelu / ConvGroupRelu (nndet/arch/conv.py:195,271; nndet/arch/layers/norm.py:26-50).
  * Statistics are per (n, group) over the group's channels and all voxels; groups == C is InstanceNorm.

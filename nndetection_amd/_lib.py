@@ -39,8 +39,18 @@ class NndetHeadLevels(C.Structure):
                 ("points", C.c_int64 * HEAD_MAX_LEVELS)]
 
 
+MAX_ITEMS = 32
+
+
+class NndetItems(C.Structure):
+    """Ragged batch: items of different spatial size in one [rows, C_p] buffer (include/nndet_amd.h)."""
+    _fields_ = [("n_items", C.c_int32), ("reserved_", C.c_int32),
+                ("dims", (C.c_int32 * 3) * MAX_ITEMS), ("row_off", C.c_int64 * MAX_ITEMS)]
+
+
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _CONVP = C.POINTER(NndetConv)
+_ITEMSP = C.POINTER(NndetItems)
 
 # name -> (restype, argtypes); every symbol include/nndet_amd.h declares
 SIGNATURES = {
@@ -81,6 +91,11 @@ SIGNATURES = {
     "nndet_conv3d_backward_data_acc": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
     "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
     "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _SZ, _P]),
+    "nndet_conv3d_forward_items": (C.c_int, [_CONVP, _ITEMSP, _P, _P, _P, _P, _P, _P]),
+    "nndet_conv3d_backward_data_items": (C.c_int, [_CONVP, _ITEMSP, _P, _P, _P, _P]),
+    "nndet_conv3d_backward_weight_items": (C.c_int, [_CONVP, _ITEMSP, _P, _P, _P, _P, _P, _SZ, _P]),
+    "nndet_norm_apply_items": (C.c_int, [_I32, _P, _P, _P, _P, _ITEMSP, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
+    "nndet_norm_backward_items": (C.c_int, [_I32, _P, _P, _P, _P, _P, _ITEMSP, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nndet_norm_stats": (C.c_int, [_I32, _P, _I32, _I64, _I32, _P, _P]),
     "nndet_norm_finalize": (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _F, _P, _P, _P]),
     "nndet_affine_apply": (C.c_int, [_I32, _P, _P, _I32, _I64, _I32, _I32, _P, _P]),

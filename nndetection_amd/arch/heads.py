@@ -195,8 +195,57 @@ class DetectionHeadHNMNative(nn.Module):
         return pool[:n]
 
     gather_levels = os.environ.get("NNDET_HEAD_GATHER", "1") != "0"      # one flatten + Scale + cat launch per branch (csrc/headio.hip)
+    # all pyramid levels through a trunk layer in ONE launch (arch/pyramid.py: the levels are the items of a ragged batch);
+    # NNDET_HEAD_ITEMS=0 selects the per-level launches on side streams below
+    items_levels = os.environ.get("NNDET_HEAD_ITEMS", "1") != "0"
+
+    def _forward_items(self, fmaps: List[Tensor]) -> Dict[str, Tensor]:
+        """comb.py:85-109 with the level loop folded into the kernels: 3 conv + 2 norm launches per branch for ALL levels."""
+        from . import pyramid as P
+        x2d, meta = P.cat_levels(fmaps)
+        sdim = fmaps[0].ndim - 2
+        nc, a = self.classifier.num_classes, self.classifier.anchors_per_pos
+        outs = {}
+        # the regressor trunk is issued first, on a side stream forked here; the classifier trunk follows on the main stream, so the
+        # two (independent until the loss) fill each other's last round of workgroups
+        branches = (("reg", self.regressor, self.regressor.anchors_per_pos * sdim * 2,
+                     [sc.scale for sc in self.regressor.scales[:len(fmaps)]] if self.regressor.learn_scale else []),
+                    ("cls", self.classifier, nc * a, []))
+        two_streams = self.multi_stream
+        main = torch.cuda.current_stream(x2d.device)
+        side = self._side_streams(x2d.device, 1)[0] if two_streams else None
+        if two_streams and torch.is_grad_enabled() and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # intended: one trunk per stream
+        for name, head, cout, scales in branches:
+            on_side = two_streams and name == "reg"
+            if on_side:
+                side.wait_stream(main)
+                x2d.record_stream(side)
+            with torch.cuda.stream(side if on_side else main):
+                t = x2d
+                for blk in head.conv_internal:
+                    t = P.items_block(blk, t, meta)
+                t = P.items_block(head.conv_out, t, meta)
+                o = P.head_gather_items(t, meta, cout, scales)
+            if on_side:
+                o.record_stream(main)
+            outs[name] = o
+        if two_streams:
+            main.wait_stream(side)
+        return {"box_deltas": outs["reg"].view(-1, sdim * 2), "box_logits": outs["cls"].view(-1, nc)}
+
+    def _items_ok(self, fmaps: List[Tensor]) -> bool:
+        if not (self.items_levels and self.gather_levels and fmaps[0].is_cuda and len(fmaps) <= L.HEAD_MAX_LEVELS
+                and type(self.classifier) is BCECLassifier and type(self.regressor) is GIoURegressor):
+            return False
+        from . import pyramid as P
+        from .conv import DEFER_NORM
+        blocks = list(self.classifier.conv_internal) + [self.classifier.conv_out] + list(self.regressor.conv_internal) + [self.regressor.conv_out]
+        return (not DEFER_NORM) and P.supports(fmaps, blocks)
 
     def forward(self, fmaps: List[Tensor]) -> Dict[str, Tensor]:
+        if self._items_ok(fmaps):
+            return self._forward_items(fmaps)
         logits, offsets = [None] * len(fmaps), [None] * len(fmaps)
         fused = (self.gather_levels and fmaps[0].is_cuda and len(fmaps) <= L.HEAD_MAX_LEVELS
                  and type(self.classifier) is BCECLassifier and type(self.regressor) is GIoURegressor)

@@ -84,3 +84,28 @@ extern "C" int nndet_conv3d_backward_weight(const NndetConv* c, const void* x, c
     }
     return rc;
 }
+
+// ---- ragged batches (NndetItems): the pyramid levels through the shared detection-head convolutions in one launch
+extern "C" int nndet_conv3d_forward_items(const NndetConv* c, const NndetItems* items, const void* x, const void* w, const float* bias,
+                                          void* y, double* stats, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!items || !x || !w || !y || c->cin_p == 1) return NNDET_EINVAL;
+    return igemm_items_run(c, items, 0, x, w, bias, y, stats, as_stream(stream));
+}
+
+extern "C" int nndet_conv3d_backward_data_items(const NndetConv* c, const NndetItems* items, const void* dy, const void* w, void* dx,
+                                                void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!items || !dy || !w || !dx || c->cin_p == 1) return NNDET_EINVAL;
+    return igemm_items_run(c, items, 1, dy, w, nullptr, dx, nullptr, as_stream(stream));
+}
+
+extern "C" int nndet_conv3d_backward_weight_items(const NndetConv* c, const NndetItems* items, const void* x, const void* dy, float* dw,
+                                                  float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!items || !x || !dy || !dw || c->cin_p == 1) return NNDET_EINVAL;
+    return wgrad_items_run(c, items, x, dy, dw, dbias, workspace, workspace_bytes, as_stream(stream));
+}

@@ -11,6 +11,12 @@
 // conv_igemm.hip
 int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x, const void* w, const float* bias,
               const void* res, void* y, double* stats, hipStream_t st, float* dbias = nullptr);
+// ragged batches (NndetItems): 3x3x3 / stride 1 / pad 1 only
+int items_check(const NndetConv* c, const NndetItems* it);
+int igemm_items_run(const NndetConv* c, const NndetItems* it, int kind, const void* x, const void* w, const float* bias, void* y,
+                    double* stats, hipStream_t st);
+int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, const void* dy, float* dw, float* dbias, void* ws,
+                    size_t ws_bytes, hipStream_t st);
 // conv_pw.hip: 1x1x1 / kernel == stride transposed convolutions streamed without LDS staging; returns 1 = not covered
 int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, hipStream_t st,
            float* dbias = nullptr);

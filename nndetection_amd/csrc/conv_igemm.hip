@@ -111,6 +111,14 @@ struct IgArgs {
     IgTapX tapx[28];      // per-tap LDS offset / swizzle flip / weight byte offset, precomputed on the host (PIPE kernels)
 };
 
+// Ragged batch (NndetItems): per-item dims and first voxel row; only k_ig3<..., ITEMS = true> reads it (blockIdx.z = item,
+// blockIdx.x = tile of the LARGEST item: workgroups beyond an item's own tile count exit at once)
+struct IgItems {
+    int32_t n, pad_;
+    int32_t dims[NNDET_MAX_ITEMS][3];
+    int64_t row_off[NNDET_MAX_ITEMS];
+};
+
 // Wave layout inside the workgroup: WR waves along the output rows (channels) x 4/WR waves along the lattice points.
 // A wave owns MT row tiles x NT point tiles of 16. Splitting rows across waves (WR = 2) halves the weight-fragment
 // traffic from L2 (every wave used to stream the weights of ALL rows: 432 KB per workgroup and chunk, the bottleneck of
@@ -464,8 +472,8 @@ __device__ __forceinline__ float dpp_row_sum(float v) {   // sum over the 16 lan
     return v;
 }
 
-template <typename T, int WR, int MT, int NT, int MINW, bool AFF = false>
-__global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
+template <typename T, int WR, int MT, int NT, int MINW, bool AFF = false, bool ITEMS = false>
+__global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems IT) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
     constexpr int TD = NT / WR, TH = 8, TW = 8;
@@ -482,15 +490,28 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
     const int wr = wv % WR, wc = wv / WR;
 
     const int n = blockIdx.z;
-    int tt = xcd_compact(blockIdx.x, gridDim.x, 512);
-    const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
-    const int th_i = tt % A.nt[1];
-    const int td_i = tt / A.nt[1];
+    // spatial size of this workgroup's volume: the launch's (uniform batch) or the item's own (ragged batch: input == output size)
+    int I0 = A.I[0], I1 = A.I[1], I2 = A.I[2], O0 = A.O[0], O1 = A.O[1], O2 = A.O[2], nt1 = A.nt[1], nt2 = A.nt[2];
+    int tt;
+    int64_t row_off = 0;
+    if constexpr (ITEMS) {
+        I0 = O0 = IT.dims[n][0]; I1 = O1 = IT.dims[n][1]; I2 = O2 = IT.dims[n][2];
+        nt1 = (I1 + TH - 1) / TH; nt2 = (I2 + TW - 1) / TW;
+        tt = blockIdx.x;
+        if (tt >= ((I0 + TD - 1) / TD) * nt1 * nt2) return;      // uniform
+        row_off = IT.row_off[n];
+    } else {
+        tt = xcd_compact(blockIdx.x, gridDim.x, 512);
+    }
+    const int tw_i = tt % nt2; tt /= nt2;
+    const int th_i = tt % nt1;
+    const int td_i = tt / nt1;
     const int l0d = td_i * TD, l0h = th_i * TH, l0w = tw_i * TW;
     const int row0 = blockIdx.y * (WR * MT * 16);
-    const int img_bytes = A.I[0] * A.I[1] * A.I[2] * A.Cx * (int)sizeof(T);     // < 2^31 (checked on the host)
+    const int img_bytes = I0 * I1 * I2 * A.Cx * (int)sizeof(T);     // < 2^31 (checked on the host)
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (int64_t)n * img_bytes, 0, img_bytes, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (ITEMS ? row_off * A.Cx * (int64_t)sizeof(T) : (int64_t)n * img_bytes),
+        0, img_bytes, 0x00020000);
 
     int32_t goff[MAXP];
     const int cp = tid % ROWP, sr0 = tid / ROWP;       // column piece (voxel hw = cp >> 2, 16-byte part cp & 3), first row
@@ -498,8 +519,8 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
     const int st_dst0 = ((sr0 * ROWP + cp) * 16) ^ ((sr0 & 1) << 5);
     {
         const int iw = l0w - 1 + (cp >> 2);
-        const bool okw = st_active && (unsigned)iw < (unsigned)A.I[2];
-        const int rowb = A.I[2] * A.Cx * (int)sizeof(T);
+        const bool okw = st_active && (unsigned)iw < (unsigned)I2;
+        const int rowb = I2 * A.Cx * (int)sizeof(T);
         const int colb = iw * A.Cx * (int)sizeof(T) + (cp & 3) * 16;
 #pragma unroll
         for (int s = 0; s < MAXP; ++s) {
@@ -507,8 +528,8 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
             const int hd = r / HH, hh = r - hd * HH;
             const int id = l0d - 1 + hd, ih = l0h - 1 + hh;
             // out-of-tensor pieces (= the zero padding) get an offset beyond num_records: the buffer load returns 0 for them
-            const bool ok = okw && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (s + 1 < MAXP || r < NROW);
-            goff[s] = ok ? (id * A.I[1] + ih) * rowb + colb : (int32_t)0x80000000;
+            const bool ok = okw && (unsigned)id < (unsigned)I0 && (unsigned)ih < (unsigned)I1 && (s + 1 < MAXP || r < NROW);
+            goff[s] = ok ? (id * I1 + ih) * rowb + colb : (int32_t)0x80000000;
         }
     }
     const int par = (li >> 3) & 1;
@@ -608,12 +629,13 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
-    const int out_bytes = A.O[0] * A.O[1] * A.O[2] * A.Cy * (int)sizeof(T);     // < 2^31 (checked on the host)
-    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(A.y) + (int64_t)n * out_bytes, 0, out_bytes, 0x00020000);
+    const int out_bytes = O0 * O1 * O2 * A.Cy * (int)sizeof(T);     // < 2^31 (checked on the host)
+    const int64_t out_base = ITEMS ? row_off * A.Cy * (int64_t)sizeof(T) : (int64_t)n * out_bytes;
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(A.y) + out_base, 0, out_bytes, 0x00020000);
     const auto rrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(A.res)) + (int64_t)n * out_bytes, 0, A.res ? out_bytes : 0, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(A.res)) + out_base, 0, A.res ? out_bytes : 0, 0x00020000);
     const int lw = l0w + (li & 7), lh0 = l0h + (li >> 3), ld0 = l0d + wc * (NT / 4);
-    const int orow = A.O[2] * A.Cy * (int)sizeof(T), oslab = A.O[1] * orow;
+    const int orow = O2 * A.Cy * (int)sizeof(T), oslab = O1 * orow;
     const int rl = row0 + wr * MT * 16 + q * 4;                                  // first of this lane's 4 rows (i = 0)
     const int vb = ld0 * oslab + lh0 * orow + (lw * A.Cy + rl) * (int)sizeof(T);
     float bia[MT][4];
@@ -624,7 +646,7 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int ld = ld0 + (j >> 2), lh = lh0 + 2 * (j & 3);
-        const bool valid = (ld < A.O[0]) && (lh < A.O[1]) && (lw < A.O[2]);
+        const bool valid = (ld < O0) && (lh < O1) && (lw < O2);
         const int so = (j >> 2) * oslab + 2 * (j & 3) * orow;
         if constexpr (sizeof(T) == 2 && MT == 2) {
             // bf16, two row tiles per wave: ONE 16-byte store per lane instead of two 8-byte ones (the epilogue is store-issue bound).
@@ -1040,7 +1062,7 @@ static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[
 }
 
 // kind: 0 forward, 1 backward-data
-static int build_plan(const NndetConv* c, int kind, Plan* P) {
+static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = false) {
     IgArgs& a = P->a;
     memset(&a, 0, sizeof(a));
     const int KCb = c->dtype == NNDET_BF16 ? 32 : 16;
@@ -1132,9 +1154,10 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     // Small pyramid levels: with 256 / 512-point tiles a level of 150 ... 4800 positions gives 8 ... 200 workgroups for 256 CUs and
     // every one of them walks serially through 27 taps x all K chunks of a mostly padded tile. Below `small_wg` workgroups the
     // 64-point tiles are used instead (4 - 8x as many workgroups, each with 1/4 - 1/8 of the serial work): latency, not throughput.
-    static const int small_wg = getenv("NNDET_IGEMM_SMALLWG") ? atoi(getenv("NNDET_IGEMM_SMALLWG")) : 200;   // measured: 40 -> 160 workgroups halves the kernel, 200 -> 800 gains nothing
+    const char* swg_env = getenv("NNDET_IGEMM_SMALLWG");          // read per call so tests can flip it
+    const int small_wg = swg_env ? atoi(swg_env) : 200;   // measured: 40 -> 160 workgroups halves the kernel, 200 -> 800 gains nothing
     bool small = false;
-    if (!strided && small_wg > 0) {
+    if (!strided && small_wg > 0 && !force_spec) {
         const int64_t lat = (int64_t)Lmax[0] * Lmax[1] * Lmax[2];
         const int64_t wgs = ceil_div64(lat, CFG_PTS[P->cfg]) * (a.Cy / CFG_ROWS[P->cfg]) * a.N * a.ncls;
         if (wgs < small_wg) { small = true; P->cfg = r64 ? 9 : 10; }
@@ -1175,7 +1198,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     // pads the volume noticeably more than the tile choose_tile() found
     // NNDET_IGEMM_SPEC: 0 = never, 1 (default) = by the padding rule, 2 = always (tests); read per call so tests can flip it
     const char* spec_env = getenv("NNDET_IGEMM_SPEC");
-    const int spec_on = spec_env ? atoi(spec_env) : 1;
+    const int spec_on = force_spec ? 2 : (spec_env ? atoi(spec_env) : 1);
     if (spec_on && !small && !strided && !tr && a.ncls == 1 && ntaps == 27 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 &&
         c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1) {
         // 64-row layers: (8,8,8) tiles with NT = 16 (2 workgroups per CU, ~1.6x the main-loop rate) or (4,8,8) tiles with NT = 8
@@ -1210,6 +1233,8 @@ static int build_plan(const NndetConv* c, int kind, Plan* P) {
     return 0;
 }
 
+static const IgItems g_no_items = {};
+
 template <typename T, bool AFF>
 static int launch_cfg(const Plan& P, hipStream_t st) {
     switch (P.cfg) {
@@ -1220,9 +1245,9 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
         case 8: k_igemm<T, 2, 2, 2, 16, 3, true, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 9: k_igemm<T, 4, 1, 4, 16, 3, true, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
         case 10: k_igemm<T, 2, 1, 2, 16, 4, true, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 5: k_ig3<T, 1, 2, 8, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 6: k_ig3<T, 2, 2, 8, 3, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
-        case 7: k_ig3<T, 2, 2, 16, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
+        case 5: k_ig3<T, 1, 2, 8, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
+        case 6: k_ig3<T, 2, 2, 8, 3, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
+        case 7: k_ig3<T, 2, 2, 16, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
         default: k_igemm<T, 1, 2, 4, 16, 4, false, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
     }
     LAUNCH_CHECK();
@@ -1242,6 +1267,8 @@ static int set_lds_attr3() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, WR, MT, NT, MINW, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, WR, MT, NT, MINW, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, WR, MT, NT, MINW, false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     return rc;
 }
@@ -1327,6 +1354,67 @@ int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const 
     if (!P.a.ss && !res && ig3r_applicable(c, P)) return ig3r_launch(P, st);
     if (P.a.ss) return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t, true>(P, st) : launch_cfg<float, true>(P, st);
     return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t, false>(P, st) : launch_cfg<float, false>(P, st);
+}
+
+// ------------------------------------------------------------------------------------------------ ragged batches (NndetItems)
+// 3x3x3 / stride 1 / pad 1 forward or data gradient over items of different spatial size in ONE k_ig3 launch: grid.z = item,
+// grid.x = tiles of the largest item (the others exit early), same compile-time tile, same tap / accumulation order as the per-level
+// launches, so every output element is bit-identical to the one the uniform entry point produces for that level.
+template <typename T>
+static int launch_items(const Plan& P, const IgItems& it, hipStream_t st) {
+    switch (P.cfg) {
+        case 5: k_ig3<T, 1, 2, 8, 2, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
+        case 6: k_ig3<T, 2, 2, 8, 3, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
+        case 7: k_ig3<T, 2, 2, 16, 2, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
+        default: return NNDET_EINVAL;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int items_check(const NndetConv* c, const NndetItems* it) {
+    if (!c || !it || it->n_items < 1 || it->n_items > NNDET_MAX_ITEMS) return NNDET_EINVAL;
+    if (c->transposed || c->in_affine || c->cin_p % 32 || c->cout_p % 32) return NNDET_EINVAL;
+    for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 1 || c->p[i] != 1) return NNDET_EINVAL;
+    const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
+    const int cmax = c->cin_p > c->cout_p ? c->cin_p : c->cout_p;
+    for (int i = 0; i < it->n_items; ++i) {
+        const int32_t* d = it->dims[i];
+        if (d[0] <= 0 || d[1] <= 0 || d[2] <= 0 || it->row_off[i] < 0) return NNDET_EINVAL;
+        if ((int64_t)d[0] * d[1] * d[2] * cmax * esz >= (1LL << 31)) return NNDET_EINVAL;      // 32-bit buffer offsets per item
+    }
+    return 0;
+}
+
+int igemm_items_run(const NndetConv* c, const NndetItems* it, int kind, const void* x, const void* w, const float* bias, void* y,
+                    double* stats, hipStream_t st) {
+    int rc = items_check(c, it);
+    if (rc) return rc;
+    NndetConv cc = *c;                          // the plan of the bounding volume: channels, taps, tile kind, grid.x
+    cc.batch = it->n_items;
+    int mx[3] = {0, 0, 0};
+    for (int i = 0; i < it->n_items; ++i) for (int a = 0; a < 3; ++a) if (it->dims[i][a] > mx[a]) mx[a] = it->dims[i][a];
+    cc.in_d = cc.out_d = mx[0]; cc.in_h = cc.out_h = mx[1]; cc.in_w = cc.out_w = mx[2];
+    Plan P;
+    rc = build_plan(&cc, kind, &P, true);
+    if (rc) return rc;
+    if (P.cfg < 5 || P.cfg > 7) return NNDET_EINVAL;
+    rc = ensure_attrs();
+    if (rc) return rc;
+    P.a.x = x; P.a.w = w; P.a.bias = bias; P.a.y = y; P.a.stats = stats; P.a.res = nullptr; P.a.ss = nullptr; P.a.ss_relu = 0;
+    IgItems ig;
+    memset(&ig, 0, sizeof(ig));
+    ig.n = it->n_items;
+    const int TD = P.a.T[0];
+    int max_tiles = 0;
+    for (int i = 0; i < it->n_items; ++i) {
+        for (int a = 0; a < 3; ++a) ig.dims[i][a] = it->dims[i][a];
+        ig.row_off[i] = it->row_off[i];
+        const int t = ceil_div(it->dims[i][0], TD) * ceil_div(it->dims[i][1], 8) * ceil_div(it->dims[i][2], 8);
+        if (t > max_tiles) max_tiles = t;
+    }
+    P.grid.x = max_tiles;                       // (the bounding volume of items with different aspect ratios could ask for more)
+    return c->dtype == NNDET_BF16 ? launch_items<bf16_t>(P, ig, st) : launch_items<float>(P, ig, st);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing

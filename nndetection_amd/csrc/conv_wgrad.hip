@@ -45,6 +45,15 @@ struct WgArgs {
     WgTap taps[27];
 };
 
+// Ragged batch (NndetItems) for k_wgrad3<..., ITEMS = true>: the persistent tile walk runs over the tiles of ALL items
+// (tile_begin = running tile count), so the weight gradient of parameters shared by the items is summed inside the kernel
+struct WgItems {
+    int32_t n, pad_;
+    int32_t dims[NNDET_MAX_ITEMS][3];
+    int32_t tile_begin[NNDET_MAX_ITEMS];
+    int64_t row_off[NNDET_MAX_ITEMS];
+};
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -308,8 +317,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 //     LDS round trip was exposed, 25 % MFMA utilisation);
 //   * 256 registers per wave -> two workgroups per CU.
 // Work split as in k_wgrad: the 4 waves take taps wv, wv + 4, ... (7 slots, 27 of 28 used), all 8 contraction steps.
-template <typename T, int MINW, bool AFF = false, int QDEPTH = 2>
-__global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
+template <typename T, int MINW, bool AFF = false, int QDEPTH = 2, bool ITEMS = false>
+__global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgItems IT) {
     constexpr int RB = 32 * (int)sizeof(T), PPV = RB / 16;
     constexpr int KS = 8, NTS = 7, TD = 4, TH = 8, HD = TD + 2, HH = TH + 2, HW = 10;
     constexpr int PROW = 8 * RB + RB / 2, QROW = HW * RB + RB / 2;     // bytes per row of 8 points / per halo row (with bank padding)
@@ -376,38 +385,54 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
     int n_staged = 0;
 
     auto issue = [&](int tile) {
-        const int n = tile / tiles_per_n;
+        int n, tt, nt1 = A.nt[1], nt2 = A.nt[2];
+        int PL0 = A.PL[0], PL1 = A.PL[1], PL2 = A.PL[2], QD0 = A.QD[0], QD1 = A.QD[1], QD2 = A.QD[2];
+        int pi_bytes = p_img, qi_bytes = q_img, prb = p_rowb, psl = p_slab, qrb = q_rowb;
+        int64_t p_base, q_base;
+        if constexpr (ITEMS) {                      // `tile` is workgroup-uniform: a scalar walk over <= 32 running tile counts
+            n = 0;
+            while (n + 1 < IT.n && tile >= IT.tile_begin[n + 1]) ++n;
+            tt = tile - IT.tile_begin[n];
+            PL0 = QD0 = IT.dims[n][0]; PL1 = QD1 = IT.dims[n][1]; PL2 = QD2 = IT.dims[n][2];
+            nt1 = (PL1 + TH - 1) / TH; nt2 = (PL2 + 7) / 8;
+            prb = PL2 * A.Cp * (int)sizeof(T); psl = PL1 * prb; qrb = QD2 * A.Cq * (int)sizeof(T);
+            pi_bytes = PL0 * psl; qi_bytes = QD0 * QD1 * qrb;
+            p_base = IT.row_off[n] * A.Cp * (int64_t)sizeof(T); q_base = IT.row_off[n] * A.Cq * (int64_t)sizeof(T);
+        } else {
+            n = tile / tiles_per_n;
+            tt = tile - n * tiles_per_n;
+            p_base = (int64_t)n * p_img; q_base = (int64_t)n * q_img;
+        }
         n_staged = n; okq = 0;
-        int tt = tile - n * tiles_per_n;
-        const int tw_i = tt % A.nt[2]; tt /= A.nt[2];
-        const int th_i = tt % A.nt[1];
-        const int td_i = tt / A.nt[1];
+        const int tw_i = tt % nt2; tt /= nt2;
+        const int th_i = tt % nt1;
+        const int td_i = tt / nt1;
         const int l0d = td_i * TD, l0h = th_i * TH, l0w = tw_i * 8;
         const auto prs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(A.p)) + (int64_t)n * p_img + r0 * (int)sizeof(T), 0, p_img - r0 * (int)sizeof(T), 0x00020000);
+            const_cast<char*>(reinterpret_cast<const char*>(A.p)) + p_base + r0 * (int)sizeof(T), 0, pi_bytes - r0 * (int)sizeof(T), 0x00020000);
         const auto qrs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(A.q)) + (int64_t)n * q_img + k0 * (int)sizeof(T), 0, q_img - k0 * (int)sizeof(T), 0x00020000);
-        const int p_org = ((l0d * A.PL[1] + l0h) * A.PL[2] + l0w) * A.Cp * (int)sizeof(T);
+            const_cast<char*>(reinterpret_cast<const char*>(A.q)) + q_base + k0 * (int)sizeof(T), 0, qi_bytes - k0 * (int)sizeof(T), 0x00020000);
+        const int p_org = ((l0d * PL1 + l0h) * PL2 + l0w) * A.Cp * (int)sizeof(T);
 #pragma unroll
         for (int s2 = 0; s2 < PSTEPS; ++s2) {
             const int tr = p_tr0 + s2 * TRSTEP;
             const int pd = tr >> 3, ph = tr & 7;
             const int ld = l0d + pd, lh = l0h + ph, lw = l0w + p_pw;
-            const bool ok = ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2];
-            vp[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, ok ? pd * p_slab + ph * p_rowb + p_col : (int)0x80000000, p_org, 0));
+            const bool ok = ld < PL0 && lh < PL1 && lw < PL2;
+            vp[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, ok ? pd * psl + ph * prb + p_col : (int)0x80000000, p_org, 0));
         }
         const int q0d = l0d - 1, q0h = l0h - 1, qw = l0w - 1 + q_hw;
-        const bool okw = q_active && (unsigned)qw < (unsigned)A.QD[2];
+        const bool okw = q_active && (unsigned)qw < (unsigned)QD2;
         const int q_org = (l0w - 1) * A.Cq * (int)sizeof(T);
 #pragma unroll
         for (int s2 = 0; s2 < QSTEPS; ++s2) {
             const int r = q_r0 + s2 * QRPS;
             const int hd = r / HH, hh = r - hd * HH;
             const int qd = q0d + hd, qh = q0h + hh;
-            const bool ok = okw && (unsigned)qd < (unsigned)A.QD[0] && (unsigned)qh < (unsigned)A.QD[1] && (s2 + 1 < QSTEPS || r < QNROW);
+            const bool ok = okw && (unsigned)qd < (unsigned)QD0 && (unsigned)qh < (unsigned)QD1 && (s2 + 1 < QSTEPS || r < QNROW);
             if constexpr (AFF) okq |= (uint32_t)ok << s2;
             vq[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                qrs, ok ? (qd * A.QD[1] + qh) * q_rowb + q_colb + q_org : (int)0x80000000, 0, 0));
+                qrs, ok ? (qd * QD1 + qh) * qrb + q_colb + q_org : (int)0x80000000, 0, 0));
         }
     };
     auto commit = [&]() {
@@ -501,6 +526,8 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A) {
         }
     }
 }
+
+static const WgItems g_wg_no_items = {};
 
 // dW[r][k][tap] += sum_s part[s][pair][tap][r%32][k%32]; one thread per (pair, tap, r, k); consecutive threads = consecutive k.
 // With !SPLIT (1-3 taps) every wave holds a partial of every tap: those are summed here too (nsub = 4 sub-slices).
@@ -681,9 +708,9 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
                 // QDEPTH 1: 248 registers, no spill. With depth 2 the kernel needs > 256 registers at two workgroups per CU and the
                 // spill reloads (scratch shares vmcnt) serialise the staging loads of every tile (profiles/round2_wgrad3_spill.txt)
                 static const int qd = getenv("NNDET_WGRAD3_QD") ? atoi(getenv("NNDET_WGRAD3_QD")) : 1;
-                if (b.qss) k_wgrad3<bf16_t, 2, true, 1><<<g3, 256, lds3, st>>>(b);
-                else if (qd == 2) k_wgrad3<bf16_t, 2, false, 2><<<g3, 256, lds3, st>>>(b);
-                else k_wgrad3<bf16_t, 2, false, 1><<<g3, 256, lds3, st>>>(b);
+                if (b.qss) k_wgrad3<bf16_t, 2, true, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+                else if (qd == 2) k_wgrad3<bf16_t, 2, false, 2><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+                else k_wgrad3<bf16_t, 2, false, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
             } else {
                 static bool at = false;
                 if (!at) {
@@ -691,8 +718,8 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
                     at = true;
                 }
-                if (b.qss) k_wgrad3<float, 1, true><<<g3, 256, lds3, st>>>(b);
-                else k_wgrad3<float, 1, false><<<g3, 256, lds3, st>>>(b);
+                if (b.qss) k_wgrad3<float, 1, true><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+                else k_wgrad3<float, 1, false><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
             }
             LAUNCH_CHECK();
             const int64_t total3 = (int64_t)rb * kb * 27 * 1024;
@@ -706,6 +733,68 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
     if (rc) return rc;
     const int64_t total = (int64_t)rb * kb * a.ntap * 1024;
     k_wgrad_reduce<<<dim3((unsigned)ceil_div64(total, 256), ceil_div(slices, 32)), 256, 0, st>>>(a.part, slices, rb * kb, kb, a.ntap, a.R, a.K, a.sr, a.sk, dw, total);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ ragged batches (NndetItems)
+// Weight (+ bias) gradient of a 3x3x3 / stride 1 / pad 1 convolution over items of different spatial size in ONE k_wgrad3 launch:
+// the persistent workgroups walk the tiles of all items, so dW comes out summed over the items (the pyramid levels that share the
+// detection-head parameters) and goes through the same two-stage reduction as the uniform entry point.
+int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, const void* dy, float* dw, float* dbias, void* ws,
+                    size_t ws_bytes, hipStream_t st) {
+    int rc = items_check(c, it);
+    if (rc) return rc;
+    const bool bf = c->dtype == NNDET_BF16;
+    const int esz = bf ? 2 : 4;
+    const int RB = 32 * esz;
+    WgArgs b;
+    memset(&b, 0, sizeof(b));
+    b.N = it->n_items; b.dw = dw;
+    b.p = dy; b.q = x; b.Cp = c->cout_p; b.Cq = c->cin_p; b.R = c->cout; b.K = c->cin;
+    b.sr = (int64_t)c->cin * 27; b.sk = 27;
+    b.ntap = 27;
+    int nt = 0;
+    for (int td = 0; td < 3; ++td) for (int th = 0; th < 3; ++th) for (int tw = 0; tw < 3; ++tw) {
+        WgTap& t = b.taps[nt++];
+        t.d[0] = td; t.d[1] = th; t.d[2] = tw; t.wt = (td * 3 + th) * 3 + tw;
+    }
+    b.TD = 4; b.TH = 8; b.lTH = 3;
+    for (int i = 0; i < 3; ++i) { b.step[i] = 1; b.qbase[i] = -1; }
+    b.H[0] = 6; b.H[1] = 10; b.H[2] = 10;
+    b.dbias = dbias;
+    WgItems wi;
+    memset(&wi, 0, sizeof(wi));
+    wi.n = it->n_items;
+    int total = 0;
+    for (int i = 0; i < it->n_items; ++i) {
+        for (int a = 0; a < 3; ++a) wi.dims[i][a] = it->dims[i][a];
+        wi.row_off[i] = it->row_off[i];
+        wi.tile_begin[i] = total;
+        total += ceil_div(it->dims[i][0], 4) * ceil_div(it->dims[i][1], 8) * ceil_div(it->dims[i][2], 8);
+    }
+    b.total_tiles = total;
+    // (PL / QD / nt of the uniform kernel are unused in ITEMS mode; keep them at the first item's values for the dead code)
+    for (int i = 0; i < 3; ++i) { b.PL[i] = b.QD[i] = it->dims[0][i]; }
+    b.nt[0] = ceil_div(b.PL[0], 4); b.nt[1] = ceil_div(b.PL[1], 8); b.nt[2] = ceil_div(b.PL[2], 8);
+    const int rb = b.Cp / 32, kb = b.Cq / 32;
+    const int S3 = wgrad_slices(rb * kb, b.total_tiles);
+    const size_t need3 = (size_t)S3 * rb * kb * 27 * 1024 * sizeof(float);
+    if (!ws || ws_bytes < need3) return NNDET_EWORKSPACE;
+    b.part = reinterpret_cast<float*>(ws);
+    const size_t lds3 = (size_t)32 * (8 * RB + RB / 2) + (size_t)60 * (10 * RB + RB / 2);
+    dim3 g3(S3, rb, kb);
+    static bool at = false;
+    if (!at) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        at = true;
+    }
+    if (bf) k_wgrad3<bf16_t, 2, false, 1, true><<<g3, 256, lds3, st>>>(b, wi);
+    else k_wgrad3<float, 1, false, 2, true><<<g3, 256, lds3, st>>>(b, wi);
+    LAUNCH_CHECK();
+    const int64_t total3 = (int64_t)rb * kb * 27 * 1024;
+    k_wgrad_reduce<<<dim3((unsigned)ceil_div64(total3, 256), ceil_div(S3, 32)), 256, 0, st>>>(b.part, S3, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, total3);
     LAUNCH_CHECK();
     return 0;
 }

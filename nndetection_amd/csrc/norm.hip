@@ -35,6 +35,14 @@ template <> struct Vec16<bf16_t> {
     }
 };
 
+// Ragged batch (NndetItems): per-item voxel count and first row; n == 0 = uniform batch (image n = rows [n * spatial, (n + 1) * spatial))
+struct NormItems {
+    int32_t n, pad_;
+    int32_t spatial[NNDET_MAX_ITEMS];
+    int64_t row_off[NNDET_MAX_ITEMS];
+};
+static const NormItems g_norm_uniform = {};
+
 #define ROWS_PER_BLOCK 512    // max rows (voxels) handled by one workgroup in the element-wise (apply) kernels
 // rows per workgroup of the element-wise kernels: 512 for the big layers; the pyramid levels P3-P5 (150 ... 4800 rows per image) got
 // 1-10 workgroups per image of 32 dependent load -> store iterations each (24-33 us for 0.6-5 MB): aim at >= ~1024 workgroups
@@ -114,11 +122,12 @@ extern "C" int nndet_norm_stats(int32_t dtype, const void* x, int32_t batch, int
 // ------------------------------------------------------------------ finalize: replicas -> per-channel (mean, rstd) of its group
 // grid N, block 256 (loops channels)
 __global__ void k_norm_finalize(const double* __restrict__ stats, int N, int c, int c_p, int groups, int64_t spatial,
-                                float eps, float* __restrict__ mean_rstd, const float* __restrict__ gamma = nullptr,
-                                const float* __restrict__ beta = nullptr, float* __restrict__ scale_shift = nullptr) {
+                                float eps, float* __restrict__ mean_rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                float* __restrict__ scale_shift, const NormItems IT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* ch = reinterpret_cast<double*>(smem);   // [c_p][2]
     const int n = blockIdx.x;
+    if (IT.n) spatial = IT.spatial[n];
     for (int i = threadIdx.x; i < c_p * 2; i += blockDim.x) {
         double v = 0.0;
         for (int r = 0; r < NNDET_STATS_REPLICAS; ++r) v += stats[(((int64_t)r * N + n) * c_p) * 2 + i];
@@ -156,7 +165,7 @@ extern "C" int nndet_norm_finalize(const double* stats, const float* gamma, cons
     if (!stats || !gamma || !beta || !mean_rstd_out || !scale_shift_out) return NNDET_EINVAL;
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
     k_norm_finalize<<<batch, 256, (size_t)c_p * 16, as_stream(stream)>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out,
-                                                                        gamma, beta, scale_shift_out);
+                                                                        gamma, beta, scale_shift_out, g_norm_uniform);
     LAUNCH_CHECK();
     return 0;
 }
@@ -165,12 +174,17 @@ extern "C" int nndet_norm_finalize(const double* stats, const float* gamma, cons
 template <typename T>
 __global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, const float* __restrict__ mean_rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    int64_t spatial, int c, int c_p, int relu, T* __restrict__ y, int RPB) {
+                                                    int64_t spatial, int c, int c_p, int relu, T* __restrict__ y, int RPB,
+                                                    const NormItems IT) {
     constexpr int E = Vec16<T>::E;
     const int ppr = c_p / E, rpi = 256 / ppr;
     const int n = blockIdx.y;
     const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
     if (rr >= rpi) return;
+    int64_t row0 = (int64_t)n * spatial;
+    if (IT.n) { spatial = IT.spatial[n]; row0 = IT.row_off[n]; }
+    const int64_t r0 = (int64_t)blockIdx.x * RPB;
+    if (r0 >= spatial) return;                        // ragged batch: the grid covers the largest item
     float sc[E], sh[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -183,9 +197,8 @@ __global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, con
         }
         sc[e] = a; sh[e] = b;
     }
-    const int64_t r0 = (int64_t)blockIdx.x * RPB;
     const int64_t r1 = min(r0 + RPB, spatial);
-    const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
+    const int64_t base = row0 * c_p + cp * E;
     for (int64_t r = r0 + rr; r < r1; r += rpi)      // AffinePiece: the SAME code the convolutions run when they apply the norm on load
         *reinterpret_cast<u32x4*>(y + base + r * c_p) = AffinePiece<T>::apply(*reinterpret_cast<const u32x4*>(x + base + r * c_p), sc, sh, relu);
 }
@@ -196,14 +209,54 @@ extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stat
     if (!x || !stats || !gamma || !beta || !y || !mean_rstd_out) return NNDET_EINVAL;
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
-    k_norm_finalize<<<batch, 256, (size_t)c_p * 16, st>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out);
+    k_norm_finalize<<<batch, 256, (size_t)c_p * 16, st>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out, nullptr, nullptr,
+                                                          nullptr, g_norm_uniform);
     LAUNCH_CHECK();
     const int rpb = apply_rows(spatial * batch, c_p, dtype == NNDET_BF16 ? 2 : 4);
     dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
     if (dtype == NNDET_BF16)
-        k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (bf16_t*)y, rpb);
+        k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (bf16_t*)y, rpb, g_norm_uniform);
     else
-        k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (float*)y, rpb);
+        k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (float*)y, rpb, g_norm_uniform);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// per-item voxel counts / first rows of a ragged batch + the totals the launch geometry needs
+static int norm_items(const NndetItems* it, NormItems* ni, int64_t* total_rows, int64_t* max_spatial) {
+    if (!it || it->n_items < 1 || it->n_items > NNDET_MAX_ITEMS) return NNDET_EINVAL;
+    memset(ni, 0, sizeof(*ni));
+    ni->n = it->n_items;
+    *total_rows = 0; *max_spatial = 0;
+    for (int i = 0; i < it->n_items; ++i) {
+        const int64_t sp = (int64_t)it->dims[i][0] * it->dims[i][1] * it->dims[i][2];
+        if (it->dims[i][0] <= 0 || it->dims[i][1] <= 0 || it->dims[i][2] <= 0 || sp >= (1LL << 31) || it->row_off[i] < 0) return NNDET_EINVAL;
+        ni->spatial[i] = (int32_t)sp;
+        ni->row_off[i] = it->row_off[i];
+        *total_rows += sp;
+        if (sp > *max_spatial) *max_spatial = sp;
+    }
+    return 0;
+}
+
+extern "C" int nndet_norm_apply_items(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
+                                      const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, float eps, int32_t relu,
+                                      void* y, float* mean_rstd_out, void* stream) {
+    if (!x || !stats || !gamma || !beta || !y || !mean_rstd_out) return NNDET_EINVAL;
+    if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
+    NormItems ni;
+    int64_t total = 0, mx = 0;
+    const int rc = norm_items(items, &ni, &total, &mx);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    k_norm_finalize<<<ni.n, 256, (size_t)c_p * 16, st>>>(stats, ni.n, c, c_p, groups, 0, eps, mean_rstd_out, nullptr, nullptr, nullptr, ni);
+    LAUNCH_CHECK();
+    const int rpb = apply_rows(total, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    dim3 grid((unsigned)ceil_div64(mx, rpb), ni.n);
+    if (dtype == NNDET_BF16)
+        k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (bf16_t*)y, rpb, ni);
+    else
+        k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (float*)y, rpb, ni);
     LAUNCH_CHECK();
     return 0;
 }
@@ -247,12 +300,19 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
                                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int64_t spatial, int c, int c_p,
                                                          int N, int relu, double* __restrict__ red_ws, int RED_ROWS, int groups,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, const NormItems IT) {
     constexpr int E = Vec16<T>::E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem);
     const int ppr = c_p / E, rpi = 256 / ppr;
     const int n = blockIdx.y;
+    int64_t row0 = (int64_t)n * spatial;
+    unsigned int nblk = gridDim.x;                    // workgroups that work on (and draw a ticket for) image / item n
+    if (IT.n) {
+        spatial = IT.spatial[n]; row0 = IT.row_off[n];
+        nblk = (unsigned int)((spatial + RED_ROWS - 1) / RED_ROWS);
+        if (blockIdx.x >= nblk) return;               // ragged batch: the grid covers the largest item
+    }
     for (int i = threadIdx.x; i < c_p * 2; i += 256) red[i] = 0.0;
     __syncthreads();
     const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
@@ -270,7 +330,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
         }
         const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
         const int64_t r1 = min(r0 + RED_ROWS, spatial);
-        const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
+        const int64_t base = row0 * c_p + cp * E;
         for (int64_t r = r0 + rr; r < r1; r += rpi) {
             float xv[E], gv[E];
             Vec16<T>::ld(x + base + r * c_p, xv);
@@ -303,7 +363,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned int* ticket = reinterpret_cast<unsigned int*>(red_ws + (int64_t)NNDET_STATS_REPLICAS * N * c_p * 2);
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ticket[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ticket[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
     __syncthreads();
     if (!s_last) return;
     __threadfence();
@@ -345,12 +405,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy,
                                                         const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const double* __restrict__ red_ws,
-                                                        int64_t spatial, int c, int c_p, int relu, T* __restrict__ dx, int RPB) {
+                                                        int64_t spatial, int c, int c_p, int relu, T* __restrict__ dx, int RPB,
+                                                        const NormItems IT) {
     constexpr int E = Vec16<T>::E;
     const int ppr = c_p / E, rpi = 256 / ppr;
     const int n = blockIdx.y;
     const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
     if (rr >= rpi) return;
+    int64_t row0 = (int64_t)n * spatial;
+    if (IT.n) { spatial = IT.spatial[n]; row0 = IT.row_off[n]; }
+    const int64_t r0 = (int64_t)blockIdx.x * RPB;
+    if (r0 >= spatial) return;                        // ragged batch: the grid covers the largest item
     const float* coef = reinterpret_cast<const float*>(red_ws + ((int64_t)n * c_p) * 2);
     float mu[E], rs[E], ga[E], sc[E], sh[E], k1[E], k2[E];
 #pragma unroll
@@ -365,9 +430,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const T* __restrict__ x,
         k1[e] = ok ? coef[ci * 2] : 0.f;
         k2[e] = ok ? coef[ci * 2 + 1] : 0.f;
     }
-    const int64_t r0 = (int64_t)blockIdx.x * RPB;
     const int64_t r1 = min(r0 + RPB, spatial);
-    const int64_t base = ((int64_t)n * spatial) * c_p + cp * E;
+    const int64_t base = row0 * c_p + cp * E;
     for (int64_t r = r0 + rr; r < r1; r += rpi) {
         float xv[E], gv[E];
         Vec16<T>::ld(x + base + r * c_p, xv);
@@ -395,14 +459,42 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     dim3 rgrid((unsigned)ceil_div64(spatial, rr), batch);
     const size_t lds = (size_t)c_p * 16;
     if (dtype == NNDET_BF16)
-        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta);
+        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
     else
-        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta);
+        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
-        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx, rpb);
+        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx, rpb, g_norm_uniform);
     else
-        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (float*)dx, rpb);
+        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (float*)dx, rpb, g_norm_uniform);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nndet_norm_backward_items(int32_t dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma,
+                                         const float* beta, const NndetItems* items, int32_t c, int32_t c_p, int32_t groups,
+                                         int32_t relu, void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream) {
+    if (!x || !dy || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red_ws) return NNDET_EINVAL;
+    if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
+    NormItems ni;
+    int64_t total = 0, mx = 0;
+    const int rc = norm_items(items, &ni, &total, &mx);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    const int rpb = apply_rows(total, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    dim3 grid((unsigned)ceil_div64(mx, rpb), ni.n);
+    const int rr = red_rows(total);
+    dim3 rgrid((unsigned)ceil_div64(mx, rr), ni.n);
+    const size_t lds = (size_t)c_p * 16;
+    if (dtype == NNDET_BF16)
+        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
+    else
+        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
+    LAUNCH_CHECK();
+    if (dtype == NNDET_BF16)
+        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (bf16_t*)dx, rpb, ni);
+    else
+        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (float*)dx, rpb, ni);
     LAUNCH_CHECK();
     return 0;
 }

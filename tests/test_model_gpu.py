@@ -179,7 +179,8 @@ def test_head_gather_matches_per_level_flatten(golden_dir, dtype):
             sc.scale.fill_(1.0 + 0.25 * i)              # the golden weights leave every Scale at 1
     x = torch.from_numpy(gn["x"]).cuda().to(dtype)
     res = {}
-    old = DetectionHeadHNMNative.gather_levels
+    old, old_items = DetectionHeadHNMNative.gather_levels, DetectionHeadHNMNative.items_levels
+    DetectionHeadHNMNative.items_levels = False        # per-level convolutions on both sides: this test is about the gather alone
     try:
         for mode in (True, False):
             DetectionHeadHNMNative.gather_levels = mode
@@ -193,7 +194,7 @@ def test_head_gather_matches_per_level_flatten(golden_dir, dtype):
             res[mode] = (pred, {k: float(v.detach()) for k, v in losses.items()},
                          {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
     finally:
-        DetectionHeadHNMNative.gather_levels = old
+        DetectionHeadHNMNative.gather_levels, DetectionHeadHNMNative.items_levels = old, old_items
     (p1, l1, g1), (p0, l0, g0) = res[True], res[False]
     assert p1["box_logits"].dtype == torch.float32 and p1["box_logits"].shape == p0["box_logits"].shape
     assert torch.equal(p1["box_logits"], p0["box_logits"]) and torch.equal(p1["box_deltas"], p0["box_deltas"])
@@ -341,6 +342,8 @@ def test_deferred_norm_equals_materialised(golden_dir, monkeypatch, dtype):
     activation. Same arithmetic (fmaf, max, one rounding) on both routes -> identical losses; gradients identical up to the
     summation order of the atomically reduced ones."""
     import nndetection_amd.arch.conv as C
+    from nndetection_amd.arch.heads import DetectionHeadHNMNative
+    monkeypatch.setattr(DetectionHeadHNMNative, "items_levels", False)     # the ragged head path has no deferred variant: compare like with like
     gn, plan, tg = _load(golden_dir)
     x = torch.from_numpy(gn["x"]).cuda().to(dtype)
     res = {}

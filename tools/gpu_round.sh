@@ -23,6 +23,8 @@ for s in $STAGES; do
              tag=$(echo $pass | cut -d' ' -f1); (cd /tmp && timeout 300 rocprofv3 --pmc $pass -d $OLDPWD/gpurun_out/nmspmc/$tag -- python $OLDPWD/tools/nms_microbench.py 10000 3 > $OLDPWD/gpurun_out/nmspmc_$tag.txt 2>&1); done
            python tools/rocpd_pmc.py $(find gpurun_out/nmspmc -name "*_results.db") > gpurun_out/nmspmc_summary.txt 2>&1; grep -A12 "k_nms" gpurun_out/nmspmc_summary.txt | head -70; rm -rf gpurun_out/nmspmc;;
     parity) timeout 1500 python -m pytest tests/test_parity_full_gpu.py tests/test_postprocess_gpu.py tests/test_targets_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_parity.txt 2>&1; tail -40 gpurun_out/t_parity.txt;;
+    pyr)   timeout 900 python -m pytest tests/test_pyramid_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_pyr.txt 2>&1; tail -40 gpurun_out/t_pyr.txt;;
+    ab)    for v in 1 0 1 0; do NNDET_HEAD_ITEMS=$v timeout 600 python bench.py --steps 60 --warmup 15 --no-extras > gpurun_out/ab_items$v.txt 2>&1; echo "items=$v $(grep -o '"value": [0-9.]*' gpurun_out/ab_items$v.txt | head -1) $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_items$v.txt | head -1)" | tee -a gpurun_out/ab.txt; done;;
     suite) timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_suite.txt 2>&1; tail -8 gpurun_out/t_suite.txt;;
   esac
 done
