@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
     float ev[2][4];
     uint32_t epk[2][2];
     v4u_t est;
-    auto epi = [&](int j, int m, __amdgpu_buffer_rsrc_t yrs, int soff) {
+    auto epi_on = [&](float (&ev)[2][4], uint32_t (&epk)[2][2], v4u_t& est, int j, int m, __amdgpu_buffer_rsrc_t yrs, int soff) {
         if (m < 8) ev[m >> 2][m & 3] = acc[m >> 2][j][m & 3] + bia[m >> 2][m & 3];
         else if (m < 12) { const int i = (m - 8) >> 1, h = (m - 8) & 1; epk[i][h] = pack_bf16x2(ev[i][2 * h], ev[i][2 * h + 1]); }
         else if (m < 14) {
@@ -902,6 +902,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
         else if (m < 31) { const int i = (m - 23) >> 2, r = (m - 23) & 3; ssum[i][r] += ev[i][r]; }
         else { const int i = (m - 31) >> 2, r = (m - 31) & 3; ssq[i][r] = fmaf(ev[i][r], ev[i][r], ssq[i][r]); }
     };
+    auto epi = [&](int j, int m, __amdgpu_buffer_rsrc_t yrs, int soff) { epi_on(ev, epk, est, j, m, yrs, soff); };
 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     // activation fragments: read PD steps (of 8 MFMAs) ahead into a ring of PD + 1 register sets (54 steps per tile: 54 % (PD + 1) == 0)
@@ -1003,15 +1004,40 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
         if (!has_next) break;
         g = g_next;
     }
-    // plane 1 of the last tile
+    // plane 1 of the last tile. Its accumulators were written by the inline-asm MFMAs just above: the compiler does not know that
+    // these are MFMAs and inserts none of the wait states a VALU read of a matrix-core result needs (inside the loop every
+    // accumulator is read >= 8 MFMA slots after its last MFMA); without them the last tile of every workgroup came out with a few
+    // stale values at full size (tools/diag_ig3r.py). Wait out the matrix pipe before the first read.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // Second hazard, the one tools/diag_ig3r.py actually showed (lanes 12-15 of the second data dword of the LAST tile of every
+    // workgroup overwritten, at full size only): a 16-byte buffer store followed at once by a VALU write of its data registers.
+    // hipcc guards that write-after-read hazard only for stores WITHOUT an SGPR offset (GCNHazardRecognizer::createsVALUHazard);
+    // with one it assumes the hardware is safe, and under load it is not. Inside the loop an MFMA slot separates the store from the
+    // next micro-op; here every point tile gets its OWN registers, the four stores are issued back to back after all the arithmetic
+    // and nothing overwrites their data before the wave ends (tools/scan_store_hazard.py checks the emitted ISA for the pattern).
     {
         const auto yrs = y_rsrc(n_prev, true);
         const int ebase = tout_prev + (wv * 2 + 1) * slab;
+        float ev4[4][2][4];
+        uint32_t epk4[4][2][2];
+        v4u_t est4[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int m = 0; m < NM; ++m) epi(4 + f, m, yrs, ebase + 2 * f * rowb);
-        if (STATS) flush(stat_n);
+            for (int m = 0; m < 14; ++m) epi_on(ev4[f], epk4[f], est4[f], 4 + f, m, yrs, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) epi_on(ev4[f], epk4[f], est4[f], 4 + f, 14, yrs, ebase + 2 * f * rowb);
+        asm volatile("s_nop 3" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (STATS) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int m = 15; m < NM; ++m) epi_on(ev4[f], epk4[f], est4[f], 4 + f, m, yrs, 0);
+            flush(stat_n);
+        }
     }
 }
 

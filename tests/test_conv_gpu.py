@@ -309,3 +309,50 @@ def test_fused_seg_head_matches_unfused(dtype):
     for k, name in ((2, "dx"), (3, "dW"), (4, "dbias")):
         e = relerr(b[k], a[k])
         assert e <= (5e-5 if dtype == torch.float32 else 4e-2), f"{name} rel err {e:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------- full size (load-dependent hazards)
+FULL = [
+    # name, cin, cout, k, s, p, transposed, input spatial, env
+    ("e0_32x32_ig3r", 32, 32, 3, 1, 1, False, (160, 160, 96), {}),
+    ("e0_32x32_ig3", 32, 32, 3, 1, 1, False, (160, 160, 96), {"NNDET_IG3R": "0"}),
+    ("e0_32x32_ig3r_ragged", 32, 32, 3, 1, 1, False, (152, 160, 88), {}),          # 4180 tiles on 256 workgroups: 16 or 17 each
+    ("e1_32to64_s2", 32, 64, 3, 2, 1, False, (160, 160, 96), {}),
+    ("e1_64x64", 64, 64, 3, 1, 1, False, (80, 80, 48), {}),
+    ("lat_p0_1x1", 32, 32, 1, 1, 0, False, (160, 160, 96), {}),
+    ("up_p1_64to32", 64, 32, 2, 2, 0, True, (80, 80, 48), {}),
+]
+
+
+@pytest.mark.parametrize("name", [c[0] for c in FULL])
+def test_full_size_bf16_kernels_against_fp32_kernels(name, monkeypatch):
+    """The bf16 kernels at the benchmarked layer sizes (one 160x160x96 patch) against the exact-fp32 kernels on the same rounded
+    inputs and weights, forward and data gradient, every element: <= 1 bf16 ulp of the tensor maximum. Small-size parity cannot
+    see hazards that only bite when all 256 CUs saturate the memory pipe (round 2: the last tile of every k_ig3r workgroup had
+    4 points x 8 channels overwritten after a 16-byte store; tools/diag_ig3r.py)."""
+    from nndetection_amd.arch.conv import ConvInstanceRelu
+    _, cin, cout, k, s, p, tr, sp, env = {c[0]: c for c in FULL}[name]
+    for kk, vv in env.items():
+        monkeypatch.setenv(kk, vv)
+    torch.manual_seed(3)
+    m = ConvInstanceRelu(3, cin, cout, k, stride=s, padding=p, transposed=tr, add_norm=False, add_act=False).cuda()
+    with torch.no_grad():
+        m.conv.weight.copy_((torch.randn_like(m.conv.weight) / (m.conv.weight[0].numel() ** 0.5)).bfloat16().float())
+        m.conv.bias.copy_(torch.randn_like(m.conv.bias) * 0.3)
+    x16 = torch.randn(1, cin, *sp, device="cuda").bfloat16()
+    res = {}
+    for dt in (torch.bfloat16, torch.float32):
+        x = x16.detach().to(dt).clone().requires_grad_(True)
+        y = m(x)
+        if dt == torch.bfloat16:
+            gy16 = torch.randn(y.shape, device="cuda").bfloat16()
+        y.backward(gy16.to(dt))
+        torch.cuda.synchronize()
+        res[dt] = (y.detach().float(), x.grad.float())
+        m.zero_grad(set_to_none=True)
+    for (a, b), what in zip(zip(res[torch.bfloat16], res[torch.float32]), ("forward", "data gradient")):
+        assert torch.isfinite(a).all(), what
+        err = (a - b).abs()
+        tol = 2.0 ** -7 * float(b.abs().max())
+        nbad = int((err > tol).sum())
+        assert nbad == 0, f"{name} {what}: {nbad} elements off by more than {tol:.4f} (max {float(err.max()):.4f})"
