@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnndet_amd.so")
+# NNDET_AMD_LIB: another build of the same library (A/B measurements of two kernel versions in one gpurun call, tools/gpu_round.sh)
+LIB_PATH = os.environ.get("NNDET_AMD_LIB") or os.path.join(_HERE, "csrc", "libnndet_amd.so")
 
 F32, BF16 = 0, 1
 STATS_REPLICAS = 32

@@ -66,7 +66,10 @@ def main():
         flops = 2.0 * (B * sp[0] * sp[1] * sp[2] if tr else nvox_out) * taps * cin * cout
         byts = 2.0 * (x.numel() + y.numel())
         res = []
-        fns = {"fwd": f, "dgrad": g, "wgrad": h}
+        r = torch.randn_like(y)
+        fr = lambda: L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, L.ptr(r), L.ptr(y), None, st)     # + fused residual (decoder top-down add)
+        ga = lambda: L.call("nndet_conv3d_backward_data_acc", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx), None, st)            # dx += (fused gradient accumulation)
+        fns = {"fwd": f, "dgrad": g, "wgrad": h, "fwd_res": fr, "dgrad_acc": ga}
         for nm in order:
             ms = timeit(fns[nm], iters)
             res.append(f"{nm} {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF/s {byts / ms / 1e6:7.0f} GB/s")
