@@ -397,6 +397,29 @@ int nndet_head_gather_f32(int32_t dtype, const NndetHeadLevels* levels, int32_t 
 int nndet_head_gather_backward(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t cout, int32_t cout_p,
                                const float* grad_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused detection loss on the sampled anchors -- replaces the tail of DetectionHeadHNM.compute_loss (nndet/arch/heads/comb.py:
+ * 351-405): decode of the sampled positives (nndet/core/boxes/coder.py:90-155, unit weights, clamp at bbox_xform_clip) ->
+ * GIoULoss (nndet/losses/regression.py:118-162: -sum diag GIoU(pred, target, eps)) / max(1, num_pos), and
+ * BCEWithLogitsLossOneHot (nndet/losses/classification.py:137-181: one-hot without the background column) of positives +
+ * negatives -- forward and the per-row gradients in one single-workgroup launch instead of ~250 element-wise launches.
+ *   logits [M_tot, C], deltas [M_tot, 6] fp32 (all anchors of the batch); pos [pos_cap] / neg [neg_cap] int64 anchor indices padded
+ *   with -1 and counts = {num_pos, num_neg, ...} as nndet_hnm_sample_f32 writes them; labels [M_tot] (>= 1 foreground class + 1);
+ *   matched_gt [M_tot, 6]; anchors [m_anchors, 6] (anchor of index i = anchors[i % m_anchors]: the images share one anchor set).
+ *   reg = reg_weight * -1 * S / max(num_pos, 1) with S = sum GIoU (reg_mean: S / max(num_pos, 1));
+ *   cls = cls_weight * sum BCE (cls_mean: / (max(num_pos + num_neg, 1) * C)).
+ *   losses_out [2] = {reg, cls}; g_deltas_out [pos_cap, 6], g_logits_out [pos_cap + neg_cap, C]: d loss / d row (padding rows 0).
+ * nndet_detloss_scatter_f32: backward -- d_deltas [M_tot, 6] / d_logits [M_tot, C] (ZEROED by the caller) receive the sampled rows
+ * scaled by upstream = {d/d reg, d/d cls} (device).
+ * ---------------------------------------------------------------------------------------------- */
+int nndet_detloss_f32(const float* logits, const float* deltas, const int64_t* pos, int32_t pos_cap, const int64_t* neg,
+                      int32_t neg_cap, const int64_t* counts, const float* labels, const float* matched_gt, const float* anchors,
+                      int64_t m_anchors, int32_t C, float eps, float clip, float reg_weight, int32_t reg_mean, float cls_weight,
+                      int32_t cls_mean, float* losses_out, float* g_deltas_out, float* g_logits_out, void* stream);
+int nndet_detloss_scatter_f32(const int64_t* pos, int32_t pos_cap, const int64_t* neg, int32_t neg_cap, int32_t C,
+                              const float* g_deltas, const float* g_logits, const float* upstream, float* d_deltas, float* d_logits,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,40 @@ class _HeadGatherFn(torch.autograd.Function):
         return (None, None) + tuple(dsc[l].reshape(()) for l in range(ctx.n_scales)) + tuple(logical(d, ctx.cout) for d in dys)
 
 
+class _DetLossFn(torch.autograd.Function):
+    """(reg, cls) losses of the sampled anchors and their gradients in one launch each way (csrc/boxes.hip: k_detloss,
+    k_detloss_scatter; include/nndet_amd.h: nndet_detloss_f32). Arithmetic = _compute_loss_sync_free below (decode_single,
+    giou_diag, binary_cross_entropy_with_logits on the one-hot labels, masked sums, the reference's divisors)."""
+
+    @staticmethod
+    def forward(ctx, box_logits, box_deltas, pos, neg, counts, labels, matched_gt, anchors, cfg):
+        dev = box_logits.device
+        lg, dl = box_logits.detach().float().contiguous(), box_deltas.detach().float().contiguous()
+        C = lg.shape[1]
+        P, Q = pos.shape[0], neg.shape[0]
+        losses = torch.empty((2,), dtype=torch.float32, device=dev)
+        g_d = torch.empty((P, 6), dtype=torch.float32, device=dev)
+        g_l = torch.empty((P + Q, C), dtype=torch.float32, device=dev)
+        lab, gt, an = labels.detach().float().contiguous(), matched_gt.detach().float().contiguous(), anchors.detach().float().contiguous()
+        L.call("nndet_detloss_f32", L.ptr(lg), L.ptr(dl), L.ptr(pos), P, L.ptr(neg), Q, L.ptr(counts), L.ptr(lab), L.ptr(gt), L.ptr(an),
+               an.shape[0], C, float(cfg["eps"]), float(cfg["clip"]), float(cfg["reg_w"]), int(cfg["reg_mean"]), float(cfg["cls_w"]),
+               int(cfg["cls_mean"]), L.ptr(losses), L.ptr(g_d), L.ptr(g_l), L.stream())
+        ctx.save_for_backward(pos, neg, g_d, g_l)
+        ctx.shapes = (tuple(box_logits.shape), box_logits.dtype, tuple(box_deltas.shape), box_deltas.dtype)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, neg, g_d, g_l = ctx.saved_tensors
+        ls, lt, ds, dt = ctx.shapes
+        up = g.detach().float().contiguous()
+        d_logits = torch.zeros(ls, dtype=torch.float32, device=g.device)
+        d_deltas = torch.zeros(ds, dtype=torch.float32, device=g.device)
+        L.call("nndet_detloss_scatter_f32", L.ptr(pos), pos.shape[0], L.ptr(neg), neg.shape[0], g_l.shape[1], L.ptr(g_d), L.ptr(g_l),
+               L.ptr(up), L.ptr(d_deltas), L.ptr(d_logits), L.stream())
+        return d_logits.to(lt), d_deltas.to(dt), None, None, None, None, None, None, None
+
+
 class BCECLassifier(nn.Module):
     def __init__(self, conv, in_channels: int, internal_channels: int, num_classes: int, anchors_per_pos: int,
                  num_levels: int, num_convs: int = 3, add_norm: bool = True, prior_prob: Optional[float] = None,
@@ -304,6 +338,7 @@ class DetectionHeadHNMNative(nn.Module):
     # device sampler and masks the padding out of the two reductions instead (same sums, same divisors; summation order aside).
     # NNDET_SYNCFREE_LOSS=0, a patched / overridden select_indices, a foreign sampler or reduction=None select the compact path.
     sync_free = os.environ.get("NNDET_SYNCFREE_LOSS", "1") != "0"
+    fused_loss = os.environ.get("NNDET_FUSED_DETLOSS", "1") != "0"        # (sync-free path only) the loss tail as one kernel
     _unit_box: Dict[torch.device, Tensor] = {}
 
     def _use_sync_free(self) -> bool:
@@ -343,6 +378,20 @@ class DetectionHeadHNMNative(nn.Module):
         With no positive anchor the reference leaves "reg" out of the dict; here it is an exact 0 (the total is the same)."""
         labels = target_labels[0] if len(target_labels) == 1 else torch.cat(target_labels, dim=0)
         pos, neg, counts = self.fg_bg_sampler.sample_device(labels, box_logits, len(target_labels))
+        from ..core.boxes.coder import BoxCoderND
+        if (self.fused_loss and type(self.coder) is BoxCoderND and box_logits.dim() == 2 and box_deltas.dim() == 2
+                and box_deltas.shape[1] == 6 and pos.numel() > 0):
+            # one launch for both losses and their gradients instead of ~250 element-wise ones (csrc/boxes.hip: k_detloss)
+            same = all(a is anchors[0] for a in anchors)
+            an = anchors[0] if same else torch.cat(anchors, dim=0)
+            gt = matched_gt_boxes
+            if isinstance(gt, (list, tuple)):
+                gt = gt[0] if len(gt) == 1 else torch.cat(gt, dim=0)
+            cfg = {"eps": self.regressor.eps, "clip": getattr(self.coder, "bbox_xform_clip", math.log(1000. / 16)),
+                   "reg_w": self.regressor.loss_weight, "reg_mean": self.regressor.reduction == "mean",
+                   "cls_w": self.classifier.loss_weight, "cls_mean": self.classifier.reduction == "mean"}
+            both = _DetLossFn.apply(box_logits, box_deltas, pos, neg, counts, labels, gt, an, cfg)
+            return {"reg": both[0], "cls": both[1]}, pos, neg
         n_pos, n_neg = counts[0], counts[1]
         pos_ok, neg_ok = pos >= 0, neg >= 0
         pos_c, neg_c = pos.clamp(min=0), neg.clamp(min=0)

@@ -135,12 +135,7 @@ __global__ void k_giou_diag_fwd(const float* __restrict__ a, const float* __rest
 // max/min route the gradient to the selected operand -- on ties torch.max/min(a, b) split 0.5/0.5 --
 // and clamp(min=0) passes gradient where the argument is > 0... torch passes it for >= 0? No: clamp's
 // backward mask is (x >= min), so exactly-0 extents still receive gradient.
-__global__ void k_giou_diag_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ go,
-                                int64_t n, float eps, float* __restrict__ ga) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* A = a + i * 6;
-    const float* B = b + i * 6;
+__device__ __forceinline__ void giou_grad(const float* A, const float* B, float g, float eps, float* gout) {
     // axis k: lo index, hi index
     const int LO[3] = {0, 1, 4}, HI[3] = {2, 3, 5};
     float ext[3], iw[3], hw[3];           // box extent, clamped intersection extent, clamped hull extent
@@ -167,14 +162,14 @@ __global__ void k_giou_diag_bwd(const float* __restrict__ a, const float* __rest
     float un = va + vb - inter;
     float vol = hw[0] * hw[1] * hw[2] + eps;
     // giou = inter/un - (vol - un)/vol = inter/un - 1 + un/vol
-    float g = go[i];
     float d_inter = g * (1.f / un);
     float d_un = g * (-inter / (un * un) + 1.f / vol);
     float d_vol = g * (-un / (vol * vol));
     // un = va + vb - inter
     float d_va = d_un;
     d_inter -= d_un;
-    float gout[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gout[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
@@ -190,6 +185,14 @@ __global__ void k_giou_diag_bwd(const float* __restrict__ a, const float* __rest
         gout[HI[k]] += d_hw * hhi_w[k];
         gout[LO[k]] -= d_hw * hlo_w[k];
     }
+}
+
+__global__ void k_giou_diag_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ go,
+                                int64_t n, float eps, float* __restrict__ ga) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gout[6];
+    giou_grad(a + i * 6, b + i * 6, go[i], eps, gout);
 #pragma unroll
     for (int k = 0; k < 6; ++k) ga[i * 6 + k] = gout[k];
 }
@@ -286,6 +289,129 @@ extern "C" int nndet_sigmoid_max_f32(const float* logits, int64_t n, int32_t C, 
     if (n < 0 || C <= 0) return NNDET_EINVAL;
     if (n == 0) return 0;
     k_sigmoid_max<<<(unsigned)ceil_div64(n, 256), 256, 0, as_stream(stream)>>>(logits, n, C, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused detection loss on the sampled anchors
+// DetectionHeadHNM.compute_loss (nndet/arch/heads/comb.py:351-405) after the sampler: decode of the <= pos_cap positives
+// (coder.py:90-155, unit weights) -> -GIoU of (decoded, matched GT) (losses/regression.py:118-162) and BCE-with-logits of the
+// positives + negatives against the one-hot labels without the background column (losses/classification.py:137-181), forward AND
+// the per-row gradients in ONE single-workgroup launch. In torch this is ~250 element-wise launches of 1-170 elements (index,
+// decode, where, one_hot, bce, sum, ... and their autograd mirror images): 1.5-3 ms of pure launch latency on the critical path of
+// every training step between the forward and the backward pass (profiles/round2_v4_timeline_one_step.txt).
+// Index lists are the device sampler's: fixed capacity, padded with -1; counts = {num_pos, num_neg, ...} (int64, device).
+struct DetLossArgs {
+    const float* logits; const float* deltas; const int64_t* pos; const int64_t* neg; const int64_t* counts;
+    const float* labels; const float* gt; const float* anchors;
+    int64_t m_anchors;
+    int32_t P, Q, C, reg_mean, cls_mean;
+    float eps, clip, reg_w, cls_w;
+    float* losses; float* g_deltas; float* g_logits;
+};
+
+__global__ __launch_bounds__(256) void k_detloss(const DetLossArgs A) {
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    const float n_pos = (float)A.counts[0], n_neg = (float)A.counts[1];
+    const float n_pos_f = fmaxf(n_pos, 1.f);
+    // loss = reg_w * -1 * (sum giou [/ n_pos_f if mean]) / n_pos_f  +  cls_w * (sum bce [/ (max(n_pos + n_neg, 1) * C) if mean])
+    const float reg_coef = -A.reg_w / n_pos_f / (A.reg_mean ? n_pos_f : 1.f);
+    const float cls_coef = A.cls_w / (A.cls_mean ? fmaxf(n_pos + n_neg, 1.f) * (float)A.C : 1.f);
+    float reg_part = 0.f, cls_part = 0.f;
+    for (int r = tid; r < A.P; r += 256) {
+        const int64_t idx = A.pos[r];
+        float gd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (idx >= 0) {
+            const float* d = A.deltas + idx * 6;
+            const float* b = A.anchors + (idx % A.m_anchors) * 6;
+            // coder.py:107-151 with weights == 1 (the expression order of k_decode_clip)
+            const float w = b[2] - b[0], h = b[3] - b[1], dd_ = b[5] - b[4];
+            const float cx = b[0] + 0.5f * w, cy = b[1] + 0.5f * h, cz = b[4] + 0.5f * dd_;
+            const float dw = fminf(d[2], A.clip), dh = fminf(d[3], A.clip), dz = fminf(d[5], A.clip);
+            const float pcx = d[0] * w + cx, pcy = d[1] * h + cy, pcz = d[4] * dd_ + cz;
+            const float pw = expf(dw) * w, ph = expf(dh) * h, pd = expf(dz) * dd_;
+            const float p[6] = {pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph, pcz - 0.5f * pd, pcz + 0.5f * pd};
+            const float* t = A.gt + idx * 6;
+            const Box pb = ldbox(p), tb = ldbox(t);
+            reg_part += giou_val(pb, vol3(pb), tb, vol3(tb), A.eps);
+            float G[6];
+            giou_grad(p, t, reg_coef, A.eps, G);                       // d loss / d decoded box
+            // decode backward: clamp(max) passes the gradient where x <= max
+            gd[0] = (G[0] + G[2]) * w; gd[1] = (G[1] + G[3]) * h; gd[4] = (G[4] + G[5]) * dd_;
+            gd[2] = d[2] <= A.clip ? (G[2] - G[0]) * 0.5f * pw : 0.f;
+            gd[3] = d[3] <= A.clip ? (G[3] - G[1]) * 0.5f * ph : 0.f;
+            gd[5] = d[5] <= A.clip ? (G[5] - G[4]) * 0.5f * pd : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) A.g_deltas[r * 6 + k] = gd[k];
+    }
+    for (int r = tid; r < A.P + A.Q; r += 256) {
+        const int64_t idx = r < A.P ? A.pos[r] : A.neg[r - A.P];
+        const float lab = idx >= 0 ? A.labels[idx] : 0.f;
+        for (int c = 0; c < A.C; ++c) {
+            float g = 0.f;
+            if (idx >= 0) {
+                const float x = A.logits[idx * A.C + c];
+                const float y = ((int)lab == c + 1) ? 1.f : 0.f;
+                // binary_cross_entropy_with_logits: (1 - y) * x + max(-x, 0) + log(exp(-max(-x, 0)) + exp(-x - max(-x, 0)))
+                const float mv = fmaxf(-x, 0.f);
+                cls_part += (1.f - y) * x + mv + logf(expf(-mv) + expf(-x - mv));
+                g = (1.f / (1.f + expf(-x)) - y) * cls_coef;
+            }
+            A.g_logits[r * A.C + c] = g;
+        }
+    }
+    reg_part = wave_sum_f32(reg_part); cls_part = wave_sum_f32(cls_part);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = reg_part; red[1][tid >> 6] = cls_part; }
+    __syncthreads();
+    if (tid == 0) {
+        const float gs = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), bs = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        A.losses[0] = gs * reg_coef;
+        A.losses[1] = bs * cls_coef;
+    }
+}
+
+// d_deltas / d_logits (dense, zeroed by the caller): the sampled rows scaled by the upstream gradients of the two losses
+__global__ __launch_bounds__(256) void k_detloss_scatter(const int64_t* __restrict__ pos, int P, const int64_t* __restrict__ neg, int Q, int C,
+                                                         const float* __restrict__ g_deltas, const float* __restrict__ g_logits,
+                                                         const float* __restrict__ up, float* __restrict__ d_deltas,
+                                                         float* __restrict__ d_logits) {
+    const float u_reg = up[0], u_cls = up[1];
+    for (int r = threadIdx.x; r < P + Q; r += 256) {
+        const int64_t idx = r < P ? pos[r] : neg[r - P];
+        if (idx < 0) continue;
+        if (r < P) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d_deltas[idx * 6 + k] = u_reg * g_deltas[r * 6 + k];
+        }
+        for (int c = 0; c < C; ++c) d_logits[idx * C + c] = u_cls * g_logits[r * C + c];
+    }
+}
+
+extern "C" int nndet_detloss_f32(const float* logits, const float* deltas, const int64_t* pos, int32_t pos_cap, const int64_t* neg,
+                                 int32_t neg_cap, const int64_t* counts, const float* labels, const float* matched_gt,
+                                 const float* anchors, int64_t m_anchors, int32_t C, float eps, float clip, float reg_weight,
+                                 int32_t reg_mean, float cls_weight, int32_t cls_mean, float* losses_out, float* g_deltas_out,
+                                 float* g_logits_out, void* stream) {
+    if (!logits || !deltas || !pos || !neg || !counts || !labels || !matched_gt || !anchors || !losses_out || !g_deltas_out || !g_logits_out)
+        return NNDET_EINVAL;
+    if (pos_cap < 1 || neg_cap < 0 || C < 1 || m_anchors < 1) return NNDET_EINVAL;
+    DetLossArgs a;
+    a.logits = logits; a.deltas = deltas; a.pos = pos; a.neg = neg; a.counts = counts; a.labels = labels; a.gt = matched_gt;
+    a.anchors = anchors; a.m_anchors = m_anchors; a.P = pos_cap; a.Q = neg_cap; a.C = C; a.reg_mean = reg_mean; a.cls_mean = cls_mean;
+    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight;
+    a.losses = losses_out; a.g_deltas = g_deltas_out; a.g_logits = g_logits_out;
+    k_detloss<<<1, 256, 0, as_stream(stream)>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nndet_detloss_scatter_f32(const int64_t* pos, int32_t pos_cap, const int64_t* neg, int32_t neg_cap, int32_t C,
+                                         const float* g_deltas, const float* g_logits, const float* upstream, float* d_deltas,
+                                         float* d_logits, void* stream) {
+    if (!pos || !neg || !g_deltas || !g_logits || !upstream || !d_deltas || !d_logits || pos_cap < 1 || neg_cap < 0 || C < 1) return NNDET_EINVAL;
+    k_detloss_scatter<<<1, 256, 0, as_stream(stream)>>>(pos, pos_cap, neg, neg_cap, C, g_deltas, g_logits, upstream, d_deltas, d_logits);
     LAUNCH_CHECK();
     return 0;
 }

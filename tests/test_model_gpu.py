@@ -388,3 +388,86 @@ def test_materialize_of_deferred_activation(monkeypatch):
         outs[defer] = (y.detach().clone(), xi.grad.clone(), m.conv.weight.grad.clone(), m.norm.weight.grad.clone())
     for a, b in zip(outs[False], outs[True]):
         assert torch.equal(a, b)
+
+
+def _rand_loss_inputs(M, B, C, seed):
+    """logits / deltas / labels / matched boxes / anchors of B images with M anchors each + padded index lists"""
+    g = torch.Generator().manual_seed(seed)
+    anchors = torch.rand(M, 3, generator=g) * 40
+    size = torch.rand(M, 3, generator=g) * 20 + 2
+    an = torch.stack([anchors[:, 0], anchors[:, 1], anchors[:, 0] + size[:, 0], anchors[:, 1] + size[:, 1], anchors[:, 2],
+                      anchors[:, 2] + size[:, 2]], 1).cuda()
+    logits = (torch.randn(B * M, C, generator=g) * 2).cuda().requires_grad_(True)
+    deltas = (torch.randn(B * M, 6, generator=g) * 0.5)
+    deltas[3, 2] = 6.0; deltas[7, 5] = 4.2                                     # above bbox_xform_clip = log(1000 / 16) = 4.135
+    deltas = deltas.cuda().requires_grad_(True)
+    labels = torch.randint(0, C + 1, (B * M,), generator=g).float().cuda()
+    gt = an.repeat(B, 1) + torch.randn(B * M, 6, generator=g).cuda()
+    gt[:, 2:4] = torch.maximum(gt[:, 2:4], gt[:, 0:2] + 1); gt[:, 5] = torch.maximum(gt[:, 5], gt[:, 4] + 1)
+    return an, logits, deltas, labels, gt
+
+
+@pytest.mark.parametrize("C,npos,nneg", [(1, 5, 9), (3, 7, 20), (1, 0, 4)], ids=["c1", "c3", "nopos"])
+def test_fused_detection_loss_matches_torch_ops(C, npos, nneg):
+    """csrc/boxes.hip k_detloss / k_detloss_scatter against the torch expressions of DetectionHeadHNMNative._compute_loss_sync_free
+    (decode_single, giou_diag, binary_cross_entropy_with_logits, masked sums): losses 1e-6, gradients 1e-5 relative."""
+    from nndetection_amd.arch.heads import _DetLossFn
+    from nndetection_amd.core.boxes.coder import decode_single, BBOX_XFORM_CLIP
+    from nndetection_amd.core.boxes.ops import giou_diag
+    M, B, P, Q = 64, 2, 10, 24
+    an, logits, deltas, labels, gt = _rand_loss_inputs(M, B, C, 11 + C)
+    fg = torch.where(labels > 0)[0][:npos]
+    if npos:
+        fg = torch.cat([torch.tensor([3, 7], device="cuda"), fg])[:npos].unique()       # the clamped rows are among the positives
+        labels[fg] = labels[fg].clamp(min=1)
+    bgr = torch.where(labels == 0)[0][:nneg]
+    pos = torch.full((P,), -1, dtype=torch.int64, device="cuda"); pos[:fg.numel()] = fg
+    neg = torch.full((Q,), -1, dtype=torch.int64, device="cuda"); neg[:bgr.numel()] = bgr
+    counts = torch.tensor([fg.numel(), bgr.numel(), 0, 0], dtype=torch.int64, device="cuda")
+    cfg = {"eps": 1e-7, "clip": BBOX_XFORM_CLIP, "reg_w": 1.0, "reg_mean": False, "cls_w": 1.0, "cls_mean": True}
+    out = _DetLossFn.apply(logits, deltas, pos, neg, counts, labels, gt, an, cfg)
+    (out[0] * 1.7 + out[1] * 0.6).backward()
+    g_l, g_d = logits.grad.clone(), deltas.grad.clone()
+    logits.grad = None; deltas.grad = None
+    # torch reference on the compact lists
+    pi, ni = pos[:fg.numel()], neg[:bgr.numel()]
+    pred = decode_single(deltas[pi], an[pi % M])
+    reg = -1 * giou_diag(pred, gt[pi], eps=1e-7).sum() / max(1, pi.numel()) if pi.numel() else deltas.sum() * 0
+    idx = torch.cat([pi, ni])
+    onehot = torch.nn.functional.one_hot(labels[idx].long(), C + 1)[:, 1:].float()
+    cls = torch.nn.functional.binary_cross_entropy_with_logits(logits[idx], onehot, reduction="mean")
+    (reg * 1.7 + cls * 0.6).backward()
+    assert abs(float(out[0].detach()) - float(reg.detach())) <= 1e-6 * max(1.0, abs(float(reg.detach()))), (float(out[0].detach()), float(reg.detach()))
+    assert abs(float(out[1].detach()) - float(cls.detach())) <= 1e-6 * max(1.0, abs(float(cls.detach()))), (float(out[1].detach()), float(cls.detach()))
+    assert float((g_l - logits.grad).abs().max()) <= 1e-5 * float(logits.grad.abs().max())
+    if pi.numel():
+        assert float((g_d - deltas.grad).abs().max()) <= 1e-5 * float(deltas.grad.abs().max())
+        assert float(g_d[3, 2]) == 0.0 and float(deltas.grad[3, 2]) == 0.0                 # clamped delta: no gradient on both routes
+    else:
+        assert not g_d.any()
+
+
+def test_fused_detection_loss_in_train_step(golden_dir, monkeypatch):
+    """One training step of the tiny model with the fused loss tail (default) and with the torch ops: same losses, same gradients."""
+    from nndetection_amd.arch.heads import DetectionHeadHNMNative
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    x = torch.from_numpy(gn["x"]).cuda()
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(DetectionHeadHNMNative, "fused_loss", mode)
+        net.zero_grad(set_to_none=True)
+        losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
+                     {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    (l1, g1), (l0, g0) = res[True], res[False]
+    for k in l0:
+        assert abs(l1[k] - l0[k]) <= 1e-6 * max(1.0, abs(l0[k])), (k, l1[k], l0[k])
+    assert set(g1) == set(g0)
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-12
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-5 * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)

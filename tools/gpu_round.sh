@@ -24,7 +24,7 @@ for s in $STAGES; do
            python tools/rocpd_pmc.py $(find gpurun_out/nmspmc -name "*_results.db") > gpurun_out/nmspmc_summary.txt 2>&1; grep -A12 "k_nms" gpurun_out/nmspmc_summary.txt | head -70; rm -rf gpurun_out/nmspmc;;
     parity) timeout 1500 python -m pytest tests/test_parity_full_gpu.py tests/test_postprocess_gpu.py tests/test_targets_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_parity.txt 2>&1; tail -40 gpurun_out/t_parity.txt;;
     pyr)   timeout 900 python -m pytest tests/test_pyramid_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_pyr.txt 2>&1; tail -40 gpurun_out/t_pyr.txt;;
-    ab)    for v in 1 0 1 0; do NNDET_HEAD_ITEMS=$v timeout 600 python bench.py --steps 60 --warmup 15 --no-extras > gpurun_out/ab_items$v.txt 2>&1; echo "items=$v $(grep -o '"value": [0-9.]*' gpurun_out/ab_items$v.txt | head -1) $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_items$v.txt | head -1)" | tee -a gpurun_out/ab.txt; done;;
+    ab)    for v in 1 0 1 0; do env "${AB_VAR:-NNDET_HEAD_ITEMS}=$v" timeout 600 python bench.py --steps 60 --warmup 15 --no-extras > gpurun_out/ab_items$v.txt 2>&1; echo "items=$v $(grep -o '"value": [0-9.]*' gpurun_out/ab_items$v.txt | head -1) $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_items$v.txt | head -1)" | tee -a gpurun_out/ab.txt; done;;
     ablib) # A/B of two builds of the library in one session: nndetection_amd/csrc/libnndet_amd_prev.so (git archive <rev> + build.sh) vs the current one
            for v in cur prev cur prev; do lib=$PWD/nndetection_amd/csrc/libnndet_amd.so; [ $v = prev ] && lib=$PWD/nndetection_amd/csrc/libnndet_amd_prev.so
              NNDET_AMD_LIB=$lib timeout 600 python bench.py --steps 60 --warmup 15 --no-extras > gpurun_out/ablib_$v.txt 2>&1; echo "lib=$v $(grep -o '"value": [0-9.]*' gpurun_out/ablib_$v.txt | head -1) $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ablib_$v.txt | head -1)" | tee -a gpurun_out/ablib.txt; done;;
