@@ -344,6 +344,12 @@ int nndet_seghead_forward(int32_t dtype, const void* x, int32_t c_p, int32_t cin
                           const uint8_t* target, int64_t nvox, double* sums_out, void* stream);
 int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
                            const uint8_t* target, int64_t nvox, const float* coeffs, void* dx, double* dwb_out, void* stream);
+/* Scalar tail of the loss: sums [4] fp32 (what the forward entry points above produce, cast to fp32) ->
+ * losses_out [2] = {alpha * CE_sum / nvox, (1 - alpha) * (1 - (2 tp + smooth_nom) / (2 tp + fp + fn + smooth_denom))} and
+ * coeffs_out [2, 4] = d losses / d sums, in one launch instead of ~45 one-element torch launches (forward + autograd). */
+int nndet_segloss_tail_f32(const float* sums, int64_t nvox, float alpha, float smooth_nom, float smooth_denom, float* losses_out,
+                           float* coeffs_out, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Batch-level hard-negative sampling on the device -- replaces DetectionHeadHNM.select_indices (nndet/arch/heads/comb.py:247-276)

@@ -88,6 +88,22 @@ class _HeadGatherFn(torch.autograd.Function):
         return (None, None) + tuple(dsc[l].reshape(()) for l in range(ctx.n_scales)) + tuple(logical(d, ctx.cout) for d in dys)
 
 
+def _cat_rows(ts) -> Tensor:
+    """torch.cat(ts, dim=0) -- without the copy when the tensors are the rows base[0], base[1], ... of one contiguous tensor (what
+    the batched target assignment returns: labels [B, M] / boxes [B, M, 6] unbound into per-image lists)."""
+    if isinstance(ts, Tensor):
+        return ts
+    if len(ts) == 1:
+        return ts[0]
+    t0 = ts[0]
+    if t0.dim() >= 1 and t0.is_contiguous() and not t0.requires_grad:
+        nb, st = t0.numel() * t0.element_size(), t0.untyped_storage().data_ptr()
+        if all(t.shape == t0.shape and t.dtype == t0.dtype and t.is_contiguous() and not t.requires_grad
+               and t.untyped_storage().data_ptr() == st and t.data_ptr() == t0.data_ptr() + i * nb for i, t in enumerate(ts)):
+            return torch.as_strided(t0, (len(ts) * t0.shape[0],) + tuple(t0.shape[1:]), t0.stride(), t0.storage_offset())
+    return torch.cat(list(ts), dim=0)
+
+
 class _DetLossFn(torch.autograd.Function):
     """(reg, cls) losses of the sampled anchors and their gradients in one launch each way (csrc/boxes.hip: k_detloss,
     k_detloss_scatter; include/nndet_amd.h: nndet_detloss_f32). Arithmetic = _compute_loss_sync_free below (decode_single,
@@ -376,7 +392,7 @@ class DetectionHeadHNMNative(nn.Module):
                                 anchors: List[Tensor]):
         """comb.py:351-405 without a host read. Returns the PADDED index lists (-1 = unused slot) in place of the compact ones.
         With no positive anchor the reference leaves "reg" out of the dict; here it is an exact 0 (the total is the same)."""
-        labels = target_labels[0] if len(target_labels) == 1 else torch.cat(target_labels, dim=0)
+        labels = _cat_rows(target_labels)
         pos, neg, counts = self.fg_bg_sampler.sample_device(labels, box_logits, len(target_labels))
         from ..core.boxes.coder import BoxCoderND
         if (self.fused_loss and type(self.coder) is BoxCoderND and box_logits.dim() == 2 and box_deltas.dim() == 2
@@ -384,9 +400,7 @@ class DetectionHeadHNMNative(nn.Module):
             # one launch for both losses and their gradients instead of ~250 element-wise ones (csrc/boxes.hip: k_detloss)
             same = all(a is anchors[0] for a in anchors)
             an = anchors[0] if same else torch.cat(anchors, dim=0)
-            gt = matched_gt_boxes
-            if isinstance(gt, (list, tuple)):
-                gt = gt[0] if len(gt) == 1 else torch.cat(gt, dim=0)
+            gt = _cat_rows(matched_gt_boxes)
             cfg = {"eps": self.regressor.eps, "clip": getattr(self.coder, "bbox_xform_clip", math.log(1000. / 16)),
                    "reg_w": self.regressor.loss_weight, "reg_mean": self.regressor.reduction == "mean",
                    "cls_w": self.classifier.loss_weight, "cls_mean": self.classifier.reduction == "mean"}

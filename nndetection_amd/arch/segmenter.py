@@ -73,6 +73,25 @@ class _SegHeadFused(torch.autograd.Function):
         return logical(dx, cin), dw, db, None
 
 
+class _SegTail(torch.autograd.Function):
+    """(sum CE, tp, fp, fn) fp32 [4] -> (seg_ce, seg_dice) fp32 [2] and, for backward, their 2 x 4 Jacobian: one launch
+    (csrc/segloss.hip k_segloss_tail) instead of the scalar algebra as ~45 one-element torch launches."""
+
+    @staticmethod
+    def forward(ctx, s, nvox, alpha, sn, sd):
+        s = s.detach().float().contiguous()
+        out = torch.empty((2,), dtype=torch.float32, device=s.device)
+        jac = torch.empty((2, 4), dtype=torch.float32, device=s.device)
+        L.call("nndet_segloss_tail_f32", L.ptr(s), int(nvox), float(alpha), float(sn), float(sd), L.ptr(out), L.ptr(jac), L.stream())
+        ctx.save_for_backward(jac)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        jac, = ctx.saved_tensors
+        return torch.mv(jac.t(), g.float()), None, None, None, None
+
+
 class DiCESegmenterFgBg(nn.Module):
     def __init__(self, conv, seg_classes: int, in_channels: Sequence[int], decoder_levels: Sequence[int],
                  internal_channels: Optional[int] = None, num_internal: int = 0, add_norm: bool = True, add_act: bool = True,
@@ -89,6 +108,8 @@ class DiCESegmenterFgBg(nn.Module):
         self.conv_out = conv(in_channels[0], self.seg_classes, kernel_size=1, padding=0, add_norm=None, add_act=None, bias=True)
         self.conv_intermediate = None
 
+    fused_tail = os.environ.get("NNDET_SEG_TAIL", "1") != "0"      # the scalar algebra on the four sums as one kernel (_SegTail)
+
     def forward(self, x: List[Tensor], fused: bool = False) -> Dict[str, Tensor]:
         """fused=True (training steps that do not need the logits): hand the decoder map to compute_loss, which runs the output
         conv and the loss in one pass; else the logits as in the reference."""
@@ -102,6 +123,9 @@ class DiCESegmenterFgBg(nn.Module):
             s = _SegHeadFused.apply(pred_seg["seg_input"], self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
         else:
             s = _SegSums.apply(pred_seg["seg_logits"], tgt)
+        if s.is_cuda and self.fused_tail:
+            both = _SegTail.apply(s, tgt.numel(), self.alpha, self.smooth_nom, self.smooth_denom)
+            return {"seg_ce": both[0], "seg_dice": both[1]}
         nvox = float(tgt.numel())
         ce = s[0] / nvox                                          # CrossEntropyLoss mean over voxels
         tp, fp, fn = s[1], s[2], s[3]

@@ -248,3 +248,32 @@ extern "C" int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p,
     LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------ scalar tail of the segmentation loss
+// DiCESegmenterFgBg.compute_loss after the per-voxel sums (nndet/arch/heads/segmenter.py:184-206; losses/segmentation.py:32-151):
+//   seg_ce = alpha * CE_sum / nvox,  seg_dice = (1 - alpha) * (1 - (2 tp + s_nom) / (2 tp + fp + fn + s_den))
+// and the 2 x 4 Jacobian d(losses) / d(sums) in ONE tiny launch: as torch scalar algebra this was ~45 launches of one element each
+// (forward + autograd), 0.3-0.5 ms of launch latency between the two streaming passes of the segmentation head.
+__global__ void k_segloss_tail(const float* __restrict__ s, float nvox, float alpha, float sn, float sd, float* __restrict__ losses,
+                               float* __restrict__ coeffs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float ce = s[0] / nvox, tp = s[1], fp = s[2], fn = s[3];
+    const float num = 2.f * tp + sn, den = 2.f * tp + fp + fn + sd;
+    const float dc = num / den;
+    losses[0] = alpha * ce;
+    losses[1] = (1.f - alpha) * (1.f - dc);
+    const float k = -(1.f - alpha);                  // d seg_dice / d dc
+    coeffs[0] = alpha / nvox; coeffs[1] = 0.f; coeffs[2] = 0.f; coeffs[3] = 0.f;
+    coeffs[4] = 0.f;
+    coeffs[5] = k * (2.f * den - 2.f * num) / (den * den);      // d dc / d tp = (2 den - 2 num) / den^2
+    coeffs[6] = k * (-num / (den * den));                       // d dc / d fp
+    coeffs[7] = k * (-num / (den * den));                       // d dc / d fn
+}
+
+extern "C" int nndet_segloss_tail_f32(const float* sums, int64_t nvox, float alpha, float smooth_nom, float smooth_denom,
+                                      float* losses_out, float* coeffs_out, void* stream) {
+    if (!sums || !losses_out || !coeffs_out || nvox <= 0) return NNDET_EINVAL;
+    k_segloss_tail<<<1, 64, 0, as_stream(stream)>>>(sums, (float)nvox, alpha, smooth_nom, smooth_denom, losses_out, coeffs_out);
+    LAUNCH_CHECK();
+    return 0;
+}
