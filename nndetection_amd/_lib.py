@@ -165,10 +165,12 @@ def check(rc: int, what: str):
 _workspaces = {}
 
 
-def workspace(nbytes: int, device) -> "torch.Tensor":
+def workspace(nbytes: int, device, raw_stream=None) -> "torch.Tensor":
     """One grow-only scratch buffer per (device, stream): launches on one stream are serialised, so they can share it;
-    branches that run concurrently on side streams (the detection head levels) get their own."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    branches that run concurrently on side streams (the detection head levels) get their own. raw_stream: the stream the
+    launch goes to if it is not torch's current one (the weight-gradient stream)."""
+    key = (device.type, device.index, (raw_stream if raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
+           if device.type == "cuda" else 0)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
@@ -251,6 +253,58 @@ class _GradPool:
 
 
 grad_pool = _GradPool()
+
+
+class _WgradStreams:
+    """Weight-gradient kernels on their own stream. Within a backward pass the data-gradient / norm-backward chain is the critical
+    path; a weight gradient is only needed by the optimizer. Launched on a second stream the weight-gradient kernels fill the CUs the
+    chain leaves idle -- above all under the deep, small pyramid levels, whose kernels are latency-bound launches of a few
+    workgroups (2 ms of a 19 ms step at 5 % of its FLOPs). `side(dev, weight)` returns the stream for one node (or None: stay on the
+    current stream); the first use inside a backward pass queues an engine callback that makes the caller's stream wait for the side
+    stream when the pass ends, i.e. before the optimizer (or anything else on that stream) reads a gradient. Gradient hooks that read
+    gradients DURING the pass (nndetection_amd.ddp) take the stream from `active`. NNDET_WGRAD_STREAM=0 disables it."""
+
+    enabled = os.environ.get("NNDET_WGRAD_STREAM", "1") != "0"
+
+    def __init__(self):
+        self.streams, self.active, self.pending, self.task = {}, {}, [], -1
+
+    def side(self, dev, weight):
+        if not self.enabled or dev.type != "cuda":
+            return None
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        task = torch._C._current_graph_task_id()
+        if task != self.task:                        # a new backward pass (the previous one may have died before its callback ran)
+            for w in self.pending:
+                w._nndet_wg_pending = False
+            self.active, self.pending, self.task = {}, [], task
+        if weight.grad is not None or getattr(weight, "_nndet_wg_pending", False):
+            # the engine will ADD this contribution to an existing gradient on the current stream (a module used twice in one pass,
+            # accumulation over several passes): order that add behind the earlier weight-gradient kernels and stay on this stream
+            ws = self.active.get(idx)
+            if ws is not None:
+                torch.cuda.current_stream(dev).wait_stream(ws)
+            return None
+        ws = self.streams.get(idx)
+        if ws is None:
+            ws = self.streams[idx] = torch.cuda.Stream(device=dev)
+        if not self.active:
+            torch.autograd.Variable._execution_engine.queue_callback(self._done)
+        self.active[idx] = ws
+        weight._nndet_wg_pending = True
+        self.pending.append(weight)
+        ws.wait_stream(torch.cuda.current_stream(dev))       # dY (and the zero-filled gradient pool) are ready
+        return ws
+
+    def _done(self):
+        for idx, ws in self.active.items():
+            torch.cuda.current_stream(idx).wait_stream(ws)
+        for w in self.pending:
+            w._nndet_wg_pending = False
+        self.active, self.pending = {}, []
+
+
+wgrad_streams = _WgradStreams()
 
 
 def call(name: str, *args):

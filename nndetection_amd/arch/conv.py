@@ -208,6 +208,9 @@ class _ConvFn(torch.autograd.Function):
         # dW and dbias of this node are views of the per-step gradient pool (ONE zero fill per step, _lib.grad_pool)
         nw = weight.numel()
         gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
+        # (a bias gradient that comes out of the data-gradient launch is written on THIS stream: such nodes keep the weight gradient here too)
+        ctx.wg_side = None if (ctx.has_bias and ctx.needs_input_grad[0] and desc.cin_p != 1 and
+                               bool(L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)))) else L.wgrad_streams.side(dev, weight)
         dw = gbuf[:nw].view(weight.shape)
         dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
         dx = None
@@ -240,9 +243,13 @@ class _ConvFn(torch.autograd.Function):
                 if gacc is not None:
                     gacc["buf"] = dx_p        # first consumer: the second one adds into this buffer (same stream: encoder / decoder)
         ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
-        ws = L.workspace(ws_bytes, dev)
+        side = ctx.wg_side                                 # weight-gradient stream (forked at the top of backward, before the data gradient)
+        if side is not None:
+            x_p.record_stream(side); dconv.record_stream(side)
+        raw = side.cuda_stream if side is not None else L.stream()
+        ws = L.workspace(ws_bytes, dev, raw_stream=raw if side is not None else None)
         L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw),
-               None if bias_from_dgrad else L.ptr(dbias), L.ptr(ws), ws_bytes, L.stream())
+               None if bias_from_dgrad else L.ptr(dbias), L.ptr(ws), ws_bytes, raw)
         # d(residual) = grad_out: the same NDHWC buffer is handed to both consumers (no copy, no add kernel)
         return dx, None, None, dw.to(weight.dtype), dbias, None, (logical(dconv, cout) if ctx.has_res else None), None
 

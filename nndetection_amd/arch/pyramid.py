@@ -148,6 +148,7 @@ class _ItemsConvFn(torch.autograd.Function):
         gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
         dw = gbuf[:nw].view(weight.shape)
         dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
+        side = L.wgrad_streams.side(dev, weight)            # weight-gradient stream, forked before the data gradient is queued
         dx = None
         if ctx.needs_input_grad[0]:
             w1 = _packed(mod, 1, weight, desc, dt)
@@ -155,9 +156,12 @@ class _ItemsConvFn(torch.autograd.Function):
             L.call("nndet_conv3d_backward_data_items", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(dconv), L.ptr(w1),
                    L.ptr(dx), L.stream())
         ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
-        ws = L.workspace(ws_bytes, dev)
+        if side is not None:
+            x2d.record_stream(side); dconv.record_stream(side)
+        raw = side.cuda_stream if side is not None else L.stream()
+        ws = L.workspace(ws_bytes, dev, raw_stream=raw if side is not None else None)
         L.call("nndet_conv3d_backward_weight_items", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(x2d), L.ptr(dconv),
-               L.ptr(dw), L.ptr(dbias), L.ptr(ws), ws_bytes, L.stream())
+               L.ptr(dw), L.ptr(dbias), L.ptr(ws), ws_bytes, raw)
         return dx, dw.to(weight.dtype), dbias, None, None, None
 
 

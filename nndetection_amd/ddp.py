@@ -140,6 +140,10 @@ class GradAllReducer:
             if sid not in self._stream_objs:
                 self._stream_objs[sid] = torch.cuda.current_stream()     # the stream this gradient was accumulated on
             b.streams.add(sid)
+            from . import _lib as L                      # the weight-gradient kernels themselves run on their own stream (_lib.wgrad_streams)
+            for ws in L.wgrad_streams.active.values():
+                self._stream_objs.setdefault(ws.cuda_stream, ws)
+                b.streams.add(ws.cuda_stream)
         # collectives must be issued in the SAME order on every rank: a bucket is only launched once all
         # earlier buckets are (a bucket holding a parameter that is unused on this rank is launched by finish())
         while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
