@@ -6,6 +6,7 @@ Same update rule as `torch.optim.SGD(momentum, nesterov, weight_decay)` as confi
 tensor lists: torch.optim's per-step Python bookkeeping cost ~5 ms of GPU idle time per step after backward
 (profiles/round1_v2_kernel_stats.txt gap analysis), which is 10 % of the whole step at MI355X speed.
 """
+import os
 from typing import List
 
 import torch
@@ -21,6 +22,8 @@ class SGDNesterov:
         self.defaults = {"lr": lr, "momentum": momentum, "nesterov": nesterov}
         self._buf = {}
 
+    fused = os.environ.get("NNDET_FUSED_SGD", "1") != "0"   # one multi-tensor launch per group (torch._fused_sgd_, the kernel behind torch.optim.SGD(fused=True))
+
     @torch.no_grad()
     def step(self):
         for g in self.param_groups:
@@ -29,6 +32,21 @@ class SGDNesterov:
                 continue
             grads = [p.grad for p in ps]
             wd, lr, mu = g["weight_decay"], g["lr"], self.momentum
+            if (self.fused and mu != 0.0 and hasattr(torch, "_fused_sgd_")
+                    and all(p.is_cuda and p.dtype == torch.float32 and gr.dtype == torch.float32 for p, gr in zip(ps, grads))):
+                # weight decay, momentum, Nesterov and the update in ONE pass over (p, g, buf) instead of 4-5 foreach passes
+                new = {id(p) for p in ps if p not in self._buf}
+                for first in (True, False):
+                    sel = [(p, gr) for p, gr in zip(ps, grads) if (id(p) in new) == first]
+                    if not sel:
+                        continue
+                    if first:
+                        for p, gr in sel:
+                            self._buf[p] = torch.empty_like(gr)               # filled by the kernel: buf = g (+ wd * p)
+                    torch._fused_sgd_([p for p, _ in sel], [gr.contiguous() for _, gr in sel], [self._buf[p] for p, _ in sel],
+                                      weight_decay=wd, momentum=mu, lr=lr, dampening=0.0, nesterov=self.nesterov, maximize=False,
+                                      is_first_step=first)
+                continue
             if wd != 0.0:
                 grads = torch._foreach_add(grads, ps, alpha=wd)          # g + wd * p (new tensors, p.grad untouched)
             if mu != 0.0:
