@@ -287,7 +287,10 @@ class _WgradStreams:
             return None
         ws = self.streams.get(idx)
         if ws is None:
-            ws = self.streams[idx] = torch.cuda.Stream(device=dev)
+            # lowest queue priority the device offers: the critical chain on the other streams gets the CUs first, the weight
+            # gradients take what is left (NNDET_WGRAD_PRIO overrides: -1 high, 0 normal, 1 low on ROCm)
+            prio = int(os.environ.get("NNDET_WGRAD_PRIO", "1"))
+            ws = self.streams[idx] = torch.cuda.Stream(device=dev, priority=prio)
         if not self.active:
             torch.autograd.Variable._execution_engine.queue_callback(self._done)
         self.active[idx] = ws

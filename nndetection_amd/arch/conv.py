@@ -208,9 +208,10 @@ class _ConvFn(torch.autograd.Function):
         # dW and dbias of this node are views of the per-step gradient pool (ONE zero fill per step, _lib.grad_pool)
         nw = weight.numel()
         gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
-        # (a bias gradient that comes out of the data-gradient launch is written on THIS stream: such nodes keep the weight gradient here too)
-        ctx.wg_side = None if (ctx.has_bias and ctx.needs_input_grad[0] and desc.cin_p != 1 and
-                               bool(L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)))) else L.wgrad_streams.side(dev, weight)
+        # (NNDET_WGRAD_ALL=0: nodes whose bias gradient comes out of the data-gradient launch keep their weight gradient on this stream)
+        keep = (os.environ.get("NNDET_WGRAD_ALL", "1") == "0" and ctx.has_bias and ctx.needs_input_grad[0] and desc.cin_p != 1 and
+                bool(L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc))))
+        ctx.wg_side = None if keep else L.wgrad_streams.side(dev, weight)
         dw = gbuf[:nw].view(weight.shape)
         dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
         dx = None

@@ -370,7 +370,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
     double* ch = red;                               // [c_p][2]
     for (int i = threadIdx.x; i < c_p * 2; i += 256) {
         double v = 0.0;
-        for (int r = 0; r < NNDET_STATS_REPLICAS; ++r)
+        const int nrep = nblk < (unsigned)NNDET_STATS_REPLICAS ? (int)nblk : NNDET_STATS_REPLICAS;     // replica = workgroup index % 32: only these were written
+        for (int r = 0; r < nrep; ++r)
             v += __hip_atomic_load(&red_ws[(((int64_t)r * N + n) * c_p) * 2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ch[i] = v;
     }
