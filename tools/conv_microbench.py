@@ -76,5 +76,33 @@ def main():
         print(f"{name:16s} {flops / 1e9:7.1f} GF {byts / 1e6:7.0f} MB | " + " | ".join(res), flush=True)
 
 
+def items_bench():
+    """The head-trunk convolution over all pyramid levels as one ragged batch (NndetItems): 128 -> 128, luna160 pyramid, batch 4."""
+    from nndetection_amd.arch import pyramid as P
+    from nndetection_amd.arch.conv import ConvGroupRelu
+    dt = torch.bfloat16
+    lev = [(40, 40, 24), (20, 20, 12), (10, 10, 6), (5, 5, 6)]
+    iters = int(os.environ.get("MICRO_ITERS", "20"))
+    for cin, cout in ((128, 128), (128, 162), (128, 27)):
+        m = ConvGroupRelu(3, cin, cout, 3, stride=1, padding=1, add_norm=False, add_act=False).cuda()
+        meta = P.pyramid_meta([(4, *s) for s in lev])
+        x = torch.randn(meta.rows, cin, device="cuda").to(dt)
+        d = P._items_desc(x, m, meta)
+        w0 = _packed(m, 0, m.conv.weight, d, dt); w1 = _packed(m, 1, m.conv.weight, d, dt)
+        y = torch.empty(meta.rows, d.cout_p, dtype=dt, device="cuda")
+        dy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.zeros_like(m.conv.weight)
+        st = L.stream()
+        it = ctypes.byref(meta.items)
+        f = lambda: L.call("nndet_conv3d_forward_items", ctypes.byref(d), it, L.ptr(x), L.ptr(w0), None, L.ptr(y), None, st)
+        g = lambda: L.call("nndet_conv3d_backward_data_items", ctypes.byref(d), it, L.ptr(dy), L.ptr(w1), L.ptr(dx), st)
+        wsb = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+        ws = L.workspace(wsb, x.device)
+        h = lambda: L.call("nndet_conv3d_backward_weight_items", ctypes.byref(d), it, L.ptr(x), L.ptr(dy), L.ptr(dw), None, L.ptr(ws), wsb, st)
+        flops = 2.0 * meta.rows * 27 * cin * cout
+        res = [f"{nm} {timeit(fn, iters):8.3f} ms" for nm, fn in (("fwd", f), ("dgrad", g), ("wgrad", h))]
+        ms = [timeit(fn, iters) for fn in (f, g, h)]
+        print(f"head_items {cin}->{cout} {flops / 1e9:7.1f} GF | " + " | ".join(f"{nm} {t:7.3f} ms {flops / t / 1e9:7.1f} TF/s" for nm, t in zip(("fwd", "dgrad", "wgrad"), ms)), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    items_bench() if "--items" in sys.argv else main()
