@@ -471,3 +471,47 @@ def test_fused_detection_loss_in_train_step(golden_dir, monkeypatch):
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-12
         assert float((g1[n] - g0[n]).abs().max()) <= 2e-5 * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stream_overlap_does_not_change_training(golden_dir, monkeypatch, dtype):
+    """Four optimizer steps on toy64; at every step the SAME parameters go through a train step with every overlap feature on (head
+    branches, target assignment and segmentation branch on side streams, weight gradients on their own stream) and with everything
+    on the caller's stream: same losses, same gradients for every parameter. A missing stream dependency shows up as a difference
+    here -- the kernels and their inputs are identical, only the order of atomically reduced sums may differ (fp32: 2e-5 of the
+    tensor maximum; bf16: storage noise of the atomically accumulated statistics, 2e-2). Parameters after several steps are NOT
+    compared: two runs of the same configuration already differ by 4e-4 there (tools/diag_overlap.py: chaotic amplification)."""
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch.heads import DetectionHeadHNMNative
+    from nndetection_amd.core.retina import BaseRetinaNet
+    from nndetection_amd.ptmodule import build_model, configure_optimizer
+    from tests.gpu_util import synth_inputs
+    plan = get_plan("toy64")
+    x, tg = synth_inputs(plan)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    torch.manual_seed(0)
+    net = build_model(plan).cuda()
+    opt, sched = configure_optimizer(net)
+    for g in opt.param_groups:
+        g["lr"] = 1e-2
+    ltol, gtol = (2e-5, 2e-5) if dtype == torch.float32 else (1e-3, 2e-2)
+    for it in range(4):
+        res = {}
+        for mode in (True, False):
+            monkeypatch.setattr(DetectionHeadHNMNative, "multi_stream", mode)
+            monkeypatch.setattr(BaseRetinaNet, "overlap_aux", mode)
+            monkeypatch.setattr(L.wgrad_streams, "enabled", mode)
+            opt.zero_grad(set_to_none=True)
+            losses, _ = net.train_step(x.cuda().to(dtype), _cuda_targets(tg), evaluation=False)
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+            res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
+                         {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+        (l1, g1), (l0, g0) = res[True], res[False]
+        for k in l0:
+            assert abs(l1[k] - l0[k]) <= ltol * max(1.0, abs(l0[k])), (it, k, l1[k], l0[k])
+        assert set(g1) == set(g0)
+        for n in g0:
+            d = float((g1[n] - g0[n]).abs().max())
+            assert d <= gtol * (float(g0[n].abs().max()) + 1e-9), (it, n, d, float(g0[n].abs().max()))
+        opt.step()
