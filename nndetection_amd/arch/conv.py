@@ -224,6 +224,9 @@ class _ConvFn(torch.autograd.Function):
             fuses_bias = dbias is not None and bool(L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)))
             if gacc is not None and gacc["buf"] is not None and gacc["buf"].shape == x_p.shape and gacc["buf"].dtype == dt:
                 # second consumer of this activation: add into the gradient the first consumer wrote and hand autograd nothing
+                if gacc.get("ev") is not None:               # the first consumer may have run on another stream (decoder tail)
+                    torch.cuda.current_stream(dev).wait_event(gacc["ev"])
+                    gacc["buf"].record_stream(torch.cuda.current_stream(dev))
                 L.call("nndet_conv3d_backward_data_acc", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(gacc["buf"]),
                        L.ptr(dbias) if fuses_bias else None, L.stream())
                 gacc["buf"] = None
@@ -242,7 +245,10 @@ class _ConvFn(torch.autograd.Function):
             if dx_p is not None:
                 dx = logical(dx_p, desc.cin)  # gradient w.r.t. the input AS THE CONV SAW IT (i.e. after a deferred norm + ReLU)
                 if gacc is not None:
-                    gacc["buf"] = dx_p        # first consumer: the second one adds into this buffer (same stream: encoder / decoder)
+                    gacc["buf"] = dx_p        # first consumer: the second one adds into this buffer
+                    if dx_p.is_cuda:
+                        gacc["ev"] = torch.cuda.Event()
+                        gacc["ev"].record()   # (on this node's stream; the second consumer waits for it if it runs elsewhere)
         ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
         side = ctx.wg_side                                 # weight-gradient stream (forked at the top of backward, before the data gradient)
         if side is not None:

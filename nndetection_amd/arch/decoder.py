@@ -5,6 +5,7 @@ One deliberate difference: `skip_unused_out` (default True) do
 whose result nothing consumes (`out.P1` with decoder_levels (2,3,4,5): heads read levels 2-5, the segmenter
 level 0). The parameters stay in the module (state-dict parity), the forward result for that level is `None`.
 """
+import os
 from typing import Callable, List, Optional, Sequence
 
 import torch
@@ -62,19 +63,52 @@ class UFPNModular(nn.Module):
     def get_channels(self) -> List[int]:
         return self.out_channels
 
+    # The full-resolution tail of the decoder -- lateral P0, the last top-down step up.P1 (+ its residual add) and out.P0 -- only feeds
+    # the segmentation branch; the detection head reads the levels >= 1. On a side stream these three HBM-bound launches (0.2 + 0.43 +
+    # 0.33 ms at 160x160x96, and their backward passes) run next to the MFMA-bound head instead of in front of it. `tail_event` tells
+    # the consumer of level 0 when it is ready. NNDET_DECODER_TAIL=0: everything on the caller's stream.
+    split_tail = os.environ.get("NNDET_DECODER_TAIL", "1") != "0"
+    _tail_streams: dict = {}
+
     def forward(self, inp_seq: Sequence[torch.Tensor]) -> List[Optional[torch.Tensor]]:
-        fpn = [self.lateral[f"P{l}"](fm) for l, fm in enumerate(inp_seq)]
+        self.tail_event = None
+        need0 = not (self.skip_unused_out and self.used_levels is not None and 0 not in self.used_levels)
+        split = self.split_tail and self.num_level >= 3 and inp_seq[0].is_cuda and need0
+        fpn: List[Optional[torch.Tensor]] = [None] * self.num_level
+        if split:
+            dev = inp_seq[0].device
+            main = torch.cuda.current_stream(dev)
+            side = UFPNModular._tail_streams.get(dev.index or 0)
+            if side is None:
+                side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)                               # the encoder outputs are ready
+            inp_seq[0].record_stream(side)
+            with torch.cuda.stream(side):
+                fpn[0] = self.lateral["P0"](inp_seq[0])
+        for l, fm in enumerate(inp_seq):
+            if fpn[l] is None:
+                fpn[l] = self.lateral[f"P{l}"](fm)
         xs: List[Optional[torch.Tensor]] = [None] * self.num_level
         x = fpn[self.num_level - 1]
         xs[self.num_level - 1] = x
-        for level in range(self.num_level - 2, -1, -1):
+        for level in range(self.num_level - 2, 0 if split else -1, -1):
             # x_l = lateral_l + up_{l+1}(x_{l+1})  (decoder/base.py:405-413): the add is the epilogue of the transposed conv
             x = self.up[f"P{level + 1}"](x, residual=fpn[level])
             xs[level] = x
-        outs = []
-        for level in range(self.num_level):
+        outs: List[Optional[torch.Tensor]] = [None] * self.num_level
+        if split:
+            ev = torch.cuda.Event()
+            ev.record(main)                                      # x_1 is ready
+            side.wait_event(ev)
+            xs[1].record_stream(side)
+            with torch.cuda.stream(side):
+                xs[0] = self.up["P1"](xs[1], residual=fpn[0])
+                outs[0] = self.out["P0"](xs[0])
+                self.tail_event = torch.cuda.Event()
+                self.tail_event.record(side)
+        for level in range(1 if split else 0, self.num_level):
             if self.skip_unused_out and self.used_levels is not None and level not in self.used_levels:
-                outs.append(None)
+                outs[level] = None
             else:
-                outs.append(self.out[f"P{level}"](xs[level]))
+                outs[level] = self.out[f"P{level}"](xs[level])
         return outs

@@ -66,12 +66,22 @@ class BaseRetinaNet(nn.Module):
                 L.grad_pool.begin(self._grad_numel, inp.device)
         features_maps_all = self.decoder(self.encoder(inp))
         feature_maps_head = [features_maps_all[i] for i in self.decoder_levels]
+        tail_ev = getattr(self.decoder, "tail_event", None)    # level 0 (the segmenter's input) comes from the decoder's side stream
         if getattr(self, "_seg_side", None) is not None:       # train_step: the segmentation branch forks HERE (before the head is queued)
-            self._dec_event = torch.cuda.Event()
-            self._dec_event.record()
+            if tail_ev is not None:
+                self._dec_event = tail_ev
+            else:
+                self._dec_event = torch.cuda.Event()
+                self._dec_event.record()
         pred_detection = self.head(feature_maps_head)
         anchors = self.anchor_generator(inp, feature_maps_head)
         pred_seg = None
+        if tail_ev is not None and inp.is_cuda:
+            if getattr(self, "_seg_side", None) is None:       # level 0 is consumed on this stream (inference, evaluation): join here,
+                torch.cuda.current_stream(inp.device).wait_event(tail_ev)      # behind the head that was queued in the meantime
+            for t in features_maps_all[:1]:
+                if t is not None:
+                    t.record_stream(torch.cuda.current_stream(inp.device))
         if self.segmenter is not None:
             pred_seg = self.segmenter(features_maps_all, fused=True) if getattr(self, "_fuse_seg_head", False) \
                 else self.segmenter(features_maps_all)
