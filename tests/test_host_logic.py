@@ -279,3 +279,36 @@ def test_lean_sgd_state_dict_roundtrip_matches_torch_layout():
     assert len(o3.state) == len(sd_o["state"])
     lr_now = sd_o["param_groups"][0]["lr"]
     assert abs(o3.param_groups[0]["lr"] - lr_now) < 1e-15
+
+
+def test_cat_rows_without_copy():
+    """arch/heads._cat_rows: per-image lists that are the rows of one contiguous tensor (what the batched target assignment returns)
+    are concatenated as a view; anything else falls back to torch.cat."""
+    import torch
+    from nndetection_amd.arch.heads import _cat_rows
+    a = torch.arange(24.).view(4, 6)
+    r = _cat_rows(list(a.unbind(0)))
+    assert r.data_ptr() == a.data_ptr() and torch.equal(r, a.reshape(-1))
+    b = torch.arange(48.).view(2, 4, 6)
+    r = _cat_rows(list(b.unbind(0)))
+    assert r.shape == (8, 6) and r.data_ptr() == b.data_ptr() and torch.equal(r, b.reshape(-1, 6))
+    r = _cat_rows([b[1], b[0]])                                  # not consecutive: a copy, in list order
+    assert torch.equal(r, torch.cat([b[1], b[0]])) and r.data_ptr() != b.data_ptr()
+    r = _cat_rows([torch.zeros(3), torch.ones(3)])               # separate storages
+    assert torch.equal(r, torch.tensor([0., 0, 0, 1, 1, 1]))
+    assert _cat_rows(a) is a and _cat_rows([a[0]]).data_ptr() == a.data_ptr()
+
+
+def test_pyramid_meta_item_table():
+    """arch/pyramid.PyramidMeta: level-major items, running voxel-row offsets, the C struct of include/nndet_amd.h (NndetItems)."""
+    import ctypes
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch.pyramid import pyramid_meta
+    shapes = [(4, 40, 40, 24), (4, 20, 20, 12), (4, 10, 10, 6), (4, 5, 5, 6)]
+    m = pyramid_meta(shapes)
+    assert m is pyramid_meta(shapes)                              # cached per shape key
+    assert m.n_items == 16 and m.batch == 4 and m.rows == 4 * (38400 + 4800 + 600 + 150)
+    assert m.level_rows == [(0, 153600), (153600, 19200), (172800, 2400), (175200, 600)]
+    assert list(m.items.dims[0]) == [40, 40, 24] and list(m.items.dims[5]) == [20, 20, 12] and list(m.items.dims[15]) == [5, 5, 6]
+    assert m.items.row_off[0] == 0 and m.items.row_off[4] == 153600 and m.items.row_off[5] == 153600 + 4800 and m.items.row_off[15] == 175200 + 450
+    assert ctypes.sizeof(L.NndetItems) == 8 + L.MAX_ITEMS * 12 + L.MAX_ITEMS * 8 and L.MAX_ITEMS == 32
