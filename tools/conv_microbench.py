@@ -28,6 +28,13 @@ SHAPES = {
     "lat_p1_1x1": (64, 64, 1, 1, 0, False, (80, 80, 48), 4),
     "p3_128x128": (128, 128, 3, 1, 1, False, (20, 20, 12), 4),
     "p4_128x128": (128, 128, 3, 1, 1, False, (10, 10, 6), 4),
+    "e4_320x320": (320, 320, 3, 1, 1, False, (10, 10, 6), 4),
+    "e5_320x320": (320, 320, 3, 1, 1, False, (5, 5, 6), 4),
+    "e4_320x320_b1": (320, 320, 3, 1, 1, False, (10, 10, 6), 1),            # scaling probes of the small-level kernel
+    "e4_64to320": (64, 320, 3, 1, 1, False, (10, 10, 6), 4),
+    "e4_320to64": (320, 64, 3, 1, 1, False, (10, 10, 6), 4),
+    "e4_320x320_444": (320, 320, 3, 1, 1, False, (4, 4, 4), 4),
+    "e4_256to320_s2": (256, 320, 3, 2, 1, False, (20, 20, 12), 4),
 }
 
 
