@@ -7,8 +7,18 @@ A "step" = one full training step of RetinaUNetV001 on one batch of synthetic 16
 (BASELINE.json configs[1]: Task016_Luna-like plan, batch 4 per GPU, bf16 activations): forward, ATSS target
 assignment, hard-negative sampling, losses, backward, gradient all-reduce (N > 1), SGD(nesterov) step, LR step.
 Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0:
-  metric/value = patches/s (whole job), roofline = dominant conv kernel vs the HBM roofline (HIP-event timed here),
+  metric/value = patches/s (whole job),
+  roofline = the kernel with the most FLOPs per launch (k_ig3r) vs the MFMA roofline, HIP-event timed here, HBM traffic from PMC
+             passes run by this process when rocprofv3 is installed (else the committed profiles/*.json, marked as such),
+  roofline_dominant = the kernel with the most TIME per step (the ragged head trunk launch), step_roofline = algorithmic FLOPs and
+             bytes of the whole step / ms_per_step,
+  routes = the same step through the registered plugin's `training_step` (batch dicts, device-side targets), in fp32 and in fp16
+           (+ GradScaler), each timed on a short run next to the headline,
+  ddp (N > 1) = exposed (non-overlapped) gradient all-reduce time per step and per-bucket launch offsets,
   cpu_baseline = the CPU oracle ("port" of the reference, plain PyTorch fp32) timed on this host's cores.
+
+    --via-plugin   the headline itself goes through RetinaUNetAMDSteps.training_step (what nnDetection + Lightning would call)
+    --dtype f16    fp16 activations + torch.amp.GradScaler (the reference's precision=16); bf16 is BASELINE.json's configs[1]
 """
 import argparse
 import json
@@ -43,6 +53,247 @@ def synth_batch(plan, batch, dtype, device, seed):
     return x, {"target_boxes": boxes, "target_classes": classes, "target_seg": seg.to(device)}
 
 
+def synth_plugin_batch(plan, batch, device, seed):
+    """The same patch / boxes as `synth_batch`, as the raw nnDetection batch dict a data loader hands `training_step`
+    (nndet/ptmodule/retinaunet/base.py:135-154): fp32 image, instance-id volume, {instance id: class} per image."""
+    x, tg = synth_batch(plan, batch, torch.float32, "cpu", seed)
+    P = plan["patch_size"]
+    inst = torch.zeros(batch, 1, *P)
+    maps = []
+    for b in range(batch):
+        m = {}
+        for i, q in enumerate(tg["target_boxes"][b].numpy(), start=1):
+            inst[b, 0, int(q[0]):int(q[2]) + 1, int(q[1]):int(q[3]) + 1, int(q[4]):int(q[5]) + 1] = i
+            m[i] = 0
+        m[len(m) + 5] = 0                       # an instance of the case that is not inside this patch
+        maps.append(m)
+    return {"data": x.to(device), "target": inst.to(device), "instance_mapping": maps}
+
+
+_TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+class Route:
+    """One way of running the training step: direct (BaseRetinaNet.train_step on prepared targets) or via the plugin
+    (RetinaUNetAMDSteps.training_step on a batch dict, inside torch.autocast as Lightning's native AMP does), in a given activation
+    dtype; fp16 uses torch.amp.GradScaler (scale -> backward -> unscale + inf check -> step, sync-free with the fused optimizer)."""
+
+    def __init__(self, plan, batch, dtype_name, device, rank, via_plugin, ddp_factory=None):
+        import contextlib
+        from nndetection_amd.plans import MODEL_CFG_V001, TRAINER_CFG_V001
+        from nndetection_amd.ptmodule import build_model, configure_optimizer, StandaloneRetinaUNetV001AMD
+        import copy
+        self.dtype_name, self.via_plugin = dtype_name, via_plugin
+        dt = _TORCH_DT[dtype_name]
+        torch.manual_seed(0)
+        if via_plugin:
+            pl_plan = {"architecture": plan["arch"], "anchors": plan["anchors"], "patch_size": plan["patch_size"], "batch_size": batch}
+            cfg = dict(TRAINER_CFG_V001, precision=32 if dtype_name == "f32" else 16)
+            self.mod = StandaloneRetinaUNetV001AMD(copy.deepcopy(MODEL_CFG_V001), cfg, pl_plan).to(device)
+            self.net = self.mod.model
+            self.opt, self.sched = self.mod.configure_optimizers()
+            self.batch = synth_plugin_batch(plan, batch, device, seed=1000 + rank)
+            self.ctx = (lambda: torch.autocast("cuda", dtype=dt)) if dtype_name != "f32" else contextlib.nullcontext
+        else:
+            self.net = build_model(plan).to(device)
+            self.opt, self.sched = configure_optimizer(self.net)
+            self.x, self.tg = synth_batch(plan, batch, dt, device, seed=1000 + rank)
+        self.scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14) if dtype_name == "f16" else None
+        self.ddp = ddp_factory(self.net) if ddp_factory is not None else None
+        torch.manual_seed(1234 + rank)
+
+    def step(self):
+        if self.via_plugin:
+            with self.ctx():
+                out = self.mod.training_step(self.batch, 0)
+            loss = out["loss"]
+        else:
+            losses, _ = self.net.train_step(self.x, self.tg, evaluation=False, batch_num=0)
+            loss = sum(losses.values())
+        if self.ddp is not None:
+            self.ddp.begin_step()
+        (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
+        if self.ddp is not None:
+            self.ddp.finish()
+        if self.scaler is not None:
+            self.scaler.step(self.opt)
+            self.scaler.update()
+        else:
+            self.opt.step()
+        self.sched.step()
+        self.opt.zero_grad(set_to_none=True)
+        return loss
+
+    def timed(self, warmup, steps, world=1):
+        for _ in range(warmup):
+            last = self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, last
+
+
+def side_route(plan, batch, dtype_name, device, via_plugin, warmup=8, steps=24):
+    r = Route(plan, batch, dtype_name, device, 0, via_plugin)
+    dt, last = r.timed(warmup, steps)
+    out = {"patches_per_s": round(batch * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+           "dtype": dtype_name, "via_plugin": bool(via_plugin), "final_loss": round(float(last.detach().float().item()), 5)}
+    if r.scaler is not None:
+        out["grad_scale"] = float(r.scaler.get_scale())
+    del r
+    torch.cuda.empty_cache()
+    return out
+
+
+def step_algorithmic_work(net, plan, batch, esz):
+    """Algorithmic FLOPs / HBM bytes of one training step (every convolution reads its input once and writes its output
+    once; forward + data gradient + weight gradient = 3 x the forward figures; norm / ReLU / loss passes count as zero bytes).
+    Walks the network's own conv blocks with the feature-map sizes of the plan; `decoder.out.P<l>` blocks nobody reads are not
+    computed by this implementation and not counted."""
+    import math
+    from nndetection_amd.arch.conv import BaseConvNormAct
+    from nndetection_amd.layout import cpad
+    P = tuple(plan["patch_size"])
+    strides = net.encoder.get_strides()
+    size = [tuple(int(math.ceil(P[a] / st[a])) for a in range(3)) for st in strides]      # feature-map size per stage / level
+    flops = byts = 0.0
+
+    def add(m, sp_in, n_dir=3):
+        nonlocal flops, byts
+        k, s = m.k, m.s
+        if m.transposed:
+            sp_out = tuple(sp_in[a] * s[a] for a in range(3)); gemm_vox = math.prod(sp_in)
+        else:
+            sp_out = tuple((sp_in[a] + 2 * m.p[a] - k[a]) // s[a] + 1 for a in range(3)); gemm_vox = math.prod(sp_out)
+        flops += n_dir * 2.0 * gemm_vox * math.prod(k) * m.in_channels * m.out_channels
+        cin_p = 1 if m.in_channels == 1 else cpad(m.in_channels)
+        byts += n_dir * esz * (math.prod(sp_in) * cin_p + math.prod(sp_out) * cpad(m.out_channels))
+        return sp_out
+
+    for i, stage in enumerate(net.encoder.stages):
+        sp = P if i == 0 else size[i - 1]
+        for j, m in enumerate([q for q in stage.modules() if isinstance(q, BaseConvNormAct)]):
+            sp = add(m, sp, 2 if (i == 0 and j == 0) else 3)             # the stem has no data gradient
+    used = getattr(net.decoder, "used_levels", None)
+    convs = lambda mod: [q for q in mod.modules() if isinstance(q, BaseConvNormAct)]
+    for name, mod in net.decoder.lateral.items():
+        for m in convs(mod):
+            add(m, size[int(name[1:])])
+    for name, mod in net.decoder.up.items():
+        for m in convs(mod):
+            add(m, size[int(name[1:])])
+    for name, mod in net.decoder.out.items():
+        l = int(name[1:])
+        if used is None or l in used:
+            for m in convs(mod):
+                add(m, size[l])
+    for l in net.decoder_levels:
+        for head in (net.head.classifier, net.head.regressor):
+            for m in [q for q in head.modules() if isinstance(q, BaseConvNormAct)]:
+                add(m, size[l])
+    if net.segmenter is not None:
+        add(net.segmenter.conv_out, size[0])
+    return flops * batch, byts * batch
+
+
+def head_trunk_roofline(plan, batch, dtype, device, iters=30):
+    """The launch with the most TIME per training step: the shared 128 -> 128 head-trunk convolution over ALL pyramid levels of all
+    images as one ragged batch (k_ig3<..., ITEMS>, arch/pyramid.py): 4 such forward launches + 4 data gradients per step."""
+    import ctypes
+    import math
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch import pyramid as PY
+    from nndetection_amd.arch.conv import ConvGroupRelu, _packed
+    from nndetection_amd.ptmodule import build_model
+    Pz = tuple(plan["patch_size"])
+    arch = plan["arch"]
+    st = [[1, 1, 1]]
+    for s_ in arch["strides"]:
+        st.append([a * b for a, b in zip(st[-1], s_)])
+    lev = [tuple(int(math.ceil(Pz[a] / st[l][a])) for a in range(3)) for l in arch["decoder_levels"]]
+    c = arch["head_channels"]
+    m = ConvGroupRelu(3, c, c, 3, stride=1, padding=1, add_norm=False, add_act=False).to(device)
+    meta = PY.pyramid_meta([(batch, *s_) for s_ in lev])
+    x = torch.randn(meta.rows, c, device=device).to(dtype)
+    d = PY._items_desc(x, m, meta)
+    w0 = _packed(m, 0, m.conv.weight, d, dtype)
+    y = torch.empty(meta.rows, d.cout_p, dtype=dtype, device=device)
+    it = ctypes.byref(meta.items)
+    stq = L.stream()
+    f = lambda: L.call("nndet_conv3d_forward_items", ctypes.byref(d), it, L.ptr(x), L.ptr(w0), None, L.ptr(y), None, stq)
+    for _ in range(10):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * meta.rows * 27 * c * c
+    esz = x.element_size()
+    byts = meta.rows * 2 * c * esz + 27 * c * c * esz
+    tfs = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_ig3<%s, NT=16, ITEMS> conv3d 3x3x3 %d->%d over the pyramid levels %s x batch %d as one ragged batch (forward)"
+            % (str(dtype).replace("torch.", ""), c, c, "/".join("x".join(map(str, s_)) for s_ in lev), batch),
+            "achieved": round(tfs, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tfs / 2500.0, 4), "traffic": None,
+            "algorithmic_flops_per_launch": int(flops), "algorithmic_bytes_per_launch": int(byts), "ms_per_launch": round(float(ms), 4),
+            "flop_per_byte": round(flops / byts, 1), "launches_per_step": 8,
+            "note": "in isolation; inside the step the classifier / regressor trunks and the weight-gradient stream share the CUs"}
+
+
+def measure_traffic_pmc(timeout_s=150):
+    """HBM bytes per launch of the roofline kernel from the PMC counters, measured NOW: two rocprofv3 passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md "Counter slots") over tools/conv_microbench.py e0_32x32_full (the same
+    launch as `conv_roofline`), FETCH_SIZE doubled as the guide prescribes for gfx950 (wide coalesced reads are tallied at half
+    their bytes), both in KB. Returns None when rocprofv3 is not installed or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("NNDET_BENCH_PMC", "1") == "0":
+        return None
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="nndet_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", MICRO_ORDER="fwd", MICRO_ITERS="6")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "-d", out, "--", sys.executable, os.path.join(ROOT, "tools", "conv_microbench.py"), "e0_32x32_full"]
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            tot, n = 0.0, 0
+            for dbp in glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True):
+                db = sqlite3.connect(dbp)
+                cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+                kcol = "kernel_name" if "kernel_name" in cols else "name"
+                vcol = "value" if "value" in cols else "counter_value"
+                for k, c, v in db.execute(f"select {kcol}, counter_name, {vcol} from counters_collection"):
+                    if c == ctr and "k_ig3r" in k:
+                        tot += float(v); n += 1
+            if n == 0:
+                return None
+            vals[ctr] = (tot / n, n)
+        rd = vals["FETCH_SIZE"][0] * 1024.0 * 2.0
+        wr = vals["WRITE_SIZE"][0] * 1024.0
+        return {"hbm_bytes": int(rd + wr), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr), "dispatches": vals["FETCH_SIZE"][1],
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, measured in this run (FETCH_SIZE x 2: gfx950 correction)"}
+    except Exception as e:                                        # noqa: BLE001 -- any failure: fall back to the committed figure
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def conv_roofline(plan, batch, dtype, device, iters=50):
     """Dominant kernel: the 3x3x3 implicit-GEMM conv at full resolution (encoder.stages.0.convs.0.1 and
     decoder.out.P0 have this shape: 32 -> 32 channels, 135.9 GFLOP per patch each).
@@ -72,24 +323,38 @@ def conv_roofline(plan, batch, dtype, device, iters=50):
     # HBM traffic per launch from the PMC passes of the same kernel / shape (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate
     # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): measured by `tools/gpu_round.sh pmc`, committed
     # as profiles/round1_pmc_traffic.json together with the raw summary. Not re-measured inside this run (PMC needs rocprofv3).
-    traffic = None
-    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
-        tj = os.path.join(pdir, name)
-        if os.path.isfile(tj) and batch == 4 and tuple(P) == (160, 160, 96) and dtype == torch.bfloat16:
-            with open(tj) as f:
-                tr = json.load(f)
-                key = "k_ig3r_e0" if os.environ.get("NNDET_IG3R", "1") != "0" and "k_ig3r_e0" in tr else "k_ig3_cfgA_e0"
-                traffic = int(tr[key]["hbm_bytes"])
-            break
+    traffic, traffic_src = None, None
+    head = batch == 4 and tuple(P) == (160, 160, 96) and dtype == torch.bfloat16 and os.environ.get("NNDET_IG3R", "1") != "0"
+    if head and MEASURE_PMC[0]:
+        pm = measure_traffic_pmc()
+        if pm is not None and "hbm_bytes" in pm:
+            traffic, traffic_src = pm["hbm_bytes"], pm
+        elif pm is not None:
+            traffic_src = pm
+    if traffic is None:
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        for name in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+            tj = os.path.join(pdir, name)
+            if os.path.isfile(tj) and batch == 4 and tuple(P) == (160, 160, 96) and dtype == torch.bfloat16:
+                with open(tj) as f:
+                    tr = json.load(f)
+                    key = "k_ig3r_e0" if os.environ.get("NNDET_IG3R", "1") != "0" and "k_ig3r_e0" in tr else "k_ig3_cfgA_e0"
+                    traffic = int(tr[key]["hbm_bytes"])
+                    traffic_src = dict(traffic_src or {}, fallback="profiles/%s (committed PMC summary, NOT re-measured in this run)" % name)
+                break
     # 432 FLOP per algorithmic byte is above the MFMA/HBM ridge (2500 TF/s / 8 TB/s = 312): the kernel is priced against the
     # dense bf16 MFMA peak; the HBM view (algorithmic bytes / time) is reported next to it
-    kname = "k_ig3r<bf16> (persistent, weights in registers)" if os.environ.get("NNDET_IG3R", "1") != "0" else "k_ig3<bf16,WR=1,MT=2,NT=8>"
+    dn = str(dtype).replace("torch.", "").replace("bfloat16", "bf16").replace("float16", "f16").replace("float32", "f32")
+    kname = ("k_ig3r<%s> (persistent, weights in registers)" % dn) if (os.environ.get("NNDET_IG3R", "1") != "0" and dtype != torch.float32) \
+        else "k_ig3<%s,WR=1,MT=2,NT=8>" % dn
     return {"bound": "mfma", "kernel": kname + " conv3d 3x3x3 32->32 @%dx%dx%d, batch %d (forward)" % (*P, batch),
             "achieved": round(tfs, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tfs / 2500.0, 4),
-            "traffic": traffic, "algorithmic_flops_per_launch": int(flops), "algorithmic_bytes_per_launch": int(alg_bytes),
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops_per_launch": int(flops), "algorithmic_bytes_per_launch": int(alg_bytes),
             "ms_per_launch": round(float(ms), 4), "algorithmic_GBs": round(gbs, 1), "hbm_frac_of_8TBs": round(gbs / 8000.0, 4),
             "measured_mfma_ceiling_TFs": 1900.0}
+
+
+MEASURE_PMC = [True]
 
 
 def nms_rate(device, n=10000, iters=5):
@@ -195,10 +460,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--plan", default="luna160")
     ap.add_argument("--batch", type=int, default=None, help="patches per GPU (default: the plan's batch size, 4)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--via-plugin", action="store_true", help="the timed steps go through the plugin's training_step (batch dicts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-routes", action="store_true", help="skip the short plugin / fp32 / fp16 comparison runs")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes for roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / NMS / CPU legs (only the timed steps)")
     args = ap.parse_args()
+    MEASURE_PMC[0] = not args.no_pmc
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -217,72 +486,87 @@ def main():
     device = torch.device("cuda", local)
 
     from nndetection_amd.plans import get_plan
-    from nndetection_amd.ptmodule import build_model, configure_optimizer
     from nndetection_amd.ddp import GradAllReducer
 
     plan = get_plan(args.plan)
     batch = args.batch or plan["batch_size"]
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    torch.manual_seed(0)
-    net = build_model(plan).to(device)
-    opt, sched = configure_optimizer(net)
-    ddp = GradAllReducer(net, force_overlap=force_dist, overlap=os.environ.get("NNDET_DDP_OVERLAP", "1") != "0") if (world > 1 or force_dist) else None
-    x, tg = synth_batch(plan, batch, dtype, device, seed=1000 + rank)
-    torch.manual_seed(1234 + rank)
-
-    def step():
-        losses, _ = net.train_step(x, tg, evaluation=False, batch_num=0)
-        loss = sum(losses.values())
-        loss.backward()
-        if ddp is not None:
-            ddp.finish()
-        opt.step()
-        sched.step()
-        opt.zero_grad(set_to_none=True)
-        return loss
-
-    for _ in range(args.warmup):
-        last = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dtype = _TORCH_DT[args.dtype]
+    ddp_factory = None
+    if world > 1 or force_dist:
+        # bucket sizes / dtype: NNDET_DDP_FIRST_MB, NNDET_DDP_BUCKET_MB, NNDET_DDP_BF16 (the sweep switches, nndetection_amd/ddp.py)
+        ddp_factory = lambda net: GradAllReducer(net, force_overlap=force_dist, overlap=os.environ.get("NNDET_DDP_OVERLAP", "1") != "0",
+                                                 profile=os.environ.get("NNDET_DDP_PROFILE", "1") != "0")
+    route = Route(plan, batch, args.dtype, device, rank, args.via_plugin, ddp_factory)
+    net = route.net
+    dt, last = route.timed(args.warmup, args.steps, world)
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(last.detach().float().item())
     peak_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    ddp_prof = None
+    if route.ddp is not None and route.ddp.profile:
+        route.ddp.profile_collect()                      # (events of the timed AND warm-up steps; outside the timed region)
+        ddp_prof = route.ddp.profile_summary()
 
     if rank == 0:
+        ms_step = dt / args.steps * 1e3
         out = {
             "metric": "patches/sec (fwd+bwd) %dx%dx%d RetinaUNet" % tuple(plan["patch_size"]), "value": round(batch * world * args.steps / dt, 3),
             "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[1]: Task016_Luna-like plan (SURVEY 8)" if args.plan == "luna160" else
                                     "plan '%s' (not the headline configuration)" % args.plan) +
                                    ", RetinaUNetV001 train step (fwd + ATSS + losses + bwd + SGD), %dx%dx%d patches" % tuple(plan["patch_size"]),
                        "plan": args.plan, "batch_per_gpu": batch, "global_batch": batch * world,
-                       "parallelism": "dp%d" % world, "params": sum(p.numel() for p in net.parameters())},
+                       "parallelism": "dp%d" % world, "params": sum(p.numel() for p in net.parameters()),
+                       "route": "plugin training_step (batch dict -> device-side targets -> train_step)" if args.via_plugin else
+                                "BaseRetinaNet.train_step on prepared targets",
+                       "loss_scaling": "torch.amp.GradScaler (sync-free: fused SGD takes scale / found_inf on the device)" if route.scaler is not None else None},
             "final_loss": round(loss_val, 5), "peak_hbm_gib": round(peak_gb, 2),
         }
+        if route.scaler is not None:
+            out["grad_scale"] = float(route.scaler.get_scale())
+        if ddp_prof is not None:
+            out["ddp"] = ddp_prof
+        # whole-step roofline: algorithmic work of all convolutions / measured step time, per GPU
+        fl, by = step_algorithmic_work(net, plan, batch, 4 if args.dtype == "f32" else 2)
+        peak_tf = 2500.0 if args.dtype != "f32" else 157.3
+        out["step_roofline"] = {"algorithmic_flops_per_step": int(fl), "algorithmic_bytes_per_step": int(by),
+                                "achieved_TFLOPs": round(fl / (ms_step * 1e-3) / 1e12, 1), "mfma_peak_TFLOPs": peak_tf,
+                                "mfma_frac": round(fl / (ms_step * 1e-3) / 1e12 / peak_tf, 4),
+                                "achieved_GBs": round(by / (ms_step * 1e-3) / 1e9, 1), "hbm_peak_GBs": 8000.0,
+                                "hbm_frac": round(by / (ms_step * 1e-3) / 1e9 / 8000.0, 4),
+                                "floor_ms_mfma": round(fl / (peak_tf * 1e12) * 1e3, 3), "floor_ms_hbm": round(by / 8e12 * 1e3, 3),
+                                "note": "convolutions only: each reads its input and writes its output once, forward + data gradient + weight gradient; "
+                                        "norm / ReLU / loss / optimizer passes count as zero algorithmic bytes"}
         if not args.no_extras:
-            out["inference"] = inference_rate(net, x)
-            del x, tg
+            x_inf = route.batch["data"].to(dtype) if args.via_plugin else route.x
+            out["inference"] = inference_rate(net, x_inf)
+            del route, x_inf, net
             torch.cuda.empty_cache()
             out["roofline"] = conv_roofline(plan, batch, dtype, device)      # rank 0's GPU; the other ranks are done
+            out["roofline_dominant"] = head_trunk_roofline(plan, batch, dtype, device)
             out["nms"] = nms_rate(device)
+            if world == 1 and not args.no_routes:
+                # the other routes on short runs in this process: what the drop-in (plugin) delivers next to the direct route, the
+                # exact-fp32 kernels (north_star's 1e-4 parity path), fp16 + GradScaler (the reference's own precision=16)
+                routes = {}
+                for key, dn, vp in (("plugin_" + args.dtype, args.dtype, True), ("direct_f32", "f32", False),
+                                    ("plugin_f16_gradscaler", "f16", True), ("direct_" + args.dtype, args.dtype, False)):
+                    if key == "direct_" + args.dtype and not args.via_plugin:
+                        continue                                             # that IS the headline
+                    if key == "plugin_" + args.dtype and args.via_plugin:
+                        continue
+                    try:
+                        routes[key] = side_route(plan, batch, dn, device, vp)
+                        routes[key]["vs_headline"] = round(routes[key]["patches_per_s"] / out["value"], 4)
+                    except Exception as e:                                   # noqa: BLE001 -- a side leg must not cost the headline
+                        routes[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                out["routes"] = routes
             if not args.no_cpu_baseline and world == 1:                      # the CPU leg only at N = 1 (rank 0)
-                del net, opt, sched
                 torch.cuda.empty_cache()
                 out["cpu_baseline"], out["parity_check"] = cpu_baseline(plan, device)
         print(json.dumps(out), flush=True)

@@ -14,7 +14,10 @@
  *     (NNDET_EINVAL ...). Nothing is thrown.
  *   - boxes are fp32 (x1, y1, x2, y2, z1, z2), nndet/core/boxes/ops.py:131-159;
  *   - activations are NDHWC (channels-last-3d) with the channel count padded to a multiple of 32,
- *     dtype NNDET_BF16 or NNDET_F32; accumulation is always fp32.
+ *     dtype NNDET_BF16, NNDET_F16 or NNDET_F32; accumulation is always fp32. NNDET_F16 (IEEE half, round to nearest even) is the
+ *     storage type of the reference's own mixed-precision training: pl.Trainer(precision=16, amp_backend='native'),
+ *     scripts/train.py:277-278 -- convolutions under torch.autocast(float16), loss scaled by a GradScaler. The kernels neither
+ *     scale nor clamp: a value beyond 65504 becomes inf exactly as in the reference, and the caller's GradScaler skips the step.
  */
 #ifndef NNDET_AMD_H
 #define NNDET_AMD_H
@@ -32,6 +35,7 @@ extern "C" {
 
 #define NNDET_F32 0
 #define NNDET_BF16 1
+#define NNDET_F16 2
 
 const char* nndet_version(void);
 /* Number of bytes of LDS / registers are compile-time; this reports the arch the library was built for. */
@@ -196,7 +200,7 @@ int nndet_instances_to_targets_f32(const float* inst, int32_t B, int32_t D, int3
 #define NNDET_STATS_REPLICAS 32   /* stats buffers are [NNDET_STATS_REPLICAS][N][C_p][2] fp64 (atomic-contention spreading) */
 
 typedef struct NndetConv {
-    int32_t dtype;            /* NNDET_F32 | NNDET_BF16 (activations + packed weights) */
+    int32_t dtype;            /* NNDET_F32 | NNDET_BF16 | NNDET_F16 (activations + packed weights) */
     int32_t transposed;       /* 0: Conv3d, 1: ConvTranspose3d (requires kernel == stride, padding 0) */
     int32_t batch;
     int32_t cin, cout;        /* logical channels */

@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NNDET_AMD_LIB: another build of the same library (A/B measurements of two kernel versions in one gpurun call, tools/gpu_round.sh)
 LIB_PATH = os.environ.get("NNDET_AMD_LIB") or os.path.join(_HERE, "csrc", "libnndet_amd.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 STATS_REPLICAS = 32
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
 class NndetError(RuntimeError):
@@ -134,7 +134,20 @@ def dtype_code(t: torch.Tensor) -> int:
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise NndetError(f"unsupported activation dtype {t.dtype}; use float32 or bfloat16")
+        raise NndetError(f"unsupported activation dtype {t.dtype}; use float32, bfloat16 or float16")
+
+
+def autocast_input(x: torch.Tensor) -> torch.Tensor:
+    """B2: under `torch.autocast` the reference's convolutions run in the autocast dtype whatever the dtype of their
+    input (nndet/arch/conv.py:54-143 under pl.Trainer(precision=16)). The HIP kernels take their arithmetic type from the
+    activation tensor, so an fp32 CUDA activation that enters a conv block / the network inside an autocast region is cast to the
+    autocast dtype first (a differentiable torch cast); 16-bit inputs and everything outside autocast pass through unchanged."""
+    if x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled():
+        get = getattr(torch, "get_autocast_dtype", None)
+        dt = get("cuda") if get is not None else torch.get_autocast_gpu_dtype()
+        if dt in _DT:
+            return x.to(dt)
+    return x
 
 
 def ptr(t):

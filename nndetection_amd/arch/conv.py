@@ -360,6 +360,10 @@ class BaseConvNormAct(nn.Sequential):
         our own convolutions consume) the result is one: its norm + ReLU is applied by the consumers on load."""
         has_norm = self.norm_groups > 0
         d = deferred(x)
+        if d is None:
+            x = L.autocast_input(x)
+            if residual is not None and residual.dtype != x.dtype:
+                residual = residual.to(x.dtype)
         if d is not None and (self.transposed or self.in_channels == 1):
             x, d = materialize(x), None
         x_ss, x_relu = d if d is not None else (None, False)

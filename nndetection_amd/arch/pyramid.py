@@ -58,13 +58,13 @@ def supports(fmaps: Sequence[torch.Tensor], blocks: Sequence[torch.nn.Module]) -
     if len(fmaps) < 2 or not all(f.is_cuda and f.dim() == 5 for f in fmaps):
         return False
     f0 = fmaps[0]
-    if f0.dtype not in (torch.float32, torch.bfloat16):
+    if f0.dtype not in L._DT:
         return False
     if any(f.dtype != f0.dtype or f.shape[:2] != f0.shape[:2] for f in fmaps):
         return False
     if f0.shape[0] * len(fmaps) > L.MAX_ITEMS or f0.shape[1] == 1:
         return False
-    esz = 2 if f0.dtype == torch.bfloat16 else 4
+    esz = f0.element_size()
     cmax = cpad(f0.shape[1])
     for b in blocks:
         if not isinstance(b, BaseConvNormAct) or b.transposed or b.k != (3, 3, 3) or b.s != (1, 1, 1) or b.p != (1, 1, 1):

@@ -110,10 +110,15 @@ class DiCESegmenterFgBg(nn.Module):
 
     fused_tail = os.environ.get("NNDET_SEG_TAIL", "1") != "0"      # the scalar algebra on the four sums as one kernel (_SegTail)
 
+    def takes_fused_route(self, x: List[Tensor]) -> bool:
+        """Would forward(x, fused=True) hand the decoder map on unread (so that nothing of this module touches it on the caller's
+        stream)? BaseRetinaNet.forward decides its stream join from this."""
+        return bool(x[0].is_cuda and self.in_channels[0] <= 32 and os.environ.get("NNDET_SEG_FUSED", "1") != "0")
+
     def forward(self, x: List[Tensor], fused: bool = False) -> Dict[str, Tensor]:
         """fused=True (training steps that do not need the logits): hand the decoder map to compute_loss, which runs the output
         conv and the loss in one pass; else the logits as in the reference."""
-        if fused and x[0].is_cuda and self.in_channels[0] <= 32 and os.environ.get("NNDET_SEG_FUSED", "1") != "0":
+        if fused and self.takes_fused_route(x):
             return {"seg_input": x[0]}
         return {"seg_logits": self.conv_out(x[0])}
 

@@ -55,10 +55,11 @@ class BaseRetinaNet(nn.Module):
     # ------------------------------------------------------------------ forward (retina.py:198-226)
     def forward(self, inp: Tensor):
         L.arena_reset(inp.device)                # one fill for all per-layer statistics buffers of the previous step
+        inp = L.autocast_input(inp)              # under torch.autocast: the image in the autocast dtype (B2: conv in half precision)
         if inp.is_cuda:
             from ..arch.conv import prepack_all
             grad = torch.is_grad_enabled()
-            prepack_all(self, inp.dtype if inp.dtype in (torch.float32, torch.bfloat16) else torch.float32,
+            prepack_all(self, inp.dtype if inp.dtype in L._DT else torch.float32,
                         modes=(0, 1) if grad else (0,))        # all stale packed weights in one launch (after an optimizer step)
             if grad:                                           # one zero fill for every parameter-gradient accumulator of the step
                 if getattr(self, "_grad_numel", None) is None:
@@ -76,15 +77,20 @@ class BaseRetinaNet(nn.Module):
         pred_detection = self.head(feature_maps_head)
         anchors = self.anchor_generator(inp, feature_maps_head)
         pred_seg = None
+        fused = self.segmenter is not None and getattr(self, "_fuse_seg_head", False)
+        # does the segmenter consume level 0 on its side stream (fused head + loss, train_step) or on THIS stream (inference,
+        # evaluation, NNDET_SEG_FUSED=0, wide level 0)? Decided from what it will actually do, not from a flag a previous step may
+        # have left behind: only the former may skip the join with the decoder's tail stream.
+        seg_on_side = fused and getattr(self, "_seg_side", None) is not None and \
+            bool(getattr(self.segmenter, "takes_fused_route", lambda fm: False)(features_maps_all))
         if tail_ev is not None and inp.is_cuda:
-            if getattr(self, "_seg_side", None) is None:       # level 0 is consumed on this stream (inference, evaluation): join here,
+            if not seg_on_side:                                # level 0 is consumed on this stream: join here,
                 torch.cuda.current_stream(inp.device).wait_event(tail_ev)      # behind the head that was queued in the meantime
             for t in features_maps_all[:1]:
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream(inp.device))
         if self.segmenter is not None:
-            pred_seg = self.segmenter(features_maps_all, fused=True) if getattr(self, "_fuse_seg_head", False) \
-                else self.segmenter(features_maps_all)
+            pred_seg = self.segmenter(features_maps_all, fused=True) if fused else self.segmenter(features_maps_all)
         return pred_detection, anchors, pred_seg
 
     # Target assignment (ATSS on the anchors + GT boxes) does not depend on the network: with the anchors of the previous step with
@@ -103,28 +109,57 @@ class BaseRetinaNet(nn.Module):
 
     # ------------------------------------------------------------------ train step (retina.py:86-159)
     def train_step(self, images: Tensor, targets: dict, evaluation: bool, batch_num: int = 0):
-        target_boxes: List[Tensor] = targets["target_boxes"]
-        target_classes: List[Tensor] = targets["target_classes"]
-        target_seg: Tensor = targets["target_seg"]
+        """`targets`: the reference's dict (target_boxes, target_classes, target_seg) or a `core.targets.DeferredTargets`, whose
+        box lists become available on the host only after `resolve()`: then the forward pass is queued FIRST and the target
+        assignment afterwards (still under the forward pass on the GPU), so the one device -> host read of a plugin training step
+        does not drain the queue."""
+        from .targets import DeferredTargets
+        lazy = targets if isinstance(targets, DeferredTargets) else None
+        if lazy is None:
+            target_boxes: List[Tensor] = targets["target_boxes"]
+            target_classes: List[Tensor] = targets["target_classes"]
+            target_seg: Tensor = targets["target_seg"]
+        else:
+            target_boxes = target_classes = None
+            target_seg = lazy.target_seg
         # the segmentation logits are only materialised when a prediction is asked for (evaluation); else conv + loss are fused
         self._fuse_seg_head = (not evaluation) and torch.is_grad_enabled()
         overlap = self.overlap_aux and images.is_cuda
-        pre, main = None, None
+        pre, main, cached = None, None, None
         if overlap:
             main = torch.cuda.current_stream(images.device)
             cached = getattr(self, "_anchors_by_shape", {}).get(tuple(images.shape))
-            if cached is not None:
+            if cached is not None and lazy is None:
                 side = self._aux(images.device, 0)
                 side.wait_stream(main)                   # the targets (and everything of the previous step) are ready
                 with torch.cuda.stream(side):
                     pre = self.assign_targets_to_anchors(cached, target_boxes, target_classes)
+            elif cached is not None:
+                self._lazy_fork = torch.cuda.Event()
+                self._lazy_fork.record(main)             # the target tensors are ready here; the forward pass is queued behind it
         self._seg_side = self._aux(images.device, 1) if (overlap and self.segmenter is not None and self._fuse_seg_head) else None
         try:
-            pred_detection, anchors, pred_seg = self(images)
-        finally:
+            return self._train_step_body(images, lazy, target_boxes, target_classes, target_seg, evaluation, overlap, pre, main, cached)
+        finally:                                          # never leave the fork state behind for a later forward() / inference_step()
             self._fuse_seg_head = False
+            self._seg_side = None
+
+    def _train_step_body(self, images, lazy, target_boxes, target_classes, target_seg, evaluation, overlap, pre, main, cached):
+        pred_detection, anchors, pred_seg = self(images)
         if self._seg_side is not None and not (isinstance(pred_seg, dict) and "seg_input" in pred_seg):
-            self._seg_side = None                        # the segmenter did not take the fused route: stay on the main stream
+            # the segmenter did not take the fused route and read decoder level 0 on the main stream: forward() has joined the
+            # decoder's tail stream for it (see there); the loss stays on the main stream as well
+            self._seg_side = None
+        if lazy is not None:                             # the forward pass is queued: now read the instance counts
+            tg = lazy.resolve()
+            target_boxes, target_classes = tg["target_boxes"], tg["target_classes"]
+            if overlap and cached is not None and len(anchors) == len(cached) and all(a is c for a, c in zip(anchors, cached)):
+                side = self._aux(images.device, 0)
+                side.wait_event(self._lazy_fork)
+                with torch.cuda.stream(side):
+                    pre = self.assign_targets_to_anchors(cached, target_boxes, target_classes)
+                    for t in list(target_boxes) + list(target_classes):
+                        t.record_stream(side)
         if pre is not None and len(anchors) == len(cached) and all(a is c for a, c in zip(anchors, cached)):
             main.wait_stream(self._aux(images.device, 0))
             labels, matched_gt_boxes = pre

@@ -2,12 +2,12 @@
 #include "common.h"
 #include "conv_common.h"
 
-extern "C" const char* nndet_version(void) { return "nndetection_amd 0.1.0 (round 1)"; }
+extern "C" const char* nndet_version(void) { return "nndetection_amd 0.3.0 (round 3: f32 | bf16 | f16)"; }
 extern "C" const char* nndet_arch(void) { return "gfx950"; }
 
 static int check_conv(const NndetConv* c) {
     if (!c) return NNDET_EINVAL;
-    if (c->dtype != NNDET_F32 && c->dtype != NNDET_BF16) return NNDET_EINVAL;
+    if (c->dtype != NNDET_F32 && c->dtype != NNDET_BF16 && c->dtype != NNDET_F16) return NNDET_EINVAL;
     if (c->batch <= 0 || c->cin <= 0 || c->cout <= 0 || c->cin > c->cin_p || c->cout > c->cout_p) return NNDET_EINVAL;
     if (c->cout_p % 32) return NNDET_EINVAL;
     if (c->cin_p != 1 && c->cin_p % 32) return NNDET_EINVAL;

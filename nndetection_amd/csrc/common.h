@@ -44,6 +44,56 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
+// ---- fp16 (IEEE half, round-to-nearest-even conversions: what torch.autocast(float16) stores). The reference trains with
+// pl.Trainer(precision=16, amp_backend='native') (scripts/train.py:277-278), i.e. exactly this type.
+typedef _Float16 f16_t;
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
+}
+
+// 16-byte vector used for every global <-> LDS <-> register fragment move
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// Everything the kernels need to know about a 16-bit storage type T (bf16_t / f16_t): packed conversion of two floats, the two
+// halves of a packed pair as floats, 1.0 twice, the 16x16x32 MFMA. The kernels are written once against H16<T>.
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+    static constexpr uint32_t ONE2 = 0x3f803f80u;
+    __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    __device__ static __forceinline__ float lo(uint32_t u) { return __uint_as_float(u << 16); }
+    __device__ static __forceinline__ float hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+    __device__ static __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct H16<f16_t> {
+    static constexpr uint32_t ONE2 = 0x3c003c00u;
+    __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    __device__ static __forceinline__ float lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[0]; }
+    __device__ static __forceinline__ float hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[1]; }
+    __device__ static __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct H16<float> {   // never used: keeps discarded `if constexpr (sizeof(T) == 2)` branches well-formed
+    static constexpr uint32_t ONE2 = 0;
+    __device__ static __forceinline__ uint32_t pack2(float, float) { return 0; }
+    __device__ static __forceinline__ float lo(uint32_t) { return 0.f; }
+    __device__ static __forceinline__ float hi(uint32_t) { return 0.f; }
+    __device__ static __forceinline__ f32x4 mma(const u32x4&, const u32x4&, const f32x4& c) { return c; }
+};
+
+// run `F<T>` for the activation type a dtype code names (NNDET_F32 / NNDET_BF16 / NNDET_F16)
+#define NNDET_DISPATCH_DTYPE(dt, CALL)                                      \
+    ((dt) == NNDET_BF16 ? CALL(bf16_t) : (dt) == NNDET_F16 ? CALL(f16_t) : CALL(float))
+static inline int nndet_esize(int dt) { return dt == NNDET_F32 ? 4 : 2; }
+static inline bool nndet_is16(int dt) { return dt == NNDET_BF16 || dt == NNDET_F16; }
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     __device__ static __forceinline__ float ld(float v) { return v; }
@@ -53,11 +103,10 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ float ld(bf16_t v) { return bf16_to_f32(v); }
     __device__ static __forceinline__ bf16_t st(float v) { return f32_to_bf16(v); }
 };
-
-// 16-byte vector used for every global <-> LDS <-> register fragment move
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
+template <> struct Elem<f16_t> {
+    __device__ static __forceinline__ float ld(f16_t v) { return (float)v; }
+    __device__ static __forceinline__ f16_t st(float v) { return (f16_t)v; }
+};
 
 // Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2), so spatially adjacent tiles -- whose halos
 // overlap -- land on different L2s and every halo is fetched from HBM / Infinity Cache again (measured: 1.9x / 2.3x the

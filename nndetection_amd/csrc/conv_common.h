@@ -39,19 +39,18 @@ int norm_stats_run(int dtype, const void* x, int batch, int64_t spatial, int c_p
 // ---- deferred input normalisation (NndetConv.in_affine): x' = relu?(x * scale + shift) on one 16-byte piece while it is staged.
 // Exactly the arithmetic of k_norm_apply (fmaf, fmaxf, round-to-nearest-even pack), so a consumer that applies the norm on load
 // sees bit-identical activations to one that reads the materialised tensor.
-template <typename T> struct AffinePiece;
-template <> struct AffinePiece<bf16_t> {
+template <typename T> struct AffinePiece {       // the 16-bit storage types (bf16_t, f16_t: both sign-magnitude)
     static constexpr int E = 8;
-    // 20 VALU ops per piece: 8 unpack, 4 v_pk_fma_f32, 4 v_cvt_pk_bf16_f32, 4 v_pk_max_i16 (ReLU on the packed bf16 pair: a
-    // negative bf16 -- incl. -0 -- is a negative int16; rounding is monotone, so relu(round(x)) == round(relu(x)))
+    // 20 VALU ops per piece: 8 unpack, 4 v_pk_fma_f32, 4 v_cvt_pk_bf16_f32, 4 v_pk_max_i16 (ReLU on the packed pair: a
+    // negative bf16 / fp16 -- incl. -0 -- is a negative int16; rounding is monotone, so relu(round(x)) == round(relu(x)))
     __device__ static __forceinline__ u32x4 apply(const u32x4 v, const float* sc, const float* sh, int relu) {
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x2_t x = {__uint_as_float(v[i] << 16), __uint_as_float(v[i] & 0xffff0000u)};
+            const f32x2_t x = {H16<T>::lo(v[i]), H16<T>::hi(v[i])};
             const f32x2_t r = __builtin_elementwise_fma(x, f32x2_t{sc[2 * i], sc[2 * i + 1]}, f32x2_t{sh[2 * i], sh[2 * i + 1]});
-            uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
+            uint32_t p = H16<T>::pack2(r[0], r[1]);
             if (relu) p = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));
             o[i] = p;
         }

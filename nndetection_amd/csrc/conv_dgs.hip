@@ -16,22 +16,17 @@
 #include "common.h"
 #include "conv_common.h"
 
-typedef __bf16 dgs_bf16x8 __attribute__((ext_vector_type(8)));
-
-template <typename T> struct DgMma;
-template <> struct DgMma<bf16_t> {
+template <typename T> struct DgMma {     // the 16-bit storage types (bf16_t, f16_t)
     static constexpr int KC = 32, EPL = 8;
-    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dgs_bf16x8, a), __builtin_bit_cast(dgs_bf16x8, b), c, 0, 0, 0);
-    }
-    __device__ static __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
-        uint2 v; v.x = pack_bf16x2(a, b); v.y = pack_bf16x2(c, d);
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) { c = H16<T>::mma(a, b, c); }
+    __device__ static __forceinline__ void store4(T* p, float a, float b, float c, float d) {
+        uint2 v; v.x = H16<T>::pack2(a, b); v.y = H16<T>::pack2(c, d);
         *reinterpret_cast<uint2*>(p) = v;
     }
-    __device__ static __forceinline__ void load4(const bf16_t* p, float* v) {
+    __device__ static __forceinline__ void load4(const T* p, float* v) {
         const uint2 u = *reinterpret_cast<const uint2*>(p);
-        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        v[0] = H16<T>::lo(u.x); v[1] = H16<T>::hi(u.x);
+        v[2] = H16<T>::lo(u.y); v[3] = H16<T>::hi(u.y);
     }
 };
 template <> struct DgMma<float> {
@@ -224,10 +219,10 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 1) void k_dgs(const DgsArgs A) {
                         for (int h = 0; h < 2; ++h) {
                             float v0 = acc[g][i + h][j][0], v1 = acc[g][i + h][j][1], v2 = acc[g][i + h][j][2], v3 = acc[g][i + h][j][3];
                             if (rsn) {
-                                v0 += __uint_as_float(rk[h][0] << 16); v1 += __uint_as_float(rk[h][0] & 0xffff0000u);
-                                v2 += __uint_as_float(rk[h][1] << 16); v3 += __uint_as_float(rk[h][1] & 0xffff0000u);
+                                v0 += H16<T>::lo(rk[h][0]); v1 += H16<T>::hi(rk[h][0]);
+                                v2 += H16<T>::lo(rk[h][1]); v3 += H16<T>::hi(rk[h][1]);
                             }
-                            pk[h][0] = pack_bf16x2(v0, v1); pk[h][1] = pack_bf16x2(v2, v3);
+                            pk[h][0] = H16<T>::pack2(v0, v1); pk[h][1] = H16<T>::pack2(v2, v3);
                         }
                         const dgs_v2u s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                         const dgs_v2u s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
@@ -264,8 +259,8 @@ int dgs_covers(const NndetConv* c) {
         strided |= c->s[i] == 2;
     }
     if (!strided) return 0;
-    const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
-    const int kcb = c->dtype == NNDET_BF16 ? 32 : 16;
+    const int esz = nndet_esize(c->dtype);
+    const int kcb = nndet_is16(c->dtype) ? 32 : 16;
     int hv = 1;
     const int T[3] = {DGS_TD, DGS_TH, DGS_TW};
     for (int i = 0; i < 3; ++i) hv *= T[i] + (c->s[i] == 2 ? 1 : 2);
@@ -343,17 +338,18 @@ int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, 
         C.ntap = ntaps - C.tap0;
     }
     a.ncls = ncls;
-    const int kcb = c->dtype == NNDET_BF16 ? 32 : 16;
+    const int kcb = nndet_is16(c->dtype) ? 32 : 16;
     const int nchunk = a.K / kcb;
     const size_t lds = (size_t)a.chb * nchunk;
     const int pieces = ceil_div(hv * 4 * nchunk, 256);
     const int mt = (a.R % 64 == 0 && lds > 70 * 1024) ? 4 : 2;     // one workgroup per CU anyway: 64 rows per workgroup halve the staging
     const dim3 grid(a.nt[0] * a.nt[1] * a.nt[2], a.R / (mt * 16), a.N);
-    const bool bf = c->dtype == NNDET_BF16;
+    const int dt = c->dtype;
     const bool g2 = c->s[2] == 2;          // classes are enumerated with the W parity fastest: (2k, 2k + 1) differ in cw only
-#define DGS_GO(MT_, MP_) (g2 ? (bf ? dgs_launch<bf16_t, MT_, MP_, 2>(a, grid, lds, st) : dgs_launch<float, MT_, MP_, 2>(a, grid, lds, st)) \
-                             : (bf ? dgs_launch<bf16_t, MT_, MP_, 1>(a, grid, lds, st) : dgs_launch<float, MT_, MP_, 1>(a, grid, lds, st)))
+#define DGS_T(T_, MT_, MP_) (g2 ? dgs_launch<T_, MT_, MP_, 2>(a, grid, lds, st) : dgs_launch<T_, MT_, MP_, 1>(a, grid, lds, st))
+#define DGS_GO(MT_, MP_) (dt == NNDET_BF16 ? DGS_T(bf16_t, MT_, MP_) : dt == NNDET_F16 ? DGS_T(f16_t, MT_, MP_) : DGS_T(float, MT_, MP_))
     if (pieces <= 16) return mt == 2 ? DGS_GO(2, 16) : DGS_GO(4, 16);
     return mt == 2 ? DGS_GO(2, 32) : DGS_GO(4, 32);
 #undef DGS_GO
+#undef DGS_T
 }

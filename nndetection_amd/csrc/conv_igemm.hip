@@ -26,17 +26,13 @@
 #include "common.h"
 #include "conv_common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int v2u_t __attribute__((__vector_size__(8)));
 typedef unsigned int v4u_t __attribute__((__vector_size__(16)));
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
+template <typename T> struct Mma {     // the 16-bit storage types (bf16_t, f16_t)
     static constexpr int KC = 32;   // channels per 64-byte chunk
     static constexpr int EPL = 8;   // elements per 16-byte fragment
-    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) { c = H16<T>::mma(a, b, c); }
 };
 template <> struct Mma<float> {
     static constexpr int KC = 16;
@@ -51,27 +47,25 @@ template <> struct Mma<float> {
 };
 
 // stores 4 consecutive channels and returns (through a..d) the values as stored (i.e. rounded to T)
-template <typename T> __device__ __forceinline__ void store4r(T* p, float& a, float& b, float& c, float& d);
+template <typename T> __device__ __forceinline__ void store4r(T* p, float& a, float& b, float& c, float& d) {   // 16-bit types
+    uint2 v;
+    v.x = H16<T>::pack2(a, b);
+    v.y = H16<T>::pack2(c, d);
+    *reinterpret_cast<uint2*>(p) = v;
+    a = H16<T>::lo(v.x); b = H16<T>::hi(v.x);
+    c = H16<T>::lo(v.y); d = H16<T>::hi(v.y);
+}
 template <> __device__ __forceinline__ void store4r<float>(float* p, float& a, float& b, float& c, float& d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
-template <> __device__ __forceinline__ void store4r<bf16_t>(bf16_t* p, float& a, float& b, float& c, float& d) {
-    uint2 v;
-    v.x = pack_bf16x2(a, b);
-    v.y = pack_bf16x2(c, d);
-    *reinterpret_cast<uint2*>(p) = v;
-    a = __uint_as_float(v.x << 16); b = __uint_as_float(v.x & 0xffff0000u);
-    c = __uint_as_float(v.y << 16); d = __uint_as_float(v.y & 0xffff0000u);
-}
 
-template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* v) {   // 16-bit types
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = H16<T>::lo(u.x); v[1] = H16<T>::hi(u.x);
+    v[2] = H16<T>::lo(u.y); v[3] = H16<T>::hi(u.y);
+}
 template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
     const float4 f = *reinterpret_cast<const float4*>(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-}
-template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
-    const uint2 u = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
 }
 
 // max 16-byte halo pieces per thread per chunk: 16 (halo <= 1024 voxels = 64 KiB) for unit-stride tiles,
@@ -370,10 +364,10 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
                     load4<T>(reinterpret_cast<const T*>(A.res) + (yo - yb) + r0, r4);
                     v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
                 }
-                pk[i][0] = pack_bf16x2(v0, v1); pk[i][1] = pack_bf16x2(v2, v3);
+                pk[i][0] = H16<T>::pack2(v0, v1); pk[i][1] = H16<T>::pack2(v2, v3);
                 if (A.stats && valid) {
-                    v0 = __uint_as_float(pk[i][0] << 16); v1 = __uint_as_float(pk[i][0] & 0xffff0000u);
-                    v2 = __uint_as_float(pk[i][1] << 16); v3 = __uint_as_float(pk[i][1] & 0xffff0000u);
+                    v0 = H16<T>::lo(pk[i][0]); v1 = H16<T>::hi(pk[i][0]);
+                    v2 = H16<T>::lo(pk[i][1]); v3 = H16<T>::hi(pk[i][1]);
                     ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
                     ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
                 }
@@ -441,27 +435,25 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 // pd = wc * NT / 4 + (j >> 2).
 // 4 consecutive channels through a buffer descriptor (voffset = lane byte offset, soffset = scalar byte offset); the store
 // returns the values as stored (rounded to T) like store4r
-template <typename T, typename R> __device__ __forceinline__ void buf_store4r(R rs, int vo, int so, float& a, float& b, float& c, float& d);
-template <typename T, typename R> __device__ __forceinline__ void buf_load4(R rs, int vo, int so, float* v);
+template <typename T> __device__ __forceinline__ void buf_store4r(__amdgpu_buffer_rsrc_t rs, int vo, int so, float& a, float& b, float& c, float& d) {
+    v2u_t v;                                                                                        // 16-bit types
+    v[0] = H16<T>::pack2(a, b);
+    v[1] = H16<T>::pack2(c, d);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, vo, so, 0);
+    a = H16<T>::lo(v[0]); b = H16<T>::hi(v[0]);
+    c = H16<T>::lo(v[1]); d = H16<T>::hi(v[1]);
+}
 template <> __device__ __forceinline__ void buf_store4r<float>(__amdgpu_buffer_rsrc_t rs, int vo, int so, float& a, float& b, float& c, float& d) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, f32x4{a, b, c, d}), rs, vo, so, 0);
 }
-template <> __device__ __forceinline__ void buf_store4r<bf16_t>(__amdgpu_buffer_rsrc_t rs, int vo, int so, float& a, float& b, float& c, float& d) {
-    v2u_t v;
-    v[0] = pack_bf16x2(a, b);
-    v[1] = pack_bf16x2(c, d);
-    __builtin_amdgcn_raw_buffer_store_b64(v, rs, vo, so, 0);
-    a = __uint_as_float(v[0] << 16); b = __uint_as_float(v[0] & 0xffff0000u);
-    c = __uint_as_float(v[1] << 16); d = __uint_as_float(v[1] & 0xffff0000u);
+template <typename T> __device__ __forceinline__ void buf_load4(__amdgpu_buffer_rsrc_t rs, int vo, int so, float* v) {   // 16-bit types
+    const v2u_t u = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+    v[0] = H16<T>::lo(u[0]); v[1] = H16<T>::hi(u[0]);
+    v[2] = H16<T>::lo(u[1]); v[3] = H16<T>::hi(u[1]);
 }
 template <> __device__ __forceinline__ void buf_load4<float>(__amdgpu_buffer_rsrc_t rs, int vo, int so, float* v) {
     const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
     v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
-}
-template <> __device__ __forceinline__ void buf_load4<bf16_t>(__amdgpu_buffer_rsrc_t rs, int vo, int so, float* v) {
-    const v2u_t u = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
-    v[0] = __uint_as_float(u[0] << 16); v[1] = __uint_as_float(u[0] & 0xffff0000u);
-    v[2] = __uint_as_float(u[1] << 16); v[3] = __uint_as_float(u[1] & 0xffff0000u);
 }
 
 __device__ __forceinline__ float dpp_row_sum(float v) {   // sum over the 16 lanes of a DPP row, result in every lane
@@ -662,10 +654,10 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
                     buf_load4<T>(rrs, valid ? vb + i * 16 * (int)sizeof(T) : (int)0x80000000, so, r4);
                     v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
                 }
-                pk[i][0] = pack_bf16x2(v0, v1); pk[i][1] = pack_bf16x2(v2, v3);
+                pk[i][0] = H16<T>::pack2(v0, v1); pk[i][1] = H16<T>::pack2(v2, v3);
                 if (A.stats && valid) {
-                    v0 = __uint_as_float(pk[i][0] << 16); v1 = __uint_as_float(pk[i][0] & 0xffff0000u);
-                    v2 = __uint_as_float(pk[i][1] << 16); v3 = __uint_as_float(pk[i][1] & 0xffff0000u);
+                    v0 = H16<T>::lo(pk[i][0]); v1 = H16<T>::hi(pk[i][0]);
+                    v2 = H16<T>::lo(pk[i][1]); v3 = H16<T>::hi(pk[i][1]);
                     ssum[i][0] += v0; ssum[i][1] += v1; ssum[i][2] += v2; ssum[i][3] += v3;
                     ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
                 }
@@ -764,7 +756,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, int voff, u
 #ifndef IG3R_DBG
 #define IG3R_DBG 0      // timing experiments only (wrong results): 1 no LDS-DMA in the loop, 2 no epilogue, 4 no tile barrier
 #endif
-template <bool STATS>
+template <typename T, bool STATS>     // T: bf16_t / f16_t (same 16x16x32 MFMA shape and fragment layout, only the mnemonic differs)
 __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
     constexpr int HH = 10, HW = 10, BUF = 65536, NPIECE = 16;
     constexpr int NM = STATS ? 39 : 15;                      // epilogue micro-ops per point tile (= the two row-tile accumulators of 16 points)
@@ -891,14 +883,14 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
     v4u_t est;
     auto epi_on = [&](float (&ev)[2][4], uint32_t (&epk)[2][2], v4u_t& est, int j, int m, __amdgpu_buffer_rsrc_t yrs, int soff) {
         if (m < 8) ev[m >> 2][m & 3] = acc[m >> 2][j][m & 3] + bia[m >> 2][m & 3];
-        else if (m < 12) { const int i = (m - 8) >> 1, h = (m - 8) & 1; epk[i][h] = pack_bf16x2(ev[i][2 * h], ev[i][2 * h + 1]); }
+        else if (m < 12) { const int i = (m - 8) >> 1, h = (m - 8) & 1; epk[i][h] = H16<T>::pack2(ev[i][2 * h], ev[i][2 * h + 1]); }
         else if (m < 14) {
             const int h = m - 12;
             const v2u_t r = __builtin_amdgcn_permlane16_swap(epk[0][h], epk[1][h], false, false);
             est[h] = r[0]; est[2 + h] = r[1];
         }
         else if (m == 14) __builtin_amdgcn_raw_buffer_store_b128(est, yrs, vlane, soff, 0);
-        else if (m < 23) { const int i = (m - 15) >> 2, r = (m - 15) & 3; ev[i][r] = __uint_as_float((r & 1) ? (epk[i][r >> 1] & 0xffff0000u) : (epk[i][r >> 1] << 16)); }
+        else if (m < 23) { const int i = (m - 15) >> 2, r = (m - 15) & 3; ev[i][r] = (r & 1) ? H16<T>::hi(epk[i][r >> 1]) : H16<T>::lo(epk[i][r >> 1]); }
         else if (m < 31) { const int i = (m - 23) >> 2, r = (m - 23) & 3; ssum[i][r] += ev[i][r]; }
         else { const int i = (m - 31) >> 2, r = (m - 31) & 3; ssq[i][r] = fmaf(ev[i][r], ev[i][r], ssq[i][r]); }
     };
@@ -950,8 +942,13 @@ __global__ __launch_bounds__(256, 1) void k_ig3r(const Ig3rArgs A) {
                     // weights as AGPR operands (asm: the builtin form keeps them in VGPRs, i.e. 262 v_accvgpr_read + 104 s_nop per tile
                     // for the 60+ registers that do not fit); first tap: C = inline 0. Hazards: B comes from ds_read (counted wait by
                     // the compiler), an accumulator is next read >= 8 MFMA slots after its last MFMA
-                    if (tp == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[i][gph * 4 + jj]) : "a"(wr[tp][i]), "v"(bf[h % RING][jj]));
-                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][gph * 4 + jj]) : "a"(wr[tp][i]), "v"(bf[h % RING][jj]));
+                    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) {
+                        if (tp == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(acc[i][gph * 4 + jj]) : "a"(wr[tp][i]), "v"(bf[h % RING][jj]));
+                        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][gph * 4 + jj]) : "a"(wr[tp][i]), "v"(bf[h % RING][jj]));
+                    } else {
+                        if (tp == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[i][gph * 4 + jj]) : "a"(wr[tp][i]), "v"(bf[h % RING][jj]));
+                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][gph * 4 + jj]) : "a"(wr[tp][i]), "v"(bf[h % RING][jj]));
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     // fillers of this MFMA slot
                     if (s < 4) {
@@ -1091,7 +1088,7 @@ static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[
 static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = false) {
     IgArgs& a = P->a;
     memset(&a, 0, sizeof(a));
-    const int KCb = c->dtype == NNDET_BF16 ? 32 : 16;
+    const int KCb = nndet_is16(c->dtype) ? 32 : 16;
     const bool tr = c->transposed != 0;
     if (tr) for (int i = 0; i < 3; ++i) if (c->k[i] != c->s[i] || c->p[i] != 0) return NNDET_EINVAL;
     // which tensor is read / written
@@ -1207,7 +1204,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = f
         if (a.in_step[2] == 2) { a.deint = 1; a.HWE = (a.H[2] + 1) / 2; }
     }
     {
-        const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
+        const int esz = nndet_esize(c->dtype);
         const int64_t tapb = (int64_t)a.Cy * a.Cx * esz;
         const int64_t wb = tapb * (c->k[0] * c->k[1] * c->k[2]);
         if (wb >= (1LL << 31)) return NNDET_EINVAL;
@@ -1244,9 +1241,9 @@ static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = f
         }
         double pg = 1.0, ps = 1.0;
         for (int i = 0; i < 3; ++i) { pg *= (double)a.nt[i] * a.T[i]; ps *= (double)ceil_div(Lmax[i], st[i]) * st[i]; }
-        const int64_t img_b = (int64_t)a.I[0] * a.I[1] * a.I[2] * a.Cx * (c->dtype == NNDET_BF16 ? 2 : 4);
-        const int64_t w_b = (int64_t)27 * a.Cy * a.Cx * (c->dtype == NNDET_BF16 ? 2 : 4);
-        const int64_t out_b = (int64_t)a.O[0] * a.O[1] * a.O[2] * a.Cy * (c->dtype == NNDET_BF16 ? 2 : 4);
+        const int64_t img_b = (int64_t)a.I[0] * a.I[1] * a.I[2] * a.Cx * nndet_esize(c->dtype);
+        const int64_t w_b = (int64_t)27 * a.Cy * a.Cx * nndet_esize(c->dtype);
+        const int64_t out_b = (int64_t)a.O[0] * a.O[1] * a.O[2] * a.Cy * nndet_esize(c->dtype);
         if ((ps <= 1.05 * pg || spec_on == 2) && img_b < (1LL << 31) && w_b < (1LL << 31) && out_b < (1LL << 31)) {   // 32-bit buffer offsets
             P->cfg = spec_cfg;
             for (int i = 0; i < 3; ++i) { a.T[i] = st[i]; a.H[i] = st[i] + 2; a.nt[i] = ceil_div(Lmax[i], st[i]); }
@@ -1308,6 +1305,9 @@ static int ensure_attrs() {
     rc |= set_lds_attr<float, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<float, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<float, 2, 1, 2, 16, 4, true>();
     rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<bf16_t, 2, 2, 16, 2>();
     rc |= set_lds_attr3<float, 1, 2, 8, 2>(); rc |= set_lds_attr3<float, 2, 2, 8, 3>(); rc |= set_lds_attr3<float, 2, 2, 16, 2>();
+    rc |= set_lds_attr<f16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<f16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<f16_t, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<f16_t, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<f16_t, 1, 2, 4, 16, 4>();
+    rc |= set_lds_attr<f16_t, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<f16_t, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<f16_t, 2, 1, 2, 16, 4, true>();
+    rc |= set_lds_attr3<f16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<f16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<f16_t, 2, 2, 16, 2>();
     if (rc) return rc;
     g_attr_done = 1;
     return 0;
@@ -1319,20 +1319,22 @@ static bool ig3r_applicable(const NndetConv* c, const Plan& P) {
     const char* e = getenv("NNDET_IG3R");
     if (e && atoi(e) == 0) return false;
     const IgArgs& a = P.a;
-    if (c->dtype != NNDET_BF16 || P.cfg != 5 || a.Cx != 32 || a.Cy != 32) return false;
+    if (!nndet_is16(c->dtype) || P.cfg != 5 || a.Cx != 32 || a.Cy != 32) return false;
     for (int i = 0; i < 3; ++i) if (a.I[i] != a.O[i] || (a.I[i] % 8) != 0) return false;
     const int64_t total = (int64_t)a.N * (a.I[0] / 8) * (a.I[1] / 8) * (a.I[2] / 8);
     const int64_t min_tiles = (e && atoi(e) == 2) ? 1 : 2048;           // 2 = always (tests)
     return total >= min_tiles && total < (1 << 24);
 }
-static int ig3r_launch(const Plan& P, hipStream_t st) {
+static int ig3r_launch(const Plan& P, int dtype, hipStream_t st) {
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) return (int)hipErrorInvalidValue;
         n_cu = v & ~7;
-        int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3r<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
-        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3r<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+        int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3r<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3r<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3r<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3r<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
         if (rc) { n_cu = 0; return rc; }
     }
     const IgArgs& a = P.a;
@@ -1350,7 +1352,8 @@ static int ig3r_launch(const Plan& P, hipStream_t st) {
     const char* ge = getenv("NNDET_IG3R_GRID");                        // tests: few workgroups -> many tiles (and images) per workgroup
     if (ge && atoi(ge) >= 8) grid = atoi(ge) & ~7;
     while (grid > 8 && (grid / 8) > r.per_xcd) grid -= 8;
-    if (r.stats) k_ig3r<true><<<grid, 256, 2 * 65536, st>>>(r); else k_ig3r<false><<<grid, 256, 2 * 65536, st>>>(r);
+    if (dtype == NNDET_F16) { if (r.stats) k_ig3r<f16_t, true><<<grid, 256, 2 * 65536, st>>>(r); else k_ig3r<f16_t, false><<<grid, 256, 2 * 65536, st>>>(r); }
+    else { if (r.stats) k_ig3r<bf16_t, true><<<grid, 256, 2 * 65536, st>>>(r); else k_ig3r<bf16_t, false><<<grid, 256, 2 * 65536, st>>>(r); }
     LAUNCH_CHECK();
     return 0;
 }
@@ -1377,9 +1380,11 @@ int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const 
         if (c->transposed) return NNDET_EINVAL;
         P.a.ss = c->in_affine; P.a.ss_relu = c->in_relu;
     }
-    if (!P.a.ss && !res && ig3r_applicable(c, P)) return ig3r_launch(P, st);
-    if (P.a.ss) return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t, true>(P, st) : launch_cfg<float, true>(P, st);
-    return c->dtype == NNDET_BF16 ? launch_cfg<bf16_t, false>(P, st) : launch_cfg<float, false>(P, st);
+    if (!P.a.ss && !res && ig3r_applicable(c, P)) return ig3r_launch(P, c->dtype, st);
+#define IG_CFG_SS(T_) launch_cfg<T_, true>(P, st)
+#define IG_CFG_NS(T_) launch_cfg<T_, false>(P, st)
+    if (P.a.ss) return NNDET_DISPATCH_DTYPE(c->dtype, IG_CFG_SS);
+    return NNDET_DISPATCH_DTYPE(c->dtype, IG_CFG_NS);
 }
 
 // ------------------------------------------------------------------------------------------------ ragged batches (NndetItems)
@@ -1402,7 +1407,7 @@ int items_check(const NndetConv* c, const NndetItems* it) {
     if (!c || !it || it->n_items < 1 || it->n_items > NNDET_MAX_ITEMS) return NNDET_EINVAL;
     if (c->transposed || c->in_affine || c->cin_p % 32 || c->cout_p % 32) return NNDET_EINVAL;
     for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 1 || c->p[i] != 1) return NNDET_EINVAL;
-    const int esz = c->dtype == NNDET_BF16 ? 2 : 4;
+    const int esz = nndet_esize(c->dtype);
     const int cmax = c->cin_p > c->cout_p ? c->cin_p : c->cout_p;
     for (int i = 0; i < it->n_items; ++i) {
         const int32_t* d = it->dims[i];
@@ -1440,7 +1445,8 @@ int igemm_items_run(const NndetConv* c, const NndetItems* it, int kind, const vo
         if (t > max_tiles) max_tiles = t;
     }
     P.grid.x = max_tiles;                       // (the bounding volume of items with different aspect ratios could ask for more)
-    return c->dtype == NNDET_BF16 ? launch_items<bf16_t>(P, ig, st) : launch_items<float>(P, ig, st);
+#define IG_ITEMS(T_) launch_items<T_>(P, ig, st)
+    return NNDET_DISPATCH_DTYPE(c->dtype, IG_ITEMS);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -1484,6 +1490,8 @@ extern "C" int nndet_pack_weight(const NndetConv* c, int32_t mode, const float* 
     const unsigned nb = (unsigned)ceil_div64(total, 256);
     if (c->dtype == NNDET_BF16)
         k_pack<bf16_t><<<nb, 256, 0, as_stream(stream)>>>(w, (bf16_t*)packed, R, K, Rp, Kp, taps, sr, sk, total);
+    else if (c->dtype == NNDET_F16)
+        k_pack<f16_t><<<nb, 256, 0, as_stream(stream)>>>(w, (f16_t*)packed, R, K, Rp, Kp, taps, sr, sk, total);
     else
         k_pack<float><<<nb, 256, 0, as_stream(stream)>>>(w, (float*)packed, R, K, Rp, Kp, taps, sr, sk, total);
     LAUNCH_CHECK();
@@ -1507,6 +1515,7 @@ __global__ __launch_bounds__(256) void k_pack_batched(const PackJobs J) {
         float v = 0.f;
         if (r < job.R && k < job.K) v = job.w[r * job.sr + k * job.sk + t];
         if (job.dtype == NNDET_BF16) reinterpret_cast<bf16_t*>(job.out)[i] = f32_to_bf16(v);
+        else if (job.dtype == NNDET_F16) reinterpret_cast<f16_t*>(job.out)[i] = (f16_t)v;
         else reinterpret_cast<float*>(job.out)[i] = v;
     }
 }

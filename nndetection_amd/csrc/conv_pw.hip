@@ -14,22 +14,17 @@
 #include "common.h"
 #include "conv_common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-template <typename T> struct PwMma;
-template <> struct PwMma<bf16_t> {
+template <typename T> struct PwMma {     // the 16-bit storage types (bf16_t, f16_t)
     static constexpr int KC = 32, EPL = 8;
-    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-    __device__ static __forceinline__ void store4(bf16_t* p, const f32x4& v) {
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) { c = H16<T>::mma(a, b, c); }
+    __device__ static __forceinline__ void store4(T* p, const f32x4& v) {
         uint2 u;
-        u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+        u.x = H16<T>::pack2(v[0], v[1]); u.y = H16<T>::pack2(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = u;
     }
-    __device__ static __forceinline__ f32x4 load4(const bf16_t* p) {
+    __device__ static __forceinline__ f32x4 load4(const T* p) {
         const uint2 u = *reinterpret_cast<const uint2*>(p);
-        return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+        return f32x4{H16<T>::lo(u.x), H16<T>::hi(u.x), H16<T>::lo(u.y), H16<T>::hi(u.y)};
     }
 };
 template <> struct PwMma<float> {
@@ -46,12 +41,11 @@ template <> struct PwMma<float> {
 };
 
 // column sums of the streamed operand (fused bias gradient): add the EPL channel values of one fragment to per-lane sums
-template <typename T> __device__ __forceinline__ void pw_accum(const u32x4& v, float* acc, float w);
-template <> __device__ __forceinline__ void pw_accum<bf16_t>(const u32x4& v, float* acc, float w) {
+template <typename T> __device__ __forceinline__ void pw_accum(const u32x4& v, float* acc, float w) {   // 16-bit types
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        acc[2 * i] += w * __uint_as_float(v[i] << 16);
-        acc[2 * i + 1] += w * __uint_as_float(v[i] & 0xffff0000u);
+        acc[2 * i] += w * H16<T>::lo(v[i]);
+        acc[2 * i + 1] += w * H16<T>::hi(v[i]);
     }
 }
 template <> __device__ __forceinline__ void pw_accum<float>(const u32x4& v, float* acc, float w) {
@@ -199,7 +193,7 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
                                     const f32x4 r4 = M::load4(rb + o * A.Cy + row0 + q * 4 + (i + h) * 16);
                                     v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
                                 }
-                                pk[h][0] = pack_bf16x2(v[0], v[1]); pk[h][1] = pack_bf16x2(v[2], v[3]);
+                                pk[h][0] = H16<T>::pack2(v[0], v[1]); pk[h][1] = H16<T>::pack2(v[2], v[3]);
                             }
                             const pw_v2u s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                             const pw_v2u s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
@@ -261,8 +255,8 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
                     typedef unsigned int pw_v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
                     for (int i = 0; i < MT; i += 2) {
-                        const pw_v2u s0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[i][0], acc[i][1]), pack_bf16x2(acc[i + 1][0], acc[i + 1][1]), false, false);
-                        const pw_v2u s1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[i][2], acc[i][3]), pack_bf16x2(acc[i + 1][2], acc[i + 1][3]), false, false);
+                        const pw_v2u s0 = __builtin_amdgcn_permlane16_swap(H16<T>::pack2(acc[i][0], acc[i][1]), H16<T>::pack2(acc[i + 1][0], acc[i + 1][1]), false, false);
+                        const pw_v2u s1 = __builtin_amdgcn_permlane16_swap(H16<T>::pack2(acc[i][2], acc[i][3]), H16<T>::pack2(acc[i + 1][2], acc[i + 1][3]), false, false);
                         if (ok) *reinterpret_cast<u32x4*>(yb + p * A.Cy + row0 + i * 16 + (q >> 1) * 8 + (q & 1) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                     }
                 } else if (ok) {
@@ -334,7 +328,7 @@ static int pw_plan(const NndetConv* c, int kind, const void* x, const void* w, c
         if (c->p[i] != 0 || c->k[i] != c->s[i]) return 1;
         if (!tr && c->k[i] != 1) return 1;
     }
-    const int esz = c->dtype == NNDET_BF16 ? 2 : 4, KC = c->dtype == NNDET_BF16 ? 32 : 16;
+    const int esz = nndet_esize(c->dtype), KC = nndet_is16(c->dtype) ? 32 : 16;
     memset(&A, 0, sizeof(A));
     A.x = x; A.w = w; A.bias = bias; A.res = res; A.y = y;
     const int ncls = c->k[0] * c->k[1] * c->k[2];
@@ -388,7 +382,8 @@ int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const flo
     size_t lds;
     const int rc = pw_plan(c, kind, x, w, bias, res, y, dbias, &A, &mt_total, &nkc, &mode, &lds);
     if (rc) return rc;
-    return c->dtype == NNDET_BF16 ? pw_dispatch<bf16_t>(A, mt_total, nkc, mode, lds, st) : pw_dispatch<float>(A, mt_total, nkc, mode, lds, st);
+#define PW_GO(T_) pw_dispatch<T_>(A, mt_total, nkc, mode, lds, st)
+    return NNDET_DISPATCH_DTYPE(c->dtype, PW_GO);
 }
 
 int pw_covers(const NndetConv* c, int kind) {

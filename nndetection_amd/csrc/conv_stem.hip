@@ -12,21 +12,20 @@ struct StemArgs {
     int64_t total;   // N * O0 * O1 * O2
 };
 
-template <typename T> __device__ __forceinline__ void store_row32(T* p, const float* v);
-template <> __device__ __forceinline__ void store_row32<float>(float* p, const float* v) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-}
-template <> __device__ __forceinline__ void store_row32<bf16_t>(bf16_t* p, const float* v) {
+template <typename T> __device__ __forceinline__ void store_row32(T* p, const float* v) {     // 16-bit types
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint4 u;
-        u.x = pack_bf16x2(v[8 * i + 0], v[8 * i + 1]);
-        u.y = pack_bf16x2(v[8 * i + 2], v[8 * i + 3]);
-        u.z = pack_bf16x2(v[8 * i + 4], v[8 * i + 5]);
-        u.w = pack_bf16x2(v[8 * i + 6], v[8 * i + 7]);
+        u.x = H16<T>::pack2(v[8 * i + 0], v[8 * i + 1]);
+        u.y = H16<T>::pack2(v[8 * i + 2], v[8 * i + 3]);
+        u.z = H16<T>::pack2(v[8 * i + 4], v[8 * i + 5]);
+        u.w = H16<T>::pack2(v[8 * i + 6], v[8 * i + 7]);
         reinterpret_cast<uint4*>(p)[i] = u;
     }
+}
+template <> __device__ __forceinline__ void store_row32<float>(float* p, const float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
 
 // grid (ceil(total/256), Cy/32); thread = one output voxel x 32 output channels
@@ -78,19 +77,18 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const StemArgs A) {
 // Staging uses UNCONDITIONAL clamped loads (27 input taps + the voxel's 32-channel dY row as 16-byte vectors) so that all
 // loads of a chunk are in flight together; dys rows are padded to 36 floats: conflict-free float4 writes and reads.
 #define STEM_DYS_STRIDE 36
-template <typename T> __device__ __forceinline__ void load_row32(const T* p, float* v);
-template <> __device__ __forceinline__ void load_row32<float>(const float* p, float* v) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const float4 f = reinterpret_cast<const float4*>(p)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
-}
-template <> __device__ __forceinline__ void load_row32<bf16_t>(const bf16_t* p, float* v) {
+template <typename T> __device__ __forceinline__ void load_row32(const T* p, float* v) {      // 16-bit types
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint4 u = reinterpret_cast<const uint4*>(p)[i];
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = __uint_as_float(w[k] << 16); v[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+        for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = H16<T>::lo(w[k]); v[8 * i + 2 * k + 1] = H16<T>::hi(w[k]); }
     }
+}
+template <> __device__ __forceinline__ void load_row32<float>(const float* p, float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float4 f = reinterpret_cast<const float4*>(p)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
 }
 
 template <typename T>
@@ -168,7 +166,6 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemArgs A) {
 // and chunk and was LDS-bound at 0.9 ms (profiles/round1_v6_kernel_stats_by_grid.txt); this one is HBM-bound on dY.
 typedef short st_s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) st_s16x4* st_lds_s16x4_ptr;
-typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ u32x4 stem_trfrag(const char* p) {   // 8 points (rows p, p + 4 voxels) of channel li, see WF<bf16_t>
     const st_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_lds_s16x4_ptr)(p));
     const st_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_lds_s16x4_ptr)(p + 4 * 64));
@@ -176,6 +173,7 @@ __device__ __forceinline__ u32x4 stem_trfrag(const char* p) {   // 8 points (row
     return u32x4{ua.x, ua.y, ub.x, ub.y};
 }
 
+template <typename T>      // bf16_t / f16_t: raw 16-bit moves, the MFMA of the type
 __global__ __launch_bounds__(256, 2) void k_stem_wgrad3(const StemArgs A, int nt0, int nt1, int nt2, int total_tiles) {
     constexpr int PROW = 8 * 64 + 32;                  // bytes per row of 8 points (64 B per point + bank padding)
     constexpr int TILE = 32 * PROW;                    // 17408
@@ -276,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad3(const StemArgs A, int nt
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(st_bf16x8, pf[i]), __builtin_bit_cast(st_bf16x8, qf[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = H16<T>::mma(pf[i], qf[j], acc[i][j]);
         }
     }
     // workgroup reduction in LDS, then one atomic per (channel, tap)
@@ -308,6 +306,7 @@ __device__ __forceinline__ float stem_dpp_row_sum(float v) {
     return v;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0, int nt1, int nt2, double* __restrict__ stats) {
     constexpr int PROW = 8 * 64 + 32;
     __shared__ __attribute__((aligned(16))) char imt[32 * PROW];
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
             const int t = q * 8 + j;
             wv8[j] = (t < 27 && ch < A.cout) ? A.w[(int64_t)ch * 27 + t] : 0.f;
         }
-        af[i] = u32x4{pack_bf16x2(wv8[0], wv8[1]), pack_bf16x2(wv8[2], wv8[3]), pack_bf16x2(wv8[4], wv8[5]), pack_bf16x2(wv8[6], wv8[7])};
+        af[i] = u32x4{H16<T>::pack2(wv8[0], wv8[1]), H16<T>::pack2(wv8[2], wv8[3]), H16<T>::pack2(wv8[4], wv8[5]), H16<T>::pack2(wv8[6], wv8[7])};
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int cb = c0 + i * 16 + q * 4 + rr;
@@ -405,14 +404,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 c = f32x4{bia[i][0], bia[i][1], bia[i][2], bia[i][3]};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(st_bf16x8, af[i]), __builtin_bit_cast(st_bf16x8, bf[j]), c, 0, 0, 0);
+                c = H16<T>::mma(af[i], bf[j], c);
                 typedef unsigned int v2u_t __attribute__((__vector_size__(8)));
                 v2u_t o;
-                o[0] = pack_bf16x2(c[0], c[1]); o[1] = pack_bf16x2(c[2], c[3]);
+                o[0] = H16<T>::pack2(c[0], c[1]); o[1] = H16<T>::pack2(c[2], c[3]);
                 __builtin_amdgcn_raw_buffer_store_b64(o, yrs, vo + i * 32, 0, 0);
                 if (stats && valid) {
-                    const float r0 = __uint_as_float(o[0] << 16), r1 = __uint_as_float(o[0] & 0xffff0000u);
-                    const float r2 = __uint_as_float(o[1] << 16), r3 = __uint_as_float(o[1] & 0xffff0000u);
+                    const float r0 = H16<T>::lo(o[0]), r1 = H16<T>::hi(o[0]);
+                    const float r2 = H16<T>::lo(o[1]), r3 = H16<T>::hi(o[1]);
                     ssum[i][0] += r0; ssum[i][1] += r1; ssum[i][2] += r2; ssum[i][3] += r3;
                     ssq[i][0] += r0 * r0; ssq[i][1] += r1 * r1; ssq[i][2] += r2 * r2; ssq[i][3] += r3 * r3;
                 }
@@ -462,7 +461,7 @@ int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const fl
     a.x = x; a.w = w_f32; a.bias = bias; a.y = y;
     *stats_done = 0;
     const int64_t yb = (int64_t)a.O[0] * a.O[1] * a.O[2] * a.Cy * 2;
-    if (c->dtype == NNDET_BF16 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1 &&
+    if (nndet_is16(c->dtype) && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1 &&
         c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1 && yb < (1LL << 31) && !getenv("NNDET_STEM_VALU")) {
         const int nt0 = ceil_div(a.O[0], 4), nt1 = ceil_div(a.O[1], 8), nt2 = ceil_div(a.O[2], 8);
         const int64_t tiles = (int64_t)nt0 * nt1 * nt2;
@@ -471,7 +470,8 @@ int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const fl
             if (S < 8) S = 8;
             S = (S / 8) * 8;
             if (S > tiles) S = (int)tiles;
-            k_stem_fwd3<<<dim3(S, c->cout_p / 32, a.N), 256, 0, st>>>(a, nt0, nt1, nt2, stats);
+            if (c->dtype == NNDET_F16) k_stem_fwd3<f16_t><<<dim3(S, c->cout_p / 32, a.N), 256, 0, st>>>(a, nt0, nt1, nt2, stats);
+            else k_stem_fwd3<bf16_t><<<dim3(S, c->cout_p / 32, a.N), 256, 0, st>>>(a, nt0, nt1, nt2, stats);
             LAUNCH_CHECK();
             *stats_done = 1;
             return 0;
@@ -479,6 +479,7 @@ int stem_forward(const NndetConv* c, const void* x, const float* w_f32, const fl
     }
     dim3 grid((unsigned)ceil_div64(a.total, 256), c->cout_p / 32);
     if (c->dtype == NNDET_BF16) k_stem_fwd<bf16_t><<<grid, 256, 0, st>>>(a);
+    else if (c->dtype == NNDET_F16) k_stem_fwd<f16_t><<<grid, 256, 0, st>>>(a);
     else k_stem_fwd<float><<<grid, 256, 0, st>>>(a);
     LAUNCH_CHECK();
     return 0;
@@ -490,13 +491,14 @@ int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hip
     if (rc) return rc;
     a.x = x; a.dy = dy; a.dw = dw;
     const int64_t dyb = (int64_t)a.O[0] * a.O[1] * a.O[2] * a.Cy * 2;
-    if (c->dtype == NNDET_BF16 && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1 &&
+    if (nndet_is16(c->dtype) && c->k[0] == 3 && c->k[1] == 3 && c->k[2] == 3 && c->s[0] == 1 && c->s[1] == 1 && c->s[2] == 1 &&
         c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1 && dyb < (1LL << 31) && !getenv("NNDET_STEM_VALU")) {
         const int nt0 = ceil_div(a.O[0], 4), nt1 = ceil_div(a.O[1], 8), nt2 = ceil_div(a.O[2], 8);
         const int64_t tiles = (int64_t)a.N * nt0 * nt1 * nt2;
         if (tiles < (1LL << 31)) {
             dim3 g3((unsigned)(tiles < 512 ? tiles : 512), c->cout_p / 32);
-            k_stem_wgrad3<<<g3, 256, 0, st>>>(a, nt0, nt1, nt2, (int)tiles);
+            if (c->dtype == NNDET_F16) k_stem_wgrad3<f16_t><<<g3, 256, 0, st>>>(a, nt0, nt1, nt2, (int)tiles);
+            else k_stem_wgrad3<bf16_t><<<g3, 256, 0, st>>>(a, nt0, nt1, nt2, (int)tiles);
             LAUNCH_CHECK();
             return 0;
         }
@@ -507,10 +509,12 @@ int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hip
     static bool attr = false;
     if (!attr) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr = true;
     }
     if (c->dtype == NNDET_BF16) k_stem_wgrad<bf16_t><<<grid, 256, lds, st>>>(a);
+    else if (c->dtype == NNDET_F16) k_stem_wgrad<f16_t><<<grid, 256, lds, st>>>(a);
     else k_stem_wgrad<float><<<grid, 256, lds, st>>>(a);
     LAUNCH_CHECK();
     return 0;

@@ -20,8 +20,6 @@
 #include "common.h"
 #include "conv_common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 
 struct WgTap { int32_t d[3]; int32_t wt; };
 struct WgArgs {
@@ -60,10 +58,9 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // One MFMA operand fragment = this lane's 8 contraction values (8 consecutive lattice points of its q-group's run)
 // of channel (tile base + li). `run0` points at [first voxel of the run][first channel of the 16-channel tile],
 // `vstride` = bytes between consecutive voxels of the run.
-template <typename T> struct WF;
-template <> struct WF<bf16_t> {
+template <typename T> struct WF {        // the 16-bit storage types (bf16_t, f16_t)
     u32x4 v;
-    // bf16: the LDS transpose read (ds_read_b64_tr_b16, layout verified by tools/probe_mfma.hip): the 16 lanes of a
+    // 16-bit types: the LDS transpose read (ds_read_b64_tr_b16, layout verified by tools/probe_mfma.hip): the 16 lanes of a
     // q-group each fetch 8 bytes (4 channels of voxel li>>2) and receive, transposed, 4 voxels of channel li.
     // Two reads (voxels 0-3, 4-7) replace 8 scalar LDS reads; the voxel offset is per lane, so tap shifts cost nothing.
     __device__ __forceinline__ void load(const char* run0, int vstride, int li) {
@@ -73,10 +70,8 @@ template <> struct WF<bf16_t> {
         const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
         v = u32x4{ua.x, ua.y, ub.x, ub.y};
     }
-    __device__ __forceinline__ void set_ones() { v = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; }   // bf16 1.0
-    __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
-    }
+    __device__ __forceinline__ void set_ones() { v = u32x4{H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2}; }   // 1.0 x 8
+    __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) { c = H16<T>::mma(a.v, b.v, c); }
 };
 template <> struct WF<float> {
     float v[8];
@@ -604,13 +599,31 @@ size_t wgrad_workspace_bytes(const NndetConv* c) {
     return (size_t)slices * rb * kb * ntap * 1024 * sizeof(float);
 }
 
+// uniform k_wgrad3 launch for a 16-bit storage type
+template <typename T> static int wgrad3_launch16(const WgArgs& b, dim3 g3, size_t lds3, hipStream_t st) {
+    static bool at = false;
+    if (!at) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<T, 2, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<T, 2, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<T, 2, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        at = true;
+    }
+    // QDEPTH 1: 248 registers, no spill. With depth 2 the kernel needs > 256 registers at two workgroups per CU and the
+    // spill reloads (scratch shares vmcnt) serialise the staging loads of every tile (profiles/round2_wgrad3_spill.txt)
+    static const int qd = getenv("NNDET_WGRAD3_QD") ? atoi(getenv("NNDET_WGRAD3_QD")) : 1;
+    if (b.qss) k_wgrad3<T, 2, true, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+    else if (qd == 2) k_wgrad3<T, 2, false, 2><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+    else k_wgrad3<T, 2, false, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+    return 0;
+}
+
 int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias, int* bias_done, void* ws, size_t ws_bytes,
               hipStream_t st) {
     WgArgs a;
     memset(&a, 0, sizeof(a));
     *bias_done = 0;
     const bool tr = c->transposed != 0;
-    const bool bf = c->dtype == NNDET_BF16;
+    const bool bf = nndet_is16(c->dtype), hf = c->dtype == NNDET_F16;
     const int esz = bf ? 2 : 4;
     const int RB = 32 * esz, PPV = RB / 16;
     const int in_sp[3] = {c->in_d, c->in_h, c->in_w}, out_sp[3] = {c->out_d, c->out_h, c->out_w};
@@ -698,19 +711,8 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             const size_t lds3 = (size_t)32 * (8 * RB + RB / 2) + (size_t)60 * (10 * RB + RB / 2);
             dim3 g3(S3, rb, kb);
             if (bf) {
-                static bool at = false;
-                if (!at) {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-                    at = true;
-                }
-                // QDEPTH 1: 248 registers, no spill. With depth 2 the kernel needs > 256 registers at two workgroups per CU and the
-                // spill reloads (scratch shares vmcnt) serialise the staging loads of every tile (profiles/round2_wgrad3_spill.txt)
-                static const int qd = getenv("NNDET_WGRAD3_QD") ? atoi(getenv("NNDET_WGRAD3_QD")) : 1;
-                if (b.qss) k_wgrad3<bf16_t, 2, true, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
-                else if (qd == 2) k_wgrad3<bf16_t, 2, false, 2><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
-                else k_wgrad3<bf16_t, 2, false, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+                const int rc3 = hf ? wgrad3_launch16<f16_t>(b, g3, lds3, st) : wgrad3_launch16<bf16_t>(b, g3, lds3, st);
+                if (rc3) return rc3;
             } else {
                 static bool at = false;
                 if (!at) {
@@ -728,7 +730,8 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             return 0;
         }
     }
-    if (bf) rc = KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
+    if (hf) rc = KS == 8 ? wg_dispatch<f16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<f16_t, 2, 1, 12, true>(a, grid, lds, st);
+    else if (bf) rc = KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
     else rc = KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
     if (rc) return rc;
     const int64_t total = (int64_t)rb * kb * a.ntap * 1024;
@@ -745,7 +748,7 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
                     size_t ws_bytes, hipStream_t st) {
     int rc = items_check(c, it);
     if (rc) return rc;
-    const bool bf = c->dtype == NNDET_BF16;
+    const bool bf = nndet_is16(c->dtype), hf = c->dtype == NNDET_F16;
     const int esz = bf ? 2 : 4;
     const int RB = 32 * esz;
     WgArgs b;
@@ -787,10 +790,12 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
     static bool at = false;
     if (!at) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<f16_t, 2, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         at = true;
     }
-    if (bf) k_wgrad3<bf16_t, 2, false, 1, true><<<g3, 256, lds3, st>>>(b, wi);
+    if (hf) k_wgrad3<f16_t, 2, false, 1, true><<<g3, 256, lds3, st>>>(b, wi);
+    else if (bf) k_wgrad3<bf16_t, 2, false, 1, true><<<g3, 256, lds3, st>>>(b, wi);
     else k_wgrad3<float, 1, false, 2, true><<<g3, 256, lds3, st>>>(b, wi);
     LAUNCH_CHECK();
     const int64_t total3 = (int64_t)rb * kb * 27 * 1024;

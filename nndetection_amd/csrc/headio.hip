@@ -96,9 +96,10 @@ extern "C" int nndet_head_gather_f32(int32_t dtype, const NndetHeadLevels* lv, i
     int64_t mx = 0;
     int rc = hg_fill(&a, lv, N, cout, cout_p, &mx);
     if (rc) return rc;
-    if (!out || (dtype != NNDET_BF16 && dtype != NNDET_F32)) return NNDET_EINVAL;
+    if (!out || (dtype != NNDET_BF16 && dtype != NNDET_F32 && dtype != NNDET_F16)) return NNDET_EINVAL;
     const dim3 grid((unsigned)ceil_div64(mx, HG_PB), (unsigned)lv->nlev, (unsigned)N);
     if (dtype == NNDET_BF16) k_head_gather<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(a, out);
+    else if (dtype == NNDET_F16) k_head_gather<f16_t><<<grid, 256, 0, as_stream(stream)>>>(a, out);
     else k_head_gather<float><<<grid, 256, 0, as_stream(stream)>>>(a, out);
     LAUNCH_CHECK();
     return 0;
@@ -110,10 +111,11 @@ extern "C" int nndet_head_gather_backward(int32_t dtype, const NndetHeadLevels* 
     int64_t mx = 0;
     int rc = hg_fill(&a, lv, N, cout, cout_p, &mx);
     if (rc) return rc;
-    if (!grad_out || (dtype != NNDET_BF16 && dtype != NNDET_F32)) return NNDET_EINVAL;
+    if (!grad_out || (dtype != NNDET_BF16 && dtype != NNDET_F32 && dtype != NNDET_F16)) return NNDET_EINVAL;
     for (int l = 0; l < lv->nlev; ++l) if (!lv->dy[l] || (lv->dscale[l] && !lv->scale[l])) return NNDET_EINVAL;
     const dim3 grid((unsigned)ceil_div64(mx, HG_PB), (unsigned)lv->nlev, (unsigned)N);
     if (dtype == NNDET_BF16) k_head_gather_bwd<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(a, grad_out);
+    else if (dtype == NNDET_F16) k_head_gather_bwd<f16_t><<<grid, 256, 0, as_stream(stream)>>>(a, grad_out);
     else k_head_gather_bwd<float><<<grid, 256, 0, as_stream(stream)>>>(a, grad_out);
     LAUNCH_CHECK();
     return 0;

@@ -9,7 +9,23 @@
 #include "common.h"
 #include "conv_common.h"
 
-template <typename T> struct Vec16;
+template <typename T> struct Vec16 {      // the 16-bit storage types (bf16_t, f16_t)
+    static constexpr int E = 8;
+    __device__ static __forceinline__ void ld(const T* p, float* v) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = H16<T>::lo(w[i]); v[2 * i + 1] = H16<T>::hi(w[i]); }
+    }
+    __device__ static __forceinline__ void st(T* p, const float* v) {
+        uint4 u;
+        u.x = H16<T>::pack2(v[0], v[1]);
+        u.y = H16<T>::pack2(v[2], v[3]);
+        u.z = H16<T>::pack2(v[4], v[5]);
+        u.w = H16<T>::pack2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(p) = u;
+    }
+};
 template <> struct Vec16<float> {
     static constexpr int E = 4;
     __device__ static __forceinline__ void ld(const float* p, float* v) {
@@ -17,24 +33,6 @@ template <> struct Vec16<float> {
     }
     __device__ static __forceinline__ void st(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
-template <> struct Vec16<bf16_t> {
-    static constexpr int E = 8;
-    __device__ static __forceinline__ void ld(const bf16_t* p, float* v) {
-        const uint4 u = *reinterpret_cast<const uint4*>(p);
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-    }
-    __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
-        uint4 u;
-        u.x = pack_bf16x2(v[0], v[1]);
-        u.y = pack_bf16x2(v[2], v[3]);
-        u.z = pack_bf16x2(v[4], v[5]);
-        u.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(p) = u;
-    }
-};
-
 // Ragged batch (NndetItems): per-item voxel count and first row; n == 0 = uniform batch (image n = rows [n * spatial, (n + 1) * spatial))
 struct NormItems {
     int32_t n, pad_;
@@ -108,6 +106,7 @@ int norm_stats_run(int dtype, const void* x, int batch, int64_t spatial, int c_p
     dim3 grid((unsigned)ceil_div64(spatial, rr), batch);
     const size_t lds = (size_t)c_p * 16;
     if (dtype == NNDET_BF16) k_norm_stats<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)x, spatial, c_p, batch, stats, rr);
+    else if (dtype == NNDET_F16) k_norm_stats<f16_t><<<grid, 256, lds, st>>>((const f16_t*)x, spatial, c_p, batch, stats, rr);
     else k_norm_stats<float><<<grid, 256, lds, st>>>((const float*)x, spatial, c_p, batch, stats, rr);
     LAUNCH_CHECK();
     return 0;
@@ -212,10 +211,12 @@ extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stat
     k_norm_finalize<<<batch, 256, (size_t)c_p * 16, st>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out, nullptr, nullptr,
                                                           nullptr, g_norm_uniform);
     LAUNCH_CHECK();
-    const int rpb = apply_rows(spatial * batch, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    const int rpb = apply_rows(spatial * batch, c_p, nndet_esize(dtype));
     dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
     if (dtype == NNDET_BF16)
         k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (bf16_t*)y, rpb, g_norm_uniform);
+    else if (dtype == NNDET_F16)
+        k_norm_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (f16_t*)y, rpb, g_norm_uniform);
     else
         k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, spatial, c, c_p, relu, (float*)y, rpb, g_norm_uniform);
     LAUNCH_CHECK();
@@ -251,10 +252,12 @@ extern "C" int nndet_norm_apply_items(int32_t dtype, const void* x, const double
     hipStream_t st = as_stream(stream);
     k_norm_finalize<<<ni.n, 256, (size_t)c_p * 16, st>>>(stats, ni.n, c, c_p, groups, 0, eps, mean_rstd_out, nullptr, nullptr, nullptr, ni);
     LAUNCH_CHECK();
-    const int rpb = apply_rows(total, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    const int rpb = apply_rows(total, c_p, nndet_esize(dtype));
     dim3 grid((unsigned)ceil_div64(mx, rpb), ni.n);
     if (dtype == NNDET_BF16)
         k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (bf16_t*)y, rpb, ni);
+    else if (dtype == NNDET_F16)
+        k_norm_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (f16_t*)y, rpb, ni);
     else
         k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (float*)y, rpb, ni);
     LAUNCH_CHECK();
@@ -283,10 +286,12 @@ __global__ __launch_bounds__(256) void k_affine_apply(const T* __restrict__ x, c
 extern "C" int nndet_affine_apply(int32_t dtype, const void* x, const float* scale_shift, int32_t batch, int64_t spatial, int32_t c_p,
                                   int32_t relu, void* y, void* stream) {
     if (!x || !scale_shift || !y || c_p % 32 || c_p > 1024 || batch <= 0) return NNDET_EINVAL;
-    const int rpb = apply_rows(spatial * batch, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    const int rpb = apply_rows(spatial * batch, c_p, nndet_esize(dtype));
     dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
     if (dtype == NNDET_BF16)
         k_affine_apply<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, scale_shift, spatial, c_p, relu, (bf16_t*)y, rpb);
+    else if (dtype == NNDET_F16)
+        k_affine_apply<f16_t><<<grid, 256, 0, as_stream(stream)>>>((const f16_t*)x, scale_shift, spatial, c_p, relu, (f16_t*)y, rpb);
     else
         k_affine_apply<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, scale_shift, spatial, c_p, relu, (float*)y, rpb);
     LAUNCH_CHECK();
@@ -454,18 +459,22 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     if (!x || !dy || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red_ws) return NNDET_EINVAL;
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
-    const int rpb = apply_rows(spatial * batch, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    const int rpb = apply_rows(spatial * batch, c_p, nndet_esize(dtype));
     dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
     const int rr = red_rows(spatial * batch);
     dim3 rgrid((unsigned)ceil_div64(spatial, rr), batch);
     const size_t lds = (size_t)c_p * 16;
     if (dtype == NNDET_BF16)
         k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
+    else if (dtype == NNDET_F16)
+        k_norm_bwd_reduce<f16_t><<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
     else
         k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
         k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx, rpb, g_norm_uniform);
+    else if (dtype == NNDET_F16)
+        k_norm_bwd_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (f16_t*)dx, rpb, g_norm_uniform);
     else
         k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (float*)dx, rpb, g_norm_uniform);
     LAUNCH_CHECK();
@@ -482,18 +491,22 @@ extern "C" int nndet_norm_backward_items(int32_t dtype, const void* x, const voi
     const int rc = norm_items(items, &ni, &total, &mx);
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
-    const int rpb = apply_rows(total, c_p, dtype == NNDET_BF16 ? 2 : 4);
+    const int rpb = apply_rows(total, c_p, nndet_esize(dtype));
     dim3 grid((unsigned)ceil_div64(mx, rpb), ni.n);
     const int rr = red_rows(total);
     dim3 rgrid((unsigned)ceil_div64(mx, rr), ni.n);
     const size_t lds = (size_t)c_p * 16;
     if (dtype == NNDET_BF16)
         k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
+    else if (dtype == NNDET_F16)
+        k_norm_bwd_reduce<f16_t><<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
     else
         k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
         k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (bf16_t*)dx, rpb, ni);
+    else if (dtype == NNDET_F16)
+        k_norm_bwd_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (f16_t*)dx, rpb, ni);
     else
         k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (float*)dx, rpb, ni);
     LAUNCH_CHECK();
@@ -534,6 +547,7 @@ int colsum_run(int dtype, const void* x, int64_t rows, int c_p, int c, float* ou
     const int rr = red_rows(rows);
     const unsigned nb = (unsigned)ceil_div64(rows, rr);
     if (dtype == NNDET_BF16) k_colsum<bf16_t><<<nb, 256, (size_t)c_p * 4, st>>>((const bf16_t*)x, rows, c_p, c, out, rr);
+    else if (dtype == NNDET_F16) k_colsum<f16_t><<<nb, 256, (size_t)c_p * 4, st>>>((const f16_t*)x, rows, c_p, c, out, rr);
     else k_colsum<float><<<nb, 256, (size_t)c_p * 4, st>>>((const float*)x, rows, c_p, c, out, rr);
     LAUNCH_CHECK();
     return 0;

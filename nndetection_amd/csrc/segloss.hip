@@ -6,13 +6,12 @@
 // logits: [nvox][c_p] NDHWC, channels 0 (background) and 1 (foreground) are used. HBM-bound.
 #include "common.h"
 
-template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
+template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b) {      // 16-bit types
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+    a = H16<T>::lo(v); b = H16<T>::hi(v);
+}
 template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
     const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y;
-}
-template <> __device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, float& a, float& b) {
-    const uint32_t v = *reinterpret_cast<const uint32_t*>(p);
-    a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
 }
 
 __device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(256) void k_segloss_bwd(const T* __restrict__ logit
     T* o = dlogits + v * c_p;
     constexpr int E = 16 / (int)sizeof(T);
     uint4 first = make_uint4(0u, 0u, 0u, 0u);
-    if (sizeof(T) == 2) first.x = pack_bf16x2(-d1, d1);
+    if (sizeof(T) == 2) first.x = H16<T>::pack2(-d1, d1);
     else { first.x = __float_as_uint(-d1); first.y = __float_as_uint(d1); }
     reinterpret_cast<uint4*>(o)[0] = first;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
@@ -75,6 +74,7 @@ extern "C" int nndet_segloss_forward(int32_t dtype, const void* logits, const ui
     int64_t nb = ceil_div64(nvox, 256 * 8);
     if (nb > 4096) nb = 4096;
     if (dtype == NNDET_BF16) k_segloss_fwd<bf16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const bf16_t*)logits, target, nvox, c_p, sums_out);
+    else if (dtype == NNDET_F16) k_segloss_fwd<f16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const f16_t*)logits, target, nvox, c_p, sums_out);
     else k_segloss_fwd<float><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const float*)logits, target, nvox, c_p, sums_out);
     LAUNCH_CHECK();
     return 0;
@@ -85,30 +85,29 @@ extern "C" int nndet_segloss_backward(int32_t dtype, const void* logits, const u
     if (!logits || !target || !coeffs || !dlogits || nvox <= 0 || c_p % 32) return NNDET_EINVAL;
     const unsigned nb = (unsigned)ceil_div64(nvox, 256);
     if (dtype == NNDET_BF16) k_segloss_bwd<bf16_t><<<nb, 256, 0, as_stream(stream)>>>((const bf16_t*)logits, target, nvox, c_p, coeffs, (bf16_t*)dlogits);
+    else if (dtype == NNDET_F16) k_segloss_bwd<f16_t><<<nb, 256, 0, as_stream(stream)>>>((const f16_t*)logits, target, nvox, c_p, coeffs, (f16_t*)dlogits);
     else k_segloss_bwd<float><<<nb, 256, 0, as_stream(stream)>>>((const float*)logits, target, nvox, c_p, coeffs, (float*)dlogits);
     LAUNCH_CHECK();
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ fused head (training)
-template <typename T> __device__ __forceinline__ float round_to(float v);
+template <typename T> __device__ __forceinline__ float round_to(float v) { return H16<T>::lo(H16<T>::pack2(v, 0.f)); }    // 16-bit types
 template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
-template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); }
 
 // loads the 32-channel row of voxel v as fp32
-template <typename T> __device__ __forceinline__ void ld_row32(const T* p, float* v);
-template <> __device__ __forceinline__ void ld_row32<float>(const float* p, float* v) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const float4 f = reinterpret_cast<const float4*>(p)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
-}
-template <> __device__ __forceinline__ void ld_row32<bf16_t>(const bf16_t* p, float* v) {
+template <typename T> __device__ __forceinline__ void ld_row32(const T* p, float* v) {      // 16-bit types
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint4 u = reinterpret_cast<const uint4*>(p)[i];
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = __uint_as_float(w[k] << 16); v[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+        for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = H16<T>::lo(w[k]); v[8 * i + 2 * k + 1] = H16<T>::hi(w[k]); }
     }
+}
+template <> __device__ __forceinline__ void ld_row32<float>(const float* p, float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float4 f = reinterpret_cast<const float4*>(p)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
 }
 
 struct SegHeadW { float w0[32], w1[32], b0, b1; };
@@ -154,19 +153,18 @@ __global__ __launch_bounds__(256) void k_seghead_fwd(const T* __restrict__ x, co
     if (threadIdx.x < 4) atomicAdd(&sums[threadIdx.x], red[threadIdx.x]);
 }
 
-template <typename T> __device__ __forceinline__ void st_row32(T* p, const float* v);
-template <> __device__ __forceinline__ void st_row32<float>(float* p, const float* v) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-}
-template <> __device__ __forceinline__ void st_row32<bf16_t>(bf16_t* p, const float* v) {
+template <typename T> __device__ __forceinline__ void st_row32(T* p, const float* v) {      // 16-bit types
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint4 u;
-        u.x = pack_bf16x2(v[8 * i + 0], v[8 * i + 1]); u.y = pack_bf16x2(v[8 * i + 2], v[8 * i + 3]);
-        u.z = pack_bf16x2(v[8 * i + 4], v[8 * i + 5]); u.w = pack_bf16x2(v[8 * i + 6], v[8 * i + 7]);
+        u.x = H16<T>::pack2(v[8 * i + 0], v[8 * i + 1]); u.y = H16<T>::pack2(v[8 * i + 2], v[8 * i + 3]);
+        u.z = H16<T>::pack2(v[8 * i + 4], v[8 * i + 5]); u.w = H16<T>::pack2(v[8 * i + 6], v[8 * i + 7]);
         reinterpret_cast<uint4*>(p)[i] = u;
     }
+}
+template <> __device__ __forceinline__ void st_row32<float>(float* p, const float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
 
 // persistent grid: every thread accumulates sum(d1 * x[c]) for its voxels in registers, block reduction through LDS,
@@ -231,6 +229,7 @@ extern "C" int nndet_seghead_forward(int32_t dtype, const void* x, int32_t c_p, 
     int64_t nb = ceil_div64(nvox, 256 * 4);
     if (nb > 2048) nb = 2048;
     if (dtype == NNDET_BF16) k_seghead_fwd<bf16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const bf16_t*)x, w, bias, cin, target, nvox, sums_out);
+    else if (dtype == NNDET_F16) k_seghead_fwd<f16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const f16_t*)x, w, bias, cin, target, nvox, sums_out);
     else k_seghead_fwd<float><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const float*)x, w, bias, cin, target, nvox, sums_out);
     LAUNCH_CHECK();
     return 0;
@@ -243,6 +242,8 @@ extern "C" int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p,
     if (nb > 2048) nb = 2048;
     if (dtype == NNDET_BF16)
         k_seghead_bwd<bf16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const bf16_t*)x, w, bias, cin, target, nvox, coeffs, (bf16_t*)dx, dwb_out);
+    else if (dtype == NNDET_F16)
+        k_seghead_bwd<f16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const f16_t*)x, w, bias, cin, target, nvox, coeffs, (f16_t*)dx, dwb_out);
     else
         k_seghead_bwd<float><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const float*)x, w, bias, cin, target, nvox, coeffs, (float*)dx, dwb_out);
     LAUNCH_CHECK();

@@ -20,6 +20,7 @@ Design for 8 x MI355X (fully connected xGMI, 7 links x ~153 GB/s per GPU), 18.9 
     mining and batch-dice stay per rank, exactly what the reference under Lightning-DDP would compute.
 """
 import contextlib
+import os
 from typing import List, Optional
 
 import torch
@@ -45,14 +46,28 @@ class GradAllReducer:
     After finish() every p.grad is a VIEW of its bucket: zero_grad(set_to_none=True) (not in-place zeroing or accumulation over
     several backward passes) is required before the next backward."""
 
-    def __init__(self, model: torch.nn.Module, first_bucket_mb: float = 4.0, bucket_mb: float = 24.0,
-                 process_group=None, overlap: bool = True, static_unused=None, force_overlap: bool = False):
-        """static_unused: parameters that NEVER receive a gradient on any rank (default: `model.never_used_parameters()` if the
+    def __init__(self, model: torch.nn.Module, first_bucket_mb: Optional[float] = None, bucket_mb: Optional[float] = None,
+                 process_group=None, overlap: bool = True, static_unused=None, force_overlap: bool = False,
+                 bucket_dtype: Optional[torch.dtype] = None, profile: bool = False):
+        """first_bucket_mb / bucket_mb (defaults 4 / 24, env NNDET_DDP_FIRST_MB / NNDET_DDP_BUCKET_MB): bucket sizes in MB of fp32
+        gradients -- the sweep switch for tuning against the 7 xGMI links of a node (bench.py prints per-bucket launch offsets and
+        the exposed all-reduce time for each setting). bucket_dtype (env NNDET_DDP_BF16=1 -> bfloat16): all-reduce the buckets in a
+        16-bit type (half the wire bytes; the averaged gradient is then rounded to that type: off by default).
+        profile: record events around the bucket launches and finish() so that `profile_summary()` can report how much of the
+        communication was NOT hidden under the backward pass.
+        static_unused: parameters that NEVER receive a gradient on any rank (default: `model.never_used_parameters()` if the
         model has it -- for RetinaUNet the `decoder.out.P<l>` convs of levels nobody reads). They are zero-filled and do not
         count towards bucket readiness; otherwise their bucket -- and, because collectives are issued in order, every later
         one -- could only be launched from finish(), i.e. without overlapping the backward pass.
         force_overlap: run the hook -> bucket copy -> (all-reduce) -> gradient-view path even at world size 1, so the
         overlapped path (incl. its stream synchronisation against the multi-stream detection head) is testable on ONE GPU."""
+        if first_bucket_mb is None:
+            first_bucket_mb = float(os.environ.get("NNDET_DDP_FIRST_MB", "4"))
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get("NNDET_DDP_BUCKET_MB", "24"))
+        if bucket_dtype is None:
+            bucket_dtype = torch.bfloat16 if os.environ.get("NNDET_DDP_BF16", "0") == "1" else torch.float32
+        self.first_bucket_mb, self.bucket_mb, self.bucket_dtype = first_bucket_mb, bucket_mb, bucket_dtype
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         params = [p for p in model.parameters() if p.requires_grad]
@@ -64,9 +79,9 @@ class GradAllReducer:
         for p in reversed(params):                       # gradients arrive roughly in reverse registration order
             cur.append(p); cur_bytes += p.numel() * 4
             if cur_bytes >= limit:
-                self.buckets.append(GradBucket(cur, device)); cur, cur_bytes, limit = [], 0, bucket_mb * 2 ** 20
+                self.buckets.append(GradBucket(cur, device, bucket_dtype)); cur, cur_bytes, limit = [], 0, bucket_mb * 2 ** 20
         if cur:
-            self.buckets.append(GradBucket(cur, device))
+            self.buckets.append(GradBucket(cur, device, bucket_dtype))
         if static_unused is None and hasattr(model, "never_used_parameters"):
             static_unused = model.never_used_parameters()
         self._static_unused = {id(p) for p in (static_unused or [])}
@@ -86,6 +101,13 @@ class GradAllReducer:
         self._comm = None               # communication stream (bucket copies + collectives), created on first use
         self._event_pool, self._used_events = [], []
         self._hooks = []
+        # the mean is taken by the collective itself where the backend can (RCCL / NCCL: ReduceOp.AVG), else by one scaling pass
+        backend = dist.get_backend(self.pg) if dist.is_initialized() else ""
+        self._avg_in_collective = self.world > 1 and backend == "nccl" and hasattr(dist.ReduceOp, "AVG") and \
+            os.environ.get("NNDET_DDP_AVG", "1") != "0"
+        self.profile = bool(profile) and self._cuda
+        self._prof = {"steps": 0, "exposed_ms": 0.0, "span_ms": 0.0, "offsets_ms": [0.0] * len(self.buckets)}
+        self._prof_ev = None
         if self.overlap:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -127,6 +149,10 @@ class GradAllReducer:
             b.streams.clear()
         ctx = torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()
         with ctx:
+            if self.profile and self._prof_ev is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()                              # on the communication stream: the bucket's copy starts here
+                self._prof_ev["launch"].append(ev)
             src, dst = [], []
             for p, v in zip(b.params, b.views):
                 if p.grad is None:
@@ -136,10 +162,30 @@ class GradAllReducer:
             if dst:
                 torch._foreach_copy_(dst, src)           # one multi-tensor kernel per bucket instead of one copy per parameter
             if self.world > 1 or (self.force and dist.is_initialized()):
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+                b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
             elif self._cuda:
                 b.work = torch.cuda.Event()
                 b.work.record()                          # world 1 (force_overlap): finish() still orders against the copy stream
+
+    def begin_step(self):
+        """profile=True only: call right before backward(); marks t = 0 of the per-bucket launch offsets."""
+        if self.profile:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._prof_ev = {"t0": e0, "launch": []}
+
+    def profile_summary(self) -> dict:
+        """Averages over the profiled steps: `exposed_allreduce_ms` = GPU time the caller's stream spent in finish() waiting for
+        buckets (communication that the backward pass did not hide), `backward_to_ready_ms` = backward start -> gradients ready,
+        `bucket_launch_offset_ms[i]` = backward start -> bucket i's copy + all-reduce issued."""
+        n = max(1, self._prof["steps"])
+        return {"steps": self._prof["steps"], "world": self.world, "first_bucket_mb": self.first_bucket_mb, "bucket_mb": self.bucket_mb,
+                "bucket_dtype": str(self.bucket_dtype).replace("torch.", ""), "avg_in_collective": bool(self._avg_in_collective),
+                "bucket_mbytes": [round(b.numel * b.flat.element_size() / 2 ** 20, 2) for b in self.buckets],
+                "exposed_allreduce_ms": round(self._prof["exposed_ms"] / n, 4),
+                "backward_to_ready_ms": round(self._prof["span_ms"] / n, 4),
+                "bucket_launch_offset_ms": [round(v / n, 4) for v in self._prof["offsets_ms"]]}
 
     def _on_grad(self, p):
         bi, _ = self._where[p]
@@ -170,19 +216,44 @@ class GradAllReducer:
             self._launch(self.buckets[self._next])
             self._next += 1
         inv = 1.0 / self.world
+        prof = self._prof_ev if self.profile else None
+        if prof is not None:
+            prof["f0"] = torch.cuda.Event(enable_timing=True)
+            prof["f0"].record()                          # caller's stream: the backward pass is done here
         for b in self.buckets:
             if self._cuda and isinstance(b.work, torch.cuda.Event):
                 torch.cuda.current_stream().wait_event(b.work)
             elif b.work is not None:
                 b.work.wait()
-            if self.world > 1:
-                b.flat.mul_(inv)
+            if self.world > 1 and not self._avg_in_collective:
+                b.flat.mul_(inv)                         # (gloo has no ReduceOp.AVG; RCCL averages inside the collective)
             # hand the averaged gradients to the optimizer as views of the bucket (no copy back). They stay valid until the
             # bucket is refilled by the next backward; the training loop drops them with zero_grad(set_to_none=True).
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+            if b.flat.dtype == torch.float32:
+                for p, v in zip(b.params, b.views):
+                    p.grad = v
+            else:                                        # 16-bit buckets: the optimizer wants fp32 gradients
+                for p, v in zip(b.params, b.views):
+                    p.grad = v.float()
             b.work = None
             b.pending = b.expected
         self._next = 0
         self._event_pool.extend(self._used_events)       # every wait on them has been enqueued: safe to re-record next step
         self._used_events.clear()
+        if prof is not None:
+            f1 = torch.cuda.Event(enable_timing=True)
+            f1.record()
+            self._prof_pending = getattr(self, "_prof_pending", [])
+            self._prof_pending.append((prof["t0"], prof["f0"], f1, prof["launch"]))
+            self._prof_ev = None
+
+    def profile_collect(self):
+        """Fold the event pairs of the finished steps into the running sums (synchronises: call outside the timed region)."""
+        for t0, f0, f1, launches in getattr(self, "_prof_pending", []):
+            f1.synchronize()
+            self._prof["steps"] += 1
+            self._prof["exposed_ms"] += f0.elapsed_time(f1)
+            self._prof["span_ms"] += t0.elapsed_time(f1)
+            for i, ev in enumerate(launches[:len(self.buckets)]):
+                self._prof["offsets_ms"][i] += t0.elapsed_time(ev)
+        self._prof_pending = []

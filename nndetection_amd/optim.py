@@ -24,8 +24,15 @@ class SGDNesterov:
 
     fused = os.environ.get("NNDET_FUSED_SGD", "1") != "0"   # one multi-tensor launch per group (torch._fused_sgd_, the kernel behind torch.optim.SGD(fused=True))
 
+    # Loss scaling without a host synchronisation (fp16 activations, the reference's precision=16): torch.amp.GradScaler.step() hands
+    # an optimizer with this flag the scale and the found-inf flag as DEVICE tensors (attributes `grad_scale` / `found_inf`) instead of
+    # reading found_inf on the host; the fused kernel divides the gradients by the scale and skips the update when an inf / nan was
+    # found. (The stock path -- torch.optim.SGD without fused=True, what the reference configures -- costs one `.item()` per step.)
+    _step_supports_amp_scaling = True
+
     @torch.no_grad()
     def step(self):
+        grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
         for g in self.param_groups:
             ps = [p for p in g["params"] if p.grad is not None]
             if not ps:
@@ -45,8 +52,12 @@ class SGDNesterov:
                             self._buf[p] = torch.empty_like(gr)               # filled by the kernel: buf = g (+ wd * p)
                     torch._fused_sgd_([p for p, _ in sel], [gr.contiguous() for _, gr in sel], [self._buf[p] for p, _ in sel],
                                       weight_decay=wd, momentum=mu, lr=lr, dampening=0.0, nesterov=self.nesterov, maximize=False,
-                                      is_first_step=first)
+                                      is_first_step=first, grad_scale=grad_scale, found_inf=found_inf)
                 continue
+            if found_inf is not None and bool(found_inf.item()):      # foreach fallback (CPU / NNDET_FUSED_SGD=0): host decision
+                return
+            if grad_scale is not None:
+                grads = torch._foreach_div(grads, float(grad_scale.item()))
             if wd != 0.0:
                 grads = torch._foreach_add(grads, ps, alpha=wd)          # g + wd * p (new tensors, p.grad untouched)
             if mu != 0.0:

@@ -8,7 +8,8 @@ MODULE_REGISTRY (the `additional_imports` route); the standalone
 bench.py and the tests use (nnDetection's Lightning stack is not installed on the benchmark box).
 """
 import copy
-from typing import Dict, List
+import os
+from typing import Dict, List, Optional
 
 import torch
 import torch.nn as nn
@@ -123,62 +124,247 @@ _AMD_CLASS_ATTRS = dict(
     head_regressor_cls=GIoURegressor, head_sampler_cls=HardNegativeSamplerBatched, segmenter_cls=DiCESegmenterFgBg)
 
 
+class LazyFloat:
+    """A Python-number-like view of ONE element of a device tensor that is being copied to pinned host memory asynchronously.
+    The reference's `training_step` returns `l.detach().item()` per loss (retinaunet/base.py:154): four host synchronisations
+    BETWEEN the forward and the backward pass, i.e. the backward pass is issued into an empty queue (measured 24.9 -> 23.3 ms per
+    step when the last such sync left the step). Here all losses go to the host in one non-blocking copy; the value is
+    read (event wait) when somebody actually converts it -- `float()`, `np.mean([...])` in `training_epoch_end`, a format string."""
+    __slots__ = ("_host", "_i", "_ev", "_v")
+
+    def __init__(self, host, i, ev):
+        self._host, self._i, self._ev, self._v = host, i, ev, None
+
+    def item(self) -> float:
+        if self._v is None:
+            if self._ev is not None:
+                self._ev.synchronize()
+            self._v = float(self._host[self._i])
+            self._host = self._ev = None
+        return self._v
+
+    __float__ = item
+
+    def __array__(self, dtype=None, copy=None):
+        import numpy as np
+        return np.asarray(self.item(), dtype=dtype or np.float64)
+
+    def __repr__(self):
+        return repr(self.item())
+
+    def __format__(self, spec):
+        return format(self.item(), spec)
+
+    def __add__(self, o): return self.item() + o
+    def __radd__(self, o): return o + self.item()
+    def __sub__(self, o): return self.item() - o
+    def __rsub__(self, o): return o - self.item()
+    def __mul__(self, o): return self.item() * o
+    def __rmul__(self, o): return o * self.item()
+    def __truediv__(self, o): return self.item() / o
+    def __rtruediv__(self, o): return o / self.item()
+    def __neg__(self): return -self.item()
+    def __lt__(self, o): return self.item() < float(o)
+    def __le__(self, o): return self.item() <= float(o)
+    def __gt__(self, o): return self.item() > float(o)
+    def __ge__(self, o): return self.item() >= float(o)
+    def __eq__(self, o): return self.item() == o
+    def __hash__(self): return hash(self.item())
+
+
+def lazy_items(values: Dict[str, torch.Tensor]) -> Dict[str, "LazyFloat"]:
+    """{key: 0-dim tensor} -> {key: LazyFloat}: one stacked device tensor, one non-blocking copy to pinned memory, one event."""
+    keys = list(values)
+    if not keys:
+        return {}
+    dev = values[keys[0]].device
+    stacked = torch.stack([values[k].detach().float().reshape(()) for k in keys])
+    if dev.type != "cuda" or os.environ.get("NNDET_PLUGIN_LAZY_ITEMS", "1") == "0":
+        host = stacked.cpu()
+        return {k: LazyFloat(host, i, None) for i, k in enumerate(keys)}
+    host = torch.empty(stacked.shape, dtype=torch.float32, pin_memory=True)
+    host.copy_(stacked, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return {k: LazyFloat(host, i, ev) for i, k in enumerate(keys)}
+
+
+_PRECISION_DTYPES = {16: torch.float16, "16": torch.float16, "16-mixed": torch.float16,
+                     "bf16": torch.bfloat16, "bf16-mixed": torch.bfloat16}
+_NAMED_DTYPES = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                 "bfloat16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16, "float16": torch.float16}
+
+
+class RetinaUNetAMDSteps:
+    """The step bodies of the registered plugin module, free of any nnDetection / Lightning import so that the SAME code runs in
+    `RetinaUNetV001AMD` (mixed in in front of the reference's `RetinaUNetV001`, `register_with_nndet`) and on the GPU box
+    (`tests/test_plugin_gpu.py`, `bench.py --via-plugin`) where neither package exists. Expects `self.model` (our
+    `BaseRetinaNet`), `self.trainer_cfg` (dict) and -- validation only -- `self.evaluation_step`.
+
+    Replaces retinaunet/base.py:135-181 (`training_step`, `validation_step`) and the Lightning DDP pass-through of
+    scripts/train.py:265-289 (`on_fit_start` / `on_after_backward`).
+
+    Precision (scripts/train.py:277-278, conf/train/v001.yaml:32-33: `pl.Trainer(precision=16, amp_backend='native')`): Lightning's
+    native AMP runs `training_step` inside `torch.autocast` (float16) and scales the loss with a GradScaler. The HIP kernels take
+    their arithmetic type from the activation tensor, so the step casts `batch["data"]` to
+      1. `NNDET_AMD_DTYPE` / `trainer_cfg["amd_dtype"]` (f32 | bf16 | f16) if given, else
+      2. the autocast dtype when autocast is enabled (float16 under precision=16, bfloat16 under precision='bf16'), else
+      3. bfloat16 when `trainer_cfg["precision"]` asks for 16-bit but no autocast context is active (no GradScaler can be assumed
+         then: bf16 has fp32's exponent range and needs none), else
+      4. the dtype of the batch (fp32: the exact-fp32 MFMA kernels).
+    Parameters, gradients and the optimizer stay fp32 in every case (the packed low-precision weight copies are internal), which is
+    exactly what autocast gives the reference. `amd_last_dtype` records what the last step ran in."""
+
+    amd_last_dtype: Optional[torch.dtype] = None
+
+    def amd_compute_dtype(self, data: torch.Tensor) -> torch.dtype:
+        cfg = getattr(self, "trainer_cfg", None) or {}
+        forced = os.environ.get("NNDET_AMD_DTYPE") or cfg.get("amd_dtype")
+        if forced:
+            try:
+                return _NAMED_DTYPES[str(forced).lower()]
+            except KeyError:
+                raise ValueError(f"amd_dtype / NNDET_AMD_DTYPE must be one of {sorted(_NAMED_DTYPES)}, got {forced!r}")
+        if data.is_cuda and torch.is_autocast_enabled():
+            return _autocast_dtype()
+        want = _PRECISION_DTYPES.get(cfg.get("precision", 32))
+        if want is not None and data.is_cuda:
+            return torch.bfloat16
+        return data.dtype if data.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
+
+    def amd_prepare(self, batch, deferred: bool):
+        from .core.targets import prepare_targets
+        data = batch["data"]
+        dt = self.amd_compute_dtype(data)
+        self.amd_last_dtype = dt
+        images, targets = prepare_targets(data, batch["target"], batch["instance_mapping"], deferred=deferred)
+        return (images if images.dtype == dt else images.to(dt)), targets
+
+    def training_step(self, batch, batch_idx):
+        images, targets = self.amd_prepare(batch, deferred=True)
+        with torch.autocast("cuda", enabled=False):        # the kernels already run in the chosen type; torch glue stays fp32
+            losses, _ = self.model.train_step(images=images, targets=targets, evaluation=False, batch_num=batch_idx)
+            loss = sum(losses.values())
+        return {"loss": loss, **lazy_items(losses)}
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            images, targets = self.amd_prepare(batch, deferred=False)
+            with torch.autocast("cuda", enabled=False):
+                losses, prediction = self.model.train_step(images=images, targets=targets, evaluation=True, batch_num=batch_idx)
+                loss = sum(losses.values())
+        self.evaluation_step(prediction=prediction, targets=targets)
+        return {"loss": loss.detach().item(), **{key: l.detach().item() for key, l in losses.items()}}
+
+    # ---- data parallel: one process per GPU, gradient all-reduce over RCCL (nndetection_amd/ddp.py)
+    def on_fit_start(self):
+        import torch.distributed as dist
+        self._amd_reducer = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not self._amd_under_lightning_ddp():
+            from .ddp import GradAllReducer
+            cfg = getattr(self, "trainer_cfg", None) or {}
+            self._amd_reducer = GradAllReducer(self.model, **{k[len("amd_ddp_"):]: v for k, v in cfg.items() if k.startswith("amd_ddp_")})
+        parent = getattr(super(), "on_fit_start", None)
+        return parent() if parent is not None else None
+
+    def _amd_under_lightning_ddp(self) -> bool:
+        """True if somebody else already reduces the gradients: Lightning's own DDP strategy wraps the module in
+        DistributedDataParallel (scripts/train.py:273-275 with accelerator='ddp'); a second all-reduce from our hooks would
+        double the communication and swap `p.grad` behind DDP's back. `NNDET_AMD_DDP=1` forces ours, `=0` disables it."""
+        sw = os.environ.get("NNDET_AMD_DDP")
+        if sw is not None:
+            return sw == "0"
+        tr = getattr(self, "_trainer", None) or getattr(self, "trainer", None)
+        for obj in (getattr(tr, "model", None), getattr(getattr(tr, "strategy", None), "model", None),
+                    getattr(getattr(tr, "training_type_plugin", None), "model", None)):
+            if isinstance(obj, torch.nn.parallel.DistributedDataParallel):
+                return True
+        name = type(getattr(tr, "strategy", None) or getattr(tr, "training_type_plugin", None)).__name__.lower()
+        return "ddp" in name or "deepspeed" in name or "fsdp" in name
+
+    def configure_optimizers(self):
+        """The reference's `configure_optimizers` (retinaunet/base.py:300-336: SGD + nesterov, no weight decay on norms,
+        LinearWarmupPolyLR per iteration) unchanged, then `amd_fuse_sgd` on every torch.optim.SGD it returned."""
+        parent = getattr(super(), "configure_optimizers", None)
+        res = parent() if parent is not None else configure_optimizer(self.model, getattr(self, "trainer_cfg", None), lean=True)
+        opts = res[0] if isinstance(res, (tuple, list)) and res and isinstance(res[0], (tuple, list)) else [res]
+        for o in opts:
+            amd_fuse_sgd(o)
+        return res
+
+    def on_after_backward(self):
+        red = getattr(self, "_amd_reducer", None)
+        if red is not None:
+            red.finish()
+        parent = getattr(super(), "on_after_backward", None)
+        return parent() if parent is not None else None
+
+
+def amd_fuse_sgd(opt) -> bool:
+    """Switch a `torch.optim.SGD` (as built by the reference) to torch's fused multi-tensor implementation when its parameters live
+    on the GPU: one launch per parameter group instead of ~5 foreach passes, and -- under native AMP -- GradScaler hands a fused
+    optimizer the scale / found-inf flag as device tensors instead of synchronising on `found_inf.item()` every step
+    (`_step_supports_amp_scaling`). Same update rule (torch/optim/sgd.py); `NNDET_AMD_FUSED_OPT=0` leaves the optimizer alone."""
+    if os.environ.get("NNDET_AMD_FUSED_OPT", "1") == "0" or not isinstance(opt, torch.optim.SGD):
+        return False
+    params = [p for g in opt.param_groups for p in g["params"]]
+    if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params) or not hasattr(torch, "_fused_sgd_"):
+        return False
+    for g in opt.param_groups:
+        if g.get("differentiable") or g.get("maximize"):
+            return False
+    for g in opt.param_groups:
+        g["fused"], g["foreach"] = True, False
+    opt.defaults["fused"], opt.defaults["foreach"] = True, False
+    opt._step_supports_amp_scaling = True
+    return True
+
+
+def _autocast_dtype() -> torch.dtype:
+    get = getattr(torch, "get_autocast_dtype", None)
+    return get("cuda") if get is not None else torch.get_autocast_gpu_dtype()
+
+
+class StandaloneRetinaUNetV001AMD(RetinaUNetAMDSteps, nn.Module):
+    """The registered module without nnDetection / Lightning: same step bodies (`RetinaUNetAMDSteps`), same constructor arguments
+    `(model_cfg, trainer_cfg, plan)` as `LightningBaseModule` (nndet/ptmodule/base_module.py:33-59), `self.model` built by the same
+    `from_config_plan`. Used by `bench.py --via-plugin` and the GPU tests; a training loop drives it like Lightning drives the
+    registered class: `training_step` -> `["loss"].backward()` -> `on_after_backward()` -> optimizer."""
+
+    def __init__(self, model_cfg: dict, trainer_cfg: dict, plan: dict, **kwargs):
+        super().__init__()
+        self.model_cfg, self.trainer_cfg, self.plan = model_cfg, trainer_cfg, plan
+        self.model = RetinaUNetV001.from_config_plan(copy.deepcopy(model_cfg), plan["architecture"], plan["anchors"])
+        self.evaluated = []
+
+    def evaluation_step(self, prediction: dict, targets: dict):
+        self.evaluated.append((prediction, targets))
+
+
 def register_with_nndet():
     """Register the HIP-backed module in nnDetection's MODULE_REGISTRY (requires nnDetection + Lightning to be importable).
 
-    `RetinaUNetV001AMD` subclasses the reference's `RetinaUNetV001` (nndet/ptmodule/retinaunet/v001.py:29-38), so Lightning
-    hooks, evaluators, predictor / ensembler / sweep plumbing are inherited unchanged. It overrides
+    `RetinaUNetV001AMD` = `RetinaUNetAMDSteps` mixed in in front of the reference's `RetinaUNetV001`
+    (nndet/ptmodule/retinaunet/v001.py:29-38), so Lightning hooks, evaluators, predictor / ensembler / sweep plumbing are inherited
+    unchanged. It overrides
       * the component class attributes (retinaunet/base.py:74-85) -- the reference's own `from_config_plan` accepts them too;
       * `from_config_plan` (base.py:338-466): builds `nndetection_amd.core.retina.BaseRetinaNet`, i.e. also the detector core
         (batched ATSS assignment, fused post-processing) runs on the HIP kernels; same constructor calls, same state-dict keys;
-      * `training_step` / `validation_step` (base.py:135-180): device-side target preparation instead of `self.pre_trafo`;
-      * `on_fit_start` / `on_after_backward`: the bucketed RCCL gradient all-reduce of nndetection_amd.ddp when the job runs as
-        one process per GPU under torch.distributed (the reference leaves multi-GPU to pl.Trainer, scripts/train.py:265-289).
+      * `training_step` / `validation_step` (base.py:135-180) from the mixin: device-side target preparation instead of
+        `self.pre_trafo`, activation dtype from the autocast state / `trainer_cfg.precision`, losses to the host without a sync;
+      * `on_fit_start` / `on_after_backward` from the mixin: the bucketed RCCL gradient all-reduce of nndetection_amd.ddp when the
+        job runs as one process per GPU under torch.distributed and Lightning's own DDP wrapper is not active (the reference
+        leaves multi-GPU to pl.Trainer, scripts/train.py:265-289).
     """
     from nndet.ptmodule import MODULE_REGISTRY
     from nndet.ptmodule.retinaunet.v001 import RetinaUNetV001 as _RefV001
 
-    class RetinaUNetV001AMD(_RefV001):
+    class RetinaUNetV001AMD(RetinaUNetAMDSteps, _RefV001):
         locals().update(_AMD_CLASS_ATTRS)
 
         @classmethod
         def from_config_plan(cls, model_cfg: dict, plan_arch: dict, plan_anchors: dict, log_num_anchors: str = None, **kwargs):
             return RetinaUNetV001.from_config_plan(model_cfg, plan_arch, plan_anchors, log_num_anchors, **kwargs)
-
-        def _prepare(self, batch):
-            from .core.targets import prepare_targets
-            return prepare_targets(batch["data"], batch["target"], batch["instance_mapping"])
-
-        def training_step(self, batch, batch_idx):
-            images, targets = self._prepare(batch)
-            losses, _ = self.model.train_step(images=images, targets=targets, evaluation=False, batch_num=batch_idx)
-            loss = sum(losses.values())
-            return {"loss": loss, **{key: l.detach().item() for key, l in losses.items()}}
-
-        def validation_step(self, batch, batch_idx):
-            with torch.no_grad():
-                images, targets = self._prepare(batch)
-                losses, prediction = self.model.train_step(images=images, targets=targets, evaluation=True, batch_num=batch_idx)
-                loss = sum(losses.values())
-            self.evaluation_step(prediction=prediction, targets=targets)
-            return {"loss": loss.detach().item(), **{key: l.detach().item() for key, l in losses.items()}}
-
-        # ---- data parallel: one process per GPU, gradient all-reduce over RCCL (nndetection_amd/ddp.py)
-        def on_fit_start(self):
-            import torch.distributed as dist
-            self._amd_reducer = None
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                from .ddp import GradAllReducer
-                self._amd_reducer = GradAllReducer(self.model)
-            parent = getattr(super(), "on_fit_start", None)
-            return parent() if parent is not None else None
-
-        def on_after_backward(self):
-            red = getattr(self, "_amd_reducer", None)
-            if red is not None:
-                red.finish()
-            parent = getattr(super(), "on_after_backward", None)
-            return parent() if parent is not None else None
 
     if "RetinaUNetV001AMD" not in MODULE_REGISTRY.mapping:
         MODULE_REGISTRY.register(RetinaUNetV001AMD)

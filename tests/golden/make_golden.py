@@ -243,6 +243,55 @@ def golden_net(name, lite=False, batch=None, tag=None):
     np.savez_compressed(os.path.join(OUT, f"net_{tag or name}_golden.npz"), **g)
 
 
+def golden_fp64(name="luna160", batch=1):
+    """Arbitration of the fp32 box tolerance: the SAME network evaluated in float64 (the oracle's modules
+    cast with .double(); weights, input, anchors identical). For every detection the reference (fp32, oneDNN) reported in
+    net_<name>_golden.npz the anchor it came from is identified in the fp64 run (same score to 1e-5, nearest box) and the fp64
+    decoded + clipped box is stored: `tests/test_parity_full_gpu.py::test_luna160_fp32_boxes_arbitrated_by_fp64` then measures
+    the HIP fp32 boxes AND the reference's fp32 boxes against it."""
+    plan = get_plan(name)
+    plan["batch_size"] = batch
+    gold = np.load(os.path.join(OUT, f"net_{name}_golden.npz"))
+    ora = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
+    fill_state(ora)
+    ora = ora.double()
+    x, _ = synth_inputs(plan)
+    with torch.no_grad():
+        pred, anchors, npl, _ = ora(x.double())
+    M = anchors.shape[0]
+    deltas = pred["box_deltas"].numpy().reshape(batch, M, 6)
+    probs = torch.sigmoid(pred["box_logits"]).numpy().reshape(batch, M, -1)
+    P = np.asarray(plan["patch_size"], np.float64)
+    g = {"batch": np.int64(batch)}
+    a = anchors.astype(np.float64)
+    for b in range(batch):
+        rb, rs = gold[f"det_boxes_{b}"].astype(np.float64), gold[f"det_scores_{b}"].astype(np.float64)
+        w, h, d = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1], a[:, 5] - a[:, 4]
+        cx, cy, cz = a[:, 0] + 0.5 * w, a[:, 1] + 0.5 * h, a[:, 4] + 0.5 * d
+        dl = deltas[b]
+        clipv = np.log(1000.0 / 16)
+        pw, ph, pd = np.exp(np.minimum(dl[:, 2], clipv)) * w, np.exp(np.minimum(dl[:, 3], clipv)) * h, np.exp(np.minimum(dl[:, 5], clipv)) * d
+        pcx, pcy, pcz = dl[:, 0] * w + cx, dl[:, 1] * h + cy, dl[:, 4] * d + cz
+        raw = np.stack([pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph, pcz - 0.5 * pd, pcz + 0.5 * pd], 1)
+        box64 = raw.copy()
+        box64[:, [0, 2]] = np.clip(box64[:, [0, 2]], 0, P[0]); box64[:, [1, 3]] = np.clip(box64[:, [1, 3]], 0, P[1])
+        box64[:, [4, 5]] = np.clip(box64[:, [4, 5]], 0, P[2])
+        sc64 = probs[b].max(1)
+        idx, out, size, err_ref = [], [], [], []
+        for i in range(len(rb)):
+            cand = np.nonzero(np.abs(sc64 - rs[i]) <= 1e-5)[0]
+            assert len(cand) > 0, (b, i, rs[i])
+            k = cand[np.abs(box64[cand] - rb[i]).max(1).argmin()]
+            idx.append(k); out.append(box64[k]); err_ref.append(np.abs(box64[k] - rb[i]).max())
+            size.append(max(raw[k, 2] - raw[k, 0], raw[k, 3] - raw[k, 1], raw[k, 5] - raw[k, 4]))       # decoded size BEFORE clipping
+        g[f"anchor_idx_{b}"], g[f"det_boxes64_{b}"] = np.asarray(idx, np.int64), np.asarray(out, np.float64)
+        g[f"det_scores64_{b}"] = sc64[np.asarray(idx)]
+        g[f"ref_err_{b}"], g[f"raw_size_{b}"] = np.asarray(err_ref, np.float64), np.asarray(size, np.float64)
+        print(f"  [{name} fp64] image {b}: reference fp32 boxes vs fp64: max {max(err_ref):.3e}, median {np.median(err_ref):.3e}; "
+              f"max |score| diff {np.abs(g[f'det_scores64_{b}'] - rs).max():.2e}; largest decoded size {max(size):.1f}")
+    np.savez_compressed(os.path.join(OUT, f"net_{name}_fp64.npz"), **g)
+
+
 def golden_targets():
     """the three `pre_trafo` transforms of RetinaUNetModule (retinaunet/base.py:108-131) run unmodified on a small
     synthetic instance volume; the oracle restatement must reproduce them exactly (integer work)."""
@@ -335,3 +384,5 @@ if __name__ == "__main__":
         golden_net("toy64", lite=True)        # BASELINE.json configs[0]: the reference's own CPU-runnable case
     if "luna160" in which:
         golden_net("luna160", lite=True, batch=1)   # BASELINE.json configs[1] (the benchmarked plan), one 160x160x96 patch, fp32
+    if "luna160_fp64" in which:
+        golden_fp64("luna160", 1)

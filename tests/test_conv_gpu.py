@@ -14,7 +14,8 @@ from tests.gpu_util import relerr
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: dict(fwd=2e-5, dx=2e-5, dw=5e-5), torch.bfloat16: dict(fwd=6e-3, dx=8e-3, dw=8e-3)}
+TOL = {torch.float32: dict(fwd=2e-5, dx=2e-5, dw=5e-5), torch.bfloat16: dict(fwd=6e-3, dx=8e-3, dw=8e-3),
+       torch.float16: dict(fwd=8e-4, dx=1e-3, dw=1e-3)}       # fp16: 1 ulp = 2^-11 of the tensor's max (8 x tighter than bf16)
 
 # (cin, cout, kernel, stride, padding, transposed, spatial)
 CONVS = [
@@ -69,7 +70,7 @@ def _ref_forward(m, x, cfg, dtype, norm, act):
     y = F.conv_transpose3d(xr, w, b, stride=s) if tr else F.conv3d(xr, w, b, stride=s, padding=p)
     g = be = None
     if norm is not None:
-        if dtype == torch.bfloat16:
+        if dtype != torch.float32:
             y = y + (y.to(dtype).float() - y).detach()          # the kernel normalises the bf16-rounded conv output
         g = m.norm.weight.detach().clone().requires_grad_(True)
         be = m.norm.bias.detach().clone().requires_grad_(True)
@@ -82,7 +83,7 @@ def _ref_forward(m, x, cfg, dtype, norm, act):
     return xr, w, b, g, be, y
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name,spec", [(c[0], "lib") for c in CONVS] + [(n, v) for v in ("generic", "ig3-nt8", "ig3-nt16") for n in SPEC3] +
                          [(n, v) for v in ("strided-0", "strided-1", "strided-2") for n in STRIDED])
 def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
@@ -102,7 +103,7 @@ def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
     tol = TOL[dtype]
     xr, w, b, _, _, yref = _ref_forward(m, x, cfg, dtype, None, False)
     gy = torch.randn_like(yref)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         gy = gy.to(dtype).float()
     yref.backward(gy)
     m = m.cuda()
@@ -123,23 +124,23 @@ def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
         assert e <= tol["dw"], f"bias grad rel err {e:.3e}"
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name,norm", [("c32_k3", "instance"), ("c64_k3", "instance"), ("c32to64_s2", "instance"),
                                         ("stem", "instance"), ("c128_k3", "group"), ("c64_k3", "group")])
 def test_conv_norm_relu_block(name, norm, dtype):
     m, x, cfg = _mk(name, dtype, norm, True)
     xr, w, b, g, be, yref = _ref_forward(m, x, cfg, dtype, norm, True)
     gy = torch.randn_like(yref)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         gy = gy.to(dtype).float()
     yref.backward(gy)
     m = m.cuda()
     xg = x.detach().clone().cuda().to(dtype).requires_grad_(cfg[1] != 1)
     y = m(xg)
-    ft = 2e-5 if dtype == torch.float32 else 1.2e-2
+    ft = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, torch.float16: 1.5e-3}[dtype]
     # bf16: the tiny test volumes make sums like dbeta = sum(g) cancel to ~sqrt(n), one flipped ReLU-mask element of the
     # bf16-rounded conv output is worth ~3 % of that sum -> 6e-2 (the fp32 path pins the arithmetic at 1e-4)
-    gt = 1e-4 if dtype == torch.float32 else 1e-1
+    gt = {torch.float32: 1e-4, torch.bfloat16: 1e-1, torch.float16: 2e-2}[dtype]
     e = relerr(y.float(), yref)
     assert e <= ft, f"block forward rel err {e:.3e}"
     y.backward(gy.cuda().to(dtype))
@@ -152,7 +153,7 @@ def test_conv_norm_relu_block(name, norm, dtype):
     assert not bad, f"block backward rel errs {errs}"
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_segloss(dtype):
     from nndetection_amd.arch import Generator, ConvInstanceRelu, DiCESegmenterFgBg
     torch.manual_seed(0)
@@ -165,7 +166,7 @@ def test_segloss(dtype):
     w = rd(seg.conv_out.conv.weight.detach()).requires_grad_(True)
     b = seg.conv_out.conv.bias.detach().clone().requires_grad_(True)
     sl = F.conv3d(xr, w, b)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         sl = sl + (sl.to(dtype).float() - sl).detach()
     t = (tgt > 0).long()
     ce = 0.5 * F.cross_entropy(sl, t)
@@ -188,9 +189,10 @@ def test_segloss(dtype):
     assert torch.allclose(pr.sum(1).cpu(), torch.ones(2, 8, 9, 10), atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("grid", ["8", "16", "0"], ids=["grid8", "grid16", "gridall"])
 @pytest.mark.parametrize("norm", [None, "instance"], ids=["bias", "instnorm"])
-def test_ig3r_persistent_32to32(norm, grid, monkeypatch):
+def test_ig3r_persistent_32to32(norm, grid, dtype, monkeypatch):
     """k_ig3r (persistent, register-resident weights, LDS-DMA staging; bf16 32 -> 32 with every dim a multiple of 8): forward
     with bias / with the fused InstanceNorm statistics + ReLU, data gradient (mirrored taps), weight gradient of the block.
     NNDET_IG3R=2 forces the kernel for small problems; NNDET_IG3R_GRID=8/16 makes every workgroup walk over 6-12 tiles that
@@ -199,7 +201,6 @@ def test_ig3r_persistent_32to32(norm, grid, monkeypatch):
     if grid != "0":
         monkeypatch.setenv("NNDET_IG3R_GRID", grid)
     from nndetection_amd.arch.conv import ConvInstanceRelu
-    dtype = torch.bfloat16
     torch.manual_seed(5)
     m = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=norm is not None, add_act=norm is not None)
     with torch.no_grad():
@@ -254,7 +255,7 @@ def test_full_size_layer_against_torch_gpu():
     assert relerr(y2 - b, 2.5 * (y - b)) < 1e-5
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_transposed_conv_with_fused_residual(dtype):
     """decoder top-down step x_l = lateral_l + up(x_{l+1}) (nndet/arch/decoder/base.py:405-413) from one kernel."""
     m, x, cfg = _mk("up_222", dtype)
@@ -269,7 +270,7 @@ def test_transposed_conv_with_fused_residual(dtype):
     xg = x.detach().clone().cuda().to(dtype).requires_grad_(True)
     rg = res.detach().clone().cuda().to(dtype).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
     y = m(xg, residual=rg)
-    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    tol = {torch.float32: 2e-5, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
     assert relerr(y.float(), yref) <= tol
     y.backward(gy.cuda().to(dtype))
     assert relerr(xg.grad.float(), xr.grad) <= tol
@@ -277,7 +278,7 @@ def test_transposed_conv_with_fused_residual(dtype):
     assert relerr(m.conv.weight.grad, w.grad) <= tol
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_fused_seg_head_matches_unfused(dtype):
     """nndet_seghead_forward / _backward (1x1x1 output conv + loss sums in one pass) == conv (nndet_conv3d_forward) followed by
     nndet_segloss_*: the four sums, d(input), dW, dbias. fp32: summation order only; bf16: the logits may differ in the last
@@ -324,9 +325,10 @@ FULL = [
 ]
 
 
+@pytest.mark.parametrize("lp", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("name", [c[0] for c in FULL])
-def test_full_size_bf16_kernels_against_fp32_kernels(name, monkeypatch):
-    """The bf16 kernels at the benchmarked layer sizes (one 160x160x96 patch) against the exact-fp32 kernels on the same rounded
+def test_full_size_bf16_kernels_against_fp32_kernels(name, lp, monkeypatch):
+    """The 16-bit (bf16 / fp16) kernels at the benchmarked layer sizes (one 160x160x96 patch) against the exact-fp32 kernels on the same rounded
     inputs and weights, forward and data gradient, every element: <= 1 bf16 ulp of the tensor maximum. Small-size parity cannot
     see hazards that only bite when all 256 CUs saturate the memory pipe (round 2: the last tile of every k_ig3r workgroup had
     4 points x 8 channels overwritten after a 16-byte store; tools/diag_ig3r.py)."""
@@ -337,22 +339,22 @@ def test_full_size_bf16_kernels_against_fp32_kernels(name, monkeypatch):
     torch.manual_seed(3)
     m = ConvInstanceRelu(3, cin, cout, k, stride=s, padding=p, transposed=tr, add_norm=False, add_act=False).cuda()
     with torch.no_grad():
-        m.conv.weight.copy_((torch.randn_like(m.conv.weight) / (m.conv.weight[0].numel() ** 0.5)).bfloat16().float())
+        m.conv.weight.copy_((torch.randn_like(m.conv.weight) / (m.conv.weight[0].numel() ** 0.5)).to(lp).float())
         m.conv.bias.copy_(torch.randn_like(m.conv.bias) * 0.3)
-    x16 = torch.randn(1, cin, *sp, device="cuda").bfloat16()
+    x16 = torch.randn(1, cin, *sp, device="cuda").to(lp)
     res = {}
-    for dt in (torch.bfloat16, torch.float32):
+    for dt in (lp, torch.float32):
         x = x16.detach().to(dt).clone().requires_grad_(True)
         y = m(x)
-        if dt == torch.bfloat16:
-            gy16 = torch.randn(y.shape, device="cuda").bfloat16()
+        if dt == lp:
+            gy16 = torch.randn(y.shape, device="cuda").to(lp)
         y.backward(gy16.to(dt))
         torch.cuda.synchronize()
         res[dt] = (y.detach().float(), x.grad.float())
         m.zero_grad(set_to_none=True)
-    for (a, b), what in zip(zip(res[torch.bfloat16], res[torch.float32]), ("forward", "data gradient")):
+    for (a, b), what in zip(zip(res[lp], res[torch.float32]), ("forward", "data gradient")):
         assert torch.isfinite(a).all(), what
         err = (a - b).abs()
-        tol = 2.0 ** -7 * float(b.abs().max())
+        tol = (2.0 ** -7 if lp == torch.bfloat16 else 2.0 ** -10) * float(b.abs().max())
         nbad = int((err > tol).sum())
         assert nbad == 0, f"{name} {what}: {nbad} elements off by more than {tol:.4f} (max {float(err.max()):.4f})"

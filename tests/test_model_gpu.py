@@ -165,7 +165,7 @@ def test_head_side_streams_match_sequential(golden_dir):
         assert max(d) <= 2e-5 * scale, (n, d, scale)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_head_gather_matches_per_level_flatten(golden_dir, dtype):
     """One gather launch per head branch (csrc/headio.hip: flatten + Scale + cat of all levels, forward and backward) == the
     reference's per-level permute / contiguous / view / Scale / cat chain in torch: identical predictions and losses (the same
@@ -206,7 +206,7 @@ def test_head_gather_matches_per_level_flatten(golden_dir, dtype):
         assert float((g1[n] - g0[n]).abs().max()) <= tol * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_fused_input_gradient_accumulation(golden_dir, dtype, monkeypatch):
     """Encoder stage outputs feed the next stage and the decoder lateral. With set_fuse_grad_accum the second data gradient is added
     into the first one's buffer (nndet_conv3d_backward_data_acc) instead of autograd adding two tensors: same gradients (fp32: the
@@ -335,7 +335,7 @@ def test_lean_sgd_matches_torch_sgd_on_gpu():
         assert torch.allclose(pa, pb, atol=1e-7, rtol=1e-6), n
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_deferred_norm_equals_materialised(golden_dir, monkeypatch, dtype):
     """with deferred normalisation (default) the consumers apply InstanceNorm / GroupNorm + ReLU while staging
     their input (NndetConv.in_affine) and `k_norm_apply` never runs; with NNDET_DEFER_NORM=0 every block materialises its
@@ -473,7 +473,7 @@ def test_fused_detection_loss_in_train_step(golden_dir, monkeypatch):
         assert float((g1[n] - g0[n]).abs().max()) <= 2e-5 * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_stream_overlap_does_not_change_training(golden_dir, monkeypatch, dtype):
     """Four optimizer steps on toy64; at every step the SAME parameters go through a train step with every overlap feature on (head
     branches, target assignment, segmentation branch and the full-resolution decoder tail on side streams, weight gradients on their

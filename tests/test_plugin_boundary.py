@@ -40,6 +40,26 @@ def test_additional_import_registers_module_and_nms(ref):
         ref.MODULE_REGISTRY.register(plugin.RetinaUNetV001AMD)
 
 
+def test_registered_class_runs_the_reference_free_step_mixin(ref):
+    """a19: the step bodies the GPU tests and `bench.py --via-plugin` exercise on the box (tests/test_plugin_gpu.py, where
+    nnDetection does not exist) ARE the ones the registered class runs: `RetinaUNetAMDSteps` sits in front of the reference's
+    RetinaUNetV001 in the MRO and provides training_step / validation_step / configure_optimizers / the two DDP hooks."""
+    import nndetection_amd.plugin as plugin
+    from nndetection_amd.ptmodule import RetinaUNetAMDSteps, StandaloneRetinaUNetV001AMD
+    from nndet.ptmodule.retinaunet.v001 import RetinaUNetV001 as RefV001
+    cls = plugin.RetinaUNetV001AMD
+    mro = cls.__mro__
+    assert mro.index(RetinaUNetAMDSteps) < mro.index(RefV001)
+    for name in ("training_step", "validation_step", "configure_optimizers", "on_fit_start", "on_after_backward", "amd_compute_dtype"):
+        assert getattr(cls, name) is getattr(RetinaUNetAMDSteps, name), name
+        assert getattr(StandaloneRetinaUNetV001AMD, name) is getattr(RetinaUNetAMDSteps, name), name
+    model_cfg, trainer_cfg, plan = _plan("tiny")
+    amd = cls(model_cfg, dict(trainer_cfg, precision=16), plan)
+    assert amd.amd_compute_dtype(torch.zeros(1)) == torch.float32            # CPU batch: untouched; the CUDA mapping is a GPU test
+    (opt,), sched = amd.configure_optimizers()                              # the reference's optimizer, fused only on the GPU
+    assert isinstance(opt, torch.optim.SGD) and not opt.param_groups[0].get("fused")
+
+
 def test_module_builds_with_reference_state_dict(ref):
     """Constructed like scripts/train.py:237 does (`MODULE_REGISTRY[cfg.module](model_cfg, trainer_cfg, plan)`): the 92
     parameter names / shapes equal those of the reference module, so reference checkpoints load strictly."""
