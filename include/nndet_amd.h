@@ -148,6 +148,19 @@ int nndet_postprocess3d_f32(const float* scores, int32_t scores_are_probs, const
                             float* out_scores, int64_t* out_labels, int64_t* out_counts, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* Same pipeline for ROWS that already are (box, probability, label) triples -- replaces the single-model stage of the
+ * inference ensembler, BoxEnsemblerSelective.postprocess_image (nndet/inference/ensembler/detection.py:166-217: sort by
+ * probability -> first model_topk -> score threshold -> clip_boxes_to_image -> remove_small_boxes -> model_nms_fn =
+ * batched_nms_model, nndet/inference/detection/model.py:25-54 -> first model_detections_per_image):
+ *   probs [B, M], boxes [B, M, 6] decoded, labels [B, M] int32 (the class offsets of batched_nms use them);
+ *   out_index [B, max_det]: row (0 .. M-1) each kept detection came from, -1 padding -- the caller gathers whatever else
+ *   travels with a row (the ensembler's per-box weights). workspace: nndet_postprocess3d_workspace_bytes(B, M, 1, topk). */
+int nndet_postprocess3d_rows_f32(const float* probs, const float* boxes, const int32_t* labels, int32_t B, int64_t M,
+                                 float img_x, float img_y, float img_z, int32_t topk, float score_thresh,
+                                 int32_t use_score_thresh, float min_size, int32_t use_min_size, float nms_thresh,
+                                 int32_t max_det, float* out_boxes, float* out_scores, int64_t* out_labels,
+                                 int64_t* out_index, int64_t* out_counts, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weighted box clustering -- replaces wbc / batched_wbc (nndet/inference/detection/wbc.py:22-160,163-199), the cross-model /
  * cross-tile consolidation of the ensemblers (nndet/inference/ensembler/detection.py:166-217,476-537). No [N, N] IoU matrix,

@@ -73,6 +73,8 @@ SIGNATURES = {
     "nndet_postprocess3d_workspace_bytes": (_SZ, [_I32, _I64, _I32, _I32]),
     "nndet_postprocess3d_f32": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _I32, _F, _F, _F, _F, _I32, _F, _I32, _F, _I32, _F, _I32,
                                           _P, _P, _P, _P, _P, _SZ, _P]),
+    "nndet_postprocess3d_rows_f32": (C.c_int, [_P, _P, _P, _I32, _I64, _F, _F, _F, _I32, _F, _I32, _F, _I32, _F, _I32,
+                                               _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_instances_to_targets_f32": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_hnm_sample_workspace_bytes": (_SZ, [_I32, C.c_double, _I32, C.c_double]),
     "nndet_hnm_neg_capacity": (_I32, [_I32, C.c_double, _I32]),
@@ -186,6 +188,11 @@ def workspace(nbytes: int, device, raw_stream=None) -> "torch.Tensor":
            if device.type == "cuda" else 0)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and raw_stream is not None and device.type == "cuda":
+            # the buffer being replaced was allocated under torch's current stream but is USED on `raw_stream` (the lagging
+            # weight-gradient stream): tell the caching allocator, or the next allocation on the current stream could alias it while
+            # a weight-gradient kernel still writes its split-K partials (only while the workspace is still growing)
+            buf.record_stream(torch.cuda.ExternalStream(raw_stream, device=device))
         buf = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf

@@ -229,6 +229,14 @@ class _ConvFn(torch.autograd.Function):
                     gacc["buf"].record_stream(torch.cuda.current_stream(dev))
                 L.call("nndet_conv3d_backward_data_acc", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(gacc["buf"]),
                        L.ptr(dbias) if fuses_bias else None, L.stream())
+                # This node hands autograd NO gradient (the sum lives in the first consumer's buffer), so the engine inserts no
+                # stream synchronisation for it: order the producer's backward stream (= its forward stream) behind the accumulation
+                # ourselves, whichever stream this node runs on.
+                ps = gacc.get("stream")
+                if ps is not None and x_p.is_cuda and ps != torch.cuda.current_stream(dev):
+                    ev2 = torch.cuda.Event()
+                    ev2.record()
+                    ps.wait_event(ev2)
                 gacc["buf"] = None
                 bias_from_dgrad = fuses_bias
                 dx_p = None

@@ -43,7 +43,9 @@ class Encoder(nn.Module):
             if sid in self.out_stages:
                 outputs.append(x)
                 if self.fuse_grad_accum and sid + 1 < self.num_stages and torch.is_grad_enabled() and x.requires_grad:
-                    x._nndet_gacc = {"buf": None}        # see set_fuse_grad_accum / arch/conv.py:_ConvFn.backward
+                    # (see set_fuse_grad_accum / arch/conv.py:_ConvFn.backward; "stream": where this activation's own backward
+                    # node will run -- the second consumer orders that stream behind its in-place accumulation)
+                    x._nndet_gacc = {"buf": None, "stream": torch.cuda.current_stream(x.device) if x.is_cuda else None}
         return outputs
 
     def set_fuse_grad_accum(self, on: bool) -> None:

@@ -366,6 +366,18 @@ class DetectionHeadHNMNative(nn.Module):
 
     def compute_loss(self, prediction: Dict[str, Tensor], target_labels: List[Tensor], matched_gt_boxes: List[Tensor],
                      anchors: List[Tensor]):
+        """-> (losses dict, sampled positive indices, sampled negative indices), comb.py:351-405.
+
+        Contract of the DEFAULT (sync-free) route on the GPU -- it differs from the reference in two documented ways so that the
+        host never reads the sampler's counts between the forward and the backward pass:
+          * the dict ALWAYS has the key "reg"; with no positive anchor in the batch it is an exact 0 with zero gradients, where the
+            reference leaves the key out (comb.py:397-401). `sum(losses.values())` -- all the reference's callers do with it -- is
+            unchanged; code that iterates the KEYS (a logger) sees one more entry on such batches;
+          * the two index tensors have the sampler's fixed capacity and are padded with -1; the reference returns compact lists.
+            Nothing in nnDetection consumes them (`train_step` drops them, retina.py:123-131); a caller that indexes with them must
+            drop the -1 entries first (`idx[idx >= 0]`).
+        `NNDET_SYNCFREE_LOSS=0`, a patched `select_indices`, a foreign sampler class or `reduction=None` select the compact route,
+        which reproduces the reference's key set and index lists exactly (at the price of one host synchronisation per step)."""
         box_logits, box_deltas = prediction["box_logits"], prediction["box_deltas"]
         if box_logits.is_cuda and self._use_sync_free():
             return self._compute_loss_sync_free(box_logits, box_deltas, target_labels, matched_gt_boxes, anchors)

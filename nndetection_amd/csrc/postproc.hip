@@ -24,6 +24,7 @@ struct PpArgs {
     const float* scores;    // [B, M*C] logits (is_prob == 0) or probabilities (is_prob == 1)
     const float* deltas;    // [B, M, 6] regression deltas (anchors != NULL) or already decoded boxes (anchors == NULL)
     const float* anchors;   // [M, 6] shared by all images, or NULL
+    const int32_t* labels;  // [B, M] explicit class per row (C must be 1), or NULL: label = flat index % C
     int32_t B, C, K, is_prob;
     int64_t M, MC;
     float clip_exp, ix, iy, iz;       // ix <= 0: no clipping
@@ -106,7 +107,7 @@ __global__ void k_pp_offsets(int B, int K, int* off) {
 // One workgroup (1024 threads) per image over its K sorted candidates: decode + clip, filters, ordered compaction.
 __global__ __launch_bounds__(1024) void k_pp_finish(PpArgs A, const u64* __restrict__ cand, float* __restrict__ cboxes,
                                                     float* __restrict__ cscores, int32_t* __restrict__ clabels,
-                                                    int64_t* __restrict__ n_valid, float* __restrict__ maxc) {
+                                                    uint32_t* __restrict__ cidx, int64_t* __restrict__ n_valid, float* __restrict__ maxc) {
     __shared__ int wsum[16];
     __shared__ float wmax[16];
     __shared__ int running;
@@ -120,12 +121,13 @@ __global__ __launch_bounds__(1024) void k_pp_finish(PpArgs A, const u64* __restr
         float bx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float sc = 0.f;
         int lab = 0;
+        uint32_t idx = 0;
         if (i < A.K) {
             const u64 key = cand[(int64_t)b * A.K + i];
-            const uint32_t idx = (uint32_t)key;
+            idx = (uint32_t)key;
             sc = f32_unsortable(~(uint32_t)(key >> 32));
             const int64_t a = idx / (uint32_t)A.C;
-            lab = (int)(idx - (uint32_t)a * (uint32_t)A.C);
+            lab = A.labels ? A.labels[(int64_t)b * A.M + a] : (int)(idx - (uint32_t)a * (uint32_t)A.C);
             const float* r = A.deltas + ((int64_t)b * A.M + a) * 6;
             if (A.anchors) {
                 // decode_single, nndet/core/boxes/coder.py:107-151 with unit weights (x / 1 == x)
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(1024) void k_pp_finish(PpArgs A, const u64* __restr
             for (int q = 0; q < 6; ++q) cboxes[pos * 6 + q] = bx[q];
             cscores[pos] = sc;
             clabels[pos] = lab;
+            cidx[pos] = idx;
         }
         __syncthreads();
         if (tid == 0) { running += tot; runmax = fmaxf(runmax, bm); }
@@ -197,8 +200,8 @@ __global__ void k_pp_offset_boxes(int K, const float* __restrict__ cboxes, const
 // grid (B), block 256
 __global__ void k_pp_gather(int K, int max_det, const int64_t* __restrict__ keep, const int64_t* __restrict__ n_keep,
                             const float* __restrict__ cboxes, const float* __restrict__ cscores, const int32_t* __restrict__ clabels,
-                            float* __restrict__ out_boxes, float* __restrict__ out_scores, int64_t* __restrict__ out_labels,
-                            int64_t* __restrict__ out_counts) {
+                            const uint32_t* __restrict__ cidx, float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                            int64_t* __restrict__ out_labels, int64_t* __restrict__ out_index, int64_t* __restrict__ out_counts) {
     const int b = blockIdx.x;
     const int64_t nk = n_keep[b] < max_det ? n_keep[b] : max_det;
     for (int j = threadIdx.x; j < max_det; j += blockDim.x) {
@@ -209,11 +212,13 @@ __global__ void k_pp_gather(int K, int max_det, const int64_t* __restrict__ keep
             for (int q = 0; q < 6; ++q) out_boxes[o * 6 + q] = cboxes[p * 6 + q];
             out_scores[o] = cscores[p];
             out_labels[o] = (int64_t)clabels[p];
+            if (out_index) out_index[o] = (int64_t)cidx[p];
         } else {
 #pragma unroll
             for (int q = 0; q < 6; ++q) out_boxes[o * 6 + q] = 0.f;
             out_scores[o] = 0.f;
             out_labels[o] = -1;
+            if (out_index) out_index[o] = -1;
         }
     }
     if (threadIdx.x == 0) out_counts[b] = nk;
@@ -221,7 +226,7 @@ __global__ void k_pp_gather(int K, int max_det, const int64_t* __restrict__ keep
 
 struct PpWs {
     u64* prefix; int* krem; int* cnt; unsigned* hist; int* seg_off;
-    u64* cand; u64* cand_sorted; float* cboxes; float* cscores; int32_t* clabels; float* nboxes;
+    u64* cand; u64* cand_sorted; float* cboxes; float* cscores; int32_t* clabels; uint32_t* cidx; float* nboxes;
     int64_t* n_valid; float* maxc; int64_t* keep; int64_t* n_keep;
     void* sort_tmp; size_t sort_tmp_bytes; void* nms_ws; size_t nms_ws_bytes; size_t total;
 };
@@ -232,7 +237,7 @@ static int pp_layout(int B, int K, char* base, PpWs* w) {
     const size_t BK = (size_t)B * K;
     size_t o_p = take((size_t)B * 8), o_k = take((size_t)B * 4), o_c = take((size_t)B * 4), o_h = take((size_t)B * 256 * 4);
     size_t o_so = take((size_t)(B + 1) * 4);
-    size_t o_ca = take(BK * 8), o_cs = take(BK * 8), o_cb = take(BK * 24), o_sc = take(BK * 4), o_cl = take(BK * 4), o_nb = take(BK * 24);
+    size_t o_ca = take(BK * 8), o_cs = take(BK * 8), o_cb = take(BK * 24), o_sc = take(BK * 4), o_cl = take(BK * 4), o_ci = take(BK * 4), o_nb = take(BK * 24);
     size_t o_nv = take((size_t)B * 8), o_mx = take((size_t)B * 4), o_kp = take(BK * 8), o_nk = take((size_t)B * 8);
     size_t tmp = 0;
     hipError_t e = rocprim::segmented_radix_sort_keys<rocprim::default_config, const u64*, u64*, const int*>(
@@ -245,7 +250,7 @@ static int pp_layout(int B, int K, char* base, PpWs* w) {
     w->prefix = (u64*)(base + o_p); w->krem = (int*)(base + o_k); w->cnt = (int*)(base + o_c); w->hist = (unsigned*)(base + o_h);
     w->seg_off = (int*)(base + o_so);
     w->cand = (u64*)(base + o_ca); w->cand_sorted = (u64*)(base + o_cs); w->cboxes = (float*)(base + o_cb);
-    w->cscores = (float*)(base + o_sc); w->clabels = (int32_t*)(base + o_cl); w->nboxes = (float*)(base + o_nb);
+    w->cscores = (float*)(base + o_sc); w->clabels = (int32_t*)(base + o_cl); w->cidx = (uint32_t*)(base + o_ci); w->nboxes = (float*)(base + o_nb);
     w->n_valid = (int64_t*)(base + o_nv); w->maxc = (float*)(base + o_mx); w->keep = (int64_t*)(base + o_kp); w->n_keep = (int64_t*)(base + o_nk);
     w->sort_tmp = base + o_tmp; w->sort_tmp_bytes = tmp; w->nms_ws = base + o_nms; w->nms_ws_bytes = nms_b; w->total = off;
     return 0;
@@ -269,12 +274,42 @@ extern "C" size_t nndet_postprocess3d_workspace_bytes(int32_t B, int64_t M, int3
     return w.total;
 }
 
+static int pp_run(const float* scores, int32_t scores_are_probs, const float* deltas, const float* anchors, const int32_t* labels,
+                  int32_t B, int64_t M, int32_t C, float clip_exp, float img_x, float img_y, float img_z,
+                  int32_t topk, float score_thresh, int32_t use_score_thresh, float min_size,
+                  int32_t use_min_size, float nms_thresh, int32_t max_det, float* out_boxes,
+                  float* out_scores, int64_t* out_labels, int64_t* out_index, int64_t* out_counts, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
 extern "C" int nndet_postprocess3d_f32(const float* scores, int32_t scores_are_probs, const float* deltas, const float* anchors,
                                        int32_t B, int64_t M, int32_t C, float clip_exp, float img_x, float img_y, float img_z,
                                        int32_t topk, float score_thresh, int32_t use_score_thresh, float min_size,
                                        int32_t use_min_size, float nms_thresh, int32_t max_det, float* out_boxes,
                                        float* out_scores, int64_t* out_labels, int64_t* out_counts, void* workspace,
                                        size_t workspace_bytes, void* stream) {
+    return pp_run(scores, scores_are_probs, deltas, anchors, nullptr, B, M, C, clip_exp, img_x, img_y, img_z, topk, score_thresh,
+                  use_score_thresh, min_size, use_min_size, nms_thresh, max_det, out_boxes, out_scores, out_labels, nullptr, out_counts,
+                  workspace, workspace_bytes, stream);
+}
+
+extern "C" int nndet_postprocess3d_rows_f32(const float* probs, const float* boxes, const int32_t* labels, int32_t B, int64_t M,
+                                            float img_x, float img_y, float img_z, int32_t topk, float score_thresh,
+                                            int32_t use_score_thresh, float min_size, int32_t use_min_size, float nms_thresh,
+                                            int32_t max_det, float* out_boxes, float* out_scores, int64_t* out_labels,
+                                            int64_t* out_index, int64_t* out_counts, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+    if (!labels || !out_index) return NNDET_EINVAL;
+    return pp_run(probs, 1, boxes, nullptr, labels, B, M, 1, 0.f, img_x, img_y, img_z, topk, score_thresh, use_score_thresh, min_size,
+                  use_min_size, nms_thresh, max_det, out_boxes, out_scores, out_labels, out_index, out_counts, workspace,
+                  workspace_bytes, stream);
+}
+
+static int pp_run(const float* scores, int32_t scores_are_probs, const float* deltas, const float* anchors, const int32_t* labels,
+                  int32_t B, int64_t M, int32_t C, float clip_exp, float img_x, float img_y, float img_z,
+                  int32_t topk, float score_thresh, int32_t use_score_thresh, float min_size,
+                  int32_t use_min_size, float nms_thresh, int32_t max_det, float* out_boxes,
+                  float* out_scores, int64_t* out_labels, int64_t* out_index, int64_t* out_counts, void* workspace,
+                  size_t workspace_bytes, void* stream) {
     hipStream_t st = as_stream(stream);
     int64_t K64;
     if (B <= 0 || max_det <= 0 || !out_counts) return NNDET_EINVAL;
@@ -287,7 +322,7 @@ extern "C" int nndet_postprocess3d_f32(const float* scores, int32_t scores_are_p
     if (rc) return rc;
     if (w.total > workspace_bytes) return NNDET_EWORKSPACE;
     PpArgs A;
-    A.scores = scores; A.deltas = deltas; A.anchors = anchors; A.B = B; A.C = C; A.K = K; A.is_prob = scores_are_probs;
+    A.scores = scores; A.deltas = deltas; A.anchors = anchors; A.labels = labels; A.B = B; A.C = C; A.K = K; A.is_prob = scores_are_probs;
     A.M = M; A.MC = M * C; A.clip_exp = clip_exp; A.ix = img_x; A.iy = img_y; A.iz = img_z;
     A.score_thresh = score_thresh; A.use_thresh = use_score_thresh; A.min_size = min_size; A.use_min_size = use_min_size;
     A.max_det = max_det;
@@ -315,7 +350,7 @@ extern "C" int nndet_postprocess3d_f32(const float* scores, int32_t scores_are_p
     size_t tmp = w.sort_tmp_bytes;
     HIP_TRY((rocprim::segmented_radix_sort_keys<rocprim::default_config, const u64*, u64*, const int*>(
         w.sort_tmp, tmp, w.cand, w.cand_sorted, (unsigned)((size_t)B * K), (unsigned)B, w.seg_off, w.seg_off + 1, 0, 64, st, false)));
-    k_pp_finish<<<B, 1024, 0, st>>>(A, w.cand_sorted, w.cboxes, w.cscores, w.clabels, w.n_valid, w.maxc);
+    k_pp_finish<<<B, 1024, 0, st>>>(A, w.cand_sorted, w.cboxes, w.cscores, w.clabels, w.cidx, w.n_valid, w.maxc);
     LAUNCH_CHECK();
     k_pp_offset_boxes<<<dim3(ceil_div(K, 256), B), 256, 0, st>>>(K, w.cboxes, w.clabels, w.n_valid, w.maxc, w.nboxes);
     LAUNCH_CHECK();
@@ -324,8 +359,8 @@ extern "C" int nndet_postprocess3d_f32(const float* scores, int32_t scores_are_p
                                w.nms_ws, w.nms_ws_bytes, st);
         if (rc) return rc;
     }
-    k_pp_gather<<<B, 256, 0, st>>>(K, max_det, w.keep, w.n_keep, w.cboxes, w.cscores, w.clabels, out_boxes, out_scores,
-                                   out_labels, out_counts);
+    k_pp_gather<<<B, 256, 0, st>>>(K, max_det, w.keep, w.n_keep, w.cboxes, w.cscores, w.clabels, w.cidx, out_boxes, out_scores,
+                                   out_labels, out_index, out_counts);
     LAUNCH_CHECK();
     return 0;
 }

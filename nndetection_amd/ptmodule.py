@@ -352,6 +352,8 @@ def register_with_nndet():
         (batched ATSS assignment, fused post-processing) runs on the HIP kernels; same constructor calls, same state-dict keys;
       * `training_step` / `validation_step` (base.py:135-180) from the mixin: device-side target preparation instead of
         `self.pre_trafo`, activation dtype from the autocast state / `trainer_cfg.precision`, losses to the host without a sync;
+      * `get_ensembler_cls("boxes", 3)`: the reference's BoxEnsemblerSelective with `postprocess_image` (the per-tile top-k / clip /
+        small-box filter / model NMS, inference/ensembler/detection.py:166-217) as one fused HIP pass (inference/ensembler.py);
       * `on_fit_start` / `on_after_backward` from the mixin: the bucketed RCCL gradient all-reduce of nndetection_amd.ddp when the
         job runs as one process per GPU under torch.distributed and Lightning's own DDP wrapper is not active (the reference
         leaves multi-GPU to pl.Trainer, scripts/train.py:265-289).
@@ -365,6 +367,15 @@ def register_with_nndet():
         @classmethod
         def from_config_plan(cls, model_cfg: dict, plan_arch: dict, plan_anchors: dict, log_num_anchors: str = None, **kwargs):
             return RetinaUNetV001.from_config_plan(model_cfg, plan_arch, plan_anchors, log_num_anchors, **kwargs)
+
+        @staticmethod
+        def get_ensembler_cls(key, dim: int):
+            """retinaunet/base.py:677-695; the box ensembler's per-tile `postprocess_image` runs as one fused HIP pass."""
+            base = _RefV001.get_ensembler_cls(key, dim)
+            if key == "boxes" and dim == 3 and base is not None:
+                from .inference.ensembler import amd_box_ensembler
+                return amd_box_ensembler(base)
+            return base
 
     if "RetinaUNetV001AMD" not in MODULE_REGISTRY.mapping:
         MODULE_REGISTRY.register(RetinaUNetV001AMD)

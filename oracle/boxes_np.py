@@ -287,6 +287,21 @@ def postprocess_single_image(boxes, probs, image_shape, num_classes=1, topk=1000
     return b[keep], p[keep], labels[keep].astype(np.int64)
 
 
+def ensembler_postprocess_image(boxes, probs, labels, weights, shape, model_topk=1000, model_score_thresh=0.0,
+                                min_size=0.01, model_iou=0.1, model_detections_per_image=100):
+    """BoxEnsemblerSelective.postprocess_image (nndet/inference/ensembler/detection.py:166-217) with model_nms_fn =
+    batched_nms_model (nndet/inference/detection/model.py:25-54). Probability ties: lower row first."""
+    b, p, l, w = _f(boxes).reshape(-1, 6), _f(probs), np.asarray(labels), _f(weights)
+    idx = np.argsort(-p, kind="stable")[:model_topk]
+    idx = idx[p[idx] > F32(model_score_thresh)]
+    b, p, l, w = b[idx], p[idx], l[idx], w[idx]
+    b = clip_boxes_to_image(b, shape)
+    keep = remove_small_boxes(b, min_size)
+    b, p, l, w = b[keep], p[keep], l[keep], w[keep]
+    keep = batched_nms(b, p, l, model_iou)[:model_detections_per_image]
+    return b[keep], p[keep], l[keep], w[keep]
+
+
 # --------------------------------------------------------------------------------------
 # hard-negative sampler bookkeeping (RNG itself stays in torch on both sides)
 # --------------------------------------------------------------------------------------

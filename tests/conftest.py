@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+import tests.gpu_util  # noqa: E402,F401  (pins the name `tests` to THIS package: the reference checkout, which some CPU tests put in
+#                                  front of sys.path, ships a `tests` package of its own)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

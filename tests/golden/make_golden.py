@@ -292,6 +292,77 @@ def golden_fp64(name="luna160", batch=1):
     np.savez_compressed(os.path.join(OUT, f"net_{name}_fp64.npz"), **g)
 
 
+def golden_postproc():
+    """Direct fixtures of three reference functions that were pinned only through end-to-end runs:
+      * BaseRetinaNet.postprocess_detections_single_image (nndet/core/retina.py:332-379) on decoded boxes + probabilities,
+        1 and 3 classes, with small boxes, out-of-image boxes and a score threshold;
+      * HardNegativeSamplerBatched.__call__ (nndet/core/boxes/sampler.py:237-270) with torch.randperm := reversed arange;
+      * BoxEnsemblerSelective.postprocess_image (nndet/inference/ensembler/detection.py:166-217) with batched_nms_model.
+    Scores are distinct (ties are implementation-defined in the reference)."""
+    from types import SimpleNamespace
+    from nndet.core.retina import BaseRetinaNet
+    from nndet.core.boxes.sampler import HardNegativeSamplerBatched
+    rng = np.random.default_rng(11)
+    g = {}
+    shape = (96, 80, 64)
+    for tag, C, M, topk, thr, dets in (("c1", 1, 6000, 2000, 0.05, 100), ("c3", 3, 3000, 1500, 0.0, 50)):
+        boxes = rand_boxes(rng, M, extent=shape, smin=0.0, smax=30)
+        boxes[:40] += 70                                                   # partly / fully outside the image -> clipped to (near) zero size
+        boxes[40:60, 2] = boxes[40:60, 0] + 0.005                          # thinner than remove_small_boxes
+        probs = ((rng.permutation(M * C).astype(np.float64) + 1) / (M * C + 1)).astype(np.float32).reshape(M, C)
+        holder = SimpleNamespace(topk_candidates=topk, score_thresh=thr, num_foreground_classes=C, remove_small_boxes=0.01,
+                                 nms_thresh=0.6, detections_per_img=dets)
+        rbx, rp, rl = BaseRetinaNet.postprocess_detections_single_image(holder, torch.from_numpy(boxes.copy()), torch.from_numpy(probs.copy()), shape)
+        ob, op, ol = bx.postprocess_single_image(boxes.copy(), probs, shape, C, topk, thr, 0.01, 0.6, dets)
+        eq(ob, rbx.numpy(), f"postprocess_single_image boxes {tag}"); eq(op, rp.numpy(), f"postprocess_single_image scores {tag}")
+        eq(ol, rl.numpy(), f"postprocess_single_image labels {tag}")
+        g[f"pp_{tag}_boxes"], g[f"pp_{tag}_probs"] = boxes, probs
+        g[f"pp_{tag}_cfg"] = np.asarray([C, topk, dets, *shape], np.int64); g[f"pp_{tag}_thr"] = np.float32(thr)
+        g[f"pp_{tag}_out_boxes"], g[f"pp_{tag}_out_scores"], g[f"pp_{tag}_out_labels"] = rbx.numpy(), rp.numpy(), rl.numpy()
+    # ---- sampler
+    n = 40000
+    labels = np.zeros(n, np.float32)
+    labels[rng.choice(n, 300, replace=False)] = 1.0
+    labels[rng.choice(n, 500, replace=False)] = -1.0                      # "between thresholds": ignored by the sampler
+    fg = ((rng.permutation(n).astype(np.float64) + 1) / (n + 1)).astype(np.float32)
+    per_img = [10000, 14000, 16000]
+    sampler = HardNegativeSamplerBatched(batch_size_per_image=32, positive_fraction=0.33, min_neg=1, pool_size=20)
+    orig = torch.randperm
+    torch.randperm = det_randperm
+    try:
+        pos_m, neg_m = sampler(list(torch.from_numpy(labels).split(per_img)), torch.from_numpy(fg))
+    finally:
+        torch.randperm = orig
+    pos = torch.where(torch.cat(pos_m))[0].numpy(); neg = torch.where(torch.cat(neg_m))[0].numpy()
+    op_, on_, _ = bx.hnm_select_reversed(labels, fg, len(per_img), 32, 0.33, 1, 20)
+    eq(op_, pos, "HardNegativeSamplerBatched positives"); eq(on_, neg, "HardNegativeSamplerBatched negatives")
+    g["hnm_labels"], g["hnm_fg"], g["hnm_per_img"] = labels, fg, np.asarray(per_img, np.int64)
+    g["hnm_pos"], g["hnm_neg"] = pos.astype(np.int64), neg.astype(np.int64)
+    # ---- ensembler stage
+    from oracle.refimport import install_stub_finder
+    install_stub_finder()
+    from nndet.inference.ensembler.detection import BoxEnsemblerSelective
+    from nndet.inference.detection.model import batched_nms_model
+    N = 5000
+    eb = rand_boxes(rng, N, extent=(128, 128, 96), smin=0.0, smax=28)
+    eb[:30] += 100
+    ep = ((rng.permutation(N).astype(np.float64) + 1) / (N + 1)).astype(np.float32)
+    el = rng.integers(0, 3, N).astype(np.int64)
+    ew = rng.uniform(0.1, 1.0, N).astype(np.float32)
+    prm = {"model_iou": 0.1, "model_nms_fn": batched_nms_model, "model_score_thresh": 0.1, "model_topk": 1000,
+           "model_detections_per_image": 100, "remove_small_boxes": 1e-2}
+    holder = SimpleNamespace(parameters=prm)
+    tile = (128, 128, 96)
+    rb_, rp_, rl_, rw_ = BoxEnsemblerSelective.postprocess_image(holder, torch.from_numpy(eb.copy()), torch.from_numpy(ep.copy()),
+                                                                 torch.from_numpy(el.copy()), torch.from_numpy(ew.copy()), tile)
+    g["ens_boxes"], g["ens_probs"], g["ens_labels"], g["ens_weights"] = eb, ep, el, ew
+    g["ens_shape"] = np.asarray(tile, np.int64)
+    g["ens_out_boxes"], g["ens_out_probs"], g["ens_out_labels"], g["ens_out_weights"] = rb_.numpy(), rp_.numpy(), rl_.numpy(), rw_.numpy()
+    print(f"  ensembler postprocess_image: {len(rb_)} of {N} rows kept; postprocess_single_image c1 / c3: "
+          f"{len(g['pp_c1_out_boxes'])} / {len(g['pp_c3_out_boxes'])}; sampler: {len(pos)} pos / {len(neg)} neg")
+    np.savez_compressed(os.path.join(OUT, "postproc_golden.npz"), **g)
+
+
 def golden_targets():
     """the three `pre_trafo` transforms of RetinaUNetModule (retinaunet/base.py:108-131) run unmodified on a small
     synthetic instance volume; the oracle restatement must reproduce them exactly (integer work)."""
@@ -370,7 +441,7 @@ def golden_wbc():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["boxes", "targets", "wbc", "tiny", "toy64", "luna160"]
+    which = sys.argv[1:] or ["boxes", "targets", "wbc", "postproc", "tiny", "toy64", "luna160", "luna160_fp64"]
     if "wbc" in which:
         print("weighted box clustering:"); golden_wbc()
     if "targets" in which:
@@ -384,5 +455,7 @@ if __name__ == "__main__":
         golden_net("toy64", lite=True)        # BASELINE.json configs[0]: the reference's own CPU-runnable case
     if "luna160" in which:
         golden_net("luna160", lite=True, batch=1)   # BASELINE.json configs[1] (the benchmarked plan), one 160x160x96 patch, fp32
+    if "postproc" in which:
+        golden_postproc()
     if "luna160_fp64" in which:
         golden_fp64("luna160", 1)

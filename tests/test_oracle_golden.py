@@ -154,3 +154,21 @@ def test_wbc_oracle_vs_reference_golden(golden_dir):
         assert ob.shape == g[f"out_boxes_{tag}"].shape
         assert np.allclose(ob, g[f"out_boxes_{tag}"], rtol=1e-5, atol=1e-5) and np.allclose(os_, g[f"out_scores_{tag}"], rtol=1e-5, atol=1e-6)
         assert np.array_equal(ol, g[f"out_labels_{tag}"])
+
+
+def test_postproc_oracles_vs_reference_golden(golden_dir):
+    """postproc_golden.npz (tests/golden/make_golden.py golden_postproc): the reference's postprocess_detections_single_image,
+    HardNegativeSamplerBatched (randperm := reversed arange) and BoxEnsemblerSelective.postprocess_image, each against its numpy
+    restatement -- bit-exact (index / compare work on fp32 values that both sides compute with the same operations)."""
+    g = np.load(os.path.join(golden_dir, "postproc_golden.npz"))
+    for tag in ("c1", "c3"):
+        C, topk, dets, *shape = [int(v) for v in g[f"pp_{tag}_cfg"]]
+        b, p, l = bx.postprocess_single_image(g[f"pp_{tag}_boxes"].copy(), g[f"pp_{tag}_probs"], shape, C, topk, float(g[f"pp_{tag}_thr"]), 0.01, 0.6, dets)
+        assert np.array_equal(b, g[f"pp_{tag}_out_boxes"]) and np.array_equal(p, g[f"pp_{tag}_out_scores"])
+        assert np.array_equal(l, g[f"pp_{tag}_out_labels"])
+    pos, neg, _ = bx.hnm_select_reversed(g["hnm_labels"], g["hnm_fg"], len(g["hnm_per_img"]), 32, 0.33, 1, 20)
+    assert np.array_equal(pos, g["hnm_pos"]) and np.array_equal(neg, g["hnm_neg"])
+    b, p, l, w = bx.ensembler_postprocess_image(g["ens_boxes"], g["ens_probs"], g["ens_labels"], g["ens_weights"], tuple(g["ens_shape"]),
+                                                1000, 0.1, 0.01, 0.1, 100)
+    assert np.array_equal(b, g["ens_out_boxes"]) and np.array_equal(p, g["ens_out_probs"])
+    assert np.array_equal(l, g["ens_out_labels"]) and np.array_equal(w, g["ens_out_weights"])

@@ -60,6 +60,22 @@ def test_registered_class_runs_the_reference_free_step_mixin(ref):
     assert isinstance(opt, torch.optim.SGD) and not opt.param_groups[0].get("fused")
 
 
+def test_registered_class_hands_out_the_fused_box_ensembler(ref):
+    """f3 remainder: `get_ensembler_cls("boxes", 3)` (retinaunet/base.py:677-695, used by get_predictor :724)
+    is the reference's BoxEnsemblerSelective with `postprocess_image` replaced by the fused HIP pass; the segmentation ensembler
+    and everything else of the class are the reference's."""
+    import nndetection_amd.plugin as plugin
+    from nndetection_amd.inference.ensembler import AMDPostprocessMixin
+    from nndet.inference.ensembler.detection import BoxEnsemblerSelective
+    from nndet.inference.ensembler.segmentation import SegmentationEnsembler
+    cls = plugin.RetinaUNetV001AMD.get_ensembler_cls("boxes", 3)
+    assert issubclass(cls, BoxEnsemblerSelective) and issubclass(cls, AMDPostprocessMixin)
+    assert cls.postprocess_image is AMDPostprocessMixin.postprocess_image
+    assert cls.from_case.__func__ is BoxEnsemblerSelective.from_case.__func__ and cls.get_default_parameters() == BoxEnsemblerSelective.get_default_parameters()
+    assert plugin.RetinaUNetV001AMD.get_ensembler_cls("seg", 3) is SegmentationEnsembler
+    assert plugin.RetinaUNetV001AMD.get_ensembler_cls("boxes", 3) is cls           # one subclass, created once
+
+
 def test_module_builds_with_reference_state_dict(ref):
     """Constructed like scripts/train.py:237 does (`MODULE_REGISTRY[cfg.module](model_cfg, trainer_cfg, plan)`): the 92
     parameter names / shapes equal those of the reference module, so reference checkpoints load strictly."""

@@ -91,7 +91,8 @@ def test_precision_selects_the_low_precision_kernels(mode):
              mod.model.decoder.register_forward_hook(lambda m, i, o: seen.extend(("dec", t.dtype) for t in o if t is not None))]
     opt, _ = mod.configure_optimizers()
     scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, enabled=mode == "autocast-f16")
-    w0 = mod.model.encoder.stages[0].convs[0].conv.weight.detach().clone() if hasattr(mod.model.encoder, "stages") else None
+    first = dict(mod.model.named_parameters())["encoder.stages.0.convs.0.0.conv.weight"]
+    w0 = first.detach().clone()
     batch = _batch(p, seed=3)
     assert batch["data"].dtype == torch.float32
     import contextlib
@@ -112,8 +113,7 @@ def test_precision_selects_the_low_precision_kernels(mode):
     assert all(torch.isfinite(q).all() for q in mod.model.parameters())
     if mode == "autocast-f16":
         assert scaler.get_scale() == 1024.0                      # no inf / nan was found: the step was not skipped
-    if w0 is not None:
-        assert not torch.equal(w0, mod.model.encoder.stages[0].convs[0].conv.weight.detach())
+    assert not torch.equal(w0, first.detach())
 
 
 def test_low_precision_step_tracks_fp32_step():
