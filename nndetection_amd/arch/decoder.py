@@ -69,22 +69,65 @@ class UFPNModular(nn.Module):
     # the consumer of level 0 when it is ready. NNDET_DECODER_TAIL=0: everything on the caller's stream.
     split_tail = os.environ.get("NNDET_DECODER_TAIL", "1") != "0"
     _tail_streams: dict = {}
+    # The lateral 1x1x1 convolutions only need their own encoder stage. Issued from a hook of the encoder as soon as that stage's
+    # output exists (the detector installs it), the HBM-bound full- and half-resolution laterals (0.28 + 0.30 ms at 160x160x96) run on
+    # side streams UNDER the deep encoder stages, whose launches of 100-400 workgroups leave most of the 256 CUs idle (timeline of
+    # round 3: the GPU ran one kernel at a time from e2 to the end of the encoder). NNDET_EARLY_LATERAL=0: laterals inside forward().
+    early_laterals = os.environ.get("NNDET_EARLY_LATERAL", "1") != "0"
+    _early_streams: dict = {}
+
+    def early_lateral(self, level: int, fm: torch.Tensor) -> None:
+        """Encoder stage hook: lateral P<level> of `fm` on a side stream, forked from the caller's stream now. The result is picked
+        up (and the stream joined) by the next forward(); the deepest level is not worth a fork (the decoder needs it first)."""
+        if not (self.early_laterals and fm.is_cuda and level < self.num_level - 1):
+            return
+        dev = fm.device
+        main = torch.cuda.current_stream(dev)
+        need0 = not (self.skip_unused_out and self.used_levels is not None and 0 not in self.used_levels)
+        if level == 0 and self.split_tail and self.num_level >= 3 and need0:
+            side = UFPNModular._tail_streams.get(dev.index or 0)        # level 0 stays on the tail stream of forward()
+            if side is None:
+                side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev)
+        else:
+            side = UFPNModular._early_streams.get(dev.index or 0)
+            if side is None:
+                side = UFPNModular._early_streams[dev.index or 0] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)                                   # this stage's output is ready
+        fm.record_stream(side)
+        with torch.cuda.stream(side):
+            lat = self.lateral[f"P{level}"](fm)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        if not hasattr(self, "_early"):
+            self._early = {}
+        self._early[level] = (fm, lat, ev, side)
 
     def forward(self, inp_seq: Sequence[torch.Tensor]) -> List[Optional[torch.Tensor]]:
         self.tail_event = None
         need0 = not (self.skip_unused_out and self.used_levels is not None and 0 not in self.used_levels)
         split = self.split_tail and self.num_level >= 3 and inp_seq[0].is_cuda and need0
         fpn: List[Optional[torch.Tensor]] = [None] * self.num_level
+        early = getattr(self, "_early", None) or {}
+        self._early = {}
+        for l, (src, lat, ev, st) in early.items():              # laterals the encoder hook already issued (same input tensor only)
+            if l < len(inp_seq) and src is inp_seq[l]:
+                fpn[l] = lat
+                cons = UFPNModular._tail_streams.get(lat.device.index or 0) if (l == 0 and split) else None
+                if cons is None or cons != st:                   # consumed on another stream than it was produced on: join
+                    cur = torch.cuda.current_stream(lat.device) if cons is None else cons
+                    cur.wait_event(ev)
+                    lat.record_stream(cur)
         if split:
             dev = inp_seq[0].device
             main = torch.cuda.current_stream(dev)
             side = UFPNModular._tail_streams.get(dev.index or 0)
             if side is None:
                 side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev)
-            side.wait_stream(main)                               # the encoder outputs are ready
-            inp_seq[0].record_stream(side)
-            with torch.cuda.stream(side):
-                fpn[0] = self.lateral["P0"](inp_seq[0])
+            if fpn[0] is None:
+                side.wait_stream(main)                           # the encoder outputs are ready
+                inp_seq[0].record_stream(side)
+                with torch.cuda.stream(side):
+                    fpn[0] = self.lateral["P0"](inp_seq[0])
         for l, fm in enumerate(inp_seq):
             if fpn[l] is None:
                 fpn[l] = self.lateral[f"P{l}"](fm)

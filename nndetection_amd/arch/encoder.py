@@ -35,6 +35,7 @@ class Encoder(nn.Module):
         self.stages = nn.ModuleList(stages)
         self.defer_outputs = False       # see set_defer_outputs
         self.fuse_grad_accum = False     # see set_fuse_grad_accum
+        self.stage_hook = None           # optional callable(output index, tensor) run right after a stage output exists (decoder.early_lateral)
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         outputs = []
@@ -46,6 +47,8 @@ class Encoder(nn.Module):
                     # (see set_fuse_grad_accum / arch/conv.py:_ConvFn.backward; "stream": where this activation's own backward
                     # node will run -- the second consumer orders that stream behind its in-place accumulation)
                     x._nndet_gacc = {"buf": None, "stream": torch.cuda.current_stream(x.device) if x.is_cuda else None}
+                if self.stage_hook is not None:
+                    self.stage_hook(len(outputs) - 1, x)
         return outputs
 
     def set_fuse_grad_accum(self, on: bool) -> None:
