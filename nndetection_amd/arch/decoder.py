@@ -72,8 +72,11 @@ class UFPNModular(nn.Module):
     # The lateral 1x1x1 convolutions only need their own encoder stage. Issued from a hook of the encoder as soon as that stage's
     # output exists (the detector installs it), the HBM-bound full- and half-resolution laterals (0.28 + 0.30 ms at 160x160x96) run on
     # side streams UNDER the deep encoder stages, whose launches of 100-400 workgroups leave most of the 256 CUs idle (timeline of
-    # round 3: the GPU ran one kernel at a time from e2 to the end of the encoder). NNDET_EARLY_LATERAL=0: laterals inside forward().
-    early_laterals = os.environ.get("NNDET_EARLY_LATERAL", "1") != "0"
+    # round 3: the GPU ran one kernel at a time from e2 to the end of the encoder). MEASURED SLOWER and therefore OFF by default
+    # (A/B in one session, profiles/round3_ab_early_lateral.txt: 225.3 / 227.1 patches/s with, 229.8 / 228.9 without): the laterals
+    # then compete for HBM with the stage-1 / stage-2 convolutions that follow their fork point, which costs more than the idle CUs
+    # under e3-e5 give back. NNDET_EARLY_LATERAL=1 enables it.
+    early_laterals = os.environ.get("NNDET_EARLY_LATERAL", "0") != "0"
     _early_streams: dict = {}
 
     def early_lateral(self, level: int, fm: torch.Tensor) -> None:

@@ -158,15 +158,73 @@ __global__ void k_norm_finalize(const double* __restrict__ stats, int N, int c, 
     }
 }
 
+// Same result from a grid (N, C_p / 32): one block per image and 32-channel block, the 32 replicas of its 64 sums read by 256
+// threads in parallel (8 independent loads each) instead of 32 dependent loads per thread -- the 4-block version above took
+// 6-16 us per call, 14 calls per training step on the critical path of the forward pass. Needs whole groups inside a 32-channel
+// block (channels per group divides 32: InstanceNorm 1, the heads' GroupNorm 16). The fp64 replica sums are associated differently
+// (4 partial sums of 8 replicas): 1e-16 relative, invisible after the rounding to fp32.
+__global__ __launch_bounds__(256) void k_norm_finalize32(const double* __restrict__ stats, int N, int c, int c_p, int groups, int64_t spatial,
+                                                         float eps, float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ scale_shift, const NormItems IT) {
+    __shared__ double part[4][64];
+    __shared__ double ch[64];
+    const int n = blockIdx.x, c0 = blockIdx.y * 32, t = threadIdx.x;
+    if (IT.n) spatial = IT.spatial[n];
+    const int v = t & 63, rg = t >> 6;
+    double ld[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ld[k] = stats[(((int64_t)(rg * 8 + k) * N + n) * c_p + c0) * 2 + v];
+    double s8 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s8 += ld[k];                 // replicas rg*8 .. rg*8+7 in order
+    part[rg][v] = s8;
+    __syncthreads();
+    if (t < 64) ch[t] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+    __syncthreads();
+    if (t < 32) {
+        const int i = c0 + t, cpg = c / groups;
+        float mean = 0.f, rstd = 0.f;
+        if (i < c) {
+            const int g0 = (t / cpg) * cpg;                  // first channel of this group inside the block
+            double s = 0.0, s2 = 0.0;
+            for (int k = 0; k < cpg; ++k) { s += ch[(g0 + k) * 2]; s2 += ch[(g0 + k) * 2 + 1]; }
+            const double m = (double)cpg * (double)spatial;
+            const double mu = s / m;
+            double var = s2 / m - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            rstd = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        mean_rstd[((int64_t)n * c_p + i) * 2 + 0] = mean;
+        mean_rstd[((int64_t)n * c_p + i) * 2 + 1] = rstd;
+        if (scale_shift) {
+            float a = 0.f, b = 0.f;
+            if (i < c) { a = rstd * gamma[i]; b = beta[i] - mean * a; }
+            scale_shift[((int64_t)n * c_p + i) * 2 + 0] = a;
+            scale_shift[((int64_t)n * c_p + i) * 2 + 1] = b;
+        }
+    }
+}
+
+static int finalize_launch(const double* stats, int N, int c, int c_p, int groups, int64_t spatial, float eps, float* mean_rstd,
+                           const float* gamma, const float* beta, float* scale_shift, const NormItems& it, hipStream_t st) {
+    const int cpg = c / groups;
+    static const int fast = getenv("NNDET_NORM_FINALIZE32") ? atoi(getenv("NNDET_NORM_FINALIZE32")) : 1;
+    if (fast && cpg > 0 && 32 % cpg == 0)
+        k_norm_finalize32<<<dim3(N, c_p / 32), 256, 0, st>>>(stats, N, c, c_p, groups, spatial, eps, mean_rstd, gamma, beta, scale_shift, it);
+    else
+        k_norm_finalize<<<N, 256, (size_t)c_p * 16, st>>>(stats, N, c, c_p, groups, spatial, eps, mean_rstd, gamma, beta, scale_shift, it);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int nndet_norm_finalize(const double* stats, const float* gamma, const float* beta, int32_t batch, int64_t spatial,
                                    int32_t c, int32_t c_p, int32_t groups, float eps, float* mean_rstd_out, float* scale_shift_out,
                                    void* stream) {
     if (!stats || !gamma || !beta || !mean_rstd_out || !scale_shift_out) return NNDET_EINVAL;
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
-    k_norm_finalize<<<batch, 256, (size_t)c_p * 16, as_stream(stream)>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out,
-                                                                        gamma, beta, scale_shift_out, g_norm_uniform);
-    LAUNCH_CHECK();
-    return 0;
+    return finalize_launch(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out, gamma, beta, scale_shift_out, g_norm_uniform,
+                           as_stream(stream));
 }
 
 // ------------------------------------------------------------------ apply: y = relu?((x - mean) * rstd * gamma + beta)
@@ -208,9 +266,8 @@ extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stat
     if (!x || !stats || !gamma || !beta || !y || !mean_rstd_out) return NNDET_EINVAL;
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
-    k_norm_finalize<<<batch, 256, (size_t)c_p * 16, st>>>(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out, nullptr, nullptr,
-                                                          nullptr, g_norm_uniform);
-    LAUNCH_CHECK();
+    { const int frc = finalize_launch(stats, batch, c, c_p, groups, spatial, eps, mean_rstd_out, nullptr, nullptr, nullptr, g_norm_uniform, st);
+      if (frc) return frc; }
     const int rpb = apply_rows(spatial * batch, c_p, nndet_esize(dtype));
     dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
     if (dtype == NNDET_BF16)
@@ -250,8 +307,8 @@ extern "C" int nndet_norm_apply_items(int32_t dtype, const void* x, const double
     const int rc = norm_items(items, &ni, &total, &mx);
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
-    k_norm_finalize<<<ni.n, 256, (size_t)c_p * 16, st>>>(stats, ni.n, c, c_p, groups, 0, eps, mean_rstd_out, nullptr, nullptr, nullptr, ni);
-    LAUNCH_CHECK();
+    { const int frc = finalize_launch(stats, ni.n, c, c_p, groups, 0, eps, mean_rstd_out, nullptr, nullptr, nullptr, ni, st);
+      if (frc) return frc; }
     const int rpb = apply_rows(total, c_p, nndet_esize(dtype));
     dim3 grid((unsigned)ceil_div64(mx, rpb), ni.n);
     if (dtype == NNDET_BF16)

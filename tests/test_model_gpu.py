@@ -476,8 +476,8 @@ def test_fused_detection_loss_in_train_step(golden_dir, monkeypatch):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_stream_overlap_does_not_change_training(golden_dir, monkeypatch, dtype):
     """Four optimizer steps on toy64; at every step the SAME parameters go through a train step with every overlap feature on (head
-    branches, target assignment, segmentation branch, the full-resolution decoder tail and the early lateral convolutions on side
-    streams, weight gradients on their own stream) and with everything on the caller's stream: same losses, same gradients for every parameter. A missing stream dependency shows up as a difference
+    branches, target assignment, segmentation branch and the full-resolution decoder tail on side streams, weight gradients on their
+    own stream) and with everything on the caller's stream: same losses, same gradients for every parameter. A missing stream dependency shows up as a difference
     here -- the kernels and their inputs are identical, only the order of atomically reduced sums may differ (fp32: 2e-5 of the
     tensor maximum; bf16: storage noise of the atomically accumulated statistics, 2e-2). Parameters after several steps are NOT
     compared: two runs of the same configuration already differ by 4e-4 there (tools/diag_overlap.py: chaotic amplification)."""
@@ -503,7 +503,6 @@ def test_stream_overlap_does_not_change_training(golden_dir, monkeypatch, dtype)
             monkeypatch.setattr(BaseRetinaNet, "overlap_aux", mode)
             monkeypatch.setattr(L.wgrad_streams, "enabled", mode)
             monkeypatch.setattr(UFPNModular, "split_tail", mode)
-            monkeypatch.setattr(UFPNModular, "early_laterals", mode)      # laterals forked from the encoder's stage hook (round 3)
             opt.zero_grad(set_to_none=True)
             losses, _ = net.train_step(x.cuda().to(dtype), _cuda_targets(tg), evaluation=False)
             sum(losses.values()).backward()
