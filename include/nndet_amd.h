@@ -231,6 +231,26 @@ typedef struct NndetConv {
     int32_t reserved_;
 } NndetConv;
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused stem block: Conv3d(1 -> C, 3x3x3, stride 1, pad 1, no bias) -> InstanceNorm3d(affine) -> ReLU, the first block of the
+ * encoder (nndet/arch/conv.py:146-217 instantiated by nndet/arch/encoder/modular.py:79-108 with in_channels = 1), 16-bit
+ * activation types only. With ONE input channel the convolution costs 27 MACs per output value, so it is recomputed instead of
+ * stored: forward = statistics pass (reads the image only) + finalize + recompute-normalise-store pass; the pre-norm tensor never
+ * exists. Backward needs no input gradient (the image), so dW / dgamma / dbeta come from ONE pass over d_out (the gradient w.r.t. the
+ * block output) + the image, followed by a one-block combine (csrc/conv_stem.hip: k_stem_bwd3) -- instead of norm-backward reduce +
+ * apply + stem weight gradient (6 passes over the largest activation of the network).
+ *   x [N, D, H, W, 1] (dtype); w_f32 [C][27] fp32 (PyTorch [C,1,3,3,3]); out / d_out [N, D, H, W, C_p] (dtype);
+ *   stats [NNDET_STATS_REPLICAS][N][C_p][2] fp64 ZEROED scratch; mean_rstd_out [N][C_p][2] fp32 (kept for backward);
+ *   dw [C][27], dgamma [C], dbeta [C] fp32 (overwritten); workspace: nndet_stem_block_backward_workspace_bytes(c).
+ * nndet_stem_block_supported(c) != 0 iff the descriptor is such a block. */
+int32_t nndet_stem_block_supported(const NndetConv* c);
+int nndet_stem_block_forward(const NndetConv* c, const void* x, const float* w_f32, const float* gamma, const float* beta, float eps,
+                             int32_t relu, void* out, double* stats, float* mean_rstd_out, void* stream);
+size_t nndet_stem_block_backward_workspace_bytes(const NndetConv* c);
+int nndet_stem_block_backward(const NndetConv* c, const void* x, const void* d_out, const float* w_f32, const float* mean_rstd,
+                              const float* gamma, const float* beta, int32_t relu, float* dw, float* dgamma, float* dbeta,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* pack W (fp32, PyTorch layout) -> [taps][rows_p][k_p] in `dtype`, zero padded.
  * mode 0: rows = Cout, k = Cin (forward of Conv3d)
  * mode 1: rows = Cin,  k = Cout (data gradient of Conv3d)

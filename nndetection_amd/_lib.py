@@ -89,6 +89,10 @@ SIGNATURES = {
     "nndet_packed_weight_elems": (_SZ, [_CONVP, _I32]),
     "nndet_pack_weight": (C.c_int, [_CONVP, _I32, _P, _P, _P]),
     "nndet_pack_weights_batched": (C.c_int, [C.POINTER(NndetConv), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I32, _P]),
+    "nndet_stem_block_supported": (_I32, [_CONVP]),
+    "nndet_stem_block_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _F, _I32, _P, _P, _P, _P]),
+    "nndet_stem_block_backward_workspace_bytes": (_SZ, [_CONVP]),
+    "nndet_stem_block_backward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _SZ, _P]),
     "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
     "nndet_conv3d_dgrad_fuses_bias": (_I32, [_CONVP]),

@@ -319,6 +319,52 @@ class _NormFn(torch.autograd.Function):
         return logical(dconv, cout), dgamma, dbeta, None, None, None
 
 
+# Fused stem block (csrc/conv_stem.hip, nndet_stem_block_*): the first encoder block conv(1 -> C) -> InstanceNorm -> ReLU in 16-bit
+# types recomputes its (27-MAC) convolution instead of storing the pre-norm tensor, and its backward pass is ONE pass over the
+# incoming gradient. NNDET_STEM_FUSED=0 restores conv + norm as separate kernels (the fp32 path always uses those).
+FUSED_STEM = os.environ.get("NNDET_STEM_FUSED", "1") != "0"
+
+
+class _StemBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mod):
+        x_p, cin = phys(x)
+        desc = _desc(x_p, 1, mod.out_channels, mod.k, mod.s, mod.p, False)
+        dev, dt = x_p.device, x_p.dtype
+        N, cout, cout_p = desc.batch, desc.cout, desc.cout_p
+        w32 = weight.detach().float().contiguous()
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        out = torch.empty((N, desc.out_d, desc.out_h, desc.out_w, cout_p), dtype=dt, device=dev)
+        stats = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev)
+        mean_rstd = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
+        L.call("nndet_stem_block_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w32), L.ptr(g32), L.ptr(b32), float(mod.norm_eps),
+               int(mod.relu), L.ptr(out), L.ptr(stats), L.ptr(mean_rstd), L.stream())
+        ctx.desc, ctx.mod = desc, mod
+        ctx.save_for_backward(x_p, w32, g32, b32, mean_rstd, weight)
+        return logical(out, cout)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        desc, mod = ctx.desc, ctx.mod
+        x_p, w32, g32, b32, mean_rstd, weight = ctx.saved_tensors
+        dev, dt = x_p.device, x_p.dtype
+        cout = desc.cout
+        g_p, _ = phys(grad_out, dtype=dt, cp=desc.cout_p)
+        nw = weight.numel()
+        gbuf = L.grad_pool.take(nw + 2 * cout, dev)
+        dw, dgamma, dbeta = gbuf[:nw].view(weight.shape), gbuf[nw:nw + cout], gbuf[nw + cout:nw + 2 * cout]
+        side = L.wgrad_streams.side(dev, weight)           # parameter gradients only: off the critical chain like every weight gradient
+        raw = side.cuda_stream if side is not None else L.stream()
+        if side is not None:
+            for t in (x_p, g_p, mean_rstd, w32, g32, b32):
+                t.record_stream(side)
+        ws_bytes = L.load().nndet_stem_block_backward_workspace_bytes(ctypes.byref(desc))
+        ws = L.workspace(ws_bytes, dev, raw_stream=raw if side is not None else None)
+        L.call("nndet_stem_block_backward", ctypes.byref(desc), L.ptr(x_p), L.ptr(g_p), L.ptr(w32), L.ptr(mean_rstd), L.ptr(g32),
+               L.ptr(b32), int(mod.relu), L.ptr(dw), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws_bytes, raw)
+        return None, dw.to(weight.dtype), dgamma, dbeta, None
+
+
 class BaseConvNormAct(nn.Sequential):
     def __init__(self, dim: int, in_channels: int, out_channels: int, norm: Optional[str], act: Optional[str],
                  kernel_size, stride=1, padding=0, dilation=1, groups: int = 1, bias: Optional[bool] = None,
@@ -372,6 +418,11 @@ class BaseConvNormAct(nn.Sequential):
             x = L.autocast_input(x)
             if residual is not None and residual.dtype != x.dtype:
                 residual = residual.to(x.dtype)
+        if (FUSED_STEM and d is None and residual is None and self.in_channels == 1 and has_norm and x.is_cuda and x.dim() == 5
+                and x.dtype in (torch.bfloat16, torch.float16) and self.norm_groups == self.out_channels and not self.transposed
+                and self.k == (3, 3, 3) and self.s == (1, 1, 1) and self.p == (1, 1, 1) and self.conv.bias is None
+                and not (bool(self.defer_output) and DEFER_NORM)):
+            return _StemBlockFn.apply(x, self.conv.weight, self.norm.weight, self.norm.bias, self)
         if d is not None and (self.transposed or self.in_channels == 1):
             x, d = materialize(x), None
         x_ss, x_relu = d if d is not None else (None, False)

@@ -35,6 +35,7 @@ int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hip
 // norm.hip
 int colsum_run(int dtype, const void* x, int64_t rows, int c_p, int c, float* out, hipStream_t st);
 int norm_stats_run(int dtype, const void* x, int batch, int64_t spatial, int c_p, double* stats, hipStream_t st);
+int norm_finalize_run(const double* stats, int N, int c, int c_p, int groups, int64_t spatial, float eps, float* mean_rstd, hipStream_t st);
 
 // ---- deferred input normalisation (NndetConv.in_affine): x' = relu?(x * scale + shift) on one 16-byte piece while it is staged.
 // Exactly the arithmetic of k_norm_apply (fmaf, fmaxf, round-to-nearest-even pack), so a consumer that applies the norm on load

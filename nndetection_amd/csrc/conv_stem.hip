@@ -306,8 +306,16 @@ __device__ __forceinline__ float stem_dpp_row_sum(float v) {
     return v;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0, int nt1, int nt2, double* __restrict__ stats) {
+// MODE 0: y = conv(x) (+ bias), stored rounded to T, optional statistics of the rounded values (the stand-alone convolution).
+// MODE 1 / 2 = the two passes of the FUSED stem block conv -> InstanceNorm -> ReLU (nndet_stem_block_forward): the convolution is so
+// cheap (27 MACs per output, one input channel) that computing it twice beats writing the pre-norm tensor and reading it back:
+//   MODE 1: statistics of the (unrounded fp32) conv outputs only -- reads 2 bytes per voxel, writes nothing;
+//   MODE 2: recompute, y * scale + shift (norm coefficients per image and channel, `coef` = mean_rstd [N][Cy][2]), ReLU, store.
+// The pre-norm activation (629 MB at 160x160x96x32 bf16, batch 4) never exists in HBM.
+template <typename T, int MODE = 0>
+__global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0, int nt1, int nt2, double* __restrict__ stats,
+                                                      const float* __restrict__ coef = nullptr, const float* __restrict__ gamma = nullptr,
+                                                      const float* __restrict__ beta = nullptr, int relu = 0) {
     constexpr int PROW = 8 * 64 + 32;
     __shared__ __attribute__((aligned(16))) char imt[32 * PROW];
     __shared__ __attribute__((aligned(16))) uint16_t xh[608];
@@ -334,6 +342,22 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
             const int cb = c0 + i * 16 + q * 4 + rr;
             bia[i][rr] = (A.bias && cb < A.cout) ? A.bias[cb] : 0.f;
         }
+    }
+    float nsc[2][4], nsh[2][4];                          // MODE 2: the same two expressions k_norm_apply evaluates per channel
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int cb = c0 + i * 16 + q * 4 + rr;
+                float a_ = 0.f, b_ = 0.f;
+                if (cb < A.cout) {
+                    const float mean = coef[((int64_t)n * A.Cy + cb) * 2], rstd = coef[((int64_t)n * A.Cy + cb) * 2 + 1];
+                    a_ = rstd * gamma[cb];
+                    b_ = beta[cb] - mean * a_;
+                }
+                nsc[i][rr] = a_; nsh[i][rr] = b_;
+            }
     }
     int x_rel[3];
 #pragma unroll
@@ -406,10 +430,24 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
                 f32x4 c = f32x4{bia[i][0], bia[i][1], bia[i][2], bia[i][3]};
                 c = H16<T>::mma(af[i], bf[j], c);
                 typedef unsigned int v2u_t __attribute__((__vector_size__(8)));
+                if constexpr (MODE == 1) {               // statistics of the fp32 outputs, nothing stored
+                    if (valid) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) { ssum[i][rr] += c[rr]; ssq[i][rr] += c[rr] * c[rr]; }
+                    }
+                    continue;
+                }
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        float v_ = fmaf(c[rr], nsc[i][rr], nsh[i][rr]);
+                        c[rr] = relu ? fmaxf(v_, 0.f) : v_;
+                    }
+                }
                 v2u_t o;
                 o[0] = H16<T>::pack2(c[0], c[1]); o[1] = H16<T>::pack2(c[2], c[3]);
                 __builtin_amdgcn_raw_buffer_store_b64(o, yrs, vo + i * 32, 0, 0);
-                if (stats && valid) {
+                if (MODE == 0 && stats && valid) {
                     const float r0 = H16<T>::lo(o[0]), r1 = H16<T>::hi(o[0]);
                     const float r2 = H16<T>::lo(o[1]), r3 = H16<T>::hi(o[1]);
                     ssum[i][0] += r0; ssum[i][1] += r1; ssum[i][2] += r2; ssum[i][3] += r3;
@@ -436,6 +474,261 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
             const int rep = blockIdx.x % NNDET_STATS_REPLICAS;
             atomicAdd(stats + (((int64_t)rep * A.N + n) * A.Cy + c0 + (tid >> 1)) * 2 + (tid & 1), red[tid]);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused stem block, backward
+// conv(1 -> C) -> InstanceNorm -> ReLU with the gradient dA w.r.t. the block OUTPUT as the only large input. The input image needs no
+// gradient, so all the block has to deliver is dW [C][27], dgamma [C], dbeta [C]. With g = dA * [z > 0], xh = (y - mean) * rstd:
+//     dL/dy = rstd * gamma * (g - S1 / M - xh * S2 / M),   S1 = sum_p g, S2 = sum_p g * xh  (per image and channel, M voxels)
+//     dW[c][t] = sum_n sum_p dL/dy[n,p,c] * x[n, p + t]
+//              = sum_n rstd * gamma * (A_n[c][t] - S1 / M * B_n[t] - S2 / M * C_n[c][t])
+// with A_n = sum_p g (x) x_shifted, B_n = sum_p x_shifted, C_n = sum_p xh (x) x_shifted: three correlations that do NOT need S1 / S2
+// in advance. So ONE pass over dA computes S1, S2, A, B, C together -- the pre-norm activation y is recomputed from the one-channel
+// image in LDS (one more 32 x 32 x 32 MFMA per 16 points) -- and a 1-block kernel combines them. This replaces k_norm_bwd_reduce
+// (reads y, dA), k_norm_bwd_apply (reads y, dA, writes dy) and k_stem_wgrad3 (reads dy): 6 passes over a 629 MB tensor become 1, at
+// the very end of the backward pass where nothing else is left to overlap with (round 3 timeline: 1.25 ms -> one 0.3 ms launch).
+struct StemBwdArgs {
+    const void* x; const void* dy; const float* w; const float* coef; const float* gamma; const float* beta;
+    float* accA; float* accC; float* accB; double* accS;     // [N][Cy][32], [N][Cy][32], [N][32], [N][Cy][2]   (zeroed)
+    int32_t N, I[3], O[3], Cy, cout, relu;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int nt0, int nt1, int nt2) {
+    constexpr int PROW = 8 * 64 + 32;                  // bytes per row of 8 points (64 B per point + bank padding)
+    constexpr int TILE = 32 * PROW;
+    __shared__ __attribute__((aligned(16))) char dyt[TILE];     // dA tile, rewritten in place with g = dA * mask
+    __shared__ __attribute__((aligned(16))) char imt[TILE];     // [point][32 taps] expansion of the image halo
+    __shared__ __attribute__((aligned(16))) char xnt[TILE];     // xh = normalised pre-activation, [point][32 channels]
+    __shared__ __attribute__((aligned(16))) uint16_t xh[608];
+    __shared__ float red[2 * 32 * 32 + 32];
+    __shared__ double reds[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int c0 = blockIdx.y * 32, n = blockIdx.z;
+    for (int i = tid; i < 2 * 32 * 32 + 32; i += 256) red[i] = 0.f;
+    if (tid < 64) reds[tid] = 0.0;
+    // A fragments of the forward convolution (identical to k_stem_fwd3: the recomputed y is bit-identical to the forward pass's)
+    u32x4 af[2];
+    float n_sc[2][4], n_sh[2][4], n_rs[2][4], n_mrs[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = c0 + i * 16 + li;
+        float wv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = q * 8 + j;
+            wv8[j] = (t < 27 && ch < A.cout) ? A.w[(int64_t)ch * 27 + t] : 0.f;
+        }
+        af[i] = u32x4{H16<T>::pack2(wv8[0], wv8[1]), H16<T>::pack2(wv8[2], wv8[3]), H16<T>::pack2(wv8[4], wv8[5]), H16<T>::pack2(wv8[6], wv8[7])};
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int cb = c0 + i * 16 + q * 4 + rr;
+            float a_ = 0.f, b_ = 0.f, rs = 0.f, mrs = 0.f;
+            if (cb < A.cout) {
+                const float mean = A.coef[((int64_t)n * A.Cy + cb) * 2], rstd = A.coef[((int64_t)n * A.Cy + cb) * 2 + 1];
+                a_ = rstd * A.gamma[cb];
+                b_ = A.beta[cb] - mean * a_;
+                rs = rstd; mrs = mean * rstd;
+            }
+            n_sc[i][rr] = a_; n_sh[i][rr] = b_; n_rs[i][rr] = rs; n_mrs[i][rr] = mrs;
+        }
+    }
+    // dA staging geometry: piece s of a thread = point (pd = s, ph = tid >> 5, pw = (tid >> 2) & 7), 16-byte part tid & 3
+    const int d_ph = tid >> 5, d_pw = (tid >> 2) & 7;
+    const int d_dst0 = d_ph * PROW + d_pw * 64 + (tid & 3) * 16;
+    const int d_rel = (d_ph * A.O[2] + d_pw) * A.Cy * 2 + (tid & 3) * 16;
+    const int d_slab = A.O[1] * A.O[2] * A.Cy * 2;
+    const int dy_img = A.O[0] * d_slab, x_img = A.I[0] * A.I[1] * A.I[2] * 2;
+    const auto drs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(A.dy)) + (int64_t)n * dy_img + c0 * 2, 0, dy_img - c0 * 2, 0x00020000);
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (int64_t)n * x_img, 0, x_img, 0x00020000);
+    int x_rel[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int i = tid + s * 256;
+        x_rel[s] = ((i / 100) << 16) | (((i / 10) % 10) << 8) | (i % 10);
+    }
+    const int e_pd = tid >> 6, e_ph = (tid >> 3) & 7, e_pw = tid & 7;       // expansion: thread = point tid
+    const int e_base = (e_pd * 10 + e_ph) * 10 + e_pw;
+    char* const e_dst = imt + (tid >> 3) * PROW + (tid & 7) * 64;
+    const int f_lane = q * PROW + (li >> 2) * 64 + (li & 3) * 8;            // transposed fragment reads (see k_stem_wgrad3)
+
+    f32x4 accA[2][2], accC[2][2], accB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        accB[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { accA[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accC[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    float s1[2][4], s2[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { s1[i][rr] = 0.f; s2[i][rr] = 0.f; }
+    const u32x4 ones = u32x4{H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2};
+    const int tiles_per_n = nt0 * nt1 * nt2;
+    u32x4 vd[4];
+    uint16_t vx[3];
+    auto issue = [&](int tile, int& l0d, int& l0h, int& l0w) {
+        int tt = tile;
+        const int tw_i = tt % nt2; tt /= nt2;
+        const int th_i = tt % nt1;
+        const int td_i = tt / nt1;
+        l0d = td_i * 4; l0h = th_i * 8; l0w = tw_i * 8;
+        const int d_org = ((l0d * A.O[1] + l0h) * A.O[2] + l0w) * A.Cy * 2;
+        const bool okhw = (l0h + d_ph < A.O[1]) && (l0w + d_pw < A.O[2]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            vd[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                drs, (okhw && l0d + s < A.O[0]) ? d_rel + s * d_slab : (int)0x80000000, d_org, 0));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int id = l0d - 1 + (x_rel[s] >> 16), ih = l0h - 1 + ((x_rel[s] >> 8) & 255), iw = l0w - 1 + (x_rel[s] & 255);
+            const bool ok = (tid + s * 256 < 600) && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
+            vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, ok ? ((id * A.I[1] + ih) * A.I[2] + iw) * 2 : (int)0x80000000, 0, 0);
+        }
+    };
+    int tile = xcd_compact(blockIdx.x, gridDim.x, gridDim.x);
+    int l0d = 0, l0h = 0, l0w = 0, n0d = 0, n0h = 0, n0w = 0;
+    if (tile < tiles_per_n) issue(tile, l0d, l0h, l0w);
+    for (; tile < tiles_per_n; tile += gridDim.x) {
+        __syncthreads();                                   // the MFMA phase of the previous tile is done with the LDS tiles
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(dyt + d_dst0 + s * 8 * PROW) = vd[s];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (tid + s * 256 < 600) xh[tid + s * 256] = vx[s];
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < tiles_per_n) issue(next, n0d, n0h, n0w);    // in flight during the rest of this tile
+        {   // expansion; a point outside the volume gets a zero row (it must not contribute to B = sum of the shifted image)
+            const bool pv = (l0d + e_pd < A.O[0]) && (l0h + e_ph < A.O[1]) && (l0w + e_pw < A.O[2]);
+            uint32_t pk[16];
+#pragma unroll
+            for (int t = 0; t < 32; t += 2) {
+                uint32_t lo = 0, hi = 0;
+                if (t < 27) lo = xh[e_base + (t / 9) * 100 + ((t / 3) % 3) * 10 + t % 3];
+                if (t + 1 < 27) hi = xh[e_base + ((t + 1) / 9) * 100 + (((t + 1) / 3) % 3) * 10 + (t + 1) % 3];
+                pk[t >> 1] = pv ? (lo | (hi << 16)) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(e_dst + k * 16) = u32x4{pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]};
+        }
+        __syncthreads();
+        {   // recompute y, mask the incoming gradient, normalise: g -> dyt (in place), xh -> xnt; S1 / S2 in registers
+            u32x4 bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pt = wv * 4 + j;
+                bf[j] = *reinterpret_cast<const u32x4*>(imt + (pt * 2 + (li >> 3)) * PROW + (li & 7) * 64 + q * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = (wv * 4 + j) * 16 + li;
+                const bool valid = (l0d + (p >> 6) < A.O[0]) && (l0h + ((p >> 3) & 7) < A.O[1]) && (l0w + (p & 7) < A.O[2]);
+                const int poff = (p >> 3) * PROW + (p & 7) * 64 + q * 8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+                    c = H16<T>::mma(af[i], bf[j], c);
+                    const uint2 dv = *reinterpret_cast<const uint2*>(dyt + poff + i * 32);
+                    const float d4[4] = {H16<T>::lo(dv.x), H16<T>::hi(dv.x), H16<T>::lo(dv.y), H16<T>::hi(dv.y)};
+                    float g4[4], x4[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float z = fmaf(c[rr], n_sc[i][rr], n_sh[i][rr]);          // the forward pass's expression: same ReLU decisions
+                        const float xn = valid ? fmaf(c[rr], n_rs[i][rr], -n_mrs[i][rr]) : 0.f;
+                        const float g = (!A.relu || z > 0.f) ? d4[rr] : 0.f;             // (dA is zero outside the volume)
+                        g4[rr] = g; x4[rr] = xn;
+                        s1[i][rr] += g; s2[i][rr] = fmaf(g, xn, s2[i][rr]);
+                    }
+                    uint2 go, xo;
+                    go.x = H16<T>::pack2(g4[0], g4[1]); go.y = H16<T>::pack2(g4[2], g4[3]);
+                    xo.x = H16<T>::pack2(x4[0], x4[1]); xo.y = H16<T>::pack2(x4[2], x4[3]);
+                    *reinterpret_cast<uint2*>(dyt + poff + i * 32) = go;
+                    *reinterpret_cast<uint2*>(xnt + poff + i * 32) = xo;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {                   // wave wv takes the contraction steps 2 wv, 2 wv + 1 (32 points each)
+            const int ks = wv * 2 + kk;
+            u32x4 pf[2], xf[2], qf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                pf[i] = stem_trfrag(dyt + f_lane + ks * 4 * PROW + i * 32);
+                xf[i] = stem_trfrag(xnt + f_lane + ks * 4 * PROW + i * 32);
+                qf[i] = stem_trfrag(imt + f_lane + ks * 4 * PROW + i * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                accB[j] = H16<T>::mma(ones, qf[j], accB[j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    accA[i][j] = H16<T>::mma(pf[i], qf[j], accA[i][j]);
+                    accC[i][j] = H16<T>::mma(xf[i], qf[j], accC[i][j]);
+                }
+            }
+        }
+        l0d = n0d; l0h = n0h; l0w = n0w;
+    }
+    // workgroup reduction in LDS, then one atomic per value into the per-image accumulators
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                atomicAdd(&red[(i * 16 + q * 4 + rr) * 32 + j * 16 + li], accA[i][j][rr]);
+                atomicAdd(&red[1024 + (i * 16 + q * 4 + rr) * 32 + j * 16 + li], accC[i][j][rr]);
+            }
+    if (q == 0) {                                          // every row of the ones-product is the same: row 0 = lanes q == 0, element 0
+        atomicAdd(&red[2048 + li], accB[0][0]);
+        atomicAdd(&red[2048 + 16 + li], accB[1][0]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float a_ = stem_dpp_row_sum(s1[i][rr]), b_ = stem_dpp_row_sum(s2[i][rr]);
+            if (li == 0) {
+                atomicAdd(&reds[(i * 16 + q * 4 + rr) * 2 + 0], (double)a_);
+                atomicAdd(&reds[(i * 16 + q * 4 + rr) * 2 + 1], (double)b_);
+            }
+        }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        atomicAdd(A.accA + ((int64_t)n * A.Cy + c0) * 32 + i, red[i]);
+        atomicAdd(A.accC + ((int64_t)n * A.Cy + c0) * 32 + i, red[1024 + i]);
+    }
+    if (tid < 32 && c0 == 0) atomicAdd(A.accB + (int64_t)n * 32 + tid, red[2048 + tid]);
+    if (tid < 64) atomicAdd(A.accS + ((int64_t)n * A.Cy + c0) * 2 + tid, reds[tid]);
+}
+
+// dW, dgamma, dbeta from the per-image sums (see k_stem_bwd3). One block; thread = (channel, tap) pair.
+__global__ void k_stem_bwd_finish(const StemBwdArgs A, float* __restrict__ dw, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const double M = (double)A.O[0] * A.O[1] * A.O[2];
+    for (int i = threadIdx.x; i < A.cout * 27; i += blockDim.x) {
+        const int c = i / 27, t = i - c * 27;
+        double acc = 0.0;
+        for (int n = 0; n < A.N; ++n) {
+            const double rstd = A.coef[((int64_t)n * A.Cy + c) * 2 + 1];
+            const double S1 = A.accS[((int64_t)n * A.Cy + c) * 2], S2 = A.accS[((int64_t)n * A.Cy + c) * 2 + 1];
+            const double a_ = A.accA[((int64_t)n * A.Cy + c) * 32 + t], c_ = A.accC[((int64_t)n * A.Cy + c) * 32 + t];
+            const double b_ = A.accB[(int64_t)n * 32 + t];
+            acc += rstd * (double)A.gamma[c] * (a_ - S1 / M * b_ - S2 / M * c_);
+        }
+        dw[i] = (float)acc;
+    }
+    for (int c = threadIdx.x; c < A.cout; c += blockDim.x) {
+        double g = 0.0, b = 0.0;
+        for (int n = 0; n < A.N; ++n) { b += A.accS[((int64_t)n * A.Cy + c) * 2]; g += A.accS[((int64_t)n * A.Cy + c) * 2 + 1]; }
+        dgamma[c] = (float)g; dbeta[c] = (float)b;
     }
 }
 
@@ -516,6 +809,91 @@ int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hip
     if (c->dtype == NNDET_BF16) k_stem_wgrad<bf16_t><<<grid, 256, lds, st>>>(a);
     else if (c->dtype == NNDET_F16) k_stem_wgrad<f16_t><<<grid, 256, lds, st>>>(a);
     else k_stem_wgrad<float><<<grid, 256, lds, st>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ fused stem block (C ABI)
+static bool stem_block_ok(const NndetConv* c) {
+    if (!c || !nndet_is16(c->dtype) || c->cin_p != 1 || c->cin != 1 || c->transposed || c->cout_p % 32 || c->in_affine) return false;
+    for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 1 || c->p[i] != 1) return false;
+    const int64_t yb = (int64_t)c->out_d * c->out_h * c->out_w * c->cout_p * 2;
+    return yb < (1LL << 31) && (int64_t)ceil_div(c->out_d, 4) * ceil_div(c->out_h, 8) * ceil_div(c->out_w, 8) < (1LL << 30);
+}
+
+extern "C" int32_t nndet_stem_block_supported(const NndetConv* c) { return stem_block_ok(c) ? 1 : 0; }
+
+static int stem_block_grid(const StemArgs& a, int cout_p, int* S, int* nt) {
+    nt[0] = ceil_div(a.O[0], 4); nt[1] = ceil_div(a.O[1], 8); nt[2] = ceil_div(a.O[2], 8);
+    const int64_t tiles = (int64_t)nt[0] * nt[1] * nt[2];
+    int s_ = 512 / (a.N * (cout_p / 32));
+    if (s_ < 8) s_ = 8;
+    s_ = (s_ / 8) * 8;
+    if (s_ > tiles) s_ = (int)tiles;
+    *S = s_;
+    return 0;
+}
+
+extern "C" int nndet_stem_block_forward(const NndetConv* c, const void* x, const float* w_f32, const float* gamma, const float* beta,
+                                        float eps, int32_t relu, void* out, double* stats, float* mean_rstd_out, void* stream) {
+    if (!stem_block_ok(c) || !x || !w_f32 || !gamma || !beta || !out || !stats || !mean_rstd_out) return NNDET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    StemArgs a;
+    int rc = stem_args(c, &a);
+    if (rc) return rc;
+    a.x = x; a.w = w_f32; a.bias = nullptr; a.y = nullptr;
+    int S, nt[3];
+    stem_block_grid(a, c->cout_p, &S, nt);
+    const dim3 grid(S, c->cout_p / 32, a.N);
+    if (c->dtype == NNDET_F16) k_stem_fwd3<f16_t, 1><<<grid, 256, 0, st>>>(a, nt[0], nt[1], nt[2], stats);
+    else k_stem_fwd3<bf16_t, 1><<<grid, 256, 0, st>>>(a, nt[0], nt[1], nt[2], stats);
+    LAUNCH_CHECK();
+    const int64_t spatial = (int64_t)a.O[0] * a.O[1] * a.O[2];
+    rc = norm_finalize_run(stats, a.N, c->cout, c->cout_p, c->cout, spatial, eps, mean_rstd_out, st);     // InstanceNorm: one group per channel
+    if (rc) return rc;
+    a.y = out;
+    if (c->dtype == NNDET_F16) k_stem_fwd3<f16_t, 2><<<grid, 256, 0, st>>>(a, nt[0], nt[1], nt[2], nullptr, mean_rstd_out, gamma, beta, relu);
+    else k_stem_fwd3<bf16_t, 2><<<grid, 256, 0, st>>>(a, nt[0], nt[1], nt[2], nullptr, mean_rstd_out, gamma, beta, relu);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t nndet_stem_block_backward_workspace_bytes(const NndetConv* c) {
+    if (!stem_block_ok(c)) return 0;
+    return (size_t)c->batch * ((size_t)c->cout_p * 32 * 4 * 2 + 32 * 4 + (size_t)c->cout_p * 2 * 8) + 256;
+}
+
+extern "C" int nndet_stem_block_backward(const NndetConv* c, const void* x, const void* d_out, const float* w_f32, const float* mean_rstd,
+                                         const float* gamma, const float* beta, int32_t relu, float* dw, float* dgamma, float* dbeta,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!stem_block_ok(c) || !x || !d_out || !w_f32 || !mean_rstd || !gamma || !beta || !dw || !dgamma || !dbeta || !workspace)
+        return NNDET_EINVAL;
+    const size_t need = nndet_stem_block_backward_workspace_bytes(c);
+    if (workspace_bytes < need) return NNDET_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    StemArgs a;
+    int rc = stem_args(c, &a);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
+    StemBwdArgs b;
+    memset(&b, 0, sizeof(b));
+    b.x = x; b.dy = d_out; b.w = w_f32; b.coef = mean_rstd; b.gamma = gamma; b.beta = beta;
+    char* wsp = reinterpret_cast<char*>(workspace);
+    const size_t nA = (size_t)c->batch * c->cout_p * 32;
+    b.accS = reinterpret_cast<double*>(wsp);                                         // 8-byte aligned part first
+    b.accA = reinterpret_cast<float*>(wsp + (size_t)c->batch * c->cout_p * 2 * 8);
+    b.accC = b.accA + nA;
+    b.accB = b.accC + nA;
+    b.N = a.N; b.Cy = a.Cy; b.cout = a.cout; b.relu = relu;
+    for (int i = 0; i < 3; ++i) { b.I[i] = a.I[i]; b.O[i] = a.O[i]; }
+    int S, nt[3];
+    stem_block_grid(a, c->cout_p, &S, nt);
+    const dim3 grid(S, c->cout_p / 32, a.N);
+    if (c->dtype == NNDET_F16) k_stem_bwd3<f16_t><<<grid, 256, 0, st>>>(b, nt[0], nt[1], nt[2]);
+    else k_stem_bwd3<bf16_t><<<grid, 256, 0, st>>>(b, nt[0], nt[1], nt[2]);
+    LAUNCH_CHECK();
+    k_stem_bwd_finish<<<1, 1024, 0, st>>>(b, dw, dgamma, dbeta);
     LAUNCH_CHECK();
     return 0;
 }

@@ -218,6 +218,10 @@ static int finalize_launch(const double* stats, int N, int c, int c_p, int group
     return 0;
 }
 
+int norm_finalize_run(const double* stats, int N, int c, int c_p, int groups, int64_t spatial, float eps, float* mean_rstd, hipStream_t st) {
+    return finalize_launch(stats, N, c, c_p, groups, spatial, eps, mean_rstd, nullptr, nullptr, nullptr, g_norm_uniform, st);
+}
+
 extern "C" int nndet_norm_finalize(const double* stats, const float* gamma, const float* beta, int32_t batch, int64_t spatial,
                                    int32_t c, int32_t c_p, int32_t groups, float eps, float* mean_rstd_out, float* scale_shift_out,
                                    void* stream) {

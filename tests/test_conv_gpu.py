@@ -153,6 +153,53 @@ def test_conv_norm_relu_block(name, norm, dtype):
     assert not bad, f"block backward rel errs {errs}"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape,cout", [((3, 13, 17, 22), 32), ((2, 8, 16, 16), 64), ((1, 32, 40, 24), 32)], ids=["ragged", "c64", "tiles"])
+def test_fused_stem_block_matches_separate_kernels_and_fp32(shape, cout, dtype, monkeypatch):
+    """nndet_stem_block_forward / _backward (conv(1 -> C) + InstanceNorm + ReLU with the convolution recomputed, backward as ONE
+    pass + combine) against (a) the separate kernels conv -> statistics -> norm apply / norm backward -> stem weight gradient on the
+    same 16-bit inputs and (b) plain PyTorch fp32 on the CPU with the same rounded operands. Ragged volumes (tiles that stick out
+    in every axis), several images, 64 output channels (two channel blocks per workgroup column)."""
+    from nndetection_amd.arch import conv as conv_mod
+    from nndetection_amd.arch.conv import ConvInstanceRelu
+    torch.manual_seed(7)
+    N, D, H, W = shape
+    m = ConvInstanceRelu(3, 1, cout, 3, stride=1, padding=1)
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.randn_like(m.conv.weight) * 0.25)
+        m.norm.weight.copy_(1.0 + 0.3 * torch.randn_like(m.norm.weight))
+        m.norm.bias.copy_(0.3 * torch.randn_like(m.norm.bias))
+    x = torch.randn(N, 1, D, H, W)
+    gy = torch.randn(N, cout, D, H, W).to(dtype).float()
+    # (b) fp32 reference with the rounded operands
+    rd = lambda t_: t_.detach().to(dtype).float().clone()
+    xr = rd(x)
+    w = rd(m.conv.weight).requires_grad_(True)
+    g = m.norm.weight.detach().clone().requires_grad_(True); be = m.norm.bias.detach().clone().requires_grad_(True)
+    yref = F.relu(F.instance_norm(F.conv3d(xr, w, None, padding=1), weight=g, bias=be, eps=1e-5))
+    yref.backward(gy)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(conv_mod, "FUSED_STEM", fused)
+        mg = ConvInstanceRelu(3, 1, cout, 3, stride=1, padding=1)
+        mg.load_state_dict(m.state_dict())
+        mg = mg.cuda()
+        y = mg(x.cuda().to(dtype))
+        assert y.dtype == dtype and y.shape == yref.shape
+        y.backward(gy.cuda().to(dtype))
+        torch.cuda.synchronize()
+        res[fused] = (y.float().cpu(), mg.conv.weight.grad.cpu(), mg.norm.weight.grad.cpu(), mg.norm.bias.grad.cpu())
+    ft, gt = (1.2e-2, 4e-2) if dtype == torch.bfloat16 else (1.5e-3, 6e-3)
+    for name, i, ref in (("forward", 0, yref.detach()), ("dW", 1, w.grad), ("dgamma", 2, g.grad), ("dbeta", 3, be.grad)):
+        tol = ft if i == 0 else gt
+        e_ref, e_sep = relerr(res[True][i], ref), relerr(res[True][i], res[False][i])
+        assert e_ref <= tol, f"{name}: fused vs fp32 reference {e_ref:.3e}"
+        assert e_sep <= tol, f"{name}: fused vs separate kernels {e_sep:.3e}"
+        # the fused path keeps the pre-norm values and the norm-backward output in fp32: it must not be further from fp32 than the
+        # separate kernels are (which round both to 16 bits), up to noise
+        assert e_ref <= 1.5 * relerr(res[False][i], ref) + 0.25 * tol, name
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_segloss(dtype):
     from nndetection_amd.arch import Generator, ConvInstanceRelu, DiCESegmenterFgBg
