@@ -381,6 +381,14 @@ int nndet_seghead_forward(int32_t dtype, const void* x, int32_t c_p, int32_t cin
                           const uint8_t* target, int64_t nvox, double* sums_out, void* stream);
 int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
                            const uint8_t* target, int64_t nvox, const float* coeffs, void* dx, double* dwb_out, void* stream);
+/* Same backward pass in FACTORISED form: the gradient w.r.t. x is the outer product d1[voxel] * (w[1][:] - w[0][:]) (the two
+ * logit gradients of the 2-class softmax are d1 and -d1), so only d1_out [nvox] (dtype) is written -- 2 bytes instead of 64 per voxel.
+ * The convolution that produced x (decoder.out.P0, nndet/arch/decoder/base.py:243-270, whose output only the segmenter reads,
+ * nndet/arch/heads/segmenter.py:167-182) then gets its data gradient as a ONE-input-channel convolution of d1
+ * (nndet_conv3d_forward with cin_p == 1 and the composed, flipped kernel) and its weight gradient as (w1 - w0) (x) the
+ * one-channel weight gradient of (d1, conv input) (nndet_conv3d_backward_weight with cin_p == 1): nndetection_amd/arch/conv.py. */
+int nndet_seghead_backward_rank1(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
+                                 const uint8_t* target, int64_t nvox, const float* coeffs, void* d1_out, double* dwb_out, void* stream);
 /* Scalar tail of the loss: sums [4] fp32 (what the forward entry points above produce, cast to fp32) ->
  * losses_out [2] = {alpha * CE_sum / nvox, (1 - alpha) * (1 - (2 tp + smooth_nom) / (2 tp + fp + fn + smooth_denom))} and
  * coeffs_out [2, 4] = d losses / d sums, in one launch instead of ~45 one-element torch launches (forward + autograd). */

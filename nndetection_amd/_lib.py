@@ -114,6 +114,7 @@ SIGNATURES = {
     "nndet_segloss_backward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P, _P, _P]),
     "nndet_seghead_forward": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P]),
     "nndet_seghead_backward": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "nndet_seghead_backward_rank1": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nndet_segloss_tail_f32": (C.c_int, [_P, _I64, _F, _F, _F, _P, _P, _P]),
     "nndet_sigmoid_max_f32": (C.c_int, [_P, _I64, _I32, _P, _P]),
 }

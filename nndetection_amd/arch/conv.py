@@ -158,6 +158,55 @@ def deferred(x: torch.Tensor):
     return getattr(x, "_nndet_deferred", None)
 
 
+# ---- factorised (rank-1) output gradients -------------------------------------------------------------------------------------
+# The fused segmentation head's gradient w.r.t. its input is d1[voxel] * wd[channel] (2-class softmax: the logit gradients are d1
+# and -d1). Its autograd node hands on an UNWRITTEN tensor of the right shape and registers the factors here under that tensor's
+# address; the backward pass of the convolution that produced the head's input (decoder.out.P0: nobody else reads its output) then
+#   * gets its data gradient as a ONE-input-channel convolution of d1 with the kernel  Wf[cin][t] = sum_c wd[c] W[c][cin][2 - t]
+#     (the stem kernels: 27 MACs per output instead of 27 x 32, reads 2 bytes per voxel instead of 64), and
+#   * its weight gradient as  dW[c][cin][t] = wd[c] * E[cin][2 - t],  E = the one-channel weight gradient of (d1, conv input),
+# i.e. 1.09 TFLOP and ~2.4 GB of the 8.9 TFLOP / 27 GB of a 160x160x96 training step disappear (NNDET_SEG_RANK1=0 disables it).
+RANK1 = os.environ.get("NNDET_SEG_RANK1", "1") != "0"
+_rank1_grads = {}
+
+
+def rank1_register(fake: torch.Tensor, d1: torch.Tensor, wd: torch.Tensor, sum_d1: torch.Tensor) -> None:
+    """fake: the unwritten [N, D, H, W, C_p] gradient tensor; d1 [N, D, H, W, 1]; wd [C] fp32; sum_d1: 0-dim fp32 (= sum of d1)."""
+    _rank1_grads.clear()                                   # at most one live entry (one segmentation branch per backward pass)
+    _rank1_grads[fake.data_ptr()] = (d1, wd, sum_d1, fake)
+
+
+def _rank1_backward(ctx, dconv, weight, x_p, desc, dw, dbias, side, raw):
+    """Backward of a 3x3x3 / stride 1 / pad 1 convolution whose output gradient is d1 (x) wd (see above). Returns dx (physical)."""
+    d1, wd, sum_d1, _ = _rank1_grads.pop(dconv.data_ptr())
+    dev, dt = x_p.device, x_p.dtype
+    cout, cin = desc.cout, desc.cin
+    w_r = weight.detach().to(dt).float()                                     # what the forward kernels multiplied with
+    wf = torch.einsum("c,cidhw->idhw", wd[:cout], w_r).flip(1, 2, 3).reshape(cin, 1, 3, 3, 3).contiguous()
+    sd = L.NndetConv()
+    sd.dtype, sd.transposed, sd.batch = desc.dtype, 0, desc.batch
+    sd.cin, sd.cout, sd.cin_p, sd.cout_p = 1, cin, 1, desc.cin_p
+    sd.in_d, sd.in_h, sd.in_w = desc.in_d, desc.in_h, desc.in_w
+    sd.out_d, sd.out_h, sd.out_w = desc.in_d, desc.in_h, desc.in_w
+    sd.k = (ctypes.c_int32 * 3)(3, 3, 3); sd.s = (ctypes.c_int32 * 3)(1, 1, 1); sd.p = (ctypes.c_int32 * 3)(1, 1, 1)
+    dx_p = None
+    if ctx.needs_input_grad[0]:
+        dx_p = torch.empty_like(x_p)
+        L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(d1), L.ptr(wf), None, None, L.ptr(dx_p), None, L.stream())
+    # weight gradient on the weight-gradient stream: E[cin][t] = sum_p x[p][cin] d1[p + t - 1]  ->  dW[c][cin][t] = wd[c] E[cin][2 - t]
+    if side is not None:
+        for t in (x_p, d1, wd, sum_d1):
+            t.record_stream(side)
+    cur = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side if side is not None else cur):
+        e = torch.zeros((cin, 1, 3, 3, 3), dtype=torch.float32, device=dev)
+        L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(x_p), L.ptr(e), None, None, 0, raw)
+        torch.mul(wd[:cout].view(cout, 1, 1, 1, 1), e.flip(2, 3, 4).view(1, cin, 3, 3, 3), out=dw)
+        if dbias is not None:
+            torch.mul(wd[:cout], sum_d1, out=dbias)
+    return dx_p
+
+
 class _ConvFn(torch.autograd.Function):
     """conv (+bias, + fused residual). Input: a plain activation or a deferred one (then `x_ss` = its scale/shift table and the
     kernels read relu?(x * scale + shift): NndetConv.in_affine). Output: y and -- for blocks with a norm -- the per-(image, channel)
@@ -216,6 +265,11 @@ class _ConvFn(torch.autograd.Function):
         dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
         dx = None
         bias_from_dgrad = False
+        if dconv.data_ptr() in _rank1_grads:               # factorised output gradient (fused segmentation head): see _rank1_backward
+            side = ctx.wg_side
+            raw = side.cuda_stream if side is not None else L.stream()
+            dx_p = _rank1_backward(ctx, dconv, weight, x_p, desc, dw, dbias, side, raw)
+            return (logical(dx_p, desc.cin) if dx_p is not None else None), None, None, dw.to(weight.dtype), dbias, None, None, None
         if ctx.needs_input_grad[0]:
             if desc.cin_p == 1:
                 raise L.NndetError("gradient w.r.t. the 1-channel input image is not implemented (never needed in training)")

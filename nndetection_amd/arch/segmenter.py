@@ -56,6 +56,9 @@ class _SegHeadFused(torch.autograd.Function):
                L.ptr(sums), L.stream())
         ctx.save_for_backward(xp, w32, target_u8)
         ctx.b32, ctx.cin, ctx.wshape, ctx.wdtype = b32, cin, tuple(weight.shape), weight.dtype
+        # may the input gradient travel in factorised form (d1 (x) (w1 - w0), arch/conv.py: _rank1_backward)? Only if the tensor
+        # was produced by one of OUR plain 3x3x3 / stride-1 convolutions and nobody else consumes it -- the caller says so
+        ctx.rank1 = bool(getattr(x, "_nndet_rank1_ok", False)) and xp.dtype != torch.float32
         return sums.float()
 
     @staticmethod
@@ -66,8 +69,17 @@ class _SegHeadFused(torch.autograd.Function):
         coeffs = g.detach().float().contiguous()
         dx = torch.empty_like(xp)
         dwb = torch.zeros((2 * cin + 2,), dtype=torch.float64, device=xp.device)
-        L.call("nndet_seghead_backward", L.dtype_code(xp), L.ptr(xp), 32, cin, L.ptr(w32), L.ptr(ctx.b32), L.ptr(tgt), nvox,
-               L.ptr(coeffs), L.ptr(dx), L.ptr(dwb), L.stream())
+        from .conv import RANK1, rank1_register
+        if ctx.rank1 and RANK1:
+            d1 = torch.empty(xp.shape[:4] + (1,), dtype=xp.dtype, device=xp.device)
+            L.call("nndet_seghead_backward_rank1", L.dtype_code(xp), L.ptr(xp), 32, cin, L.ptr(w32), L.ptr(ctx.b32), L.ptr(tgt), nvox,
+                   L.ptr(coeffs), L.ptr(d1), L.ptr(dwb), L.stream())
+            wd = torch.zeros((32,), dtype=torch.float32, device=xp.device)
+            wd[:cin] = w32[1] - w32[0]
+            rank1_register(dx, d1, wd, dwb[2 * cin + 1].float())     # dx itself stays unwritten: its consumer reads the factors
+        else:
+            L.call("nndet_seghead_backward", L.dtype_code(xp), L.ptr(xp), 32, cin, L.ptr(w32), L.ptr(ctx.b32), L.ptr(tgt), nvox,
+                   L.ptr(coeffs), L.ptr(dx), L.ptr(dwb), L.stream())
         dw = dwb[:2 * cin].float().view(ctx.wshape).to(ctx.wdtype)
         db = dwb[2 * cin:].float() if ctx.b32 is not None else None
         return logical(dx, cin), dw, db, None

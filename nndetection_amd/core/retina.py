@@ -93,8 +93,25 @@ class BaseRetinaNet(nn.Module):
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream(inp.device))
         if self.segmenter is not None:
+            if fused and features_maps_all[0] is not None and self._seg_rank1_ok():
+                features_maps_all[0]._nndet_rank1_ok = True      # its gradient may travel as d1 (x) (w1 - w0): arch/conv.py
             pred_seg = self.segmenter(features_maps_all, fused=True) if fused else self.segmenter(features_maps_all)
         return pred_detection, anchors, pred_seg
+
+    def _seg_rank1_ok(self) -> bool:
+        """True if decoder level 0 is produced by one of our plain 3x3x3 / stride-1 convolutions (no norm) and read by the segmenter
+        ONLY -- then the segmentation head may hand its input gradient back in factorised form (arch/conv.py: _rank1_backward)."""
+        ok = getattr(self, "_seg_rank1_cached", None)
+        if ok is None:
+            from ..arch.conv import BaseConvNormAct
+            out = getattr(self.decoder, "out", None)
+            blk = out["P0"] if (out is not None and "P0" in out) else None
+            mods = [m for m in blk.modules() if isinstance(m, BaseConvNormAct)] if blk is not None else []
+            ok = (0 not in tuple(self.decoder_levels) and len(mods) == 1 and len(list(blk.children())) == 1
+                  and mods[0].norm_groups == 0 and not mods[0].transposed and mods[0].k == (3, 3, 3) and mods[0].s == (1, 1, 1)
+                  and mods[0].p == (1, 1, 1))
+            self._seg_rank1_cached = bool(ok)
+        return ok
 
     # Target assignment (ATSS on the anchors + GT boxes) does not depend on the network: with the anchors of the previous step with
     # the same image shape (the generator caches them) it runs on a side stream UNDER the forward pass instead of between the

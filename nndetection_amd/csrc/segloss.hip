@@ -169,7 +169,10 @@ template <> __device__ __forceinline__ void st_row32<float>(float* p, const floa
 
 // persistent grid: every thread accumulates sum(d1 * x[c]) for its voxels in registers, block reduction through LDS,
 // one fp64 atomic per (block, channel)
-template <typename T>
+// RANK1: the two logit gradients of the fg / bg softmax are d1 and -d1, so the gradient w.r.t. the input is the OUTER PRODUCT
+// d1[voxel] * (w1 - w0)[channel]. Instead of writing it (32 channels, 629 MB at 160x160x96, batch 4) the kernel writes d1 alone
+// (one value per voxel); the producer convolution's backward pass then works on the factorised form (arch/conv.py: _rank1_backward).
+template <typename T, bool RANK1 = false>
 __global__ __launch_bounds__(256) void k_seghead_bwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                      int cin, const uint8_t* __restrict__ target, int64_t nvox,
                                                      const float* __restrict__ coeffs, T* __restrict__ dx, double* __restrict__ dwb) {
@@ -195,14 +198,20 @@ __global__ __launch_bounds__(256) void k_seghead_bwd(const T* __restrict__ x, co
         float d1 = g_ce * (p1 - (t ? 1.f : 0.f));
         d1 += dp * (t ? (g_tp - g_fn) : g_fp);
         d1 = round_to<T>(d1);                      // the unfused path stores dlogits in T
-        float o[32];
+        if constexpr (RANK1) {
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            acc[c] = fmaf(d1, xv[c], acc[c]);
-            o[c] = fmaf(W.w1[c], d1, W.w0[c] * -d1);
+            for (int c = 0; c < 32; ++c) acc[c] = fmaf(d1, xv[c], acc[c]);
+            dx[v] = Elem<T>::st(d1);               // (d1 is already a value of T: exact)
+        } else {
+            float o[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                acc[c] = fmaf(d1, xv[c], acc[c]);
+                o[c] = fmaf(W.w1[c], d1, W.w0[c] * -d1);
+            }
+            st_row32<T>(dx + v * 32, o);
         }
         acc[32] += d1;
-        st_row32<T>(dx + v * 32, o);
     }
     // reduce 33 values over the block: wave shuffles, then the 4 waves through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -246,6 +255,22 @@ extern "C" int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p,
         k_seghead_bwd<f16_t><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const f16_t*)x, w, bias, cin, target, nvox, coeffs, (f16_t*)dx, dwb_out);
     else
         k_seghead_bwd<float><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const float*)x, w, bias, cin, target, nvox, coeffs, (float*)dx, dwb_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nndet_seghead_backward_rank1(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
+                                            const uint8_t* target, int64_t nvox, const float* coeffs, void* d1_out, double* dwb_out,
+                                            void* stream) {
+    if (!x || !w || !target || !coeffs || !d1_out || !dwb_out || nvox <= 0 || c_p != 32 || cin <= 0 || cin > 32) return NNDET_EINVAL;
+    int64_t nb = ceil_div64(nvox, 256 * 4);
+    if (nb > 2048) nb = 2048;
+    if (dtype == NNDET_BF16)
+        k_seghead_bwd<bf16_t, true><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const bf16_t*)x, w, bias, cin, target, nvox, coeffs, (bf16_t*)d1_out, dwb_out);
+    else if (dtype == NNDET_F16)
+        k_seghead_bwd<f16_t, true><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const f16_t*)x, w, bias, cin, target, nvox, coeffs, (f16_t*)d1_out, dwb_out);
+    else
+        k_seghead_bwd<float, true><<<(unsigned)nb, 256, 0, as_stream(stream)>>>((const float*)x, w, bias, cin, target, nvox, coeffs, (float*)d1_out, dwb_out);
     LAUNCH_CHECK();
     return 0;
 }

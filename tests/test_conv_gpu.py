@@ -202,6 +202,66 @@ def test_fused_stem_block_matches_separate_kernels_and_fp32(shape, cout, dtype, 
         assert e_ref <= 1.5 * e_sepref + 0.25 * tol, f"{name}: fused {e_ref:.3e} vs separate {e_sepref:.3e} from fp32"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 9, 10, 12), (1, 16, 24, 32)], ids=["ragged", "tiles"])
+def test_rank1_segmentation_gradient_through_the_producer_conv(shape, dtype, monkeypatch):
+    """decoder.out.P0 (3x3x3, 32 -> 32, bias) -> fused segmentation head + loss. The head's input gradient is d1 (x) (w1 - w0); with
+    NNDET_SEG_RANK1 the producer convolution's backward pass consumes the FACTORS (data gradient = one-input-channel convolution of
+    d1, weight gradient = (w1 - w0) (x) one-channel weight gradient) instead of the dense 32-channel tensor. Same gradients for the
+    conv input, conv weight / bias and the head's weight / bias as the dense route, and as plain PyTorch fp32 on the CPU."""
+    from nndetection_amd.arch import conv as conv_mod
+    from nndetection_amd.arch import Generator, ConvInstanceRelu, DiCESegmenterFgBg
+    torch.manual_seed(11)
+    N, D, H, W = shape
+    conv = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=False, add_act=False)
+    seg = DiCESegmenterFgBg(Generator(ConvInstanceRelu, 3), seg_classes=1, in_channels=[32], decoder_levels=[0],
+                            dice_kwargs={"batch_dice": True})
+    with torch.no_grad():
+        conv.conv.weight.copy_(torch.randn_like(conv.conv.weight) / 29.4); conv.conv.bias.copy_(torch.randn(32) * 0.2)
+        seg.conv_out.conv.weight.copy_(torch.randn_like(seg.conv_out.conv.weight) * 0.3); seg.conv_out.conv.bias.copy_(torch.tensor([0.2, -0.1]))
+    x0 = torch.randn(N, 32, D, H, W)
+    tgt = (torch.rand(N, D, H, W) > 0.75).float()
+    rd = lambda t_: t_.detach().to(dtype).float().clone()
+    # fp32 CPU reference on the rounded operands (the conv output and the logits are rounded to the 16-bit type like the kernels store them)
+    xr = rd(x0).requires_grad_(True)
+    w = rd(conv.conv.weight).requires_grad_(True); b = conv.conv.bias.detach().clone().requires_grad_(True)
+    ws = rd(seg.conv_out.conv.weight).requires_grad_(True); bs = seg.conv_out.conv.bias.detach().clone().requires_grad_(True)
+    o = F.conv3d(xr, w, b, padding=1)
+    o = o + (o.to(dtype).float() - o).detach()
+    sl = F.conv3d(o, ws, bs)
+    sl = sl + (sl.to(dtype).float() - sl).detach()
+    t = (tgt > 0).long()
+    p = torch.softmax(sl, 1)
+    oh = torch.zeros_like(p).scatter_(1, t[:, None], 1)
+    ax = [0, 2, 3, 4]
+    tp = (p * oh).sum(ax); fp = (p * (1 - oh)).sum(ax); fn = ((1 - p) * oh).sum(ax)
+    loss = 0.5 * F.cross_entropy(sl, t) + 0.5 * (1 - ((2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5))[1:].mean())
+    (loss * 64.0).backward()                                # (a loss scale, as a GradScaler would apply for fp16)
+    res = {}
+    for rank1 in (True, False):
+        monkeypatch.setattr(conv_mod, "RANK1", rank1)
+        cg, sg = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=False, add_act=False), \
+            DiCESegmenterFgBg(Generator(ConvInstanceRelu, 3), seg_classes=1, in_channels=[32], decoder_levels=[0], dice_kwargs={"batch_dice": True})
+        cg.load_state_dict(conv.state_dict()); sg.load_state_dict(seg.state_dict())
+        cg, sg = cg.cuda(), sg.cuda()
+        xg = x0.cuda().to(dtype).requires_grad_(True)
+        og = cg(xg)
+        og._nndet_rank1_ok = True                           # what BaseRetinaNet.forward asserts for decoder level 0
+        out = sg.compute_loss(sg([og], fused=True), tgt.cuda())
+        ((out["seg_ce"] + out["seg_dice"]) * 64.0).backward()
+        torch.cuda.synchronize()
+        assert (len(conv_mod._rank1_grads) == 0)             # consumed (or never registered)
+        res[rank1] = [xg.grad.float().cpu(), cg.conv.weight.grad.cpu(), cg.conv.bias.grad.cpu(), sg.conv_out.conv.weight.grad.cpu(),
+                      sg.conv_out.conv.bias.grad.cpu()]
+    refs = [xr.grad, w.grad, b.grad, ws.grad, bs.grad]
+    tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3
+    for name, a, d_, r in zip(("dx", "dW", "db", "dW_seg", "db_seg"), res[True], res[False], refs):
+        e_ref, e_dense, e_denseref = relerr(a, r), relerr(a, d_), relerr(d_, r)
+        assert e_ref <= tol, f"{name}: rank-1 route vs fp32 {e_ref:.3e}"
+        assert e_dense <= e_ref + e_denseref + 1e-6, f"{name}: rank-1 vs dense route {e_dense:.3e}"
+        assert e_ref <= 1.5 * e_denseref + 0.25 * tol, f"{name}: rank-1 {e_ref:.3e} vs dense {e_denseref:.3e} from fp32"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_segloss(dtype):
     from nndetection_amd.arch import Generator, ConvInstanceRelu, DiCESegmenterFgBg
