@@ -196,7 +196,7 @@ def test_fused_stem_block_matches_separate_kernels_and_fp32(shape, cout, dtype, 
         assert e_ref <= tol, f"{name}: fused vs fp32 reference {e_ref:.3e}"
         # the two HIP routes agree as far as their distances from the fp32 result allow (the sums over these small volumes cancel,
         # which amplifies the 16-bit rounding of the separate kernels' stored norm-backward output: measured up to 2.6e-2 for dW)
-        assert e_sep <= e_ref + e_sepref + 1e-6, f"{name}: fused vs separate kernels {e_sep:.3e} ({e_ref:.3e} + {e_sepref:.3e})"
+        assert e_sep <= 1.05 * (e_ref + e_sepref) + 1e-6, f"{name}: fused vs separate kernels {e_sep:.3e} ({e_ref:.3e} + {e_sepref:.3e})"
         # the fused path keeps the pre-norm values and the norm-backward output in fp32: it must not be further from fp32 than the
         # separate kernels are (which round both to 16 bits), up to noise
         assert e_ref <= 1.5 * e_sepref + 0.25 * tol, f"{name}: fused {e_ref:.3e} vs separate {e_sepref:.3e} from fp32"
@@ -258,7 +258,7 @@ def test_rank1_segmentation_gradient_through_the_producer_conv(shape, dtype, mon
     for name, a, d_, r in zip(("dx", "dW", "db", "dW_seg", "db_seg"), res[True], res[False], refs):
         e_ref, e_dense, e_denseref = relerr(a, r), relerr(a, d_), relerr(d_, r)
         assert e_ref <= tol, f"{name}: rank-1 route vs fp32 {e_ref:.3e}"
-        assert e_dense <= e_ref + e_denseref + 1e-6, f"{name}: rank-1 vs dense route {e_dense:.3e}"
+        assert e_dense <= 1.05 * (e_ref + e_denseref) + 1e-6, f"{name}: rank-1 vs dense route {e_dense:.3e}"
         assert e_ref <= 1.5 * e_denseref + 0.25 * tol, f"{name}: rank-1 {e_ref:.3e} vs dense {e_denseref:.3e} from fp32"
 
 
