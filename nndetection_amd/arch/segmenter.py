@@ -58,7 +58,7 @@ class _SegHeadFused(torch.autograd.Function):
         ctx.b32, ctx.cin, ctx.wshape, ctx.wdtype = b32, cin, tuple(weight.shape), weight.dtype
         # may the input gradient travel in factorised form (d1 (x) (w1 - w0), arch/conv.py: _rank1_backward)? Only if the tensor
         # was produced by one of OUR plain 3x3x3 / stride-1 convolutions and nobody else consumes it -- the caller says so
-        ctx.rank1 = bool(getattr(x, "_nndet_rank1_ok", False)) and xp.dtype != torch.float32
+        ctx.rank1 = bool(getattr(x, "_nndet_rank1_ok", False)) and xp.dtype != torch.float32 and cin == xp.shape[-1]
         return sums.float()
 
     @staticmethod
@@ -76,7 +76,10 @@ class _SegHeadFused(torch.autograd.Function):
                    L.ptr(coeffs), L.ptr(d1), L.ptr(dwb), L.stream())
             wd = torch.zeros((32,), dtype=torch.float32, device=xp.device)
             wd[:cin] = w32[1] - w32[0]
-            rank1_register(dx, d1, wd, dwb[2 * cin + 1].float())     # dx itself stays unwritten: its consumer reads the factors
+            # dx itself stays unwritten: its consumer reads the factors. Its first voxel is poisoned so that anything that DID read
+            # it as a dense gradient (a tensor hook, a consumer the tag should have excluded) shows up as NaN instead of as noise
+            dx[0, 0, 0, 0].fill_(float("nan"))
+            rank1_register(dx, d1, wd, dwb[2 * cin + 1].float())
         else:
             L.call("nndet_seghead_backward", L.dtype_code(xp), L.ptr(xp), 32, cin, L.ptr(w32), L.ptr(ctx.b32), L.ptr(tgt), nvox,
                    L.ptr(coeffs), L.ptr(dx), L.ptr(dwb), L.stream())

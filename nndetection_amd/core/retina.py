@@ -109,7 +109,7 @@ class BaseRetinaNet(nn.Module):
             mods = [m for m in blk.modules() if isinstance(m, BaseConvNormAct)] if blk is not None else []
             ok = (0 not in tuple(self.decoder_levels) and len(mods) == 1 and len(list(blk.children())) == 1
                   and mods[0].norm_groups == 0 and not mods[0].transposed and mods[0].k == (3, 3, 3) and mods[0].s == (1, 1, 1)
-                  and mods[0].p == (1, 1, 1))
+                  and mods[0].p == (1, 1, 1) and mods[0].out_channels % 32 == 0 and mods[0].in_channels % 32 == 0)
             self._seg_rank1_cached = bool(ok)
         return ok
 
