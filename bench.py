@@ -128,6 +128,8 @@ class Route:
         for _ in range(warmup):
             last = self.step()
         torch.cuda.synchronize()
+        if self.ddp is not None and self.ddp.profile:
+            self.ddp.profile_reset()                    # the exposed-communication figures cover the timed steps only
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -507,7 +509,7 @@ def main():
     peak_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
     ddp_prof = None
     if route.ddp is not None and route.ddp.profile:
-        route.ddp.profile_collect()                      # (events of the timed AND warm-up steps; outside the timed region)
+        route.ddp.profile_collect()                      # (events of the timed steps; read outside the timed region)
         ddp_prof = route.ddp.profile_summary()
 
     if rank == 0:

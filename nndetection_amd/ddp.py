@@ -247,6 +247,11 @@ class GradAllReducer:
             self._prof_pending.append((prof["t0"], prof["f0"], f1, prof["launch"]))
             self._prof_ev = None
 
+    def profile_reset(self):
+        """Drop everything recorded so far (bench.py: after the warm-up steps, whose first one includes one-time set-up work)."""
+        self.profile_collect()
+        self._prof = {"steps": 0, "exposed_ms": 0.0, "span_ms": 0.0, "offsets_ms": [0.0] * len(self.buckets)}
+
     def profile_collect(self):
         """Fold the event pairs of the finished steps into the running sums (synchronises: call outside the timed region)."""
         for t0, f0, f1, launches in getattr(self, "_prof_pending", []):
