@@ -448,6 +448,25 @@ int nndet_head_gather_f32(int32_t dtype, const NndetHeadLevels* levels, int32_t 
 int nndet_head_gather_backward(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t cout, int32_t cout_p,
                                const float* grad_out, void* stream);
 
+/* Sparse backward of the detection head's OUTPUT convolutions (training): the loss touches <= batch_size_per_image * batch sampled
+ * anchors (nndet/arch/heads/comb.py:351-405, nndet/core/boxes/sampler.py:237-270), so the gradient w.r.t. box_logits / box_deltas has
+ * <= 170 non-zero rows. Instead of the dense backward of permute / view / cat (classifier.py:176-181, regressor.py:163-172,
+ * comb.py:107-108) and of the two 3x3x3 output convolutions over all pyramid levels:
+ *   nndet_head_out_sparse_scatter: K entries (idx[k] = anchor index in the [N, sum_l points_l * A] order of nndet_head_gather_f32, -1 =
+ *     unused slot; val [K][G] = gradient of the G = num_classes (classifier) or 6 (regressor) values of that anchor) -> row of the ragged
+ *     head buffer, first channel a * G, values x the level's Scale (levels->scale, may be NULL); also written into dy_zeroed
+ *     [rows][cout_p] (dtype, zero-filled by the caller), which thereby is the complete dense gradient; levels->dscale[l] += d(Scale)
+ *     from y = the raw conv output. level_row0_host[l] = first row of level l (rows of level l: row0 + n * points + position).
+ *   nndet_conv_out_sparse_backward: data gradient dx [rows][cin_p] (dtype; via dx32_zeroed, an fp32 scratch of the same shape), weight
+ *     gradient dw [cout][cin][27] and dbias [cout] (fp32, ACCUMULATED with atomics) of the 3x3x3 / stride 1 / pad 1 convolution from the
+ *     entries; x = the conv input (ragged, NndetItems), w_f32 = its weights [cout][cin][27] fp32. */
+int nndet_head_out_sparse_scatter(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t A, int32_t G,
+                                  const int64_t* level_row0_host, const int64_t* idx, const float* val, int32_t K, const void* y,
+                                  int32_t cout_p, void* dy_zeroed, int32_t* rows_out, int32_t* c0_out, float* vals_out, void* stream);
+int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetItems* items, const int32_t* rows, const int32_t* c0,
+                                   const float* vals, int32_t K, int32_t G, const void* x, const float* w_f32, float* dx32_zeroed,
+                                   void* dx, float* dw, float* dbias, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused detection loss on the sampled anchors -- replaces the tail of DetectionHeadHNM.compute_loss (nndet/arch/heads/comb.py:
  * 351-405): decode of the sampled positives (nndet/core/boxes/coder.py:90-155, unit weights, clamp at bbox_xform_clip) ->

@@ -115,6 +115,9 @@ SIGNATURES = {
     "nndet_seghead_forward": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P]),
     "nndet_seghead_backward": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nndet_seghead_backward_rank1": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "nndet_head_out_sparse_scatter": (C.c_int, [_I32, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, C.POINTER(C.c_int64), _P, _P, _I32,
+                                               _P, _I32, _P, _P, _P, _P, _P]),
+    "nndet_conv_out_sparse_backward": (C.c_int, [_CONVP, _ITEMSP, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_segloss_tail_f32": (C.c_int, [_P, _I64, _F, _F, _F, _P, _P, _P]),
     "nndet_sigmoid_max_f32": (C.c_int, [_P, _I64, _I32, _P, _P]),
 }
@@ -333,6 +336,34 @@ class _WgradStreams:
 
 
 wgrad_streams = _WgradStreams()
+
+
+class _GradHints:
+    """Side channel between autograd nodes: a node that KNOWS more about the gradient it returns than the dense tensor says (it is
+    sparse: arch/heads.py) registers that knowledge under the tensor's address; the node that receives exactly this tensor (same
+    address -- views and no-op casts keep it, anything that copies or accumulates does not) may use it instead of reading the
+    tensor. The dense tensor stays a VALID gradient, so a consumer that finds no hint computes the same result the slow way. An entry
+    keeps its tensor alive (its address cannot be reused while the hint exists) and is dropped when consumed or after 16 newer ones."""
+
+    def __init__(self):
+        self.d = {}
+
+    def put(self, t: torch.Tensor, payload: dict) -> None:
+        if len(self.d) >= 16:
+            self.d.pop(next(iter(self.d)))
+        self.d[t.data_ptr()] = (t, payload)
+
+    def pop(self, t: torch.Tensor):
+        e = self.d.pop(t.data_ptr(), None)
+        if e is None:
+            return None
+        keep, payload = e
+        if keep.numel() * keep.element_size() != t.numel() * t.element_size() or keep.dtype != t.dtype:
+            return None                                  # same address, other tensor (a sub-view): not ours
+        return payload
+
+
+grad_hints = _GradHints()
 
 
 def call(name: str, *args):

@@ -104,6 +104,12 @@ def _cat_rows(ts) -> Tensor:
     return torch.cat(list(ts), dim=0)
 
 
+# Sparse backward of the two head OUTPUT convolutions (csrc/sparse_out.hip): the detection loss touches <= 170 sampled anchors, so
+# the dense data / weight gradients of conv_out (0.47 TFLOP per step) are replaced by per-entry scatter kernels. NNDET_SPARSE_OUT=0:
+# dense backward as in the reference.
+SPARSE_OUT = os.environ.get("NNDET_SPARSE_OUT", "1") != "0"
+
+
 class _DetLossFn(torch.autograd.Function):
     """(reg, cls) losses of the sampled anchors and their gradients in one launch each way (csrc/boxes.hip: k_detloss,
     k_detloss_scatter; include/nndet_amd.h: nndet_detloss_f32). Arithmetic = _compute_loss_sync_free below (decode_single,
@@ -135,7 +141,13 @@ class _DetLossFn(torch.autograd.Function):
         d_deltas = torch.zeros(ds, dtype=torch.float32, device=g.device)
         L.call("nndet_detloss_scatter_f32", L.ptr(pos), pos.shape[0], L.ptr(neg), neg.shape[0], g_l.shape[1], L.ptr(g_d), L.ptr(g_l),
                L.ptr(up), L.ptr(d_deltas), L.ptr(d_logits), L.stream())
-        return d_logits.to(lt), d_deltas.to(dt), None, None, None, None, None, None, None
+        d_logits, d_deltas = d_logits.to(lt), d_deltas.to(dt)
+        if SPARSE_OUT and lt == torch.float32 and dt == torch.float32:
+            # both gradients are zero except at the <= P + Q sampled rows: tell the consumers (arch/pyramid.py: the gather / output
+            # convolution backward then touch those rows only). The dense tensors above stay complete, valid gradients.
+            L.grad_hints.put(d_deltas, {"idx": pos, "val": g_d * up[0], "G": 6})
+            L.grad_hints.put(d_logits, {"idx": torch.cat([pos, neg]), "val": g_l * up[1], "G": int(g_l.shape[1])})
+        return d_logits, d_deltas, None, None, None, None, None, None, None
 
 
 class BCECLassifier(nn.Module):

@@ -148,6 +148,16 @@ class _ItemsConvFn(torch.autograd.Function):
         gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
         dw = gbuf[:nw].view(weight.shape)
         dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
+        hint = L.grad_hints.pop(dconv)                      # set by _HeadGatherItemsFn.backward: dconv is zero except at <= 170 rows
+        if hint is not None:
+            # sparse data + weight gradient of this output convolution (csrc/sparse_out.hip); dw / dbias are views of the zeroed pool
+            w32 = weight.detach().to(dt).float().contiguous()                # the values the forward kernel multiplied with
+            dx32 = torch.zeros((meta.rows, desc.cin_p), dtype=torch.float32, device=dev)
+            dx = torch.empty_like(x2d)
+            L.call("nndet_conv_out_sparse_backward", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(hint["rows"]), L.ptr(hint["c0"]),
+                   L.ptr(hint["vals"]), int(hint["rows"].numel()), int(hint["G"]), L.ptr(x2d), L.ptr(w32), L.ptr(dx32), L.ptr(dx),
+                   L.ptr(dw), L.ptr(dbias), L.stream())
+            return (dx if ctx.needs_input_grad[0] else None), dw.to(weight.dtype), dbias, None, None, None
         side = L.wgrad_streams.side(dev, weight)            # weight-gradient stream, forked before the data gradient is queued
         dx = None
         if ctx.needs_input_grad[0]:
@@ -239,10 +249,29 @@ class _HeadGatherItemsFn(torch.autograd.Function):
         y2d, sc = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         cout_p, esz = y2d.shape[1], y2d.element_size()
         g = g.contiguous().float()
-        dy = torch.empty_like(y2d)
+        hint = L.grad_hints.pop(g)                     # set by heads._DetLossFn.backward: g is zero except at <= 170 sampled anchors
         dsc = torch.zeros((max(ctx.n_scales, 1),), dtype=torch.float32, device=g.device)
         lv = L.NndetHeadLevels()
         lv.nlev = len(ctx.pts)
+        if hint is not None and hint["idx"].numel() > 0 and ctx.cout % hint["G"] == 0:
+            # sparse route (csrc/sparse_out.hip): entries -> rows of the ragged buffer; dy = zeros + those rows (still the complete
+            # dense gradient), and a hint for the output convolution's backward pass
+            dy = torch.zeros_like(y2d)
+            K, G = int(hint["idx"].numel()), int(hint["G"])
+            rows = torch.empty((K,), dtype=torch.int32, device=g.device)
+            c0 = torch.empty((K,), dtype=torch.int32, device=g.device)
+            vals = torch.empty((K, G), dtype=torch.float32, device=g.device)
+            for l in range(len(ctx.pts)):
+                lv.points[l] = ctx.pts[l]
+                if ctx.n_scales:
+                    lv.scale[l], lv.dscale[l] = sc[l].data_ptr(), dsc.data_ptr() + 4 * l
+            row0 = (ctypes.c_int64 * len(ctx.pts))(*[r0 for (r0, _) in meta.level_rows])
+            L.call("nndet_head_out_sparse_scatter", L.dtype_code(y2d), ctypes.byref(lv), meta.batch, ctx.cout // G, G, row0,
+                   L.ptr(hint["idx"].contiguous()), L.ptr(hint["val"].float().contiguous()), K, L.ptr(y2d), cout_p, L.ptr(dy),
+                   L.ptr(rows), L.ptr(c0), L.ptr(vals), L.stream())
+            L.grad_hints.put(dy, {"rows": rows, "c0": c0, "vals": vals, "G": G})
+            return (None, None, None) + tuple(dsc[l].reshape(()) for l in range(ctx.n_scales)) + (dy,)
+        dy = torch.empty_like(y2d)
         yb, db = y2d.data_ptr(), dy.data_ptr()
         for l, (r0, _) in enumerate(meta.level_rows):
             lv.y[l], lv.dy[l], lv.points[l] = yb + r0 * cout_p * esz, db + r0 * cout_p * esz, ctx.pts[l]

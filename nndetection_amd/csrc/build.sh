@@ -40,6 +40,7 @@ build conv_stem.hip
 build norm.hip
 build segloss.hip
 build headio.hip
+build sparse_out.hip
 build api.hip
 rc=0
 for p in "${pids[@]}"; do wait $p || rc=1; done

@@ -1,0 +1,177 @@
+// Sparse backward of the detection head's OUTPUT convolutions (training).
+//
+// The detection loss touches at most batch_size_per_image * batch sampled anchors (nndet/arch/heads/comb.py:351-405,
+// nndet/core/boxes/sampler.py:237-270: <= 42 positives for the regression loss, <= 128 positives + negatives for the classification
+// loss at batch 4), so the gradient w.r.t. the head outputs box_deltas [B * 1 186 650, 6] / box_logits [.., C] has <= 170 non-zero
+// rows. The reference (and rounds 1-2 here) nevertheless run the dense backward of the two output convolutions over all pyramid
+// levels: flatten / cat backward (114 + 19 MB), data gradient 128 <- 162 and 128 <- 27 (3x3x3, 197 + 39 GFLOP) and the weight
+// gradients (the same again) -- 0.47 TFLOP and ~1.1 ms of kernel time per step for <= 170 x 27 x 128 x 6 useful products.
+//
+//   k_ho_scatter : (anchor index, gradient values) entries -> (row of the ragged head buffer, first channel, values x level Scale),
+//                  writes them into the (zero-filled) DENSE gradient buffer as well, so that tensor stays a valid gradient for any
+//                  consumer that does not know about the sparse form; d(Scale) of the regressor (nndet/arch/layers/scale.py:21-43).
+//   k_ho_backward: per entry and tap: dX32[row + tap] += sum_g v_g W[c0+g][:, tap] (fp32 atomics), dW[c0+g][:, tap] += v_g X[row + tap],
+//                  dbias[c0+g] += v_g. One workgroup per entry, one thread per input channel.
+//   k_ho_convert : fp32 scratch -> activation dtype.
+// Replaces, for these two layers only, nndet_head_gather_backward + nndet_conv3d_backward_data_items +
+// nndet_conv3d_backward_weight_items. Same mathematics; the values are not rounded to 16 bits on the way (closer to fp32).
+#include "common.h"
+#include "conv_common.h"
+
+#define HO_MAX_LEVELS 8
+
+struct HoLevels {
+    int32_t nlev, A, G, N;
+    int64_t anchors_per_image;                 // sum over levels of points * A
+    int64_t anchor_off[HO_MAX_LEVELS + 1];     // first anchor of level l inside an image
+    int64_t points[HO_MAX_LEVELS];
+    int64_t row0[HO_MAX_LEVELS];               // first row of level l in the ragged buffer (level-major: row = row0 + n * points + pos)
+    const float* scale[HO_MAX_LEVELS];         // per-level Scale (regressor) or NULL
+    float* dscale[HO_MAX_LEVELS];
+};
+
+// grid ceil(K / 64), block 64: one thread per entry
+template <typename T>
+__global__ void k_ho_scatter(const int64_t* __restrict__ idx, const float* __restrict__ val, int K, const HoLevels Lv,
+                             const T* __restrict__ y, int cout_p, T* __restrict__ dy, int32_t* __restrict__ rows,
+                             int32_t* __restrict__ c0s, float* __restrict__ vals) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int64_t i = idx[k];
+    if (i < 0 || i >= Lv.anchors_per_image * Lv.N) { rows[k] = -1; c0s[k] = 0; return; }
+    const int n = (int)(i / Lv.anchors_per_image);
+    const int64_t j = i - (int64_t)n * Lv.anchors_per_image;
+    int l = 0;
+    while (l + 1 < Lv.nlev && j >= Lv.anchor_off[l + 1]) ++l;
+    const int64_t jl = j - Lv.anchor_off[l];
+    const int64_t pos = jl / Lv.A;
+    const int a = (int)(jl - pos * Lv.A);
+    const int64_t row = Lv.row0[l] + (int64_t)n * Lv.points[l] + pos;
+    const int c0 = a * Lv.G;
+    const float sc = Lv.scale[l] ? *Lv.scale[l] : 1.f;
+    float ds = 0.f;
+    for (int g = 0; g < Lv.G; ++g) {
+        const float v = val[(int64_t)k * Lv.G + g];
+        if (Lv.scale[l]) ds += v * Elem<T>::ld(y[row * cout_p + c0 + g]);        // out = scale * y  =>  d(scale) += g * y
+        const float vs = v * sc;
+        vals[(int64_t)k * Lv.G + g] = vs;
+        dy[row * cout_p + c0 + g] = Elem<T>::st(vs);     // (two sampled anchors never share (row, channel): distinct anchors)
+    }
+    if (Lv.dscale[l]) atomicAdd(Lv.dscale[l], ds);
+    rows[k] = (int32_t)row;
+    c0s[k] = c0;
+}
+
+struct HoItems { int32_t n; int32_t dims[NNDET_MAX_ITEMS][3]; int64_t row_off[NNDET_MAX_ITEMS]; };
+
+// grid K, block 128 (thread = input channel, looped)
+template <typename T>
+__global__ __launch_bounds__(128) void k_ho_backward(const int32_t* __restrict__ rows, const int32_t* __restrict__ c0s,
+                                                     const float* __restrict__ vals, int G, const HoItems It, const T* __restrict__ x,
+                                                     int cin, int cin_p, const float* __restrict__ w, int cout, float* __restrict__ dx32,
+                                                     float* __restrict__ dw, float* __restrict__ dbias) {
+    const int k = blockIdx.x;
+    const int row = rows[k];
+    if (row < 0) return;                                                     // uniform
+    const int c0 = c0s[k];
+    float v[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v[g] = (g < G && c0 + g < cout) ? vals[(int64_t)k * G + g] : 0.f;
+    int it = 0;
+    while (it + 1 < It.n && row >= It.row_off[it + 1]) ++it;
+    const int D = It.dims[it][0], H = It.dims[it][1], W = It.dims[it][2];
+    const int pos = row - (int)It.row_off[it];
+    const int pd = pos / (H * W), ph = (pos / W) % H, pw = pos % W;
+    if (dbias && (int)threadIdx.x < G && c0 + (int)threadIdx.x < cout) atomicAdd(dbias + c0 + threadIdx.x, v[threadIdx.x]);
+    for (int t = 0; t < 27; ++t) {
+        const int qd = pd + t / 9 - 1, qh = ph + (t / 3) % 3 - 1, qw = pw + t % 3 - 1;
+        if ((unsigned)qd >= (unsigned)D || (unsigned)qh >= (unsigned)H || (unsigned)qw >= (unsigned)W) continue;       // zero padding
+        const int64_t qrow = It.row_off[it] + ((int64_t)qd * H + qh) * W + qw;
+        for (int ci = threadIdx.x; ci < cin; ci += blockDim.x) {
+            const float xv = Elem<T>::ld(x[qrow * cin_p + ci]);
+            float acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g < G && c0 + g < cout) {
+                    const int64_t wi = ((int64_t)(c0 + g) * cin + ci) * 27 + t;
+                    acc = fmaf(v[g], w[wi], acc);                            // y[p][c] = sum W[c][ci][t] x[p + t - 1][ci]
+                    atomicAdd(dw + wi, v[g] * xv);
+                }
+            }
+            atomicAdd(dx32 + qrow * cin_p + ci, acc);
+        }
+    }
+}
+
+template <typename T>
+__global__ void k_ho_convert(const float* __restrict__ src, T* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 f = reinterpret_cast<const float4*>(src)[i];
+        dst[4 * i + 0] = Elem<T>::st(f.x); dst[4 * i + 1] = Elem<T>::st(f.y);
+        dst[4 * i + 2] = Elem<T>::st(f.z); dst[4 * i + 3] = Elem<T>::st(f.w);
+    }
+}
+
+extern "C" int nndet_head_out_sparse_scatter(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t A, int32_t G,
+                                             const int64_t* level_row0_host, const int64_t* idx, const float* val, int32_t K,
+                                             const void* y, int32_t cout_p, void* dy_zeroed, int32_t* rows_out, int32_t* c0_out,
+                                             float* vals_out, void* stream) {
+    if (!levels || levels->nlev <= 0 || levels->nlev > HO_MAX_LEVELS || N <= 0 || A <= 0 || G <= 0 || G > 8 || K < 0 || !level_row0_host)
+        return NNDET_EINVAL;
+    if (K == 0) return 0;
+    if (!idx || !val || !y || !dy_zeroed || !rows_out || !c0_out || !vals_out || cout_p % 32 || A * G > cout_p) return NNDET_EINVAL;
+    HoLevels Lv;
+    memset(&Lv, 0, sizeof(Lv));
+    Lv.nlev = levels->nlev; Lv.A = A; Lv.G = G; Lv.N = N;
+    int64_t off = 0;
+    for (int l = 0; l < levels->nlev; ++l) {
+        Lv.anchor_off[l] = off; Lv.points[l] = levels->points[l]; Lv.row0[l] = level_row0_host[l];
+        Lv.scale[l] = reinterpret_cast<const float*>(levels->scale[l]); Lv.dscale[l] = reinterpret_cast<float*>(levels->dscale[l]);
+        off += levels->points[l] * A;
+    }
+    Lv.anchor_off[levels->nlev] = off;
+    Lv.anchors_per_image = off;
+    hipStream_t st = as_stream(stream);
+    const int nb = ceil_div(K, 64);
+    if (dtype == NNDET_BF16) k_ho_scatter<bf16_t><<<nb, 64, 0, st>>>(idx, val, K, Lv, (const bf16_t*)y, cout_p, (bf16_t*)dy_zeroed, rows_out, c0_out, vals_out);
+    else if (dtype == NNDET_F16) k_ho_scatter<f16_t><<<nb, 64, 0, st>>>(idx, val, K, Lv, (const f16_t*)y, cout_p, (f16_t*)dy_zeroed, rows_out, c0_out, vals_out);
+    else if (dtype == NNDET_F32) k_ho_scatter<float><<<nb, 64, 0, st>>>(idx, val, K, Lv, (const float*)y, cout_p, (float*)dy_zeroed, rows_out, c0_out, vals_out);
+    else return NNDET_EINVAL;
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetItems* items, const int32_t* rows, const int32_t* c0,
+                                              const float* vals, int32_t K, int32_t G, const void* x, const float* w_f32,
+                                              float* dx32_zeroed, void* dx, float* dw, float* dbias, void* stream) {
+    if (!c || !items || items->n_items < 1 || items->n_items > NNDET_MAX_ITEMS || K < 0 || G <= 0 || G > 8) return NNDET_EINVAL;
+    if (c->transposed || c->cin_p % 32 || c->cout_p % 32) return NNDET_EINVAL;
+    for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 1 || c->p[i] != 1) return NNDET_EINVAL;
+    if (!x || !w_f32 || !dx32_zeroed || !dx || !dw) return NNDET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    HoItems It;
+    memset(&It, 0, sizeof(It));
+    It.n = items->n_items;
+    int64_t total_rows = 0;
+    for (int i = 0; i < items->n_items; ++i) {
+        for (int a = 0; a < 3; ++a) It.dims[i][a] = items->dims[i][a];
+        It.row_off[i] = items->row_off[i];
+        const int64_t end = items->row_off[i] + (int64_t)items->dims[i][0] * items->dims[i][1] * items->dims[i][2];
+        if (end > total_rows) total_rows = end;
+    }
+    if (K > 0) {
+        if (!rows || !c0 || !vals) return NNDET_EINVAL;
+        if (c->dtype == NNDET_BF16) k_ho_backward<bf16_t><<<K, 128, 0, st>>>(rows, c0, vals, G, It, (const bf16_t*)x, c->cin, c->cin_p, w_f32, c->cout, dx32_zeroed, dw, dbias);
+        else if (c->dtype == NNDET_F16) k_ho_backward<f16_t><<<K, 128, 0, st>>>(rows, c0, vals, G, It, (const f16_t*)x, c->cin, c->cin_p, w_f32, c->cout, dx32_zeroed, dw, dbias);
+        else if (c->dtype == NNDET_F32) k_ho_backward<float><<<K, 128, 0, st>>>(rows, c0, vals, G, It, (const float*)x, c->cin, c->cin_p, w_f32, c->cout, dx32_zeroed, dw, dbias);
+        else return NNDET_EINVAL;
+        LAUNCH_CHECK();
+    }
+    const int64_t n4 = total_rows * c->cin_p / 4;
+    const unsigned nb = (unsigned)(ceil_div64(n4, 256) < 4096 ? ceil_div64(n4, 256) : 4096);
+    if (c->dtype == NNDET_BF16) k_ho_convert<bf16_t><<<nb, 256, 0, st>>>(dx32_zeroed, (bf16_t*)dx, n4);
+    else if (c->dtype == NNDET_F16) k_ho_convert<f16_t><<<nb, 256, 0, st>>>(dx32_zeroed, (f16_t*)dx, n4);
+    else k_ho_convert<float><<<nb, 256, 0, st>>>(dx32_zeroed, (float*)dx, n4);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -207,6 +207,50 @@ def test_head_gather_matches_per_level_flatten(golden_dir, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_sparse_backward_of_the_head_output_convolutions(golden_dir, dtype, monkeypatch):
+    """csrc/sparse_out.hip: the gradient w.r.t. box_logits / box_deltas is zero except at the <= 170 sampled anchors; with the hints of
+    `_DetLossFn.backward` the gather backward and the two output convolutions' data / weight gradients touch only those rows. Same
+    losses, same gradients for EVERY parameter (the head trunks, decoder and encoder see the data gradient) as the dense backward --
+    fp32: summation order only; 16-bit: the dense route rounds the output gradient to 16 bits, the sparse one does not."""
+    import nndetection_amd.arch.heads as H
+    from nndetection_amd import _lib as L
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    with torch.no_grad():
+        for i, sc in enumerate(net.head.regressor.scales):
+            sc.scale.fill_(1.0 + 0.25 * i)
+    x = torch.from_numpy(gn["x"]).cuda().to(dtype)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    calls = {"n": 0}
+    real = L.call
+
+    def counting(name, *a):
+        if name in ("nndet_head_out_sparse_scatter", "nndet_conv_out_sparse_backward"):
+            calls["n"] += 1
+        return real(name, *a)
+
+    monkeypatch.setattr(L, "call", counting)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(H, "SPARSE_OUT", mode)
+        net.zero_grad(set_to_none=True)
+        calls["n"] = 0
+        losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+        (sum(losses.values()) * (256.0 if dtype == torch.float16 else 1.0)).backward()
+        torch.cuda.synchronize()
+        assert calls["n"] == (4 if mode else 0), calls          # 2 branches x (scatter + conv backward), or none
+        res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
+                     {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert res[True][0] == res[False][0]
+    assert set(res[True][1]) == set(res[False][1]) and any("regressor.conv_out" in n for n in res[True][1])
+    tol = 2e-5 if dtype == torch.float32 else (3e-2 if dtype == torch.bfloat16 else 4e-3)
+    for n, g0 in res[False][1].items():
+        d = float((res[True][1][n] - g0).abs().max())
+        assert d <= tol * (float(g0.abs().max()) + 1e-12), (n, d, float(g0.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_fused_input_gradient_accumulation(golden_dir, dtype, monkeypatch):
     """Encoder stage outputs feed the next stage and the decoder lateral. With set_fuse_grad_accum the second data gradient is added
     into the first one's buffer (nndet_conv3d_backward_data_acc) instead of autograd adding two tensors: same gradients (fp32: the
