@@ -466,6 +466,14 @@ int nndet_head_out_sparse_scatter(int32_t dtype, const NndetHeadLevels* levels, 
 int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetItems* items, const int32_t* rows, const int32_t* c0,
                                    const float* vals, int32_t K, int32_t G, const void* x, const float* w_f32, float* dx32_zeroed,
                                    void* dx, float* dw, float* dbias, void* stream);
+/* Forward of such an output convolution at the K anchors idx[] only: out [K][G] = Scale_l * (conv(x)[row, a*G .. a*G+G-1] + bias),
+ * raw_out [K][G] the unscaled values (for d(Scale)), rows_out / c0_out as nndet_head_out_sparse_scatter emits them and level_out the
+ * pyramid level of each entry (-1 for unused slots, whose outputs are 0). Used for the regressor in training steps: nndet/arch/heads/comb.py:383-401 reads box_deltas at
+ * sampled_pos_inds and nowhere else. */
+int nndet_conv_out_sparse_forward(const NndetConv* c, const NndetItems* items, const NndetHeadLevels* levels, int32_t N, int32_t A,
+                                  int32_t G, const int64_t* level_row0_host, const int64_t* idx, int32_t K, const void* x,
+                                  const float* w_f32, const float* bias, float* out, float* raw_out, int32_t* rows_out,
+                                  int32_t* c0_out, int32_t* level_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused detection loss on the sampled anchors -- replaces the tail of DetectionHeadHNM.compute_loss (nndet/arch/heads/comb.py:
@@ -489,6 +497,14 @@ int nndet_detloss_f32(const float* logits, const float* deltas, const int64_t* p
 int nndet_detloss_scatter_f32(const int64_t* pos, int32_t pos_cap, const int64_t* neg, int32_t neg_cap, int32_t C,
                               const float* g_deltas, const float* g_logits, const float* upstream, float* d_deltas, float* d_logits,
                               void* stream);
+/* nndet_detloss_f32 with the box deltas of the sampled positives ONLY: deltas_compact [pos_cap][6], row r belongs to anchor pos[r]
+ * (produced by nndet_conv_out_sparse_forward: the regressor's output convolution evaluated at the <= 42 sampled positives instead of
+ * at all 4.75 M anchors of a batch). g_deltas_out has the same compact layout as before; nndet_detloss_scatter_f32 accepts
+ * d_deltas == NULL in that case (there is no dense delta gradient to scatter into). */
+int nndet_detloss_compact_f32(const float* logits, const float* deltas_compact, const int64_t* pos, int32_t pos_cap, const int64_t* neg,
+                              int32_t neg_cap, const int64_t* counts, const float* labels, const float* matched_gt, const float* anchors,
+                              int64_t m_anchors, int32_t C, float eps, float clip, float reg_weight, int32_t reg_mean, float cls_weight,
+                              int32_t cls_mean, float* losses_out, float* g_deltas_out, float* g_logits_out, void* stream);
 
 #ifdef __cplusplus
 }

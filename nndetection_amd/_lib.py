@@ -83,6 +83,7 @@ SIGNATURES = {
     "nndet_hnm_sample_f32": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, C.c_double, _I32, C.c_double, C.c_uint64, _I32, _P, _P, _P,
                                        _P, _SZ, _P]),
     "nndet_detloss_f32": (C.c_int, [_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _I32, _F, _I32, _P, _P, _P, _P]),
+    "nndet_detloss_compact_f32": (C.c_int, [_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _I32, _F, _I32, _P, _P, _P, _P]),
     "nndet_detloss_scatter_f32": (C.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "nndet_wbc3d_workspace_bytes": (_SZ, [_I64]),
     "nndet_wbc3d_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _I32, _F, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -117,6 +118,8 @@ SIGNATURES = {
     "nndet_seghead_backward_rank1": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nndet_head_out_sparse_scatter": (C.c_int, [_I32, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, C.POINTER(C.c_int64), _P, _P, _I32,
                                                _P, _I32, _P, _P, _P, _P, _P]),
+    "nndet_conv_out_sparse_forward": (C.c_int, [_CONVP, _ITEMSP, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, C.POINTER(C.c_int64), _P,
+                                               _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_conv_out_sparse_backward": (C.c_int, [_CONVP, _ITEMSP, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_segloss_tail_f32": (C.c_int, [_P, _I64, _F, _F, _F, _P, _P, _P]),
     "nndet_sigmoid_max_f32": (C.c_int, [_P, _I64, _I32, _P, _P]),

@@ -110,6 +110,90 @@ def _cat_rows(ts) -> Tensor:
 SPARSE_OUT = os.environ.get("NNDET_SPARSE_OUT", "1") != "0"
 
 
+# The regression loss reads box_deltas at the <= 42 sampled positives and nowhere else (comb.py:383-401). In a TRAINING step (no
+# prediction asked for) the regressor's output convolution 128 -> 162 is therefore not run over the 4.75 M anchors of the batch at all:
+# `_forward_items` hands on its input (the trunk output) as `DeferredDeltas`, and once the sampler has picked the positives the
+# convolution is evaluated at exactly those anchors (csrc/sparse_out.hip: k_ho_forward; backward: k_ho_backward). 197 GFLOP forward
+# + the [4.75 M, 6] fp32 flatten / cat and its zero-filled gradient disappear. NNDET_SPARSE_REG=0: dense deltas as in the reference.
+SPARSE_REG = os.environ.get("NNDET_SPARSE_REG", "1") != "0"
+
+
+class DeferredDeltas:
+    """box_deltas that have not been computed: the regressor trunk output of the ragged pyramid batch + what is needed to evaluate
+    the output convolution + Scale either at sampled anchors (`_RegSparseFn`) or densely (`materialize`, any other consumer)."""
+
+    def __init__(self, t2d, meta, regressor, scales, cout, sdim):
+        self.t2d, self.meta, self.regressor, self.scales, self.cout, self.sdim = t2d, meta, regressor, list(scales), cout, sdim
+
+    def materialize(self) -> Tensor:
+        from . import pyramid as P
+        y = P.items_block(self.regressor.conv_out, self.t2d, self.meta)
+        return P.head_gather_items(y, self.meta, self.cout, self.scales).view(-1, self.sdim * 2)
+
+
+class _RegSparseFn(torch.autograd.Function):
+    """Regressor conv_out (+ Scale) at the sampled positives `pos` [P] (-1 = unused slot) -> compact deltas [P, 6] fp32."""
+
+    @staticmethod
+    def forward(ctx, t2d, weight, bias, pos, dd, *scales):
+        from . import pyramid as P
+        meta, mod = dd.meta, dd.regressor.conv_out
+        t2d = t2d.contiguous()
+        desc = P._items_desc(t2d, mod, meta)
+        dev = t2d.device
+        K, G = int(pos.shape[0]), dd.sdim * 2
+        A = dd.cout // G
+        w32 = weight.detach().to(t2d.dtype).float().contiguous()              # what the dense kernel would multiply with
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        sc = [s_.detach().float().contiguous() for s_ in scales]
+        pts = [d * h * w for (_, d, h, w) in meta.level_shapes]
+        lv = L.NndetHeadLevels()
+        lv.nlev = len(pts)
+        for l in range(len(pts)):
+            lv.points[l] = pts[l]
+            lv.scale[l] = sc[l].data_ptr() if sc else None
+        row0 = (ctypes.c_int64 * len(pts))(*[r0 for (r0, _) in meta.level_rows])
+        out = torch.empty((K, G), dtype=torch.float32, device=dev)
+        raw = torch.empty((K, G), dtype=torch.float32, device=dev)
+        rows = torch.empty((K,), dtype=torch.int32, device=dev)
+        c0 = torch.empty((K,), dtype=torch.int32, device=dev)
+        lvl = torch.empty((K,), dtype=torch.int32, device=dev)
+        L.call("nndet_conv_out_sparse_forward", ctypes.byref(desc), ctypes.byref(meta.items), ctypes.byref(lv), meta.batch, A, G, row0,
+               L.ptr(pos.contiguous()), K, L.ptr(t2d), L.ptr(w32), L.ptr(b32), L.ptr(out), L.ptr(raw), L.ptr(rows), L.ptr(c0), L.ptr(lvl),
+               L.stream())
+        ctx.desc, ctx.meta, ctx.G, ctx.n_scales, ctx.has_bias = desc, meta, G, len(sc), bias is not None
+        ctx.save_for_backward(t2d, weight, w32, raw, rows, c0, lvl, *sc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        desc, meta, G = ctx.desc, ctx.meta, ctx.G
+        t2d, weight, w32, raw, rows, c0, lvl = ctx.saved_tensors[:7]
+        sc = ctx.saved_tensors[7:]
+        dev = t2d.device
+        g = g.detach().float().contiguous()
+        ok = (lvl >= 0)
+        li = lvl.clamp(min=0).long()
+        dsc_out = ()
+        if ctx.n_scales:
+            scv = torch.cat([s_.reshape(1) for s_ in sc])
+            vals = (g * scv[li][:, None]).contiguous()
+            per = (g * raw).sum(1) * ok.float()                               # out = scale * raw  =>  d(scale_l) = sum g * raw over level l
+            dsc = torch.zeros((ctx.n_scales,), dtype=torch.float32, device=dev).index_add_(0, li, per)
+            dsc_out = tuple(dsc[l].reshape(()) for l in range(ctx.n_scales))
+        else:
+            vals = g
+        nw, cout = weight.numel(), desc.cout
+        gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
+        dw = gbuf[:nw].view(weight.shape)
+        dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
+        dx32 = torch.zeros((meta.rows, desc.cin_p), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(t2d)
+        L.call("nndet_conv_out_sparse_backward", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(rows), L.ptr(c0), L.ptr(vals),
+               int(rows.numel()), G, L.ptr(t2d), L.ptr(w32), L.ptr(dx32), L.ptr(dx), L.ptr(dw), L.ptr(dbias), L.stream())
+        return (dx, dw.to(weight.dtype), dbias, None, None) + dsc_out
+
+
 class _DetLossFn(torch.autograd.Function):
     """(reg, cls) losses of the sampled anchors and their gradients in one launch each way (csrc/boxes.hip: k_detloss,
     k_detloss_scatter; include/nndet_amd.h: nndet_detloss_f32). Arithmetic = _compute_loss_sync_free below (decode_single,
@@ -125,7 +209,9 @@ class _DetLossFn(torch.autograd.Function):
         g_d = torch.empty((P, 6), dtype=torch.float32, device=dev)
         g_l = torch.empty((P + Q, C), dtype=torch.float32, device=dev)
         lab, gt, an = labels.detach().float().contiguous(), matched_gt.detach().float().contiguous(), anchors.detach().float().contiguous()
-        L.call("nndet_detloss_f32", L.ptr(lg), L.ptr(dl), L.ptr(pos), P, L.ptr(neg), Q, L.ptr(counts), L.ptr(lab), L.ptr(gt), L.ptr(an),
+        ctx.compact = bool(cfg.get("compact", False))        # box_deltas = the [P, 6] rows of the sampled positives (_RegSparseFn)
+        L.call("nndet_detloss_compact_f32" if ctx.compact else "nndet_detloss_f32", L.ptr(lg), L.ptr(dl), L.ptr(pos), P, L.ptr(neg), Q,
+               L.ptr(counts), L.ptr(lab), L.ptr(gt), L.ptr(an),
                an.shape[0], C, float(cfg["eps"]), float(cfg["clip"]), float(cfg["reg_w"]), int(cfg["reg_mean"]), float(cfg["cls_w"]),
                int(cfg["cls_mean"]), L.ptr(losses), L.ptr(g_d), L.ptr(g_l), L.stream())
         ctx.save_for_backward(pos, neg, g_d, g_l)
@@ -138,6 +224,13 @@ class _DetLossFn(torch.autograd.Function):
         ls, lt, ds, dt = ctx.shapes
         up = g.detach().float().contiguous()
         d_logits = torch.zeros(ls, dtype=torch.float32, device=g.device)
+        if ctx.compact:                                      # compact deltas: their gradient is compact too (no dense scatter)
+            L.call("nndet_detloss_scatter_f32", L.ptr(pos), pos.shape[0], L.ptr(neg), neg.shape[0], g_l.shape[1], L.ptr(g_d), L.ptr(g_l),
+                   L.ptr(up), None, L.ptr(d_logits), L.stream())
+            d_logits = d_logits.to(lt)
+            if SPARSE_OUT and lt == torch.float32:
+                L.grad_hints.put(d_logits, {"idx": torch.cat([pos, neg]), "val": g_l * up[1], "G": int(g_l.shape[1])})
+            return d_logits, (g_d * up[0]).to(dt), None, None, None, None, None, None, None
         d_deltas = torch.zeros(ds, dtype=torch.float32, device=g.device)
         L.call("nndet_detloss_scatter_f32", L.ptr(pos), pos.shape[0], L.ptr(neg), neg.shape[0], g_l.shape[1], L.ptr(g_d), L.ptr(g_l),
                L.ptr(up), L.ptr(d_deltas), L.ptr(d_logits), L.stream())
@@ -283,18 +376,23 @@ class DetectionHeadHNMNative(nn.Module):
             if on_side:
                 side.wait_stream(main)
                 x2d.record_stream(side)
+            defer = (name == "reg" and SPARSE_REG and SPARSE_OUT and getattr(self, "_defer_reg_out", False) and torch.is_grad_enabled())
             with torch.cuda.stream(side if on_side else main):
                 t = x2d
                 for blk in head.conv_internal:
                     t = P.items_block(blk, t, meta)
-                t = P.items_block(head.conv_out, t, meta)
-                o = P.head_gather_items(t, meta, cout, scales)
+                if defer:                                    # training step: conv_out + Scale only at the sampled positives, later
+                    o = DeferredDeltas(t, meta, head, scales, cout, sdim)
+                else:
+                    t = P.items_block(head.conv_out, t, meta)
+                    o = P.head_gather_items(t, meta, cout, scales)
             if on_side:
-                o.record_stream(main)
+                (o.t2d if defer else o).record_stream(main)
             outs[name] = o
         if two_streams:
             main.wait_stream(side)
-        return {"box_deltas": outs["reg"].view(-1, sdim * 2), "box_logits": outs["cls"].view(-1, nc)}
+        deltas = outs["reg"] if isinstance(outs["reg"], DeferredDeltas) else outs["reg"].view(-1, sdim * 2)
+        return {"box_deltas": deltas, "box_logits": outs["cls"].view(-1, nc)}
 
     def _items_ok(self, fmaps: List[Tensor]) -> bool:
         if not (self.items_levels and self.gather_levels and fmaps[0].is_cuda and len(fmaps) <= L.HEAD_MAX_LEVELS
@@ -393,6 +491,8 @@ class DetectionHeadHNMNative(nn.Module):
         box_logits, box_deltas = prediction["box_logits"], prediction["box_deltas"]
         if box_logits.is_cuda and self._use_sync_free():
             return self._compute_loss_sync_free(box_logits, box_deltas, target_labels, matched_gt_boxes, anchors)
+        if isinstance(box_deltas, DeferredDeltas):
+            box_deltas = box_deltas.materialize()
         losses = {}
         sampled_pos_inds, sampled_neg_inds = self.select_indices(target_labels, box_logits)
         sampled_inds = torch.cat([sampled_pos_inds, sampled_neg_inds], dim=0)
@@ -419,15 +519,23 @@ class DetectionHeadHNMNative(nn.Module):
         labels = _cat_rows(target_labels)
         pos, neg, counts = self.fg_bg_sampler.sample_device(labels, box_logits, len(target_labels))
         from ..core.boxes.coder import BoxCoderND
-        if (self.fused_loss and type(self.coder) is BoxCoderND and box_logits.dim() == 2 and box_deltas.dim() == 2
-                and box_deltas.shape[1] == 6 and pos.numel() > 0):
+        deferred = box_deltas if isinstance(box_deltas, DeferredDeltas) else None
+        fusable = self.fused_loss and type(self.coder) is BoxCoderND and box_logits.dim() == 2 and pos.numel() > 0
+        if deferred is not None:
+            if fusable and deferred.sdim == 3:
+                conv = deferred.regressor.conv_out.conv
+                box_deltas = _RegSparseFn.apply(deferred.t2d, conv.weight, conv.bias, pos, deferred, *deferred.scales)
+            else:
+                box_deltas, deferred = deferred.materialize(), None
+        if (fusable and box_deltas.dim() == 2 and box_deltas.shape[1] == 6):
             # one launch for both losses and their gradients instead of ~250 element-wise ones (csrc/boxes.hip: k_detloss)
             same = all(a is anchors[0] for a in anchors)
             an = anchors[0] if same else torch.cat(anchors, dim=0)
             gt = _cat_rows(matched_gt_boxes)
             cfg = {"eps": self.regressor.eps, "clip": getattr(self.coder, "bbox_xform_clip", math.log(1000. / 16)),
                    "reg_w": self.regressor.loss_weight, "reg_mean": self.regressor.reduction == "mean",
-                   "cls_w": self.classifier.loss_weight, "cls_mean": self.classifier.reduction == "mean"}
+                   "cls_w": self.classifier.loss_weight, "cls_mean": self.classifier.reduction == "mean",
+                   "compact": deferred is not None}
             both = _DetLossFn.apply(box_logits, box_deltas, pos, neg, counts, labels, gt, an, cfg)
             return {"reg": both[0], "cls": both[1]}, pos, neg
         n_pos, n_neg = counts[0], counts[1]

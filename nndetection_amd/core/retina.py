@@ -144,6 +144,7 @@ class BaseRetinaNet(nn.Module):
             target_seg = lazy.target_seg
         # the segmentation logits are only materialised when a prediction is asked for (evaluation); else conv + loss are fused
         self._fuse_seg_head = (not evaluation) and torch.is_grad_enabled()
+        self.head._defer_reg_out = self._fuse_seg_head     # no prediction asked for: box_deltas only at the sampled positives (arch/heads.py)
         overlap = self.overlap_aux and images.is_cuda
         pre, main, cached = None, None, None
         if overlap:
@@ -162,6 +163,7 @@ class BaseRetinaNet(nn.Module):
             return self._train_step_body(images, lazy, target_boxes, target_classes, target_seg, evaluation, overlap, pre, main, cached)
         finally:                                          # never leave the fork state behind for a later forward() / inference_step()
             self._fuse_seg_head = False
+            self.head._defer_reg_out = False
             self._seg_side = None
 
     def _train_step_body(self, images, lazy, target_boxes, target_classes, target_seg, evaluation, overlap, pre, main, cached):

@@ -306,6 +306,7 @@ struct DetLossArgs {
     const float* labels; const float* gt; const float* anchors;
     int64_t m_anchors;
     int32_t P, Q, C, reg_mean, cls_mean;
+    int32_t compact;        // deltas are [P][6] rows in the order of pos (nndet_detloss_compact_f32) instead of [B * M][6]
     float eps, clip, reg_w, cls_w;
     float* losses; float* g_deltas; float* g_logits;
 };
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void k_detloss(const DetLossArgs A) {
         const int64_t idx = A.pos[r];
         float gd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (idx >= 0) {
-            const float* d = A.deltas + idx * 6;
+            const float* d = A.deltas + (A.compact ? (int64_t)r : idx) * 6;
             const float* b = A.anchors + (idx % A.m_anchors) * 6;
             // coder.py:107-151 with weights == 1 (the expression order of k_decode_clip)
             const float w = b[2] - b[0], h = b[3] - b[1], dd_ = b[5] - b[4];
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void k_detloss_scatter(const int64_t* __restri
     for (int r = threadIdx.x; r < P + Q; r += 256) {
         const int64_t idx = r < P ? pos[r] : neg[r - P];
         if (idx < 0) continue;
-        if (r < P) {
+        if (r < P && d_deltas) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) d_deltas[idx * 6 + k] = u_reg * g_deltas[r * 6 + k];
         }
@@ -400,7 +401,25 @@ extern "C" int nndet_detloss_f32(const float* logits, const float* deltas, const
     DetLossArgs a;
     a.logits = logits; a.deltas = deltas; a.pos = pos; a.neg = neg; a.counts = counts; a.labels = labels; a.gt = matched_gt;
     a.anchors = anchors; a.m_anchors = m_anchors; a.P = pos_cap; a.Q = neg_cap; a.C = C; a.reg_mean = reg_mean; a.cls_mean = cls_mean;
-    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight;
+    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight; a.compact = 0;
+    a.losses = losses_out; a.g_deltas = g_deltas_out; a.g_logits = g_logits_out;
+    k_detloss<<<1, 256, 0, as_stream(stream)>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nndet_detloss_compact_f32(const float* logits, const float* deltas_compact, const int64_t* pos, int32_t pos_cap,
+                                         const int64_t* neg, int32_t neg_cap, const int64_t* counts, const float* labels,
+                                         const float* matched_gt, const float* anchors, int64_t m_anchors, int32_t C, float eps,
+                                         float clip, float reg_weight, int32_t reg_mean, float cls_weight, int32_t cls_mean,
+                                         float* losses_out, float* g_deltas_out, float* g_logits_out, void* stream) {
+    if (!logits || !deltas_compact || !pos || !neg || !counts || !labels || !matched_gt || !anchors || !losses_out || !g_deltas_out || !g_logits_out)
+        return NNDET_EINVAL;
+    if (pos_cap < 1 || neg_cap < 0 || C < 1 || m_anchors < 1) return NNDET_EINVAL;
+    DetLossArgs a;
+    a.logits = logits; a.deltas = deltas_compact; a.pos = pos; a.neg = neg; a.counts = counts; a.labels = labels; a.gt = matched_gt;
+    a.anchors = anchors; a.m_anchors = m_anchors; a.P = pos_cap; a.Q = neg_cap; a.C = C; a.reg_mean = reg_mean; a.cls_mean = cls_mean;
+    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight; a.compact = 1;
     a.losses = losses_out; a.g_deltas = g_deltas_out; a.g_logits = g_logits_out;
     k_detloss<<<1, 256, 0, as_stream(stream)>>>(a);
     LAUNCH_CHECK();
@@ -410,7 +429,7 @@ extern "C" int nndet_detloss_f32(const float* logits, const float* deltas, const
 extern "C" int nndet_detloss_scatter_f32(const int64_t* pos, int32_t pos_cap, const int64_t* neg, int32_t neg_cap, int32_t C,
                                          const float* g_deltas, const float* g_logits, const float* upstream, float* d_deltas,
                                          float* d_logits, void* stream) {
-    if (!pos || !neg || !g_deltas || !g_logits || !upstream || !d_deltas || !d_logits || pos_cap < 1 || neg_cap < 0 || C < 1) return NNDET_EINVAL;
+    if (!pos || !neg || !g_deltas || !g_logits || !upstream || !d_logits || pos_cap < 1 || neg_cap < 0 || C < 1) return NNDET_EINVAL;   // d_deltas may be NULL (compact deltas)
     k_detloss_scatter<<<1, 256, 0, as_stream(stream)>>>(pos, pos_cap, neg, neg_cap, C, g_deltas, g_logits, upstream, d_deltas, d_logits);
     LAUNCH_CHECK();
     return 0;

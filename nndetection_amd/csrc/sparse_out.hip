@@ -30,6 +30,8 @@ struct HoLevels {
     float* dscale[HO_MAX_LEVELS];
 };
 
+struct HoItems { int32_t n; int32_t dims[NNDET_MAX_ITEMS][3]; int64_t row_off[NNDET_MAX_ITEMS]; };
+
 // grid ceil(K / 64), block 64: one thread per entry
 template <typename T>
 __global__ void k_ho_scatter(const int64_t* __restrict__ idx, const float* __restrict__ val, int K, const HoLevels Lv,
@@ -61,8 +63,6 @@ __global__ void k_ho_scatter(const int64_t* __restrict__ idx, const float* __res
     rows[k] = (int32_t)row;
     c0s[k] = c0;
 }
-
-struct HoItems { int32_t n; int32_t dims[NNDET_MAX_ITEMS][3]; int64_t row_off[NNDET_MAX_ITEMS]; };
 
 // grid K, block 128 (thread = input channel, looped)
 template <typename T>
@@ -110,6 +110,113 @@ __global__ void k_ho_convert(const float* __restrict__ src, T* __restrict__ dst,
         dst[4 * i + 0] = Elem<T>::st(f.x); dst[4 * i + 1] = Elem<T>::st(f.y);
         dst[4 * i + 2] = Elem<T>::st(f.z); dst[4 * i + 3] = Elem<T>::st(f.w);
     }
+}
+
+// Forward of an output convolution at K sampled anchors only (training: the regression loss reads the box deltas of the <= 42 sampled
+// positives and nothing else, nndet/arch/heads/comb.py:383-401): out[k][g] = scale_l * (sum_{t, ci} W[c0+g][ci][t] x[row + t - 1][ci] +
+// b[c0+g]). One workgroup per entry, thread = input channel, LDS reduction. Also emits (row, c0) and the UNSCALED values (for d(Scale)).
+template <typename T>
+__global__ __launch_bounds__(128) void k_ho_forward(const int64_t* __restrict__ idx, int K, const HoLevels Lv, const HoItems It,
+                                                    const T* __restrict__ x, int cin, int cin_p, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int cout, float* __restrict__ out,
+                                                    float* __restrict__ raw, int32_t* __restrict__ rows, int32_t* __restrict__ c0s, int32_t* __restrict__ lvls) {
+    __shared__ float red[2][8];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int64_t i = idx[k];
+    const int G = Lv.G;
+    if (i < 0 || i >= Lv.anchors_per_image * Lv.N) {                         // unused slot (uniform)
+        if (tid < G) { out[(int64_t)k * G + tid] = 0.f; raw[(int64_t)k * G + tid] = 0.f; }
+        if (tid == 0) { rows[k] = -1; c0s[k] = 0; lvls[k] = -1; }
+        return;
+    }
+    const int n = (int)(i / Lv.anchors_per_image);
+    const int64_t j = i - (int64_t)n * Lv.anchors_per_image;
+    int l = 0;
+    while (l + 1 < Lv.nlev && j >= Lv.anchor_off[l + 1]) ++l;
+    const int64_t jl = j - Lv.anchor_off[l];
+    const int64_t pos = jl / Lv.A;
+    const int a = (int)(jl - pos * Lv.A);
+    const int64_t row = Lv.row0[l] + (int64_t)n * Lv.points[l] + pos;
+    const int c0 = a * G;
+    int it = 0;
+    while (it + 1 < It.n && row >= It.row_off[it + 1]) ++it;
+    const int D = It.dims[it][0], H = It.dims[it][1], W = It.dims[it][2];
+    const int p = (int)(row - It.row_off[it]);
+    const int pd = p / (H * W), ph = (p / W) % H, pw = p % W;
+    float acc[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[g] = 0.f;
+    for (int t = 0; t < 27; ++t) {
+        const int qd = pd + t / 9 - 1, qh = ph + (t / 3) % 3 - 1, qw = pw + t % 3 - 1;
+        if ((unsigned)qd >= (unsigned)D || (unsigned)qh >= (unsigned)H || (unsigned)qw >= (unsigned)W) continue;
+        const int64_t qrow = It.row_off[it] + ((int64_t)qd * H + qh) * W + qw;
+        for (int ci = tid; ci < cin; ci += blockDim.x) {
+            const float xv = Elem<T>::ld(x[qrow * cin_p + ci]);
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (g < G && c0 + g < cout) acc[g] = fmaf(w[((int64_t)(c0 + g) * cin + ci) * 27 + t], xv, acc[g]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float s = wave_sum_f32(acc[g]);
+        if ((tid & 63) == 0) red[tid >> 6][g] = s;
+    }
+    __syncthreads();
+    if (tid < G) {
+        float v = red[0][tid] + red[1][tid];
+        if (bias && c0 + tid < cout) v += bias[c0 + tid];
+        raw[(int64_t)k * G + tid] = v;
+        out[(int64_t)k * G + tid] = Lv.scale[l] ? v * *Lv.scale[l] : v;
+    }
+    if (tid == 0) { rows[k] = (int32_t)row; c0s[k] = c0; lvls[k] = l; }
+}
+
+static int ho_fill(const NndetHeadLevels* levels, int32_t N, int32_t A, int32_t G, const int64_t* level_row0_host, HoLevels* Lv) {
+    if (!levels || levels->nlev <= 0 || levels->nlev > HO_MAX_LEVELS || N <= 0 || A <= 0 || G <= 0 || G > 8 || !level_row0_host) return NNDET_EINVAL;
+    memset(Lv, 0, sizeof(*Lv));
+    Lv->nlev = levels->nlev; Lv->A = A; Lv->G = G; Lv->N = N;
+    int64_t off = 0;
+    for (int l = 0; l < levels->nlev; ++l) {
+        Lv->anchor_off[l] = off; Lv->points[l] = levels->points[l]; Lv->row0[l] = level_row0_host[l];
+        Lv->scale[l] = reinterpret_cast<const float*>(levels->scale[l]); Lv->dscale[l] = reinterpret_cast<float*>(levels->dscale[l]);
+        off += levels->points[l] * A;
+    }
+    Lv->anchor_off[levels->nlev] = off;
+    Lv->anchors_per_image = off;
+    return 0;
+}
+
+static void ho_items(const NndetItems* items, HoItems* It) {
+    memset(It, 0, sizeof(*It));
+    It->n = items->n_items;
+    for (int i = 0; i < items->n_items; ++i) {
+        for (int a = 0; a < 3; ++a) It->dims[i][a] = items->dims[i][a];
+        It->row_off[i] = items->row_off[i];
+    }
+}
+
+extern "C" int nndet_conv_out_sparse_forward(const NndetConv* c, const NndetItems* items, const NndetHeadLevels* levels, int32_t N,
+                                             int32_t A, int32_t G, const int64_t* level_row0_host, const int64_t* idx, int32_t K,
+                                             const void* x, const float* w_f32, const float* bias, float* out, float* raw_out,
+                                             int32_t* rows_out, int32_t* c0_out, int32_t* level_out, void* stream) {
+    if (!c || !items || items->n_items < 1 || items->n_items > NNDET_MAX_ITEMS || K < 0) return NNDET_EINVAL;
+    if (c->transposed || c->cin_p % 32 || c->cout_p % 32 || A * G > c->cout_p) return NNDET_EINVAL;
+    for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 1 || c->p[i] != 1) return NNDET_EINVAL;
+    HoLevels Lv;
+    int rc = ho_fill(levels, N, A, G, level_row0_host, &Lv);
+    if (rc) return rc;
+    if (K == 0) return 0;
+    if (!idx || !x || !w_f32 || !out || !raw_out || !rows_out || !c0_out || !level_out) return NNDET_EINVAL;
+    HoItems It;
+    ho_items(items, &It);
+    hipStream_t st = as_stream(stream);
+    if (c->dtype == NNDET_BF16) k_ho_forward<bf16_t><<<K, 128, 0, st>>>(idx, K, Lv, It, (const bf16_t*)x, c->cin, c->cin_p, w_f32, bias, c->cout, out, raw_out, rows_out, c0_out, level_out);
+    else if (c->dtype == NNDET_F16) k_ho_forward<f16_t><<<K, 128, 0, st>>>(idx, K, Lv, It, (const f16_t*)x, c->cin, c->cin_p, w_f32, bias, c->cout, out, raw_out, rows_out, c0_out, level_out);
+    else if (c->dtype == NNDET_F32) k_ho_forward<float><<<K, 128, 0, st>>>(idx, K, Lv, It, (const float*)x, c->cin, c->cin_p, w_f32, bias, c->cout, out, raw_out, rows_out, c0_out, level_out);
+    else return NNDET_EINVAL;
+    LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int nndet_head_out_sparse_scatter(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t A, int32_t G,
