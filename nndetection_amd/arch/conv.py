@@ -100,9 +100,12 @@ def prepack(mod, x: torch.Tensor, modes=(0, 1)) -> None:
     _padded_bias(mod, mod.conv.bias, cpad(mod.out_channels))
 
 
-def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1)) -> int:
+def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1), force: bool = False) -> int:
     """Refresh the packed-weight cache of EVERY conv block of `model` whose parameter changed (i.e. after an optimizer step) with
-    one batched launch (nndet_pack_weights_batched) instead of one launch per layer and mode. Returns the number of jobs."""
+    one batched launch (nndet_pack_weights_batched) instead of one launch per layer and mode. Returns the number of jobs.
+    `force`: re-pack everything regardless of the cached version -- a training-mode forward pass does this, because FUSED optimizer
+    kernels (torch._fused_sgd_ / _fused_adam_, i.e. torch.optim.*(fused=True)) write the parameters without advancing `_version`
+    (nndetection_amd.optim advances it by hand; a foreign optimizer may not)."""
     jobs = []
     for mod in model.modules():
         if not isinstance(mod, BaseConvNormAct) or mod.in_channels == 1:
@@ -110,11 +113,13 @@ def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1)) -> int:
         w = mod.conv.weight
         if not w.is_cuda:
             return 0
+        if force:
+            mod._pack_cache.pop(("bias", cpad(mod.out_channels)), None)
         _padded_bias(mod, mod.conv.bias, cpad(mod.out_channels))
         ver = (w._version, w.data_ptr())
         for mode in modes:
             hit = mod._pack_cache.get((mode, dtype))
-            if hit is not None and hit[0] == ver:
+            if hit is not None and hit[0] == ver and not force:
                 continue
             d = L.NndetConv()
             d.dtype = L._DT[dtype]

@@ -12,6 +12,11 @@ from .. import _lib as L
 from . import boxes as box_utils
 
 
+# NNDET_REPACK_EVERY_STEP=0: trust the parameters' version counters alone (valid with optimizers that advance them: torch's foreach /
+# single-tensor ones and nndetection_amd.optim.SGDNesterov), saves the re-pack launch of steps that follow no optimizer step.
+REPACK_EVERY_STEP = os.environ.get("NNDET_REPACK_EVERY_STEP", "1") != "0"
+
+
 class BaseRetinaNet(nn.Module):
     def __init__(self, dim: int, encoder, decoder, head, num_classes: int, anchor_generator, matcher,
                  decoder_levels: tuple = (2, 3, 4, 5), score_thresh: float = None, detections_per_img: int = 100,
@@ -42,6 +47,15 @@ class BaseRetinaNet(nn.Module):
                     list(getattr(self.encoder, "out_stages", [])) == list(range(self.decoder.num_level)):
                 self.encoder.stage_hook = self.decoder.early_lateral      # laterals start under the deeper encoder stages
 
+    def train(self, mode: bool = True):
+        """Switching between training and evaluation drops every packed-weight cache: the parameters may have been written since by a
+        kernel that does not advance their version counters (fused optimizers, see arch/conv.py: prepack_all)."""
+        if mode != self.training:
+            for m in self.modules():
+                if hasattr(m, "_pack_cache"):
+                    m._pack_cache.clear()
+        return super().train(mode)
+
     def never_used_parameters(self) -> List[nn.Parameter]:
         """Parameters that exist for state-dict parity with the reference but never receive a gradient: the decoder output convs
         of pyramid levels that neither the detection head nor the segmenter reads (`decoder.out.P1.*` for RetinaUNetV001)."""
@@ -62,8 +76,10 @@ class BaseRetinaNet(nn.Module):
         if inp.is_cuda:
             from ..arch.conv import prepack_all
             grad = torch.is_grad_enabled()
+            # all packed weights in one launch. In training mode they are re-packed unconditionally: an optimizer stepped since, and
+            # fused optimizer kernels do not advance the parameters' version counters (arch/conv.py: prepack_all)
             prepack_all(self, inp.dtype if inp.dtype in L._DT else torch.float32,
-                        modes=(0, 1) if grad else (0,))        # all stale packed weights in one launch (after an optimizer step)
+                        modes=(0, 1) if grad else (0,), force=self.training and REPACK_EVERY_STEP)
             if grad:                                           # one zero fill for every parameter-gradient accumulator of the step
                 if getattr(self, "_grad_numel", None) is None:
                     self._grad_numel = sum(p.numel() + 64 for p in self.parameters() if p.requires_grad)

@@ -12,6 +12,17 @@ from typing import List
 import torch
 
 
+def _bump_versions(tensors) -> None:
+    """`torch._fused_sgd_` writes the parameters WITHOUT incrementing their autograd version counters (measured on torch 2.10, CPU and
+    ROCm; the `_foreach_*` ops do increment them). Everything that caches something derived from a parameter keys it on `_version` --
+    here the packed / cast convolution weights (arch/conv.py: _packed) -- so the counters are advanced by hand after the launch."""
+    setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+    if setter is not None:
+        setter(tuple(tensors), tuple(t._version + 1 for t in tensors))
+    else:                                                      # older torch: an in-place no-op that does bump
+        torch._foreach_add_(list(tensors), 0.0)
+
+
 class SGDNesterov:
     def __init__(self, param_groups: List[dict], lr: float, momentum: float = 0.9, nesterov: bool = True):
         self.param_groups = []
@@ -53,6 +64,7 @@ class SGDNesterov:
                     torch._fused_sgd_([p for p, _ in sel], [gr.contiguous() for _, gr in sel], [self._buf[p] for p, _ in sel],
                                       weight_decay=wd, momentum=mu, lr=lr, dampening=0.0, nesterov=self.nesterov, maximize=False,
                                       is_first_step=first, grad_scale=grad_scale, found_inf=found_inf)
+                _bump_versions(ps)
                 continue
             if found_inf is not None and bool(found_inf.item()):      # foreach fallback (CPU / NNDET_FUSED_SGD=0): host decision
                 return

@@ -312,3 +312,23 @@ def test_pyramid_meta_item_table():
     assert list(m.items.dims[0]) == [40, 40, 24] and list(m.items.dims[5]) == [20, 20, 12] and list(m.items.dims[15]) == [5, 5, 6]
     assert m.items.row_off[0] == 0 and m.items.row_off[4] == 153600 and m.items.row_off[5] == 153600 + 4800 and m.items.row_off[15] == 175200 + 450
     assert ctypes.sizeof(L.NndetItems) == 8 + L.MAX_ITEMS * 12 + L.MAX_ITEMS * 8 and L.MAX_ITEMS == 32
+
+
+def test_fused_sgd_version_counters_are_advanced_by_hand():
+    """torch._fused_sgd_ writes parameters without incrementing `_version` (the packed convolution weights are cached per version):
+    nndetection_amd.optim advances the counters itself. Pins both facts -- if torch starts bumping, the helper just bumps once more."""
+    from nndetection_amd.optim import _bump_versions
+    ps = [torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(2, 3))]
+    before = [p._version for p in ps]
+    _bump_versions(ps)
+    assert [p._version for p in ps] == [v + 1 for v in before]
+    assert all(bool((p == 1).all()) for p in ps)                      # values untouched
+    if hasattr(torch, "_fused_sgd_"):
+        p, g, b = torch.ones(4), torch.ones(4), torch.empty(4)
+        v = p._version
+        try:
+            torch._fused_sgd_([p], [g], [b], weight_decay=0.0, momentum=0.9, lr=0.1, dampening=0.0, nesterov=True, maximize=False,
+                              is_first_step=True, grad_scale=None, found_inf=None)
+        except (RuntimeError, NotImplementedError):
+            return                                                        # no CPU kernel in this build
+        assert float(p[0]) != 1.0 and p._version in (v, v + 1)

@@ -206,6 +206,74 @@ def test_head_gather_matches_per_level_flatten(golden_dir, dtype):
         assert float((g1[n] - g0[n]).abs().max()) <= tol * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
 
 
+def test_optimizer_steps_track_the_oracle(golden_dir, monkeypatch):
+    """TRAINING parity, not single-step parity: SGD(nesterov) steps on the golden batch. Reference arithmetic = the torch oracle driven
+    by torch.optim.SGD (what the reference configures, nndet/ptmodule/retinaunet/base.py:300-336); here = the HIP model driven by
+    nndetection_amd.optim.SGDNesterov (torch._fused_sgd_). The losses of steps 0..2 agree to 2e-4 (measured 1e-7 .. 3e-6; from step 3
+    on a flipped hard-negative pick makes the two runs drift apart like any two fp32 runs) and the weights after 3 steps to 1e-4
+    relative -- which they only do if every kernel sees the UPDATED parameters: the convolutions read packed copies cached per
+    parameter version, and fused optimizer kernels do not advance the version counters (round 3: stale copies had gone unnoticed by
+    the single-step parity tests; with stale copies step 1 already deviates by 9 %)."""
+    from nndetection_amd.optim import SGDNesterov
+    from nndetection_amd.ptmodule import get_params_no_wd_on_norm
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    x = torch.from_numpy(gn["x"])
+    lr = 0.02
+    opt_o = torch.optim.SGD(get_params_no_wd_on_norm(ora, 3e-5), lr, momentum=0.9, nesterov=True)
+    opt_h = SGDNesterov(get_params_no_wd_on_norm(net, 3e-5), lr, momentum=0.9, nesterov=True)
+    w0 = {n: p.detach().clone() for n, p in ora.named_parameters()}
+    devs = []
+    for it in range(3):
+        lo, _ = ora.train_step(x, tg, evaluation=False)
+        opt_o.zero_grad(); sum(lo.values()).backward(); opt_o.step()
+        lh, _ = net.train_step(x.cuda(), _cuda_targets(tg), evaluation=False)
+        opt_h.zero_grad(); sum(lh.values()).backward()
+        v_before = {n: p._version for n, p in net.named_parameters() if p.grad is not None}
+        opt_h.step()
+        assert all(p._version > v_before[n] for n, p in net.named_parameters() if n in v_before), "parameter versions must advance"
+        devs.append(max(abs(float(lh[k].detach()) - float(lo[k].detach())) / max(1.0, abs(float(lo[k].detach()))) for k in lo))
+    assert max(devs) <= 2e-4, devs
+    moved, worst = 0, (0.0, "")
+    for n, p in net.named_parameters():
+        ref = dict(ora.named_parameters())[n].detach()
+        step = float((ref - w0[n]).abs().max())             # how far the oracle moved this parameter in 3 steps
+        moved += step > 1e-5
+        if step > 0:                                        # deviation relative to the distance travelled
+            worst = max(worst, (float((p.detach().cpu() - ref).abs().max()) / step, n))
+    print("largest weight deviation / distance travelled:", worst)
+    assert worst[0] <= 2e-2, worst
+    assert moved > 40                                     # the comparison is not vacuous: the parameters did change
+
+    # A foreign FUSED optimizer (torch.optim.SGD(fused=True): what ptmodule.amd_fuse_sgd switches the reference's optimizer to) does
+    # not advance the counters at all: a training-mode forward pass re-packs unconditionally, train() <-> eval() drops the caches.
+    # Reference = a FRESH model (empty caches) loaded with the trained weights.
+    def fresh():
+        m = _hip_model(plan, ora)
+        m.load_state_dict(net.state_dict())
+        return m
+
+    opt_f = torch.optim.SGD(get_params_no_wd_on_norm(net, 3e-5), lr, momentum=0.9, nesterov=True, fused=True)
+    for it in range(2):
+        lh, _ = net.train_step(x.cuda(), _cuda_targets(tg), evaluation=False)
+        opt_f.zero_grad(); sum(lh.values()).backward(); opt_f.step()
+    l2, _ = net.train_step(x.cuda(), _cuda_targets(tg), evaluation=False)
+    l3, _ = fresh().train_step(x.cuda(), _cuda_targets(tg), evaluation=False)
+    for k in l3:
+        assert abs(float(l2[k].detach()) - float(l3[k].detach())) <= 1e-5 * max(1.0, abs(float(l3[k].detach()))), (k, float(l2[k]), float(l3[k]))
+    net.eval()
+    m = fresh().eval()
+    with torch.no_grad():
+        p1, p2 = net.inference_step(x.cuda()), m.inference_step(x.cuda())
+    assert len(p1["pred_boxes"]) == len(p2["pred_boxes"])
+    for a_, b_ in zip(p1["pred_boxes"], p2["pred_boxes"]):
+        assert a_.shape == b_.shape and float((a_ - b_).abs().max()) <= 1e-4 if a_.numel() else True
+    for a_, b_ in zip(p1["pred_scores"], p2["pred_scores"]):
+        assert float((a_ - b_).abs().max()) <= 1e-5 if a_.numel() else True
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_sparse_backward_of_the_head_output_convolutions(golden_dir, dtype, monkeypatch):
     """csrc/sparse_out.hip: the gradient w.r.t. box_logits / box_deltas is zero except at the <= 170 sampled anchors; with the hints of
@@ -218,8 +286,11 @@ def test_sparse_backward_of_the_head_output_convolutions(golden_dir, dtype, monk
     ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
     net = _hip_model(plan, ora)
     with torch.no_grad():
+        # (0.9, not 1.0, on level 0: with scale 1 one sampled positive of the golden batch decodes to z2 = 13.48468 against a ground
+        # truth z2 of 13.48468 -- a tie in GIoU's min / max, where rounding the deltas to fp16 (dense route) or not (sparse forward)
+        # legitimately picks the other branch of the gradient)
         for i, sc in enumerate(net.head.regressor.scales):
-            sc.scale.fill_(1.0 + 0.25 * i)
+            sc.scale.fill_(0.9 + 0.25 * i)
     x = torch.from_numpy(gn["x"]).cuda().to(dtype)
     monkeypatch.setattr(torch, "randperm", det_randperm)
     calls = {"n": 0}
