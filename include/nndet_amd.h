@@ -389,6 +389,24 @@ int nndet_seghead_backward(int32_t dtype, const void* x, int32_t c_p, int32_t ci
  * one-channel weight gradient of (d1, conv input) (nndet_conv3d_backward_weight with cin_p == 1): nndetection_amd/arch/conv.py. */
 int nndet_seghead_backward_rank1(int32_t dtype, const void* x, int32_t c_p, int32_t cin, const float* w, const float* bias,
                                  const uint8_t* target, int64_t nvox, const float* coeffs, void* d1_out, double* dwb_out, void* stream);
+/* The whole segmentation branch of a TRAINING step -- decoder.out.P0 (Conv3d 3x3x3 C -> C + bias, no norm / activation:
+ * nndet/arch/decoder/base.py:243-270) followed by DiCESegmenterFgBg's 1x1x1 output conv and loss (nndet/arch/heads/segmenter.py:
+ * 184-206,273-289) -- as ONE convolution with a single output channel. Both layers are linear and, when no prediction is asked
+ * for, nothing but the loss reads their outputs; the fg / bg loss depends on z = logit_1 - logit_0 only, so
+ *     z[p] = c0 + sum_{t, cin} wc[t][cin] x[p + t - 1][cin],  wc[t][cin] = sum_c (w_head[1] - w_head[0])[c] W_out[c][cin][t],
+ *     c0 = (w_head[1] - w_head[0]) . b_out + (b_head[1] - b_head[0]).
+ * forward:  x [N, D, H, W, 32] (dtype: NNDET_BF16 / NNDET_F16; NNDET_F32 -> NNDET_EINVAL, the fp32 path keeps the two layers),
+ *           w_packed [27][32] values of dtype (tap t = (kd * 3 + kh) * 3 + kw, i.e. 16 dwords per tap), c0 (device scalar), target
+ *           uint8 [N, D, H, W] -> z_out fp32 [N, D, H, W] and sums_out fp64 [nndet_segbranch_replicas()][4] (zeroed by the caller;
+ *           the row sum is {sum CE, tp, fp, fn} as produced by nndet_seghead_forward).
+ * backward: d1_out [N * D * H * W] (dtype) = dL/dz from z, target and coeffs [4] = dL/d{sum CE, tp, fp, fn}; dsum_out fp64
+ *           [replicas] (zeroed) accumulates sum(d1). The gradients of x, W_out, b_out, w_head, b_head follow from d1 as for
+ *           nndet_seghead_backward_rank1 (nndetection_amd/arch/segmenter.py: _SegBranchFn). */
+int nndet_segbranch_replicas(void);
+int nndet_segbranch_forward(int32_t dtype, const void* x, int32_t N, int32_t D, int32_t H, int32_t W, int32_t c_p, const void* w_packed,
+                            const float* c0, const uint8_t* target, float* z_out, double* sums_out, void* stream);
+int nndet_segbranch_backward(int32_t dtype, const float* z, const uint8_t* target, int64_t nvox, const float* coeffs, void* d1_out,
+                             double* dsum_out, void* stream);
 /* Scalar tail of the loss: sums [4] fp32 (what the forward entry points above produce, cast to fp32) ->
  * losses_out [2] = {alpha * CE_sum / nvox, (1 - alpha) * (1 - (2 tp + smooth_nom) / (2 tp + fp + fn + smooth_denom))} and
  * coeffs_out [2, 4] = d losses / d sums, in one launch instead of ~45 one-element torch launches (forward + autograd). */

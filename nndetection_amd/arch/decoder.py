@@ -149,12 +149,23 @@ class UFPNModular(nn.Module):
             xs[1].record_stream(side)
             with torch.cuda.stream(side):
                 xs[0] = self.up["P1"](xs[1], residual=fpn[0])
-                outs[0] = self.out["P0"](xs[0])
+                outs[0] = self._out0(xs[0])
                 self.tail_event = torch.cuda.Event()
                 self.tail_event.record(side)
         for level in range(1 if split else 0, self.num_level):
             if self.skip_unused_out and self.used_levels is not None and level not in self.used_levels:
                 outs[level] = None
             else:
-                outs[level] = self.out[f"P{level}"](xs[level])
+                outs[level] = self._out0(xs[0]) if level == 0 else self.out[f"P{level}"](xs[level])
         return outs
+
+    # Set by the detector for ONE forward pass (core/retina.py): a training step without prediction whose segmentation branch
+    # computes decoder.out.P0 + output conv + loss as one composed 32 -> 1 convolution (arch/segmenter.py: _SegBranchFn) gets the
+    # level-0 map BEFORE the output convolution, tagged with that module; nothing else reads level 0.
+    defer_out0 = False
+
+    def _out0(self, x0: torch.Tensor) -> torch.Tensor:
+        if self.defer_out0:
+            x0._nndet_pre_out = self.out["P0"][0]
+            return x0
+        return self.out["P0"](x0)

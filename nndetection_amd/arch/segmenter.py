@@ -88,6 +88,64 @@ class _SegHeadFused(torch.autograd.Function):
         return logical(dx, cin), dw, db, None
 
 
+# decoder.out.P0 + the output conv + the loss as ONE 32 -> 1 convolution (csrc/segbranch.hip): the decoder hands its level-0 map
+# on BEFORE the output convolution (tagged with that module, arch/decoder.py), `_SegBranchFn` does the rest. NNDET_SEG_BRANCH=0: the
+# output convolution runs in the decoder and the head + loss as `_SegHeadFused`.
+SEG_BRANCH = os.environ.get("NNDET_SEG_BRANCH", "1") != "0"
+
+
+class _SegBranchFn(torch.autograd.Function):
+    """x = the decoder's level-0 map BEFORE decoder.out.P0 [N, 32, D, H, W] (16-bit), w_out [32, 32, 3, 3, 3] / b_out of that
+    convolution, w_head [2, 32, 1, 1, 1] / b_head of the segmenter's output conv, target uint8 -> fp32 [4] = (sum CE, tp, fp, fn).
+    Forward: z = l1 - l0 per voxel by one composed 32 -> 1 convolution; backward: d1 = dL/dz, everything else from d1
+    (arch/conv.py: rank1_branch_backward). Neither the 32-channel output of decoder.out.P0 nor the logits ever exist."""
+
+    @staticmethod
+    def forward(ctx, x, w_out, b_out, w_head, b_head, target_u8):
+        xp, cin = phys(x)
+        dev, dt = xp.device, xp.dtype
+        N, D, H, W, cp = xp.shape
+        cout = w_out.shape[0]
+        if cp != 32 or cin != 32 or tuple(w_out.shape[1:]) != (32, 3, 3, 3) or tuple(w_head.shape[:2]) != (2, cout) or dt == torch.float32:
+            raise L.NndetError("fused segmentation branch: 32 channels in 16 bits, a 3x3x3 output conv and the 2-class head")
+        wh = w_head.detach().reshape(2, cout).float()
+        wd = (wh[1] - wh[0]).contiguous()                                              # [cout]
+        wc = torch.einsum("c,cidhw->dhwi", wd, w_out.detach().float()).reshape(27, cin)   # composed kernel, tap-major
+        wq = wc.to(dt).contiguous()
+        c0 = torch.zeros((), dtype=torch.float32, device=dev)
+        if b_out is not None:
+            c0 = c0 + (wd * b_out.detach().float()).sum()
+        if b_head is not None:
+            c0 = c0 + (b_head.detach()[1] - b_head.detach()[0]).float()
+        c0 = c0.reshape(1).contiguous()
+        z = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
+        R = int(L.load().nndet_segbranch_replicas())
+        sums = torch.zeros((R, 4), dtype=torch.float64, device=dev)
+        L.call("nndet_segbranch_forward", L.dtype_code(xp), L.ptr(xp), N, D, H, W, cp, L.ptr(wq), L.ptr(c0), L.ptr(target_u8), L.ptr(z),
+               L.ptr(sums), L.stream())
+        ctx.save_for_backward(xp, w_out, b_out if b_out is not None else wd, w_head, target_u8, z, wd)
+        ctx.has_b_out, ctx.has_b_head, ctx.R, ctx.cin = b_out is not None, b_head is not None, R, cin
+        return sums.sum(0).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, w_out, b_out, w_head, tgt, z, wd = ctx.saved_tensors
+        dev = xp.device
+        nvox = z.numel()
+        coeffs = g.detach().float().contiguous()
+        d1 = torch.empty(xp.shape[:4] + (1,), dtype=xp.dtype, device=dev)
+        dsum = torch.zeros((ctx.R,), dtype=torch.float64, device=dev)
+        L.call("nndet_segbranch_backward", L.dtype_code(xp), L.ptr(z), L.ptr(tgt), nvox, L.ptr(coeffs), L.ptr(d1), L.ptr(dsum), L.stream())
+        sum_d1 = dsum.sum().float()
+        from .conv import rank1_branch_backward
+        dx_p, dw_out, db_out, gy, side = rank1_branch_backward(xp, ctx.cin, w_out, b_out if ctx.has_b_out else None, w_head, wd, d1,
+                                                               sum_d1, ctx.needs_input_grad[0])
+        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(dev)):
+            dw_head = torch.stack([-gy, gy]).view(w_head.shape).to(w_head.dtype)
+        db_head = torch.stack([-sum_d1, sum_d1]) if ctx.has_b_head else None
+        return (logical(dx_p, ctx.cin) if dx_p is not None else None), dw_out.to(w_out.dtype), db_out, dw_head, db_head, None
+
+
 class _SegTail(torch.autograd.Function):
     """(sum CE, tp, fp, fn) fp32 [4] -> (seg_ce, seg_dice) fp32 [2] and, for backward, their 2 x 4 Jacobian: one launch
     (csrc/segloss.hip k_segloss_tail) instead of the scalar algebra as ~45 one-element torch launches."""
@@ -139,7 +197,11 @@ class DiCESegmenterFgBg(nn.Module):
 
     def compute_loss(self, pred_seg: Dict[str, Tensor], target: Tensor) -> Dict[str, Tensor]:
         tgt = (target > 0).to(torch.uint8).contiguous()          # segmenter.py:288 binarises in place
-        if "seg_input" in pred_seg:
+        pre = getattr(pred_seg.get("seg_input"), "_nndet_pre_out", None) if "seg_input" in pred_seg else None
+        if pre is not None:                                       # the decoder skipped its output convolution: the whole branch here
+            s = _SegBranchFn.apply(pred_seg["seg_input"], pre.conv.weight, pre.conv.bias, self.conv_out.conv.weight,
+                                   self.conv_out.conv.bias, tgt)
+        elif "seg_input" in pred_seg:
             s = _SegHeadFused.apply(pred_seg["seg_input"], self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
         else:
             s = _SegSums.apply(pred_seg["seg_logits"], tgt)

@@ -84,7 +84,13 @@ class BaseRetinaNet(nn.Module):
                 if getattr(self, "_grad_numel", None) is None:
                     self._grad_numel = sum(p.numel() + 64 for p in self.parameters() if p.requires_grad)
                 L.grad_pool.begin(self._grad_numel, inp.device)
-        features_maps_all = self.decoder(self.encoder(inp))
+        if hasattr(self.decoder, "defer_out0"):                # decoder.out.P0 + segmentation head + loss as one 32 -> 1 convolution?
+            self.decoder.defer_out0 = self._seg_branch_ok(inp)
+        try:
+            features_maps_all = self.decoder(self.encoder(inp))
+        finally:
+            if hasattr(self.decoder, "defer_out0"):
+                self.decoder.defer_out0 = False
         feature_maps_head = [features_maps_all[i] for i in self.decoder_levels]
         tail_ev = getattr(self.decoder, "tail_event", None)    # level 0 (the segmenter's input) comes from the decoder's side stream
         if getattr(self, "_seg_side", None) is not None:       # train_step: the segmentation branch forks HERE (before the head is queued)
@@ -113,6 +119,20 @@ class BaseRetinaNet(nn.Module):
                 features_maps_all[0]._nndet_rank1_ok = True      # its gradient may travel as d1 (x) (w1 - w0): arch/conv.py
             pred_seg = self.segmenter(features_maps_all, fused=True) if fused else self.segmenter(features_maps_all)
         return pred_detection, anchors, pred_seg
+
+    def _seg_branch_ok(self, inp: Tensor) -> bool:
+        """May this forward pass skip decoder.out.P0 and leave the whole segmentation branch to `_SegBranchFn` (csrc/segbranch.hip)?
+        A training step without prediction (`_fuse_seg_head`), 16-bit activations on the GPU, a plain 32 -> 32 3x3x3 output
+        convolution whose result only the 2-class segmenter reads."""
+        from ..arch import segmenter as S
+        if not (S.SEG_BRANCH and self.segmenter is not None and getattr(self, "_fuse_seg_head", False) and inp.is_cuda
+                and inp.dtype in (torch.bfloat16, torch.float16) and torch.is_grad_enabled() and self._seg_rank1_ok()):
+            return False
+        mod = self.decoder.out["P0"][0]
+        seg = self.segmenter
+        return bool(mod.in_channels == 32 and mod.out_channels == 32 and list(getattr(seg, "in_channels", [0]))[0] == 32
+                    and getattr(seg, "conv_out", None) is not None and seg.conv_out.out_channels == 2
+                    and os.environ.get("NNDET_SEG_FUSED", "1") != "0")
 
     def _seg_rank1_ok(self) -> bool:
         """True if decoder level 0 is produced by one of our plain 3x3x3 / stride-1 convolutions (no norm) and read by the segmenter

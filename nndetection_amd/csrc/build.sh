@@ -41,6 +41,7 @@ build norm.hip
 build segloss.hip
 build headio.hip
 build sparse_out.hip
+build segbranch.hip
 build api.hip
 rc=0
 for p in "${pids[@]}"; do wait $p || rc=1; done

@@ -337,6 +337,51 @@ def test_sparse_backward_of_the_head_output_convolutions(golden_dir, dtype, monk
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_segmentation_branch_fusion_in_train_step(golden_dir, dtype, monkeypatch):
+    """A training step without prediction leaves decoder.out.P0 to the segmentation branch (`UFPNModular.defer_out0`,
+    `_SegBranchFn`, csrc/segbranch.hip: one composed 32 -> 1 convolution + loss). Same losses and the same gradient for EVERY
+    parameter as the two-layer route (16-bit: that route rounds the 32-channel map and the logits, the fused one does not); the
+    fp32 step and a step that asks for a prediction keep the two layers."""
+    from nndetection_amd.arch import segmenter as S
+    from nndetection_amd import _lib as L
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    x = torch.from_numpy(gn["x"]).cuda().to(dtype)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(S, "SEG_BRANCH", mode)
+        net.zero_grad(set_to_none=True)
+        calls.clear()
+        losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+        (sum(losses.values()) * (256.0 if dtype == torch.float16 else 1.0)).backward()
+        torch.cuda.synchronize()
+        assert ("nndet_segbranch_forward" in calls) == (mode and dtype != torch.float32), (mode, dtype)
+        assert ("nndet_segbranch_backward" in calls) == (mode and dtype != torch.float32)
+        res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
+                     {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
+    # (fp32: the same kernels both times, only the atomics' summation order differs)
+    tol = 2e-5 if dtype == torch.float32 else (3e-2 if dtype == torch.bfloat16 else 4e-3)
+    ltol = 1e-6 if dtype == torch.float32 else (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) <= ltol * max(1.0, abs(v)), (k, res[True][0][k], v)
+    assert set(res[True][1]) == set(res[False][1]) and "decoder.out.P0.0.conv.weight" in res[True][1]
+    for n, g0 in res[False][1].items():
+        d = float((res[True][1][n] - g0).abs().max())
+        assert d <= tol * (float(g0.abs().max()) + 1e-12) + 1e-7, (n, d, float(g0.abs().max()))
+    monkeypatch.setattr(S, "SEG_BRANCH", True)
+    calls.clear()
+    with torch.no_grad():
+        _, pred = net.train_step(x, _cuda_targets(tg), evaluation=True)
+    assert "nndet_segbranch_forward" not in calls and pred["pred_seg"].shape[1] == 2
+    assert net.decoder.defer_out0 is False
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_fused_input_gradient_accumulation(golden_dir, dtype, monkeypatch):
     """Encoder stage outputs feed the next stage and the decoder lateral. With set_fuse_grad_accum the second data gradient is added
     into the first one's buffer (nndet_conv3d_backward_data_acc) instead of autograd adding two tensors: same gradients (fp32: the

@@ -35,7 +35,11 @@ def timeline(path, steps, out):
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
     rows = list(db.execute(f"select start, end, name, grid_x / workgroup_x, grid_y, grid_z, {qcol} from kernels order by start"))
     # one step = from one launch of the stem forward kernel (first kernel of a forward pass) to the next
-    marks = [i for i, r in enumerate(rows) if "k_stem_fwd" in r[2]]
+    # (fused stem block: its statistics pass k_stem_fwd3<T, 1> opens the forward pass; the other instantiations also serve the
+    # recompute pass and the rank-1 backward of decoder.out.P0)
+    marks = [i for i, r in enumerate(rows) if "k_stem_fwd3<" in r[2] and ", 1>(" in r[2]]
+    if len(marks) < 2:
+        marks = [i for i, r in enumerate(rows) if "k_stem_fwd" in r[2]]
     if len(marks) >= 2:
         rows = rows[marks[-2]:marks[-1]]
     per = len(rows)
