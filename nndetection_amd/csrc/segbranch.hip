@@ -13,61 +13,59 @@
 // been in place since the rank-1 gradient (arch/conv.py: _rank1_backward); the head's weight gradient follows from the one-channel
 // correlation E the producer convolution's weight gradient needs anyway (arch/segmenter.py: _SegBranchFn).
 //
-//   k_segbranch_fwd: tile of 4 x 8 x 16 outputs per pass, halo 6 x 10 x 18 voxels x 64 B staged in LDS (16-byte parts XOR-swizzled,
-//                    odd row pitch: conflict-free ds_read_b128), two W-adjacent outputs per thread, v_dot2c_f32_{bf16,f16} with the
-//                    composed weights as SCALAR operands (s_load, 16 dwords per tap); writes z (fp32) and the four loss sums.
-//                    HBM-bound by design: reads x once (+ halo re-reads from L2), writes 4 B per voxel.
+//   k_segbranch_fwd: per 4 x 8 x 8 output tile: u[t][q] = wc[t] . x[q] for the 600 halo voxels q as 38 x 2 MFMAs 16x16x32 (rows = taps,
+//                    columns = voxels; x goes from memory straight into the B operand), u through LDS (65 KB), then z[p] = c0 + sum_t
+//                    u[t][p + t - 1] (27 conflict-free ds_read_b32 + adds per output) and the four loss sums. Bound by the read of x.
 //   k_segbranch_bwd: d1 = dL/dz from (z, target, the Jacobian of the scalar tail) -> 16-bit d1 + sum(d1); streaming.
 #include "common.h"
 
-template <typename T> struct Dot2;
-template <> struct Dot2<bf16_t> {
-    __device__ static __forceinline__ float f(uint32_t a, uint32_t b, float c) {
-        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
-    }
-};
-template <> struct Dot2<f16_t> {
-    __device__ static __forceinline__ float f(uint32_t a, uint32_t b, float c) {
-        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
-    }
-};
-
 #define SB_TD 4
 #define SB_TH 8
-#define SB_TW 16
+#define SB_TW 8
 #define SB_HD (SB_TD + 2)
 #define SB_HH (SB_TH + 2)
 #define SB_HW (SB_TW + 2)
-#define SB_PITCH 19                                   // voxels per halo row in LDS (odd: rows start on different bank quarters)
-#define SB_LDS (SB_HD * SB_HH * SB_PITCH * 64)
+#define SB_NHV (SB_HD * SB_HH * SB_HW)                // 600 halo voxels
+#define SB_NGRP ((SB_NHV + 15) / 16)                  // 38 groups of 16 voxels (one MFMA column block each)
+#define SB_UP (SB_NGRP * 16)                          // pitch of one tap row of u (608 floats)
+#define SB_LDS (32 * SB_UP * 4)                       // u[tap (27 used of 32)][halo voxel] fp32 = 77 824 bytes -> 2 workgroups per CU
 #define SB_REPL 16                                    // replicas of the loss sums (fp64 atomics of ~2000 workgroups)
 
 __device__ __forceinline__ float sb_softplus(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 
+// With ONE output channel the convolution is cheapest as "per-voxel tap products, then a shifted sum":
+//     u[t][q] = sum_cin wc[t][cin] x[q][cin]      for every voxel q of the tile's halo  -- a 32(taps, 27 used) x 32 x 16-voxel MFMA pair
+//     z[p]    = c0 + sum_t u[t][p + t - 1]                                               -- 27 LDS reads + adds per output
+// Every x value is read from memory exactly once per tile, straight into the MFMA B operand (no LDS staging of x: nothing re-uses
+// it), 76 MFMAs per 256 outputs; the kernel is bound by the 629 MB read of x (halo re-reads come from L2).
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ x, const uint32_t* __restrict__ wq, const float* __restrict__ c0p,
                                                           const uint8_t* __restrict__ target, int N, int D, int H, int W,
                                                           float* __restrict__ z, double* __restrict__ sums) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* u = reinterpret_cast<float*>(smem);
     __shared__ double red[4];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
     if (tid < 4) red[tid] = 0.0;
     const int ntd = (D + SB_TD - 1) / SB_TD, nth = (H + SB_TH - 1) / SB_TH, ntw = (W + SB_TW - 1) / SB_TW;
     const int per_img = ntd * nth * ntw, ntiles = per_img * N;
     const float c0 = *c0p;
     const int img_bytes = D * H * W * 64;                              // < 2^31 (host check)
-    const int wl = tid & 7, hl = (tid >> 3) & 7, dl = tid >> 6;
-    // LDS addresses of this thread's four input columns (halo w index 2 wl + j), 16-byte part q: voxel * 64 + ((q ^ swz) << 4)
-    int addr[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int hw = 2 * wl + j;
-        const int vox = (dl * SB_HH + hl) * SB_PITCH + hw;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) addr[j][q] = vox * 64 + ((q ^ ((hw >> 2) & 3)) << 4);
-    }
+    // A operand (weights): lane (li, q) holds tap row li (+ 16 for the second row tile), channels 8 q .. 8 q + 7; taps >= 27 are zero
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(wq + li * 16 + q * 4);
+    const u32x4 a1 = (16 + li < 27) ? *reinterpret_cast<const u32x4*>(wq + (16 + li) * 16 + q * 4) : zero4;
+    constexpr int NIT = (SB_NGRP + 3) / 4;                             // groups per wave (10)
+    // this thread's output voxel and the halo index of its tap (0, 0, 0)
+    const int ow_l = tid & 7, oh_l = (tid >> 3) & 7, od_l = tid >> 6;
+    const int ubase = (od_l * SB_HH + oh_l) * SB_HW + ow_l;
     float ce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // B operands of one tile: 16 bytes of voxel (group g = wave + 4 k, column li), channels 8 q ..; out-of-volume voxels read zeros
+    // (the conv padding). The loads of tile i + 1 are issued BEFORE tile i is processed: a tile is ~1 us of work against ~2 us of
+    // memory latency, and only two workgroups share a CU.
+    auto load_tile = [&](int tile, u32x4* bv) {
         const int n = tile / per_img;
         int tt = tile - n * per_img;
         const int tw_i = tt % ntw; tt /= ntw;
@@ -76,88 +74,80 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
         const int d0 = td_i * SB_TD, h0 = th_i * SB_TH, w0 = tw_i * SB_TW;
         const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(x)) + (int64_t)n * img_bytes,
                                                            0, img_bytes, 0x00020000);
-        __syncthreads();                                               // the previous tile's reads are done
-        // ---- stage the halo: 1080 voxels x 4 parts of 16 bytes; out-of-volume pieces read zeros (offset beyond num_records)
-        constexpr int NPIECE = SB_HD * SB_HH * SB_HW * 4, NIT = (NPIECE + 255) / 256;
-        u32x4 v[NIT];
-        int dst[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            const int id = tid + k * 256;
-            const int hv = id >> 2, q = id & 3;
+            const int g = wv + 4 * k;
+            const int hv = g * 16 + li;
             const int hd = hv / (SB_HH * SB_HW), r = hv - hd * (SB_HH * SB_HW);
             const int hh = r / SB_HW, hw = r - hh * SB_HW;
             const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-            const bool ok = id < NPIECE && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const bool ok = g < SB_NGRP && hv < SB_NHV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             const int off = ok ? ((gd * H + gh) * W + gw) * 64 + q * 16 : (int)0x80000000;
-            v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
-            dst[k] = ((hd * SB_HH + hh) * SB_PITCH + hw) * 64 + ((q ^ ((hw >> 2) & 3)) << 4);
+            bv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
         }
+    };
+    // Tile order: workgroup ids are dealt round-robin to the 8 XCDs (one L2 each). XCD k walks over the k-th eighth of the tiles, its
+    // gridDim / 8 workgroups side by side over consecutive tiles, so the halo overlap of neighbouring tiles (2.3 x the tile itself) is
+    // re-read from THAT L2 instead of from HBM (measured without: 0.29 ms = the 1.47 GB of tile + halo reads at the HBM rate).
+    const int nx = gridDim.x >> 3;                                     // workgroups per XCD (the host launches a multiple of 8)
+    const int t8 = (ntiles + 7) >> 3;                                  // tiles per XCD
+    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
+    const int t_begin = xcd * t8 + lw, t_end = min((xcd + 1) * t8, ntiles);
+    u32x4 bv[NIT], bn[NIT];
+    if (t_begin < t_end) load_tile(t_begin, bv);
+    for (int tile = t_begin; tile < t_end; tile += nx) {
+        const int n = tile / per_img;
+        int tt = tile - n * per_img;
+        const int tw_i = tt % ntw; tt /= ntw;
+        const int th_i = tt % nth;
+        const int td_i = tt / nth;
+        const int d0 = td_i * SB_TD, h0 = th_i * SB_TH, w0 = tw_i * SB_TW;
+        const int next = tile + nx;
+        if (next < t_end) load_tile(next, bn);
+        // (LDS-only barriers: __syncthreads() would also wait for the loads of the NEXT tile that were just issued)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous tile's reads of u are done
 #pragma unroll
-        for (int k = 0; k < NIT; ++k)
-            if ((k + 1) * 256 <= NPIECE || tid + k * 256 < NPIECE) *reinterpret_cast<u32x4*>(smem + dst[k]) = v[k];   // (only the last round is partial)
-        __syncthreads();
-        // ---- 27 taps x 32 channels for the two outputs (w, w + 1) of this thread; two accumulation chains per output.
-        // A REAL loop over the 9 (kd, kh) rows (fully unrolled the compiler hoists all 144 LDS reads and all 432 weight dwords to the
-        // top and spills): per row 16 ds_read_b128 (4 input columns), 3 x 16 weight dwords through the SCALAR cache (uniform address
-        // -> s_load_dwordx16; the constant address space keeps them scalar whatever the alias analysis thinks of the stores to z),
-        // 96 v_dot2c. The second workgroup of the CU covers the latency at the top of each row.
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-        typedef const uint32_t __attribute__((address_space(4))) * cw_t;
-        const cw_t wc = (cw_t) reinterpret_cast<uint64_t>(wq);
-#pragma unroll 1
-        for (int row = 0; row < 9; ++row) {
-            const int rowoff = (((row / 3) * SB_HH + row % 3) * SB_PITCH) * 64;
-            u32x4 xv[4][4];
+        for (int k = 0; k < NIT; ++k) {
+            const int g = wv + 4 * k;
+            if (g < SB_NGRP) {                                         // wave-uniform
+                const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 d0v = H16<T>::mma(a0, bv[k], zf);           // taps 4 q .. 4 q + 3 of voxel (g, li)
+                const f32x4 d1v = H16<T>::mma(a1, bv[k], zf);           // taps 16 + 4 q ..
+                float* up = u + g * 16 + li;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int r = 0; r < 4; ++r) up[(4 * q + r) * SB_UP] = d0v[r];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xv[j][q] = *reinterpret_cast<const u32x4*>(smem + addr[j][q] + rowoff);
-            uint32_t wt[3][16];
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) wt[kw][i] = wc[(row * 3 + kw) * 16 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j <= 2) {                                           // output 0 (at halo column 2 wl + 1): tap kw = j
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        a0 = Dot2<T>::f(xv[j][q][0], wt[j][q * 4 + 0], a0); a1 = Dot2<T>::f(xv[j][q][1], wt[j][q * 4 + 1], a1);
-                        a0 = Dot2<T>::f(xv[j][q][2], wt[j][q * 4 + 2], a0); a1 = Dot2<T>::f(xv[j][q][3], wt[j][q * 4 + 3], a1);
-                    }
-                }
-                if (j >= 1) {                                           // output 1 (at halo column 2 wl + 2): tap kw = j - 1
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        b0 = Dot2<T>::f(xv[j][q][0], wt[j - 1][q * 4 + 0], b0); b1 = Dot2<T>::f(xv[j][q][1], wt[j - 1][q * 4 + 1], b1);
-                        b0 = Dot2<T>::f(xv[j][q][2], wt[j - 1][q * 4 + 2], b0); b1 = Dot2<T>::f(xv[j][q][3], wt[j - 1][q * 4 + 3], b1);
-                    }
-                }
+                for (int r = 0; r < 4; ++r) up[(16 + 4 * q + r) * SB_UP] = d1v[r];      // (rows 27 .. 31: zero weights, never read)
             }
         }
-        // ---- epilogue: z and the loss sums of the two voxels
-        const int od = d0 + dl, oh = h0 + hl, ow = w0 + 2 * wl;
-        if (od < D && oh < H) {
-            const int64_t base = (((int64_t)n * D + od) * H + oh) * W + ow;
-            const float zz[2] = {a0 + a1 + c0, b0 + b1 + c0};
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- z = c0 + the 27 shifted taps; three accumulation chains
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int o = 0; o < 2; ++o)
-                if (ow + o < W) {
-                    const float zv = zz[o];
-                    z[base + o] = zv;
-                    const bool t = target[base + o] > 0;
-                    const float p1 = 1.f / (1.f + expf(-zv));
-                    ce += t ? sb_softplus(-zv) : sb_softplus(zv);       // -log softmax(l)[t]
-                    if (t) { tp += p1; fn += 1.f - p1; } else { fp += p1; }
-                }
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* ur = u + ((kd * 3 + kh) * 3) * SB_UP + ubase + (kd * SB_HH + kh) * SB_HW;
+                s0 += ur[0]; s1 += ur[SB_UP + 1]; s2 += ur[2 * SB_UP + 2];
+            }
+        const int od = d0 + od_l, oh = h0 + oh_l, ow = w0 + ow_l;
+        if (od < D && oh < H && ow < W) {
+            const int64_t idx = (((int64_t)n * D + od) * H + oh) * W + ow;
+            const float zv = (s0 + s1) + (s2 + c0);
+            z[idx] = zv;
+            const bool t = target[idx] > 0;
+            const float p1 = 1.f / (1.f + expf(-zv));
+            ce += t ? sb_softplus(-zv) : sb_softplus(zv);               // -log softmax(l)[t]
+            if (t) { tp += p1; fn += 1.f - p1; } else { fp += p1; }
         }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) bv[k] = bn[k];
     }
     double dsum[4] = {(double)ce, (double)tp, (double)fp, (double)fn};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const double s = wave_sum_f64(dsum[k]);
-        if ((tid & 63) == 0) atomicAdd(&red[k], s);
+        const double sv = wave_sum_f64(dsum[k]);
+        if (lane == 0) atomicAdd(&red[k], sv);
     }
     __syncthreads();
     if (tid < 4) atomicAdd(&sums[(blockIdx.x % SB_REPL) * 4 + tid], red[tid]);
@@ -198,7 +188,7 @@ extern "C" int nndet_segbranch_forward(int32_t dtype, const void* x, int32_t N, 
     if (!nndet_is16(dtype)) return NNDET_EINVAL;                       // the fp32 path keeps the two separate layers
     if ((int64_t)D * H * W * 64 >= (1LL << 31)) return NNDET_EINVAL;    // 32-bit buffer offsets per image
     const int64_t ntiles = (int64_t)ceil_div(D, SB_TD) * ceil_div(H, SB_TH) * ceil_div(W, SB_TW) * N;
-    const unsigned nb = (unsigned)(ntiles < 2048 ? ntiles : 2048);
+    const unsigned nb = (unsigned)(ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048);      // a multiple of 8: one share per XCD
     static int attr_done = 0;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
