@@ -405,6 +405,13 @@ int nndet_seghead_backward_rank1(int32_t dtype, const void* x, int32_t c_p, int3
 int nndet_segbranch_replicas(void);
 int nndet_segbranch_forward(int32_t dtype, const void* x, int32_t N, int32_t D, int32_t H, int32_t W, int32_t c_p, const void* w_packed,
                             const float* c0, const uint8_t* target, float* z_out, double* sums_out, void* stream);
+/* The same with the decoder's level-0 lateral absorbed too (nndet/arch/decoder/base.py:243-270, 405-413: x_0 = lateral_0(a_0) +
+ * up_1(x_1), lateral_0 = Conv3d 1x1x1 C -> C + bias): z = c0 + conv3(a_0; wc . W_lat) + conv3(u; wc) with u = up_1(x_1) + b_lat
+ * (the lateral bias rides on the transposed convolution's bias, which keeps the zero padding of the 3x3x3 convolution exact).
+ * x = a_0 with w_packed = the composition wc . W_lat, x2 = u with w2_packed = wc; both [27][32] values of dtype. */
+int nndet_segbranch_forward2(int32_t dtype, const void* x, const void* w_packed, const void* x2, const void* w2_packed, int32_t N, int32_t D,
+                             int32_t H, int32_t W, int32_t c_p, const float* c0, const uint8_t* target, float* z_out, double* sums_out,
+                             void* stream);
 int nndet_segbranch_backward(int32_t dtype, const float* z, const uint8_t* target, int64_t nvox, const float* coeffs, void* d1_out,
                              double* dsum_out, void* stream);
 /* Scalar tail of the loss: sums [4] fp32 (what the forward entry points above produce, cast to fp32) ->

@@ -118,6 +118,7 @@ SIGNATURES = {
     "nndet_seghead_backward_rank1": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nndet_segbranch_replicas": (C.c_int, []),
     "nndet_segbranch_forward": (C.c_int, [_I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "nndet_segbranch_forward2": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nndet_segbranch_backward": (C.c_int, [_I32, _P, _P, _I64, _P, _P, _P, _P]),
     "nndet_head_out_sparse_scatter": (C.c_int, [_I32, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, C.POINTER(C.c_int64), _P, _P, _I32,
                                                _P, _I32, _P, _P, _P, _P, _P]),

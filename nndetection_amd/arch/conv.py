@@ -212,15 +212,19 @@ def _rank1_backward(ctx, dconv, weight, x_p, desc, dw, dbias, side, raw):
     return dx_p
 
 
-def rank1_branch_backward(x_p, cin, weight, bias, head_weight, wd, d1, sum_d1, need_dx):
+def rank1_branch_backward(x_p, cin, weight, bias, head_weight, wd, d1, sum_d1, need_dx, lat=None):
     """Backward of `conv3x3x3(x; weight) + bias` followed by a 2-class 1x1x1 head when the loss gradient is known as d1 = dL/d(l1 - l0)
     per voxel (arch/segmenter.py: _SegBranchFn; the convolution output itself was never computed). With wd = w_head[1] - w_head[0]:
         dx           = the ONE-input-channel convolution of d1 with Wf[cin][t] = sum_c wd[c] W[c][cin][2 - t]      (stem forward kernel)
         E[cin][t]    = sum_p d1[p] x[p + t - 1][cin]                                                                (stem weight gradient)
         dW[c][cin][t] = wd[c] E[cin][t],  dbias[c] = wd[c] sum(d1)
         Gy[c]        = sum_p d1[p] y[p][c] = sum_{cin, t} W[c][cin][t] E[cin][t] + bias[c] sum(d1)  ->  dW_head = (-Gy, +Gy)
-    Returns (dx_p or None, dW, dbias or None, Gy, stream of dW / Gy or None). E / dW / Gy run on the weight-gradient stream like every
-    other weight gradient."""
+    lat = (a_p, w_lat, need_da): the convolution's input was x + W_lat a (the decoder's 1x1x1 lateral, absorbed: x is the top-down
+    term alone). Then E above becomes E_x + W_lat E_a, and additionally
+        da              = the one-input-channel convolution of d1 with  sum_c W_lat[c][k] Wf[c][t]
+        dW_lat[c][k]    = sum_t wc[c][t] E_a[k][t],  wc[c][t] = sum_o wd[o] W[o][c][t]
+    Returns (dx_p or None, dW, dbias or None, Gy, stream of dW / Gy or None, da_p or None, dW_lat or None). E / dW / Gy run on the
+    weight-gradient stream like every other weight gradient."""
     dev, dt = x_p.device, x_p.dtype
     N, D, H, W, cin_p = x_p.shape
     cout = weight.shape[0]
@@ -233,31 +237,48 @@ def rank1_branch_backward(x_p, cin, weight, bias, head_weight, wd, d1, sum_d1, n
     sd.out_d, sd.out_h, sd.out_w = D, H, W
     sd.k = (ctypes.c_int32 * 3)(3, 3, 3); sd.s = (ctypes.c_int32 * 3)(1, 1, 1); sd.p = (ctypes.c_int32 * 3)(1, 1, 1)
     nw = weight.numel()
-    gbuf = L.grad_pool.take(nw + (cout if bias is not None else 0), dev)
+    a_p, w_lat, need_da = lat if lat is not None else (None, None, False)
+    nl = w_lat.numel() if w_lat is not None else 0
+    gbuf = L.grad_pool.take(nw + (cout if bias is not None else 0) + nl, dev)
     dw = gbuf[:nw].view(weight.shape)
     dbias = gbuf[nw:nw + cout] if bias is not None else None
+    off = nw + (cout if bias is not None else 0)
+    dw_lat = gbuf[off:off + nl].view(w_lat.shape) if w_lat is not None else None
     side = L.wgrad_streams.side(dev, weight)
     if side is not None:
         L.wgrad_streams.side(dev, head_weight)               # its gradient is produced on that stream as well
-    dx_p = None
+        if w_lat is not None:
+            L.wgrad_streams.side(dev, w_lat)
+    dx_p = da_p = None
     if need_dx:
         dx_p = torch.empty_like(x_p)
         L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(d1), L.ptr(wf), None, None, L.ptr(dx_p), None, L.stream())
+    wl32 = w_lat.detach().float().reshape(w_lat.shape[0], w_lat.shape[1]) if w_lat is not None else None      # [c, k]
+    if need_da:
+        wfa = torch.einsum("ck,cdhw->kdhw", wl32, wf.view(cin, 3, 3, 3)).reshape(wl32.shape[1], 1, 3, 3, 3).contiguous()
+        da_p = torch.empty_like(a_p)
+        L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(d1), L.ptr(wfa), None, None, L.ptr(da_p), None, L.stream())
     if side is not None:
-        for t in (x_p, d1, wd, sum_d1, w32):
+        for t in (x_p, d1, wd, sum_d1, w32) + ((a_p, wl32) if a_p is not None else ()):
             t.record_stream(side)
     cur = torch.cuda.current_stream(dev)
     raw = side.cuda_stream if side is not None else L.stream()
     with torch.cuda.stream(side if side is not None else cur):
-        e = torch.zeros((cin, 1, 3, 3, 3), dtype=torch.float32, device=dev)
-        L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(x_p), L.ptr(e), None, None, 0, raw)
-        ec = e.flip(2, 3, 4).view(cin, 3, 3, 3)                                  # E[cin][t]
+        e = torch.zeros((2 if a_p is not None else 1, cin, 1, 3, 3, 3), dtype=torch.float32, device=dev)
+        L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(x_p), L.ptr(e[0]), None, None, 0, raw)
+        ec = e[0].flip(2, 3, 4).view(cin, 3, 3, 3)                               # E_x[cin][t]
+        if a_p is not None:
+            L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(a_p), L.ptr(e[1]), None, None, 0, raw)
+            ea = e[1].flip(2, 3, 4).view(cin, 3, 3, 3)                           # E_a[k][t]
+            wc = torch.einsum("o,ocdhw->cdhw", wd[:cout], w32)                   # composed kernel [c][t]
+            dw_lat.copy_(torch.einsum("cdhw,kdhw->ck", wc, ea).view(w_lat.shape))
+            ec = ec + torch.einsum("ck,kdhw->cdhw", wl32, ea)                    # correlation with the convolution's full input
         torch.mul(wd[:cout].view(cout, 1, 1, 1, 1), ec.view(1, cin, 3, 3, 3), out=dw)
         gy = torch.einsum("cidhw,idhw->c", w32, ec)
         if dbias is not None:
             torch.mul(wd[:cout], sum_d1, out=dbias)
             gy = gy + bias.detach().float() * sum_d1
-    return dx_p, dw, dbias, gy, side
+    return dx_p, dw, dbias, gy, side, da_p, dw_lat
 
 
 class _ConvFn(torch.autograd.Function):

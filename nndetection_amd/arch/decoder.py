@@ -120,26 +120,27 @@ class UFPNModular(nn.Module):
                     cur = torch.cuda.current_stream(lat.device) if cons is None else cons
                     cur.wait_event(ev)
                     lat.record_stream(cur)
+        absorb = self._absorbing(inp_seq[0])
         if split:
             dev = inp_seq[0].device
             main = torch.cuda.current_stream(dev)
             side = UFPNModular._tail_streams.get(dev.index or 0)
             if side is None:
                 side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev)
-            if fpn[0] is None:
+            if fpn[0] is None and not absorb:
                 side.wait_stream(main)                           # the encoder outputs are ready
                 inp_seq[0].record_stream(side)
                 with torch.cuda.stream(side):
                     fpn[0] = self.lateral["P0"](inp_seq[0])
         for l, fm in enumerate(inp_seq):
-            if fpn[l] is None:
+            if fpn[l] is None and not (l == 0 and absorb):
                 fpn[l] = self.lateral[f"P{l}"](fm)
         xs: List[Optional[torch.Tensor]] = [None] * self.num_level
         x = fpn[self.num_level - 1]
         xs[self.num_level - 1] = x
         for level in range(self.num_level - 2, 0 if split else -1, -1):
             # x_l = lateral_l + up_{l+1}(x_{l+1})  (decoder/base.py:405-413): the add is the epilogue of the transposed conv
-            x = self.up[f"P{level + 1}"](x, residual=fpn[level])
+            x = self._top_down0(x, inp_seq[0]) if (level == 0 and absorb) else self.up[f"P{level + 1}"](x, residual=fpn[level])
             xs[level] = x
         outs: List[Optional[torch.Tensor]] = [None] * self.num_level
         if split:
@@ -148,7 +149,7 @@ class UFPNModular(nn.Module):
             side.wait_event(ev)
             xs[1].record_stream(side)
             with torch.cuda.stream(side):
-                xs[0] = self.up["P1"](xs[1], residual=fpn[0])
+                xs[0] = self._top_down0(xs[1], inp_seq[0]) if absorb else self.up["P1"](xs[1], residual=fpn[0])
                 outs[0] = self._out0(xs[0])
                 self.tail_event = torch.cuda.Event()
                 self.tail_event.record(side)
@@ -163,9 +164,27 @@ class UFPNModular(nn.Module):
     # computes decoder.out.P0 + output conv + loss as one composed 32 -> 1 convolution (arch/segmenter.py: _SegBranchFn) gets the
     # level-0 map BEFORE the output convolution, tagged with that module; nothing else reads level 0.
     defer_out0 = False
+    # ... and, with it, may absorb the level-0 lateral: then lateral P0 is not run either, the last top-down step is the transposed
+    # convolution ALONE with both biases (b_up + b_lat: the add of two [C] vectors is differentiable, so both get their gradient), and
+    # the segmentation branch reads the encoder's level-0 map itself.
+    absorb_lat0 = False
 
     def _out0(self, x0: torch.Tensor) -> torch.Tensor:
         if self.defer_out0:
             x0._nndet_pre_out = self.out["P0"][0]
             return x0
         return self.out["P0"](x0)
+
+    def _absorbing(self, inp0: torch.Tensor) -> bool:
+        from .conv import deferred
+        return bool(self.defer_out0 and self.absorb_lat0 and inp0.is_cuda and deferred(inp0) is None and self.num_level >= 2)
+
+    def _top_down0(self, x1: torch.Tensor, inp0: torch.Tensor) -> torch.Tensor:
+        """x_0 of a pass that absorbs the lateral: up_1(x_1) + b_up + b_lat, tagged with (lateral module, its input)."""
+        from .conv import _ConvFn
+        up, lat = self.up["P1"], self.lateral["P0"][0]
+        biases = [b for b in (up.conv.bias, lat.conv.bias) if b is not None]
+        bias = (biases[0] + biases[1]) if len(biases) == 2 else (biases[0] if biases else None)
+        x0, _ = _ConvFn.apply(x1, None, False, up.conv.weight, bias, up, None, False)
+        x0._nndet_pre_lat = (lat, inp0)
+        return x0

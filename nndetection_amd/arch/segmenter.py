@@ -92,16 +92,22 @@ class _SegHeadFused(torch.autograd.Function):
 # on BEFORE the output convolution (tagged with that module, arch/decoder.py), `_SegBranchFn` does the rest. NNDET_SEG_BRANCH=0: the
 # output convolution runs in the decoder and the head + loss as `_SegHeadFused`.
 SEG_BRANCH = os.environ.get("NNDET_SEG_BRANCH", "1") != "0"
+# ... and the decoder's level-0 lateral 1x1x1 convolution with it (the level-0 map is then never formed). NNDET_SEG_LATERAL=0: the
+# lateral and the top-down add run in the decoder.
+SEG_LATERAL = os.environ.get("NNDET_SEG_LATERAL", "1") != "0"
 
 
 class _SegBranchFn(torch.autograd.Function):
     """x = the decoder's level-0 map BEFORE decoder.out.P0 [N, 32, D, H, W] (16-bit), w_out [32, 32, 3, 3, 3] / b_out of that
     convolution, w_head [2, 32, 1, 1, 1] / b_head of the segmenter's output conv, target uint8 -> fp32 [4] = (sum CE, tp, fp, fn).
     Forward: z = l1 - l0 per voxel by one composed 32 -> 1 convolution; backward: d1 = dL/dz, everything else from d1
-    (arch/conv.py: rank1_branch_backward). Neither the 32-channel output of decoder.out.P0 nor the logits ever exist."""
+    (arch/conv.py: rank1_branch_backward). Neither the 32-channel output of decoder.out.P0 nor the logits ever exist.
+    With (a0, w_lat) the decoder's level-0 LATERAL is absorbed as well: the level-0 map is x + W_lat a0 (a0 = the encoder's
+    full-resolution output, x = the top-down term up_1(x_1) carrying both biases), which never exists either:
+    z = conv3(a0; wc . W_lat) + conv3(x; wc) + c0 (nndet_segbranch_forward2)."""
 
     @staticmethod
-    def forward(ctx, x, w_out, b_out, w_head, b_head, target_u8):
+    def forward(ctx, x, a0, w_lat, w_out, b_out, w_head, b_head, target_u8):
         xp, cin = phys(x)
         dev, dt = xp.device, xp.dtype
         N, D, H, W, cp = xp.shape
@@ -121,15 +127,26 @@ class _SegBranchFn(torch.autograd.Function):
         z = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
         R = int(L.load().nndet_segbranch_replicas())
         sums = torch.zeros((R, 4), dtype=torch.float64, device=dev)
-        L.call("nndet_segbranch_forward", L.dtype_code(xp), L.ptr(xp), N, D, H, W, cp, L.ptr(wq), L.ptr(c0), L.ptr(target_u8), L.ptr(z),
-               L.ptr(sums), L.stream())
-        ctx.save_for_backward(xp, w_out, b_out if b_out is not None else wd, w_head, target_u8, z, wd)
-        ctx.has_b_out, ctx.has_b_head, ctx.R, ctx.cin = b_out is not None, b_head is not None, R, cin
+        ap = None
+        if a0 is not None:
+            ap, ka = phys(a0)
+            if tuple(ap.shape) != tuple(xp.shape) or ap.dtype != dt or ka != 32 or tuple(w_lat.shape[:2]) != (cin, 32):
+                raise L.NndetError("fused segmentation branch: the absorbed lateral needs a 32 -> 32 1x1x1 convolution of a same-sized map")
+            wqa = torch.matmul(wc, w_lat.detach().float().reshape(cin, 32)).to(dt).contiguous()     # [27][k] = sum_c wc[t][c] W_lat[c][k]
+            L.call("nndet_segbranch_forward2", L.dtype_code(xp), L.ptr(ap), L.ptr(wqa), L.ptr(xp), L.ptr(wq), N, D, H, W, cp, L.ptr(c0),
+                   L.ptr(target_u8), L.ptr(z), L.ptr(sums), L.stream())
+        else:
+            L.call("nndet_segbranch_forward", L.dtype_code(xp), L.ptr(xp), N, D, H, W, cp, L.ptr(wq), L.ptr(c0), L.ptr(target_u8), L.ptr(z),
+                   L.ptr(sums), L.stream())
+        ctx.save_for_backward(xp, w_out, b_out if b_out is not None else wd, w_head, target_u8, z, wd,
+                              ap if ap is not None else wd, w_lat if w_lat is not None else wd)
+        ctx.has_b_out, ctx.has_b_head, ctx.R, ctx.cin, ctx.has_lat = b_out is not None, b_head is not None, R, cin, ap is not None
+        ctx.gacc = getattr(a0, "_nndet_gacc", None) if a0 is not None else None       # fused accumulation of a0's gradient (encoder.py)
         return sums.sum(0).float()
 
     @staticmethod
     def backward(ctx, g):
-        xp, w_out, b_out, w_head, tgt, z, wd = ctx.saved_tensors
+        xp, w_out, b_out, w_head, tgt, z, wd, ap, w_lat = ctx.saved_tensors
         dev = xp.device
         nvox = z.numel()
         coeffs = g.detach().float().contiguous()
@@ -138,12 +155,33 @@ class _SegBranchFn(torch.autograd.Function):
         L.call("nndet_segbranch_backward", L.dtype_code(xp), L.ptr(z), L.ptr(tgt), nvox, L.ptr(coeffs), L.ptr(d1), L.ptr(dsum), L.stream())
         sum_d1 = dsum.sum().float()
         from .conv import rank1_branch_backward
-        dx_p, dw_out, db_out, gy, side = rank1_branch_backward(xp, ctx.cin, w_out, b_out if ctx.has_b_out else None, w_head, wd, d1,
-                                                               sum_d1, ctx.needs_input_grad[0])
+        lat = (ap, w_lat, ctx.needs_input_grad[1]) if ctx.has_lat else None
+        dx_p, dw_out, db_out, gy, side, da_p, dw_lat = rank1_branch_backward(xp, ctx.cin, w_out, b_out if ctx.has_b_out else None, w_head,
+                                                                             wd, d1, sum_d1, ctx.needs_input_grad[0], lat)
         with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(dev)):
             dw_head = torch.stack([-gy, gy]).view(w_head.shape).to(w_head.dtype)
         db_head = torch.stack([-sum_d1, sum_d1]) if ctx.has_b_head else None
-        return (logical(dx_p, ctx.cin) if dx_p is not None else None), dw_out.to(w_out.dtype), db_out, dw_head, db_head, None
+        da = None
+        if da_p is not None:
+            gacc = ctx.gacc
+            if gacc is not None and gacc["buf"] is not None and gacc["buf"].shape == da_p.shape and gacc["buf"].dtype == da_p.dtype:
+                # another consumer of a0 wrote its gradient first (not the usual order: this node is the last one created): add
+                if gacc.get("ev") is not None:
+                    torch.cuda.current_stream(dev).wait_event(gacc["ev"])
+                    gacc["buf"].record_stream(torch.cuda.current_stream(dev))
+                gacc["buf"].add_(da_p)
+                ps = gacc.get("stream")
+                if ps is not None and ps != torch.cuda.current_stream(dev):
+                    ev2 = torch.cuda.Event(); ev2.record(); ps.wait_event(ev2)
+                gacc["buf"] = None
+            else:
+                da = logical(da_p, 32)
+                if gacc is not None:                       # first consumer: the other one adds into this buffer (conv.py: _ConvFn.backward)
+                    gacc["buf"] = da_p
+                    gacc["ev"] = torch.cuda.Event()
+                    gacc["ev"].record()
+        return ((logical(dx_p, ctx.cin) if dx_p is not None else None), da, (dw_lat.to(w_lat.dtype) if ctx.has_lat else None),
+                dw_out.to(w_out.dtype), db_out, dw_head, db_head, None)
 
 
 class _SegTail(torch.autograd.Function):
@@ -199,8 +237,9 @@ class DiCESegmenterFgBg(nn.Module):
         tgt = (target > 0).to(torch.uint8).contiguous()          # segmenter.py:288 binarises in place
         pre = getattr(pred_seg.get("seg_input"), "_nndet_pre_out", None) if "seg_input" in pred_seg else None
         if pre is not None:                                       # the decoder skipped its output convolution: the whole branch here
-            s = _SegBranchFn.apply(pred_seg["seg_input"], pre.conv.weight, pre.conv.bias, self.conv_out.conv.weight,
-                                   self.conv_out.conv.bias, tgt)
+            lat = getattr(pred_seg["seg_input"], "_nndet_pre_lat", None)      # (lateral module, its input): absorbed as well
+            s = _SegBranchFn.apply(pred_seg["seg_input"], lat[1] if lat else None, lat[0].conv.weight if lat else None,
+                                   pre.conv.weight, pre.conv.bias, self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
         elif "seg_input" in pred_seg:
             s = _SegHeadFused.apply(pred_seg["seg_input"], self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
         else:

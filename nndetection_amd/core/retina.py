@@ -86,11 +86,12 @@ class BaseRetinaNet(nn.Module):
                 L.grad_pool.begin(self._grad_numel, inp.device)
         if hasattr(self.decoder, "defer_out0"):                # decoder.out.P0 + segmentation head + loss as one 32 -> 1 convolution?
             self.decoder.defer_out0 = self._seg_branch_ok(inp)
+            self.decoder.absorb_lat0 = self.decoder.defer_out0 and self._seg_lateral_ok()
         try:
             features_maps_all = self.decoder(self.encoder(inp))
         finally:
             if hasattr(self.decoder, "defer_out0"):
-                self.decoder.defer_out0 = False
+                self.decoder.defer_out0 = self.decoder.absorb_lat0 = False
         feature_maps_head = [features_maps_all[i] for i in self.decoder_levels]
         tail_ev = getattr(self.decoder, "tail_event", None)    # level 0 (the segmenter's input) comes from the decoder's side stream
         if getattr(self, "_seg_side", None) is not None:       # train_step: the segmentation branch forks HERE (before the head is queued)
@@ -133,6 +134,18 @@ class BaseRetinaNet(nn.Module):
         return bool(mod.in_channels == 32 and mod.out_channels == 32 and list(getattr(seg, "in_channels", [0]))[0] == 32
                     and getattr(seg, "conv_out", None) is not None and seg.conv_out.out_channels == 2
                     and os.environ.get("NNDET_SEG_FUSED", "1") != "0")
+
+    def _seg_lateral_ok(self) -> bool:
+        """... and the level-0 lateral with it (arch/segmenter.py: SEG_LATERAL): a plain 1x1x1 32 -> 32 convolution without norm."""
+        from ..arch import segmenter as S
+        from ..arch.conv import BaseConvNormAct
+        lat = getattr(self.decoder, "lateral", None)
+        blk = lat["P0"] if (lat is not None and "P0" in lat) else None
+        if not S.SEG_LATERAL or blk is None or len(list(blk.children())) != 1 or not isinstance(blk[0], BaseConvNormAct):
+            return False
+        m, up = blk[0], getattr(self.decoder, "up", {})
+        return bool(m.norm_groups == 0 and not m.transposed and m.k == (1, 1, 1) and m.s == (1, 1, 1) and m.in_channels == 32
+                    and m.out_channels == 32 and not getattr(m, "relu", False) and "P1" in up and up["P1"].norm_groups == 0)
 
     def _seg_rank1_ok(self) -> bool:
         """True if decoder level 0 is produced by one of our plain 3x3x3 / stride-1 convolutions (no norm) and read by the segmenter
@@ -236,6 +249,9 @@ class BaseRetinaNet(nn.Module):
             seg_s.wait_event(self._dec_event)            # the decoder output is ready; the head queued behind it is not waited for
             for v in pred_seg.values():
                 v.record_stream(seg_s)
+                lat = getattr(v, "_nndet_pre_lat", None)     # the absorbed lateral's input is read on that stream too
+                if lat is not None:
+                    lat[1].record_stream(seg_s)
             target_seg.record_stream(seg_s)
             with torch.cuda.stream(seg_s):
                 seg_losses = self.segmenter.compute_loss(pred_seg, target_seg)

@@ -38,8 +38,11 @@ __device__ __forceinline__ float sb_softplus(float x) { return fmaxf(x, 0.f) + l
 //     z[p]    = c0 + sum_t u[t][p + t - 1]                                               -- 27 LDS reads + adds per output
 // Every x value is read from memory exactly once per tile, straight into the MFMA B operand (no LDS staging of x: nothing re-uses
 // it), 76 MFMAs per 256 outputs; the kernel is bound by the 629 MB read of x (halo re-reads come from L2).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ x, const uint32_t* __restrict__ wq, const float* __restrict__ c0p,
+// TWO: a second 32-channel input x2 with its own composed weights wq2, accumulated into the same tap products (K = 64): the decoder's
+// lateral convolution absorbed as well (z = conv3(a0; wc . W_lat) + conv3(up; wc) + c0, see nndet_segbranch_forward2).
+template <typename T, bool TWO>
+__global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ x, const uint32_t* __restrict__ wq, const T* __restrict__ x2,
+                                                          const uint32_t* __restrict__ wq2, const float* __restrict__ c0p,
                                                           const uint8_t* __restrict__ target, int N, int D, int H, int W,
                                                           float* __restrict__ z, double* __restrict__ sums) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,6 +60,11 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const u32x4 a0 = *reinterpret_cast<const u32x4*>(wq + li * 16 + q * 4);
     const u32x4 a1 = (16 + li < 27) ? *reinterpret_cast<const u32x4*>(wq + (16 + li) * 16 + q * 4) : zero4;
+    u32x4 a20 = zero4, a21 = zero4;
+    if constexpr (TWO) {
+        a20 = *reinterpret_cast<const u32x4*>(wq2 + li * 16 + q * 4);
+        a21 = (16 + li < 27) ? *reinterpret_cast<const u32x4*>(wq2 + (16 + li) * 16 + q * 4) : zero4;
+    }
     constexpr int NIT = (SB_NGRP + 3) / 4;                             // groups per wave (10)
     // this thread's output voxel and the halo index of its tap (0, 0, 0)
     const int ow_l = tid & 7, oh_l = (tid >> 3) & 7, od_l = tid >> 6;
@@ -74,6 +82,8 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
         const int d0 = td_i * SB_TD, h0 = th_i * SB_TH, w0 = tw_i * SB_TW;
         const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(x)) + (int64_t)n * img_bytes,
                                                            0, img_bytes, 0x00020000);
+        const auto xrs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(TWO ? x2 : x)) + (int64_t)n * img_bytes,
+                                                            0, img_bytes, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int g = wv + 4 * k;
@@ -84,8 +94,10 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
             const bool ok = g < SB_NGRP && hv < SB_NHV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             const int off = ok ? ((gd * H + gh) * W + gw) * 64 + q * 16 : (int)0x80000000;
             bv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+            if constexpr (TWO) bv[NIT + k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs2, off, 0, 0));
         }
     };
+    constexpr int NB = TWO ? 2 * NIT : NIT;
     // Tile order: workgroup ids are dealt round-robin to the 8 XCDs (one L2 each). XCD k walks over the k-th eighth of the tiles, its
     // gridDim / 8 workgroups side by side over consecutive tiles, so the halo overlap of neighbouring tiles (2.3 x the tile itself) is
     // re-read from THAT L2 instead of from HBM (measured without: 0.29 ms = the 1.47 GB of tile + halo reads at the HBM rate).
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
     const int t8 = (ntiles + 7) >> 3;                                  // tiles per XCD
     const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
     const int t_begin = xcd * t8 + lw, t_end = min((xcd + 1) * t8, ntiles);
-    u32x4 bv[NIT], bn[NIT];
+    u32x4 bv[NB], bn[NB];
     if (t_begin < t_end) load_tile(t_begin, bv);
     for (int tile = t_begin; tile < t_end; tile += nx) {
         const int n = tile / per_img;
@@ -111,8 +123,9 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
             const int g = wv + 4 * k;
             if (g < SB_NGRP) {                                         // wave-uniform
                 const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 d0v = H16<T>::mma(a0, bv[k], zf);           // taps 4 q .. 4 q + 3 of voxel (g, li)
-                const f32x4 d1v = H16<T>::mma(a1, bv[k], zf);           // taps 16 + 4 q ..
+                f32x4 d0v = H16<T>::mma(a0, bv[k], zf);                 // taps 4 q .. 4 q + 3 of voxel (g, li)
+                f32x4 d1v = H16<T>::mma(a1, bv[k], zf);                 // taps 16 + 4 q ..
+                if constexpr (TWO) { d0v = H16<T>::mma(a20, bv[NIT + k], d0v); d1v = H16<T>::mma(a21, bv[NIT + k], d1v); }
                 float* up = u + g * 16 + li;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) up[(4 * q + r) * SB_UP] = d0v[r];
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
             if (t) { tp += p1; fn += 1.f - p1; } else { fp += p1; }
         }
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) bv[k] = bn[k];
+        for (int k = 0; k < NB; ++k) bv[k] = bn[k];
     }
     double dsum[4] = {(double)ce, (double)tp, (double)fp, (double)fn};
 #pragma unroll
@@ -181,27 +194,44 @@ __global__ __launch_bounds__(256) void k_segbranch_bwd(const float* __restrict__
 
 extern "C" int nndet_segbranch_replicas(void) { return SB_REPL; }
 
-extern "C" int nndet_segbranch_forward(int32_t dtype, const void* x, int32_t N, int32_t D, int32_t H, int32_t W, int32_t c_p,
-                                       const void* w_packed, const float* c0, const uint8_t* target, float* z_out, double* sums_out,
-                                       void* stream) {
+static int segbranch_launch(int32_t dtype, const void* x, const void* w_packed, const void* x2, const void* w2_packed, int32_t N, int32_t D,
+                            int32_t H, int32_t W, int32_t c_p, const float* c0, const uint8_t* target, float* z_out, double* sums_out,
+                            void* stream) {
     if (!x || !w_packed || !c0 || !target || !z_out || !sums_out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || c_p != 32) return NNDET_EINVAL;
-    if (!nndet_is16(dtype)) return NNDET_EINVAL;                       // the fp32 path keeps the two separate layers
+    if ((x2 == nullptr) != (w2_packed == nullptr)) return NNDET_EINVAL;
+    if (!nndet_is16(dtype)) return NNDET_EINVAL;                       // the fp32 path keeps the separate layers
     if ((int64_t)D * H * W * 64 >= (1LL << 31)) return NNDET_EINVAL;    // 32-bit buffer offsets per image
     const int64_t ntiles = (int64_t)ceil_div(D, SB_TD) * ceil_div(H, SB_TH) * ceil_div(W, SB_TW) * N;
     const unsigned nb = (unsigned)(ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048);      // a multiple of 8: one share per XCD
     static int attr_done = 0;
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         attr_done = 1;
     }
     hipStream_t st = as_stream(stream);
-    if (dtype == NNDET_BF16)
-        k_segbranch_fwd<bf16_t><<<nb, 256, SB_LDS, st>>>((const bf16_t*)x, (const uint32_t*)w_packed, c0, target, N, D, H, W, z_out, sums_out);
-    else
-        k_segbranch_fwd<f16_t><<<nb, 256, SB_LDS, st>>>((const f16_t*)x, (const uint32_t*)w_packed, c0, target, N, D, H, W, z_out, sums_out);
+#define SB_GO(T_, TWO_) k_segbranch_fwd<T_, TWO_><<<nb, 256, SB_LDS, st>>>((const T_*)x, (const uint32_t*)w_packed, (const T_*)x2, \
+                                                                           (const uint32_t*)w2_packed, c0, target, N, D, H, W, z_out, sums_out)
+    if (dtype == NNDET_BF16) { if (x2) SB_GO(bf16_t, true); else SB_GO(bf16_t, false); }
+    else { if (x2) SB_GO(f16_t, true); else SB_GO(f16_t, false); }
+#undef SB_GO
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int nndet_segbranch_forward(int32_t dtype, const void* x, int32_t N, int32_t D, int32_t H, int32_t W, int32_t c_p,
+                                       const void* w_packed, const float* c0, const uint8_t* target, float* z_out, double* sums_out,
+                                       void* stream) {
+    return segbranch_launch(dtype, x, w_packed, nullptr, nullptr, N, D, H, W, c_p, c0, target, z_out, sums_out, stream);
+}
+
+extern "C" int nndet_segbranch_forward2(int32_t dtype, const void* x, const void* w_packed, const void* x2, const void* w2_packed, int32_t N,
+                                        int32_t D, int32_t H, int32_t W, int32_t c_p, const float* c0, const uint8_t* target, float* z_out,
+                                        double* sums_out, void* stream) {
+    if (!x2 || !w2_packed) return NNDET_EINVAL;
+    return segbranch_launch(dtype, x, w_packed, x2, w2_packed, N, D, H, W, c_p, c0, target, z_out, sums_out, stream);
 }
 
 extern "C" int nndet_segbranch_backward(int32_t dtype, const float* z, const uint8_t* target, int64_t nvox, const float* coeffs,

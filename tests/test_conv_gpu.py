@@ -262,30 +262,37 @@ def test_rank1_segmentation_gradient_through_the_producer_conv(shape, dtype, mon
         assert e_ref <= 1.5 * e_denseref + 0.25 * tol, f"{name}: rank-1 {e_ref:.3e} vs dense {e_denseref:.3e} from fp32"
 
 
+@pytest.mark.parametrize("lateral", [False, True], ids=["out", "out+lateral"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(2, 9, 10, 12), (1, 16, 24, 32), (1, 5, 17, 35)], ids=["ragged", "tiles", "odd"])
-def test_segmentation_branch_as_one_convolution(shape, dtype, monkeypatch):
+def test_segmentation_branch_as_one_convolution(shape, dtype, lateral, monkeypatch):
     """csrc/segbranch.hip: decoder.out.P0 (3x3x3, 32 -> 32, bias) + the segmenter's 1x1x1 output conv + CE / SoftDice as ONE composed
     32 -> 1 convolution (`_SegBranchFn`): losses and the gradients of the input, both weights and both biases against plain PyTorch
     fp32 of the two layers (16-bit input, fp32 weights -- the fused route never rounds the 32-channel map or the logits, so it must be
-    at least as close to fp32 as the two-layer HIP route, which does) and against that two-layer route (`_SegHeadFused` + rank-1)."""
+    at least as close to fp32 as the two-layer HIP route, which does) and against that two-layer route (`_SegHeadFused` + rank-1).
+    lateral: the level-0 map is x + W_lat a0 with a 1x1x1 lateral absorbed into the same kernel (nndet_segbranch_forward2): gradients
+    of a0 and W_lat as well."""
     from nndetection_amd.arch import conv as conv_mod, segmenter as seg_mod
     from nndetection_amd.arch import Generator, ConvInstanceRelu, DiCESegmenterFgBg
     from nndetection_amd import _lib as L
     torch.manual_seed(13)
     N, D, H, W = shape
-    conv = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=False, add_act=False)
-    seg = DiCESegmenterFgBg(Generator(ConvInstanceRelu, 3), seg_classes=1, in_channels=[32], decoder_levels=[0],
-                            dice_kwargs={"batch_dice": True})
+    mk = lambda: (ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=False, add_act=False),
+                  DiCESegmenterFgBg(Generator(ConvInstanceRelu, 3), seg_classes=1, in_channels=[32], decoder_levels=[0], dice_kwargs={"batch_dice": True}),
+                  ConvInstanceRelu(3, 32, 32, 1, stride=1, padding=0, add_norm=False, add_act=False))
+    conv, seg, latm = mk()
     with torch.no_grad():
         conv.conv.weight.copy_(torch.randn_like(conv.conv.weight) / 29.4); conv.conv.bias.copy_(torch.randn(32) * 0.2)
         seg.conv_out.conv.weight.copy_(torch.randn_like(seg.conv_out.conv.weight) * 0.3); seg.conv_out.conv.bias.copy_(torch.tensor([0.2, -0.1]))
-    x0 = torch.randn(N, 32, D, H, W)
+        latm.conv.weight.copy_(torch.randn_like(latm.conv.weight) / 5.7); latm.conv.bias.zero_()
+    x0, a00 = torch.randn(N, 32, D, H, W), torch.randn(N, 32, D, H, W).relu()
     tgt = (torch.rand(N, D, H, W) > 0.75).float()
     xr = x0.to(dtype).float().requires_grad_(True)
+    ar = a00.to(dtype).float().requires_grad_(True)
     w = conv.conv.weight.detach().clone().requires_grad_(True); b = conv.conv.bias.detach().clone().requires_grad_(True)
     ws = seg.conv_out.conv.weight.detach().clone().requires_grad_(True); bs = seg.conv_out.conv.bias.detach().clone().requires_grad_(True)
-    sl = F.conv3d(F.conv3d(xr, w, b, padding=1), ws, bs)
+    wl = latm.conv.weight.detach().clone().requires_grad_(True)
+    sl = F.conv3d(F.conv3d(xr + F.conv3d(ar, wl) if lateral else xr, w, b, padding=1), ws, bs)
     t = (tgt > 0).long()
     p = torch.softmax(sl, 1)
     oh = torch.zeros_like(p).scatter_(1, t[:, None], 1)
@@ -299,19 +306,21 @@ def test_segmentation_branch_as_one_convolution(shape, dtype, monkeypatch):
     monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
     res = {}
     for fused in (True, False):
-        cg, sg = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=False, add_act=False), \
-            DiCESegmenterFgBg(Generator(ConvInstanceRelu, 3), seg_classes=1, in_channels=[32], decoder_levels=[0], dice_kwargs={"batch_dice": True})
-        cg.load_state_dict(conv.state_dict()); sg.load_state_dict(seg.state_dict())
-        cg, sg = cg.cuda(), sg.cuda()
+        cg, sg, lg = mk()
+        cg.load_state_dict(conv.state_dict()); sg.load_state_dict(seg.state_dict()); lg.load_state_dict(latm.state_dict())
+        cg, sg, lg = cg.cuda(), sg.cuda(), lg.cuda()
         xg = x0.cuda().to(dtype).requires_grad_(True)
+        ag = a00.cuda().to(dtype).requires_grad_(True)
         calls.clear()
         if fused:
             xin = xg * 1.0                                      # (a non-leaf, like the decoder's level-0 map)
             xin._nndet_pre_out = cg                             # what UFPNModular._out0 attaches when the detector defers out.P0
+            if lateral:
+                xin._nndet_pre_lat = (lg, ag * 1.0)             # ... and UFPNModular._top_down0 when the lateral is absorbed
             out = sg.compute_loss(sg([xin], fused=True), tgt.cuda())
-            assert "nndet_segbranch_forward" in calls and "nndet_seghead_forward" not in calls
+            assert ("nndet_segbranch_forward2" if lateral else "nndet_segbranch_forward") in calls and "nndet_seghead_forward" not in calls
         else:
-            og = cg(xg)
+            og = cg(xg + lg(ag) if lateral else xg)
             og._nndet_rank1_ok = True
             out = sg.compute_loss(sg([og], fused=True), tgt.cuda())
             assert "nndet_seghead_forward" in calls and "nndet_segbranch_forward" not in calls
@@ -319,12 +328,14 @@ def test_segmentation_branch_as_one_convolution(shape, dtype, monkeypatch):
         torch.cuda.synchronize()
         res[fused] = [out["seg_ce"].detach().cpu(), out["seg_dice"].detach().cpu(), xg.grad.float().cpu(), cg.conv.weight.grad.cpu(),
                       cg.conv.bias.grad.cpu(), sg.conv_out.conv.weight.grad.cpu(), sg.conv_out.conv.bias.grad.cpu()]
-    refs = [ce.detach(), dice.detach(), xr.grad, w.grad, b.grad, ws.grad, bs.grad]
+        if lateral:
+            res[fused] += [ag.grad.float().cpu(), lg.conv.weight.grad.cpu()]
+    refs = [ce.detach(), dice.detach(), xr.grad, w.grad, b.grad, ws.grad, bs.grad] + ([ar.grad, wl.grad] if lateral else [])
     ltol = 2e-3 if dtype == torch.bfloat16 else 3e-4
     tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3
     for i, name in enumerate(("seg_ce", "seg_dice")):
         assert abs(float(res[True][i]) - float(refs[i])) <= ltol, (name, float(res[True][i]), float(refs[i]))
-    for name, a, d_, r in zip(("dx", "dW", "db", "dW_seg", "db_seg"), res[True][2:], res[False][2:], refs[2:]):
+    for name, a, d_, r in zip(("dx", "dW", "db", "dW_seg", "db_seg", "da0", "dW_lat"), res[True][2:], res[False][2:], refs[2:]):
         e_ref, e_two, e_tworef = relerr(a, r), relerr(a, d_), relerr(d_, r)
         assert e_ref <= tol, f"{name}: fused branch vs fp32 {e_ref:.3e}"
         assert e_two <= 1.05 * (e_ref + e_tworef) + 1e-6, f"{name}: fused branch vs two-layer route {e_two:.3e}"

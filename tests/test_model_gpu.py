@@ -353,32 +353,38 @@ def test_segmentation_branch_fusion_in_train_step(golden_dir, dtype, monkeypatch
     real = L.call
     monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
     res = {}
-    for mode in (True, False):
-        monkeypatch.setattr(S, "SEG_BRANCH", mode)
+    # (whole branch incl. the level-0 lateral, nndet_segbranch_forward2) / (output conv + head only) / the separate layers
+    for mode in ((True, True), (True, False), (False, False)):
+        monkeypatch.setattr(S, "SEG_BRANCH", mode[0]); monkeypatch.setattr(S, "SEG_LATERAL", mode[1])
         net.zero_grad(set_to_none=True)
         calls.clear()
         losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
         (sum(losses.values()) * (256.0 if dtype == torch.float16 else 1.0)).backward()
         torch.cuda.synchronize()
-        assert ("nndet_segbranch_forward" in calls) == (mode and dtype != torch.float32), (mode, dtype)
-        assert ("nndet_segbranch_backward" in calls) == (mode and dtype != torch.float32)
+        lp = dtype != torch.float32
+        assert ("nndet_segbranch_forward2" in calls) == (mode == (True, True) and lp), (mode, dtype)
+        assert ("nndet_segbranch_forward" in calls) == (mode == (True, False) and lp), (mode, dtype)
+        assert ("nndet_segbranch_backward" in calls) == (mode[0] and lp)
         res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
                      {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
+    res[False] = res[(False, False)]
     # (fp32: the same kernels both times, only the atomics' summation order differs)
     tol = 2e-5 if dtype == torch.float32 else (3e-2 if dtype == torch.bfloat16 else 4e-3)
     ltol = 1e-6 if dtype == torch.float32 else (2e-3 if dtype == torch.bfloat16 else 3e-4)
-    for k, v in res[False][0].items():
-        assert abs(res[True][0][k] - v) <= ltol * max(1.0, abs(v)), (k, res[True][0][k], v)
-    assert set(res[True][1]) == set(res[False][1]) and "decoder.out.P0.0.conv.weight" in res[True][1]
-    for n, g0 in res[False][1].items():
-        d = float((res[True][1][n] - g0).abs().max())
-        assert d <= tol * (float(g0.abs().max()) + 1e-12) + 1e-7, (n, d, float(g0.abs().max()))
-    monkeypatch.setattr(S, "SEG_BRANCH", True)
+    for mode in ((True, True), (True, False)):
+        for k, v in res[False][0].items():
+            assert abs(res[mode][0][k] - v) <= ltol * max(1.0, abs(v)), (mode, k, res[mode][0][k], v)
+        assert set(res[mode][1]) == set(res[False][1]) and "decoder.out.P0.0.conv.weight" in res[mode][1] \
+            and "decoder.lateral.P0.0.conv.weight" in res[mode][1]
+        for n, g0 in res[False][1].items():
+            d = float((res[mode][1][n] - g0).abs().max())
+            assert d <= tol * (float(g0.abs().max()) + 1e-12) + 1e-7, (mode, n, d, float(g0.abs().max()))
+    monkeypatch.setattr(S, "SEG_BRANCH", True); monkeypatch.setattr(S, "SEG_LATERAL", True)
     calls.clear()
     with torch.no_grad():
         _, pred = net.train_step(x, _cuda_targets(tg), evaluation=True)
     assert "nndet_segbranch_forward" not in calls and pred["pred_seg"].shape[1] == 2
-    assert net.decoder.defer_out0 is False
+    assert net.decoder.defer_out0 is False and net.decoder.absorb_lat0 is False
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
@@ -520,6 +526,8 @@ def test_deferred_norm_equals_materialised(golden_dir, monkeypatch, dtype):
     from nndetection_amd.arch.heads import DetectionHeadHNMNative
     monkeypatch.setattr(DetectionHeadHNMNative, "items_levels", False)     # the ragged head path has no deferred variant: compare like with like
     monkeypatch.setattr(C, "FUSED_STEM", False)       # (the fused stem block normalises the UNROUNDED conv output: other arithmetic, own test)
+    import nndetection_amd.arch.segmenter as S
+    monkeypatch.setattr(S, "SEG_LATERAL", False)      # (absorbing the level-0 lateral needs a materialised encoder output: ditto)
     gn, plan, tg = _load(golden_dir)
     x = torch.from_numpy(gn["x"]).cuda().to(dtype)
     res = {}
