@@ -453,6 +453,9 @@ class _NormFn(torch.autograd.Function):
 FUSED_STEM = os.environ.get("NNDET_STEM_FUSED", "1") != "0"
 
 
+STEM_BWD_MAIN = os.environ.get("NNDET_STEM_BWD_MAIN", "1") != "0"
+
+
 class _StemBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, mod):
@@ -481,7 +484,11 @@ class _StemBlockFn(torch.autograd.Function):
         nw = weight.numel()
         gbuf = L.grad_pool.take(nw + 2 * cout, dev)
         dw, dgamma, dbeta = gbuf[:nw].view(weight.shape), gbuf[nw:nw + cout], gbuf[nw + cout:nw + 2 * cout]
-        side = L.wgrad_streams.side(dev, weight)           # parameter gradients only: off the critical chain like every weight gradient
+        # Parameter gradients only -- but this is the LAST node of a backward pass: nothing is queued behind it on the data-gradient
+        # chain, while the weight-gradient stream still has the full-resolution 32 -> 32 weight gradient in front of it. On THIS stream
+        # the two run side by side (tools/phase_times.py: the step ended 0.3 ms later with it queued behind that weight gradient).
+        # NNDET_STEM_BWD_MAIN=0: on the weight-gradient stream like every other weight gradient.
+        side = None if STEM_BWD_MAIN else L.wgrad_streams.side(dev, weight)
         raw = side.cuda_stream if side is not None else L.stream()
         if side is not None:
             for t in (x_p, g_p, mean_rstd, w32, g32, b32):

@@ -91,7 +91,10 @@ template <> struct WF<float> {
 
 // NTS = tap slots per wave (compile time: the MFMA phase is straight-line code, the compiler software-pipelines the
 // LDS transpose reads against the MFMAs); SPLIT = waves split the taps (else: the contraction steps)
-template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT, bool AFF = false>
+// RBK = 32-row blocks of dW per workgroup (1 or 2). The Q halo of a tile is staged ONCE for all of them: with one row block per
+// workgroup the strided transitions (stride 2: halo 1.5 x the tile's own voxels) read X once per row block and tile from HBM -- the
+// workgroups of different row blocks sit on different XCDs -- i.e. 3 x the tensor for the 32 -> 64 transition, which bounded it.
+template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT, bool AFF = false, int RBK = 1>
 __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     constexpr int RB = 32 * (int)sizeof(T);      // bytes of one voxel's 32-channel block
     constexpr int PPV = RB / 16;                  // 16-byte pieces per voxel
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     constexpr int PBYTES = POINTS * RB + (POINTS / 8) * (RB / 2);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sp = smem;
-    char* const sq = smem + PBYTES;
+    char* const sq = smem + RBK * PBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int r0 = blockIdx.y * 32, k0 = blockIdx.z * 32;
+    const int r0 = blockIdx.y * (32 * RBK), k0 = blockIdx.z * 32;
     const int H0 = A.H[0], H1 = A.H[1], H2 = A.H[2];
     const int QROW = H2 * RB + RB / 2;            // bytes of one halo row incl. padding
     const int NQP = H0 * H1 * H2 * PPV;           // number of Q pieces
@@ -166,11 +169,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     for (int ks = 0; ks < KS; ++ks) qrowb[ks] = qrow0[ks] * QROW;
     const int wstep = A.step[2] * RB;
 
-    f32x4 acc[NTS][2][2];
+    f32x4 acc[NTS][2 * RBK][2];
 #pragma unroll
     for (int t = 0; t < NTS; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2 * RBK; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     // staging registers: all loads of a tile are UNCONDITIONAL (invalid pieces read a clamped address and are
     // zeroed at commit) so that they are in flight together; a conditional load per piece would serialise
     // into one HBM round trip each.
-    u32x4 vp[MAXP], vq[MAXQ];
+    u32x4 vp[RBK * MAXP], vq[MAXQ];
     uint32_t okp = 0, okq = 0;
     int n_staged = 0;                             // image of the tile whose pieces sit in vq (deferred input norm)
 
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
             const bool ok = prel[s] >= 0 && ld < A.PL[0] && lh < A.PL[1] && lw < A.PL[2];
             okp |= (uint32_t)ok << s;
             const int64_t off = ok ? ((int64_t)(ld * A.PL[1] + lh) * A.PL[2] + lw) * A.Cp + (r >> 27) * E16 : 0;
-            vp[s] = *reinterpret_cast<const u32x4*>(pn + off);
+#pragma unroll
+            for (int b = 0; b < RBK; ++b) vp[b * MAXP + s] = *reinterpret_cast<const u32x4*>(pn + off + (ok ? b * 32 : 0));
         }
 #pragma unroll
         for (int s = 0; s < MAXQ; ++s) {
@@ -221,7 +225,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     auto commit = [&]() {
 #pragma unroll
         for (int s = 0; s < MAXP; ++s)
-            if (prel[s] >= 0) *reinterpret_cast<u32x4*>(sp + pdst[s]) = ((okp >> s) & 1u) ? vp[s] : u32x4{0u, 0u, 0u, 0u};
+            if (prel[s] >= 0) {
+#pragma unroll
+                for (int b = 0; b < RBK; ++b)
+                    *reinterpret_cast<u32x4*>(sp + b * PBYTES + pdst[s]) = ((okp >> s) & 1u) ? vp[b * MAXP + s] : u32x4{0u, 0u, 0u, 0u};
+            }
         float asc[E16], ash[E16];
         if constexpr (AFF) load_affine<E16>(A.qss, n_staged, A.Cq, k0 + (tid % PPV) * E16, asc, ash);
 #pragma unroll
@@ -239,12 +247,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
         for (int ks = 0; ks < KS; ++ks) {
             if (!SPLIT && (ks & 3) != wv) continue;
             // P fragments of this contraction step: point = ks*32 + q*8 + j, channels it*16 + li
-            WF<T> pf[2];
+            WF<T> pf[2 * RBK];
             {
                 const int tr = ks * 4 + q;
                 const char* b0 = sp + (tr * 8) * RB + tr * (RB / 2);
-                pf[0].load(b0, RB, li);
-                pf[1].load(b0 + 16 * (int)sizeof(T), RB, li);
+#pragma unroll
+                for (int b = 0; b < RBK; ++b) {
+                    pf[2 * b].load(b0 + b * PBYTES, RB, li);
+                    pf[2 * b + 1].load(b0 + b * PBYTES + 16 * (int)sizeof(T), RB, li);
+                }
             }
 #pragma unroll
             for (int ts = 0; ts < NTS; ++ts) {
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
                 qf[0].load(b0, wstep, li);
                 qf[1].load(b0 + 16 * (int)sizeof(T), wstep, li);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2 * RBK; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) WF<T>::mma(pf[i], qf[j], acc[ts][i][j]);
             }
@@ -285,18 +296,21 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     // v1/v2: 1536 workgroups x 27.6 K atomics onto the same 27.6 K addresses ran at ~15 G atomics/s (2.2-2.9 ms per call
     // independent of the layer's FLOPs); a two-stage reduction costs ~0.1 ms and is deterministic.
     const int64_t slice = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wv;   // !SPLIT: every wave owns a full partial
-    float* part = A.part + (slice * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)A.ntap * 1024);
 #pragma unroll
-    for (int ts = 0; ts < NTS; ++ts) {
-        if (tapw[ts] >= 0) {
-            const int t = SPLIT ? wv + ts * 4 : ts;
-            float* pt = part + (int64_t)t * 1024;
+    for (int b = 0; b < RBK; ++b) {
+        float* part = A.part + (slice * (gridDim.y * RBK * gridDim.z) + (blockIdx.y * RBK + b) * gridDim.z + blockIdx.z) * ((int64_t)A.ntap * 1024);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int ts = 0; ts < NTS; ++ts) {
+            if (tapw[ts] >= 0) {
+                const int t = SPLIT ? wv + ts * 4 : ts;
+                float* pt = part + (int64_t)t * 1024;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + q * 4 + rr) * 32 + j * 16 + li] = acc[ts][i][j][rr];
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + q * 4 + rr) * 32 + j * 16 + li] = acc[ts][2 * b + i][j][rr];
+            }
         }
     }
 }
@@ -549,18 +563,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     else atomicAdd(dst, acc);
 }
 
-template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT>
+template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT, int RBK = 1>
 static int wg_launch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, false>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, false, RBK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, true>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, true, RBK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         attr = true;
     }
-    if (a.qss) k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, true><<<grid, 256, lds, st>>>(a);      // deferred input norm applied while staging X
-    else k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, false><<<grid, 256, lds, st>>>(a);
+    if (a.qss) k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, true, RBK><<<grid, 256, lds, st>>>(a);      // deferred input norm applied while staging X
+    else k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, false, RBK><<<grid, 256, lds, st>>>(a);
     LAUNCH_CHECK();
     return 0;
 }
@@ -568,7 +582,11 @@ static int wg_launch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
 // tap-slot dispatch: >= 4 taps are split over the 4 waves (slots = ceil(taps / 4) rounded up to an instantiated count),
 // 1-3 taps are processed by every wave (the waves split the contraction steps instead)
 template <typename T, int KS, int MAXP, int MAXQ, bool PF>
-static int wg_dispatch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+static int wg_dispatch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st, int rbk = 1) {
+    if (rbk == 2) {      // strided 3x3x3 transitions in 16 bits (27 taps: 7 slots per wave), two row blocks per workgroup
+        if constexpr (sizeof(T) == 2 && KS == 2) return wg_launch<T, KS, MAXP, MAXQ, PF, 7, true, 2>(a, grid, lds, st);
+        return NNDET_EINVAL;
+    }
     if (a.ntap >= 4) {
         const int need = (a.ntap + 3) / 4;
         if (need <= 1) return wg_launch<T, KS, MAXP, MAXQ, PF, 1, true>(a, grid, lds, st);
@@ -680,10 +698,17 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
     auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); };
     a.mH2 = magic(a.H[2]); a.mH1 = magic(a.H[1]);
     a.lTH = 0; while ((1 << a.lTH) < a.TH) ++a.lTH;
-    const size_t lds = (size_t)(KS * 32) * RB + (size_t)(KS * 4) * (RB / 2) + (size_t)a.H[0] * a.H[1] * (a.H[2] * RB + RB / 2) + 64;
+    size_t lds = (size_t)(KS * 32) * RB + (size_t)(KS * 4) * (RB / 2) + (size_t)a.H[0] * a.H[1] * (a.H[2] * RB + RB / 2) + 64;
     const int rb = a.Cp / 32, kb = a.Cq / 32;
     const int S = wgrad_slices(rb * kb, a.total_tiles);
     dim3 grid(S, rb, kb);
+    // two row blocks per workgroup (k_wgrad<..., RBK = 2>): the strided 3x3x3 transitions in 16 bits; NNDET_WGRAD_RBK=1 disables it
+    const char* rbk_env = getenv("NNDET_WGRAD_RBK");
+    const int rbk = (strided && bf && !tr && T == 27 && rb % 2 == 0 && (rbk_env ? atoi(rbk_env) : 2) == 2) ? 2 : 1;
+    if (rbk == 2) {
+        grid.y = rb / 2;
+        lds += (size_t)(KS * 32) * RB + (size_t)(KS * 4) * (RB / 2);
+    }
     const int slices = (a.ntap >= 4) ? S : 4 * S;
     const size_t need = (size_t)slices * rb * kb * a.ntap * 1024 * sizeof(float);
     if (!ws || ws_bytes < need) return NNDET_EWORKSPACE;
@@ -730,8 +755,8 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             return 0;
         }
     }
-    if (hf) rc = KS == 8 ? wg_dispatch<f16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<f16_t, 2, 1, 12, true>(a, grid, lds, st);
-    else if (bf) rc = KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st);
+    if (hf) rc = KS == 8 ? wg_dispatch<f16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<f16_t, 2, 1, 12, true>(a, grid, lds, st, rbk);
+    else if (bf) rc = KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st, rbk);
     else rc = KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
     if (rc) return rc;
     const int64_t total = (int64_t)rb * kb * a.ntap * 1024;

@@ -1,75 +1,54 @@
 #!/usr/bin/env python
-"""Un-profiled GPU time of the phases of a training step (CUDA events on the main stream): encoder + decoder forward, head forward,
-targets + losses, backward until every head-input gradient exists (= loss + head backward), the rest of backward, optimizer."""
+"""GPU-side phase times of the training step WITHOUT a profiler (events on the main stream and on the weight-gradient stream):
+forward + losses | backward (main chain, joined with the weight-gradient stream) | when the weight-gradient stream finished |
+optimizer. tools/phase_times.py [steps=40] [dtype=bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
+from nndetection_amd import _lib as L
 from nndetection_amd.plans import get_plan
-from nndetection_amd.ptmodule import build_model, configure_optimizer
 
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dn = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 dev = torch.device("cuda:0")
-plan = get_plan(sys.argv[1] if len(sys.argv) > 1 else "luna160")
-net = build_model(plan).to(dev)
-opt, sched = configure_optimizer(net)
-x, tg = bench.synth_batch(plan, plan["batch_size"], torch.bfloat16, dev, seed=1000)
-ev = {}
-
-
-def mark(name):
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    ev[name] = e
-
-
-head_fwd = net.head.forward
-pending = {"n": 0}
-
-
-def timed_head(fmaps):
-    mark("head_fwd_start")
-    pending["n"] = len(fmaps)
-    for p in fmaps:
-        def hook(g):
-            pending["n"] -= 1
-            if pending["n"] == 0:
-                mark("head_bwd_done")
-            return g
-        p.register_hook(hook)
-    out = head_fwd(fmaps)
-    mark("head_fwd_end")
+plan = get_plan("luna160")
+r = bench.Route(plan, 4, dn, dev, 0, False)
+for _ in range(10):
+    r.step()
+torch.cuda.synchronize()
+ev = lambda: torch.cuda.Event(enable_timing=True)
+rec = []
+marks = {}
+_cl = r.net.head.compute_loss
+def compute_loss(*a, **k):                      # (events around the detection loss: sampler + loss kernels on the main stream)
+    marks["l0"] = ev(); marks["l0"].record()
+    out = _cl(*a, **k)
+    marks["l1"] = ev(); marks["l1"].record()
     return out
-
-
-net.head.forward = timed_head
-
-
-def step():
-    mark("start")
-    losses, _ = net.train_step(x, tg, evaluation=False, batch_num=0)
+r.net.head.compute_loss = compute_loss
+for _ in range(steps):
+    e = [ev() for _ in range(5)]
+    e[0].record()
+    losses, _ = r.net.train_step(r.x, r.tg, evaluation=False, batch_num=0)
     loss = sum(losses.values())
-    mark("loss_done")
+    e[1].record()
     loss.backward()
-    mark("bwd_done")
-    opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
-    mark("end")
-
-
-for _ in range(8):
-    step()
-acc = {}
-N = 20
-for _ in range(N):
-    step()
-    torch.cuda.synchronize()
-    seq = ["start", "head_fwd_start", "head_fwd_end", "loss_done", "head_bwd_done", "bwd_done", "end"]
-    for a, b in zip(seq[:-1], seq[1:]):
-        acc[(a, b)] = acc.get((a, b), 0.0) + ev[a].elapsed_time(ev[b])
-names = {("start", "head_fwd_start"): "encoder + decoder forward", ("head_fwd_start", "head_fwd_end"): "head forward",
-         ("head_fwd_end", "loss_done"): "anchors + ATSS + sampler + losses (+ seg head)", ("loss_done", "head_bwd_done"): "loss + head backward",
-         ("head_bwd_done", "bwd_done"): "decoder + encoder backward", ("bwd_done", "end"): "optimizer"}
-tot = 0.0
-for k, v in acc.items():
-    print(f"{names[k]:50s} {v / N:7.3f} ms")
-    tot += v / N
-print(f"{'sum':50s} {tot:7.3f} ms   (events on the main stream; the synchronize per step lets the host fall behind, so this is GPU time, not the free-running wall)")
+    e[2].record()
+    ws = L.wgrad_streams.streams.get(0)
+    if ws is not None:
+        e[4].record(ws)
+    r.opt.step(); r.sched.step(); r.opt.zero_grad(set_to_none=True)
+    e[3].record()
+    rec.append(e + [marks["l0"], marks["l1"]])
+torch.cuda.synchronize()
+import numpy as np
+rows = []
+for e in rec[5:]:
+    rows.append([e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[1].elapsed_time(e[4]) if ws is not None else float("nan"), e[2].elapsed_time(e[3]),
+                 e[0].elapsed_time(e[3]), e[0].elapsed_time(e[5]), e[5].elapsed_time(e[6]), e[6].elapsed_time(e[1])])
+m = np.mean(rows, 0)
+print(f"forward+losses {m[0]:.3f} ms | backward (joined) {m[1]:.3f} ms | weight-gradient stream done {m[2]:.3f} ms after the backward started "
+      f"(slack of the main chain behind it: {m[1] - m[2]:.3f} ms) | optimizer {m[3]:.3f} ms | step {m[4]:.3f} ms")
+print(f"forward split: network + target assignment {m[5]:.3f} ms | detection loss (sampler, sparse regressor conv, loss kernel) {m[6]:.3f} ms | "
+      f"join with the segmentation branch + loss sum {m[7]:.3f} ms")
