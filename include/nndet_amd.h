@@ -275,6 +275,18 @@ int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w_packed
 /* dx[N,id,ih,iw,cin_p] = conv^T(dy[N,od,oh,ow,cout_p]) */
 int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w_packed_mode1,
                                void* dx, void* stream);
+/* Split-K variants of nndet_conv3d_forward / nndet_conv3d_backward_data for SMALL problems (the deep encoder stages and the small
+ * pyramid levels: nndet/arch/encoder/modular.py:79-108 stages 3-5, nndet/arch/decoder/base.py:243-270 levels 3-5): with a few hundred
+ * workgroups that each walk serially through all channel chunks x 27 taps most of the 256 CUs idle. Given `ws` of at least
+ * nndet_conv3d_splitk_workspace_bytes(c, kind) bytes (kind 0 forward, 1 data gradient; 0 = this problem is not split) the channel
+ * chunks are spread over several workgroups per tile (fp32 partial sums in ws) and a second small launch adds them in a fixed order,
+ * applies bias / residual, rounds and accumulates the norm statistics. Same mathematics, fp32 summation order differs from the
+ * unsplit launch. With ws == NULL or too small they behave exactly like the plain entry points. */
+size_t nndet_conv3d_splitk_workspace_bytes(const NndetConv* c, int32_t kind);
+int nndet_conv3d_forward_ws(const NndetConv* c, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                            double* stats, void* ws, size_t ws_bytes, void* stream);
+int nndet_conv3d_backward_data_ws(const NndetConv* c, const void* dy, const void* w, void* dx, void* ws, size_t ws_bytes, void* stream);
+
 /* Data gradient that also accumulates the bias gradient dbias[cout] += sum over voxels of dy (fp32, zero it first): the pointwise
  * kernels (1x1x1 convolutions, transposed k == s) read every dy element exactly once anyway, which saves the separate
  * column-sum pass over dy (629 MB at full resolution). nndet_conv3d_dgrad_fuses_bias() tells whether a problem is covered;

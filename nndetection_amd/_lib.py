@@ -96,6 +96,9 @@ SIGNATURES = {
     "nndet_stem_block_backward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _SZ, _P]),
     "nndet_conv3d_forward": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
+    "nndet_conv3d_splitk_workspace_bytes": (_SZ, [_CONVP, _I32]),
+    "nndet_conv3d_forward_ws": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "nndet_conv3d_backward_data_ws": (C.c_int, [_CONVP, _P, _P, _P, _P, _SZ, _P]),
     "nndet_conv3d_dgrad_fuses_bias": (_I32, [_CONVP]),
     "nndet_conv3d_backward_data_bias": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data_acc": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),

@@ -212,6 +212,16 @@ def _rank1_backward(ctx, dconv, weight, x_p, desc, dw, dbias, side, raw):
     return dx_p
 
 
+def _splitk_bytes(mod, desc, kind: int) -> int:
+    """Workspace a split-K launch of this convolution wants (0: not a split-K problem); cached per module and problem."""
+    key = ("splitk", kind, desc.dtype, desc.batch, desc.in_d, desc.in_h, desc.in_w, bool(desc.in_affine), os.environ.get("NNDET_IGEMM_SPLITK"),
+           os.environ.get("NNDET_IGEMM_SMALLWG"))
+    n = mod._pack_cache.get(key)
+    if n is None:
+        n = mod._pack_cache[key] = int(L.load().nndet_conv3d_splitk_workspace_bytes(ctypes.byref(desc), kind))
+    return n
+
+
 def rank1_branch_backward(x_p, cin, weight, bias, head_weight, wd, d1, sum_d1, need_dx, lat=None):
     """Backward of `conv3x3x3(x; weight) + bias` followed by a 2-class 1x1x1 head when the loss gradient is known as d1 = dL/d(l1 - l0)
     per voxel (arch/segmenter.py: _SegBranchFn; the convolution output itself was never computed). With wd = w_head[1] - w_head[0]:
@@ -310,7 +320,13 @@ class _ConvFn(torch.autograd.Function):
             r_p, _ = phys(residual, dtype=dt, cp=cout_p)
             if tuple(r_p.shape) != tuple(y.shape):
                 raise L.NndetError(f"residual shape {tuple(residual.shape)} does not match the conv output")
-        L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats), L.stream())
+        sk = 0 if stem else _splitk_bytes(mod, desc, 0)
+        if sk:                                   # small problem: the channel chunks are spread over several workgroups per tile
+            ws = L.workspace(sk, dev)
+            L.call("nndet_conv3d_forward_ws", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats),
+                   L.ptr(ws), sk, L.stream())
+        else:
+            L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats), L.stream())
         ctx.desc, ctx.mod, ctx.has_bias, ctx.has_res = desc, mod, bias is not None, residual is not None
         ctx.gacc = None if mod.transposed else getattr(x, "_nndet_gacc", None)   # fused accumulation of the input gradient (encoder.py)
         ctx.x_ss = x_ss                      # (tiny) keeps the table alive for the weight gradient
@@ -377,7 +393,12 @@ class _ConvFn(torch.autograd.Function):
                 L.call("nndet_conv3d_backward_data_bias", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.ptr(dbias), L.stream())
                 bias_from_dgrad = True
             else:
-                L.call("nndet_conv3d_backward_data", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.stream())
+                sk = _splitk_bytes(mod, desc, 1)
+                if sk:
+                    ws = L.workspace(sk, dev)
+                    L.call("nndet_conv3d_backward_data_ws", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.ptr(ws), sk, L.stream())
+                else:
+                    L.call("nndet_conv3d_backward_data", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.stream())
             if dx_p is not None:
                 dx = logical(dx_p, desc.cin)  # gradient w.r.t. the input AS THE CONV SAW IT (i.e. after a deferred norm + ReLU)
                 if gacc is not None:

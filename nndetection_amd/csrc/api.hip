@@ -41,6 +41,27 @@ extern "C" int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, co
     return igemm_run(c, 1, dy, w, nullptr, nullptr, dx, nullptr, as_stream(stream));
 }
 
+extern "C" size_t nndet_conv3d_splitk_workspace_bytes(const NndetConv* c, int32_t kind) {
+    if (check_conv(c) || c->cin_p == 1 || (kind != 0 && kind != 1)) return 0;
+    return igemm_splitk_bytes(c, kind);
+}
+
+extern "C" int nndet_conv3d_forward_ws(const NndetConv* c, const void* x, const void* w, const float* bias, const void* residual,
+                                       void* y, double* stats, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!x || !w || !y || c->cin_p == 1) return NNDET_EINVAL;
+    return igemm_run(c, 0, x, w, bias, residual, y, stats, as_stream(stream), nullptr, ws, ws_bytes);
+}
+
+extern "C" int nndet_conv3d_backward_data_ws(const NndetConv* c, const void* dy, const void* w, void* dx, void* ws, size_t ws_bytes,
+                                             void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!dy || !w || !dx || c->cin_p == 1) return NNDET_EINVAL;
+    return igemm_run(c, 1, dy, w, nullptr, nullptr, dx, nullptr, as_stream(stream), nullptr, ws, ws_bytes);
+}
+
 extern "C" int32_t nndet_conv3d_dgrad_fuses_bias(const NndetConv* c) {
     if (check_conv(c) || c->cin_p == 1) return 0;
     static const int on = getenv("NNDET_PW_BIAS") ? atoi(getenv("NNDET_PW_BIAS")) : 1;

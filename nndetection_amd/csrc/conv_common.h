@@ -10,7 +10,8 @@
 
 // conv_igemm.hip
 int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x, const void* w, const float* bias,
-              const void* res, void* y, double* stats, hipStream_t st, float* dbias = nullptr);
+              const void* res, void* y, double* stats, hipStream_t st, float* dbias = nullptr, void* ws = nullptr, size_t ws_bytes = 0);
+size_t igemm_splitk_bytes(const NndetConv* c, int kind);   // > 0: igemm_run splits K when given that much workspace
 // ragged batches (NndetItems): 3x3x3 / stride 1 / pad 1 only
 int items_check(const NndetConv* c, const NndetItems* it);
 int igemm_items_run(const NndetConv* c, const NndetItems* it, int kind, const void* x, const void* w, const float* bias, void* y,

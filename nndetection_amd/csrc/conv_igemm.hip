@@ -103,6 +103,11 @@ struct IgArgs {
     IgClass cls[8];
     IgTap taps[27];
     IgTapX tapx[28];      // per-tap LDS offset / swizzle flip / weight byte offset, precomputed on the host (PIPE kernels)
+    // Split-K (small problems, k_igemm only): blockIdx.x = tile * ksplit + ks, workgroup ks walks the channel chunks
+    // [ks * nchunk / ksplit, (ks + 1) * nchunk / ksplit) and stores its raw fp32 accumulators to part[ks][n][voxel][Cy]; bias, residual,
+    // rounding and the norm statistics happen in k_ig_splitk_reduce. ksplit <= 1 / part == NULL: off.
+    int32_t ksplit, pad_;
+    float* part;
 };
 
 // Ragged batch (NndetItems): per-item dims and first voxel row; only k_ig3<..., ITEMS = true> reads it (blockIdx.z = item,
@@ -137,12 +142,15 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
     // input tile. Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the id is decoded as
     // (tile / 8, class, tile % 8): the classes of one tile run at the same time on the same XCD and the tile comes from HBM
     // once instead of once per class.
-    int cls_i = 0, tt = blockIdx.x;
+    const int ksp = A.part ? A.ksplit : 1;
+    const int ks_i = A.part ? (int)(blockIdx.x % ksp) : 0;
+    const int bx = A.part ? (int)(blockIdx.x / ksp) : (int)blockIdx.x;
+    int cls_i = 0, tt = bx;
     const int n = blockIdx.z;
     if (A.ncls > 1) {
-        const int g = blockIdx.x >> 3;
+        const int g = bx >> 3;
         cls_i = g % A.ncls;
-        tt = (g / A.ncls) * 8 + (blockIdx.x & 7);
+        tt = (g / A.ncls) * 8 + (bx & 7);
         if (tt >= A.nt[0] * A.nt[1] * A.nt[2]) return;   // uniform
     }
     const IgClass& C = A.cls[cls_i];
@@ -205,7 +213,8 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + wr * MT * 16 + li) * A.Cx + q * EPL;
-    const int nchunk = A.Cx / KC;
+    const int nchunk_all = A.Cx / KC;
+    const int kc_begin = ks_i * nchunk_all / ksp, nchunk = (ks_i + 1) * nchunk_all / ksp;      // this workgroup's share of the chunks
     if constexpr (PIPE) {
         const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.w), 0, A.wbytes, 0x00020000);
         int voff[MT];
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
         const IgTapX* const tx = A.tapx + C.tap0;
         const int last = C.ntap - 1;
         constexpr int NH = NT / 2;
-        for (int kc = 0; kc < nchunk; ++kc) {
+        for (int kc = kc_begin; kc < nchunk; ++kc) {
             __syncthreads();
             float asc[EPL], ash[EPL];          // deferred input norm of this thread's 16-byte part of the chunk (AFF variants only)
             if constexpr (AFF) load_affine<EPL>(A.ss, n, A.Cx, kc * KC + (tid & 3) * EPL, asc, ash);
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
             }
         }
     } else
-    for (int kc = 0; kc < nchunk; ++kc) {
+    for (int kc = kc_begin; kc < nchunk; ++kc) {
         __syncthreads();
         float asc[EPL], ash[EPL];              // deferred input norm of this thread's 16-byte part of the chunk (AFF variants only)
         if constexpr (AFF) load_affine<EPL>(A.ss, n, A.Cx, kc * KC + (tid & 3) * EPL, asc, ash);
@@ -333,6 +342,22 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
     }
 
     // ---------------- epilogue: lane holds rows row0 + i*16 + q*4 + {0..3} of voxel (tile j, li)
+    if (A.part) {                                  // split-K: raw partial sums, everything else in k_ig_splitk_reduce (uniform branch)
+        float* pb = A.part + ((int64_t)ks_i * A.N + n) * A.O[0] * A.O[1] * A.O[2] * A.Cy;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int pp = (wc * NT + j) * 16 + li;
+            const int pt2 = pp >> A.lT2;
+            const int ld = l0d + (pt2 >> A.lT1), lh = l0h + (pt2 & (A.T[1] - 1)), lw = l0w + (pp & (A.T[2] - 1));
+            if ((ld < C.L[0]) && (lh < C.L[1]) && (lw < C.L[2])) {
+                const int od = C.out_off[0] + ld * A.out_step[0], oh = C.out_off[1] + lh * A.out_step[1], ow = C.out_off[2] + lw * A.out_step[2];
+                float* po = pb + (((int64_t)od * A.O[1] + oh) * A.O[2] + ow) * A.Cy + row0 + wr * MT * 16 + q * 4;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4*>(po + i * 16) = acc[i][j];
+            }
+        }
+        return;
+    }
     T* yb = reinterpret_cast<T*>(A.y);
     float ssum[MT][4], ssq[MT][4];
 #pragma unroll
@@ -417,6 +442,48 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
             const int rep = (blockIdx.x + blockIdx.z * 7) % NNDET_STATS_REPLICAS;
             double* dst = A.stats + (((int64_t)rep * A.N + n) * A.Cy + row0 + (tid >> 1)) * 2 + (tid & 1);
             atomicAdd(dst, red[tid]);
+        }
+    }
+}
+
+// Second stage of a split-K launch: y = round(sum_ks part[ks] + bias + residual), norm statistics of the rounded values.
+// grid (ceil(voxels / 32), Cy / 32, N), block 256 = 32 voxels x 8 groups of 4 channels. The partial sums are added in ks order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_ig_splitk_reduce(const float* __restrict__ part, int ksplit, int N, int64_t vox, int Cy,
+                                                          const float* __restrict__ bias, const T* __restrict__ res, T* __restrict__ y,
+                                                          double* __restrict__ stats) {
+    __shared__ float red[32][2];
+    const int tid = threadIdx.x, cg = tid & 7, vl = tid >> 3;
+    const int n = blockIdx.z, c = blockIdx.y * 32 + cg * 4;
+    const int64_t v = (int64_t)blockIdx.x * 32 + vl;
+    if (tid < 64) red[tid >> 1][tid & 1] = 0.f;
+    __syncthreads();
+    if (v < vox) {
+        const int64_t e = ((int64_t)n * vox + v) * Cy + c;
+        f32x4 a = *reinterpret_cast<const f32x4*>(part + e);
+        for (int ks = 1; ks < ksplit; ++ks) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(part + (int64_t)ks * N * vox * Cy + e);
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
+        if (bias) { v0 += bias[c]; v1 += bias[c + 1]; v2 += bias[c + 2]; v3 += bias[c + 3]; }
+        if (res) {
+            float r4[4];
+            load4<T>(res + e, r4);
+            v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+        }
+        store4r<T>(y + e, v0, v1, v2, v3);          // returns the values as stored
+        if (stats) {
+            atomicAdd(&red[cg * 4 + 0][0], v0); atomicAdd(&red[cg * 4 + 1][0], v1); atomicAdd(&red[cg * 4 + 2][0], v2); atomicAdd(&red[cg * 4 + 3][0], v3);
+            atomicAdd(&red[cg * 4 + 0][1], v0 * v0); atomicAdd(&red[cg * 4 + 1][1], v1 * v1);
+            atomicAdd(&red[cg * 4 + 2][1], v2 * v2); atomicAdd(&red[cg * 4 + 3][1], v3 * v3);
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        if (tid < 64) {
+            const int rep = (blockIdx.x + blockIdx.z * 7) % NNDET_STATS_REPLICAS;
+            atomicAdd(stats + (((int64_t)rep * N + n) * Cy + blockIdx.y * 32 + (tid >> 1)) * 2 + (tid & 1), (double)red[tid >> 1][tid & 1]);
         }
     }
 }
@@ -1044,6 +1111,8 @@ struct Plan {
     int cfg;          // index into CFG_*
     dim3 grid;
     size_t lds;
+    int ksplit;       // > 1: split-K launch (k_igemm + k_ig_splitk_reduce), needs splitk_bytes of workspace
+    size_t splitk_bytes;
 };
 
 // cfg: 0 unit stride, rows % 64 != 0 : 32 rows x 512 points (WR = 1: the 32-row layers are not weight-traffic bound) ;
@@ -1253,6 +1322,28 @@ static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = f
     P->grid = dim3(a.ncls > 1 ? ceil_div(ntiles, 8) * 8 * a.ncls : ntiles, a.Cy / CFG_ROWS[P->cfg], a.N);
     P->lds = (size_t)a.H[0] * a.H[1] * a.H[2] * 64;
     if (P->lds < 1024) P->lds = 1024;   // room for the stats reduction
+    // Split-K for the deep stages / small pyramid levels: 100 ... 400 workgroups, each walking serially through up to 10 channel
+    // chunks x 27 taps with a global -> LDS round trip per chunk, leave most of the 256 CUs idle or with a single resident wave per
+    // SIMD (50 - 300 TFLOP/s, profiles/round3_v4_kernel_stats_by_grid.txt). Splitting the chunks over `ksplit` workgroups multiplies
+    // the resident waves and divides the serial chain. NNDET_IGEMM_SPLITK=0 disables it, =N forces N (tests).
+    P->ksplit = 1; P->splitk_bytes = 0;
+    const bool generic = P->cfg < 5 || P->cfg >= 8;              // k_igemm configurations (k_ig3 / k_ig3r have no split-K epilogue)
+    const int nchunk = a.Cx / KCb;
+    const int64_t wgs = (int64_t)P->grid.x * P->grid.y * P->grid.z;
+    const char* sk_env = getenv("NNDET_IGEMM_SPLITK");
+    const int sk = sk_env ? atoi(sk_env) : -1;
+    if (generic && sk != 0 && nchunk >= 2) {
+        int ks = 1;
+        if (sk > 1) ks = sk < nchunk ? sk : nchunk;
+        else if (wgs <= 320 && nchunk >= 4) {       // (400 workgroups x 8 chunks measured 18 % SLOWER split in two: profiles/round3_micro_splitk.txt)
+            ks = (int)ceil_div64(1024, wgs);
+            if (ks > nchunk / 2) ks = nchunk / 2;
+        }
+        if (ks >= 2) {
+            P->ksplit = ks;
+            P->splitk_bytes = (size_t)ks * a.N * a.O[0] * a.O[1] * a.O[2] * a.Cy * sizeof(float);
+        }
+    }
     return 0;
 }
 
@@ -1358,8 +1449,27 @@ static int ig3r_launch(const Plan& P, int dtype, hipStream_t st) {
     return 0;
 }
 
+size_t igemm_splitk_bytes(const NndetConv* c, int kind) {
+    if (pw_covers(c, kind)) return 0;
+    if (kind == 1 && dgs_covers(c)) return 0;
+    Plan P;
+    if (build_plan(c, kind, &P)) return 0;
+    return P.ksplit > 1 ? P.splitk_bytes : 0;
+}
+
+template <typename T>
+static int splitk_reduce_launch(const Plan& P, hipStream_t st) {
+    const IgArgs& a = P.a;
+    const int64_t vox = (int64_t)a.O[0] * a.O[1] * a.O[2];
+    dim3 g((unsigned)ceil_div64(vox, 32), a.Cy / 32, a.N);
+    k_ig_splitk_reduce<T><<<g, 256, 0, st>>>(a.part, a.ksplit, a.N, vox, a.Cy, a.bias, reinterpret_cast<const T*>(a.res),
+                                            reinterpret_cast<T*>(a.y), a.stats);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y,
-              double* stats, hipStream_t st, float* dbias) {
+              double* stats, hipStream_t st, float* dbias, void* ws, size_t ws_bytes) {
     if (!stats && !(kind == 0 && c->in_affine && c->transposed)) {   // pointwise problems (1x1x1, transposed k == s) stream straight from global memory
         const int prc = pw_run(c, kind, x, w, bias, res, y, st, dbias);
         if (prc != 1) return prc;
@@ -1381,10 +1491,18 @@ int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const 
         P.a.ss = c->in_affine; P.a.ss_relu = c->in_relu;
     }
     if (!P.a.ss && !res && ig3r_applicable(c, P)) return ig3r_launch(P, c->dtype, st);
+    const bool split = P.ksplit > 1 && ws && ws_bytes >= P.splitk_bytes;
+    if (split) {
+        P.a.ksplit = P.ksplit; P.a.part = reinterpret_cast<float*>(ws);
+        P.grid.x *= P.ksplit;
+    }
 #define IG_CFG_SS(T_) launch_cfg<T_, true>(P, st)
 #define IG_CFG_NS(T_) launch_cfg<T_, false>(P, st)
-    if (P.a.ss) return NNDET_DISPATCH_DTYPE(c->dtype, IG_CFG_SS);
-    return NNDET_DISPATCH_DTYPE(c->dtype, IG_CFG_NS);
+    if (P.a.ss) rc = NNDET_DISPATCH_DTYPE(c->dtype, IG_CFG_SS);
+    else rc = NNDET_DISPATCH_DTYPE(c->dtype, IG_CFG_NS);
+    if (rc || !split) return rc;
+#define IG_SK_RED(T_) splitk_reduce_launch<T_>(P, st)
+    return NNDET_DISPATCH_DTYPE(c->dtype, IG_SK_RED);
 }
 
 // ------------------------------------------------------------------------------------------------ ragged batches (NndetItems)

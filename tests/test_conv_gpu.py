@@ -262,6 +262,51 @@ def test_rank1_segmentation_gradient_through_the_producer_conv(shape, dtype, mon
         assert e_ref <= 1.5 * e_denseref + 0.25 * tol, f"{name}: rank-1 {e_ref:.3e} vs dense {e_denseref:.3e} from fp32"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", [(320, 320, 1, (2, 10, 10, 6)), (128, 256, 2, (2, 20, 20, 12)), (64, 96, 1, (1, 5, 5, 6)), (256, 320, (2, 2, 1), (2, 10, 10, 6))],
+                         ids=["e4", "e3s2", "odd-rows", "s221"])
+def test_split_k_matches_unsplit(case, dtype, monkeypatch):
+    """Split-K launches of the small / deep layers (k_igemm + k_ig_splitk_reduce, nndet_conv3d_forward_ws / _backward_data_ws): same
+    outputs, norm statistics (through the normalised block output) and data gradients as the unsplit launch -- fp32 summation order
+    only -- for automatic and forced split counts; and the split path really is the one that runs."""
+    from nndetection_amd.arch import ConvInstanceRelu
+    from nndetection_amd import _lib as L
+    cin, cout, stride, shape = case
+    torch.manual_seed(5)
+    N, D, H, W = shape
+    x0, r0 = torch.randn(N, cin, D, H, W), torch.randn(N, cout, D, H, W)
+    blk = ConvInstanceRelu(3, cin, cout, 3, stride=stride, padding=1)                        # conv -> IN -> ReLU (epilogue statistics)
+    plain = ConvInstanceRelu(3, cin, cout, 3, stride=1, padding=1, add_norm=False, add_act=False)   # conv + bias (+ residual)
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    res = {}
+    for mode in ("0", None, "2", "5"):
+        if mode is None:
+            monkeypatch.delenv("NNDET_IGEMM_SPLITK", raising=False)
+        else:
+            monkeypatch.setenv("NNDET_IGEMM_SPLITK", mode)
+        b, p = ConvInstanceRelu(3, cin, cout, 3, stride=stride, padding=1), ConvInstanceRelu(3, cin, cout, 3, stride=1, padding=1, add_norm=False, add_act=False)
+        b.load_state_dict(blk.state_dict()); p.load_state_dict(plain.state_dict())
+        b, p = b.cuda(), p.cuda()
+        xg = x0.cuda().to(dtype).requires_grad_(True)
+        calls.clear()
+        y = b(xg)
+        z = p(xg, residual=r0.cuda().to(dtype))
+        (y.float().square().sum() * 1e-2 + (z.float() * 0.37).sum()).backward()
+        torch.cuda.synchronize()
+        used = "nndet_conv3d_forward_ws" in calls
+        if mode is None:                         # automatic: small grids split when there are >= 4 channel chunks (32 / 16 channels each)
+            assert used == (cin // (16 if dtype == torch.float32 else 32) >= 4), (case, calls)
+        else:
+            assert used == (mode != "0") and ("nndet_conv3d_backward_data_ws" in calls) == (mode != "0"), (mode, calls)
+        res[mode] = [t.detach().float().cpu() for t in (y, z, xg.grad, b.conv.weight.grad, b.norm.weight.grad, p.conv.bias.grad)]
+    tol = 2e-5 if dtype == torch.float32 else (1.6e-2 if dtype == torch.bfloat16 else 2e-3)     # 16-bit: one ulp of the stored output
+    for mode in (None, "2", "5"):
+        for name, a, r0 in zip(("y", "z", "dx", "dW", "dgamma", "db"), res[mode], res["0"]):
+            assert relerr(a, r0) <= tol, (mode, name, relerr(a, r0))
+
+
 @pytest.mark.parametrize("lateral", [False, True], ids=["out", "out+lateral"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(2, 9, 10, 12), (1, 16, 24, 32), (1, 5, 17, 35)], ids=["ragged", "tiles", "odd"])

@@ -65,6 +65,14 @@ def main():
         st = L.stream()
         f = lambda: L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, None, L.ptr(y), None, st)
         g = lambda: L.call("nndet_conv3d_backward_data", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx), st)
+        # split-K variants (what arch/conv.py calls for the small / deep layers): workspace for the partial sums
+        sk0, sk1 = (int(L.load().nndet_conv3d_splitk_workspace_bytes(ctypes.byref(d), kk)) for kk in (0, 1))
+        if sk0:
+            wsk0 = torch.empty((sk0,), dtype=torch.uint8, device="cuda")
+            f = lambda: L.call("nndet_conv3d_forward_ws", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, None, L.ptr(y), None, L.ptr(wsk0), sk0, st)
+        if sk1:
+            wsk1 = torch.empty((sk1,), dtype=torch.uint8, device="cuda")
+            g = lambda: L.call("nndet_conv3d_backward_data_ws", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx), L.ptr(wsk1), sk1, st)
         wsb = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
         ws = L.workspace(wsb, x.device)
         h = lambda: L.call("nndet_conv3d_backward_weight", ctypes.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), None, L.ptr(ws), wsb, st)
