@@ -452,12 +452,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_ig_splitk_reduce(const float* __restrict__ part, int ksplit, int N, int64_t vox, int Cy,
                                                           const float* __restrict__ bias, const T* __restrict__ res, T* __restrict__ y,
                                                           double* __restrict__ stats) {
-    __shared__ float red[32][2];
-    const int tid = threadIdx.x, cg = tid & 7, vl = tid >> 3;
+    __shared__ float red[4][32][2];
+    const int tid = threadIdx.x, cg = tid & 7, vl = tid >> 3, wv = tid >> 6;
     const int n = blockIdx.z, c = blockIdx.y * 32 + cg * 4;
     const int64_t v = (int64_t)blockIdx.x * 32 + vl;
-    if (tid < 64) red[tid >> 1][tid & 1] = 0.f;
-    __syncthreads();
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (v < vox) {
         const int64_t e = ((int64_t)n * vox + v) * Cy + c;
         f32x4 a = *reinterpret_cast<const f32x4*>(part + e);
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(256) void k_ig_splitk_reduce(const float* __restric
             const f32x4 b = *reinterpret_cast<const f32x4*>(part + (int64_t)ks * N * vox * Cy + e);
             a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
         }
-        float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3];
+        v0 = a[0]; v1 = a[1]; v2 = a[2]; v3 = a[3];
         if (bias) { v0 += bias[c]; v1 += bias[c + 1]; v2 += bias[c + 2]; v3 += bias[c + 3]; }
         if (res) {
             float r4[4];
@@ -473,17 +472,27 @@ __global__ __launch_bounds__(256) void k_ig_splitk_reduce(const float* __restric
             v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
         }
         store4r<T>(y + e, v0, v1, v2, v3);          // returns the values as stored
-        if (stats) {
-            atomicAdd(&red[cg * 4 + 0][0], v0); atomicAdd(&red[cg * 4 + 1][0], v1); atomicAdd(&red[cg * 4 + 2][0], v2); atomicAdd(&red[cg * 4 + 3][0], v3);
-            atomicAdd(&red[cg * 4 + 0][1], v0 * v0); atomicAdd(&red[cg * 4 + 1][1], v1 * v1);
-            atomicAdd(&red[cg * 4 + 2][1], v2 * v2); atomicAdd(&red[cg * 4 + 3][1], v3 * v3);
-        }
     }
     if (stats) {
+        // DETERMINISTIC statistics: fixed shuffle tree over the 8 voxels of a wave (lanes cg + 8 i), the four waves in order, one fp64
+        // atomic per (block, channel) like the convolution epilogues (voxels beyond the tensor contribute exact zeros)
+        float sv[8] = {v0, v1, v2, v3, v0 * v0, v1 * v1, v2 * v2, v3 * v3};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = sv[k];
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            sv[k] = t;
+        }
+        if ((tid & 63) < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { red[wv][cg * 4 + r][0] = sv[r]; red[wv][cg * 4 + r][1] = sv[4 + r]; }
+        }
         __syncthreads();
         if (tid < 64) {
+            const int ch = tid >> 1, k = tid & 1;
+            const double tot = ((double)red[0][ch][k] + (double)red[1][ch][k]) + ((double)red[2][ch][k] + (double)red[3][ch][k]);
             const int rep = (blockIdx.x + blockIdx.z * 7) % NNDET_STATS_REPLICAS;
-            atomicAdd(stats + (((int64_t)rep * N + n) * Cy + blockIdx.y * 32 + (tid >> 1)) * 2 + (tid & 1), (double)red[tid >> 1][tid & 1]);
+            atomicAdd(stats + (((int64_t)rep * N + n) * Cy + blockIdx.y * 32 + ch) * 2 + k, tot);
         }
     }
 }
@@ -1335,7 +1344,8 @@ static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = f
     if (generic && sk != 0 && nchunk >= 2) {
         int ks = 1;
         if (sk > 1) ks = sk < nchunk ? sk : nchunk;
-        else if (wgs <= 320 && nchunk >= 4) {       // (400 workgroups x 8 chunks measured 18 % SLOWER split in two: profiles/round3_micro_splitk.txt)
+        // (automatic only in 16 bits: the fp32 kernels are the 1e-4 parity path, whose accumulation order the reference goldens pin)
+        else if (nndet_is16(c->dtype) && wgs <= 320 && nchunk >= 4) {       // (400 workgroups x 8 chunks measured 18 % SLOWER split in two: profiles/round3_micro_splitk.txt)
             ks = (int)ceil_div64(1024, wgs);
             if (ks > nchunk / 2) ks = nchunk / 2;
         }
