@@ -507,6 +507,11 @@ int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetItems* items, 
  * raw_out [K][G] the unscaled values (for d(Scale)), rows_out / c0_out as nndet_head_out_sparse_scatter emits them and level_out the
  * pyramid level of each entry (-1 for unused slots, whose outputs are 0). Used for the regressor in training steps: nndet/arch/heads/comb.py:383-401 reads box_deltas at
  * sampled_pos_inds and nowhere else. */
+/* Scale backward for the entries of nndet_conv_out_sparse_forward (nndet/arch/layers/scale.py:21-43: out = scale_l * raw):
+ * vals_out [K][G] = grad [K][G] * scale_l (what nndet_conv_out_sparse_backward takes), levels->dscale[l] (not NULL) = sum over the
+ * entries of level l of grad . raw (WRITTEN, not accumulated); level [K] as returned by the forward (-1 = unused slot -> zeros). */
+int nndet_conv_out_sparse_scale_backward(const NndetHeadLevels* levels, const float* grad, const float* raw, const int32_t* level,
+                                         int32_t K, int32_t G, float* vals_out, void* stream);
 int nndet_conv_out_sparse_forward(const NndetConv* c, const NndetItems* items, const NndetHeadLevels* levels, int32_t N, int32_t A,
                                   int32_t G, const int64_t* level_row0_host, const int64_t* idx, int32_t K, const void* x,
                                   const float* w_f32, const float* bias, float* out, float* raw_out, int32_t* rows_out,

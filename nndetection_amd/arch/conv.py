@@ -115,6 +115,7 @@ def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1), force: bool 
             return 0
         if force:
             mod._pack_cache.pop(("bias", cpad(mod.out_channels)), None)
+            mod._pack_cache.pop(("w32r", dtype), None)               # (arch/pyramid.py: rounded_w32)
         _padded_bias(mod, mod.conv.bias, cpad(mod.out_channels))
         ver = (w._version, w.data_ptr())
         for mode in modes:

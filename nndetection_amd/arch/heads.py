@@ -143,7 +143,7 @@ class _RegSparseFn(torch.autograd.Function):
         dev = t2d.device
         K, G = int(pos.shape[0]), dd.sdim * 2
         A = dd.cout // G
-        w32 = weight.detach().to(t2d.dtype).float().contiguous()              # what the dense kernel would multiply with
+        w32 = P.rounded_w32(mod, weight, t2d.dtype)                           # what the dense kernel would multiply with
         b32 = bias.detach().float().contiguous() if bias is not None else None
         sc = [s_.detach().float().contiguous() for s_ in scales]
         pts = [d * h * w for (_, d, h, w) in meta.level_shapes]
@@ -172,14 +172,18 @@ class _RegSparseFn(torch.autograd.Function):
         sc = ctx.saved_tensors[7:]
         dev = t2d.device
         g = g.detach().float().contiguous()
-        ok = (lvl >= 0)
-        li = lvl.clamp(min=0).long()
         dsc_out = ()
         if ctx.n_scales:
-            scv = torch.cat([s_.reshape(1) for s_ in sc])
-            vals = (g * scv[li][:, None]).contiguous()
-            per = (g * raw).sum(1) * ok.float()                               # out = scale * raw  =>  d(scale_l) = sum g * raw over level l
-            dsc = torch.zeros((ctx.n_scales,), dtype=torch.float32, device=dev).index_add_(0, li, per)
+            # out = scale_l * raw  =>  vals = g * scale_l, d(scale_l) = sum over the level's anchors of g . raw: one small launch
+            # (as torch ops: 13 launches on the critical chain between the loss and the head trunks' backward pass)
+            vals = torch.empty_like(g)
+            dsc = torch.empty((ctx.n_scales,), dtype=torch.float32, device=dev)
+            lv = L.NndetHeadLevels()
+            lv.nlev = ctx.n_scales
+            for l in range(ctx.n_scales):
+                lv.scale[l], lv.dscale[l] = sc[l].data_ptr(), dsc.data_ptr() + 4 * l
+            L.call("nndet_conv_out_sparse_scale_backward", ctypes.byref(lv), L.ptr(g), L.ptr(raw), L.ptr(lvl), int(lvl.numel()), G, L.ptr(vals),
+                   L.stream())
             dsc_out = tuple(dsc[l].reshape(()) for l in range(ctx.n_scales))
         else:
             vals = g
@@ -216,13 +220,18 @@ class _DetLossFn(torch.autograd.Function):
                int(cfg["cls_mean"]), L.ptr(losses), L.ptr(g_d), L.ptr(g_l), L.stream())
         ctx.save_for_backward(pos, neg, g_d, g_l)
         ctx.shapes = (tuple(box_logits.shape), box_logits.dtype, tuple(box_deltas.shape), box_deltas.dtype)
-        return losses
+        # two 0-dim outputs (not one [2] tensor the caller indexes: autograd would then build the incoming gradient with two zero
+        # fills, two copies and an add -- five launches on the critical chain between the loss and the backward pass)
+        return losses[0], losses[1]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_reg, g_cls):
         pos, neg, g_d, g_l = ctx.saved_tensors
         ls, lt, ds, dt = ctx.shapes
-        up = g.detach().float().contiguous()
+        dev = g_d.device
+        z = torch.zeros((), dtype=torch.float32, device=dev)
+        up = torch.stack([(g_reg if g_reg is not None else z).detach().float(), (g_cls if g_cls is not None else z).detach().float()])
+        g = up
         d_logits = torch.zeros(ls, dtype=torch.float32, device=g.device)
         if ctx.compact:                                      # compact deltas: their gradient is compact too (no dense scatter)
             L.call("nndet_detloss_scatter_f32", L.ptr(pos), pos.shape[0], L.ptr(neg), neg.shape[0], g_l.shape[1], L.ptr(g_d), L.ptr(g_l),
@@ -536,8 +545,8 @@ class DetectionHeadHNMNative(nn.Module):
                    "reg_w": self.regressor.loss_weight, "reg_mean": self.regressor.reduction == "mean",
                    "cls_w": self.classifier.loss_weight, "cls_mean": self.classifier.reduction == "mean",
                    "compact": deferred is not None}
-            both = _DetLossFn.apply(box_logits, box_deltas, pos, neg, counts, labels, gt, an, cfg)
-            return {"reg": both[0], "cls": both[1]}, pos, neg
+            reg_l, cls_l = _DetLossFn.apply(box_logits, box_deltas, pos, neg, counts, labels, gt, an, cfg)
+            return {"reg": reg_l, "cls": cls_l}, pos, neg
         n_pos, n_neg = counts[0], counts[1]
         pos_ok, neg_ok = pos >= 0, neg >= 0
         pos_c, neg_c = pos.clamp(min=0), neg.clamp(min=0)

@@ -151,7 +151,7 @@ class _ItemsConvFn(torch.autograd.Function):
         hint = L.grad_hints.pop(dconv)                      # set by _HeadGatherItemsFn.backward: dconv is zero except at <= 170 rows
         if hint is not None:
             # sparse data + weight gradient of this output convolution (csrc/sparse_out.hip); dw / dbias are views of the zeroed pool
-            w32 = weight.detach().to(dt).float().contiguous()                # the values the forward kernel multiplied with
+            w32 = rounded_w32(mod, weight, dt)                               # the values the forward kernel multiplied with
             dx32 = torch.zeros((meta.rows, desc.cin_p), dtype=torch.float32, device=dev)
             dx = torch.empty_like(x2d)
             L.call("nndet_conv_out_sparse_backward", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(hint["rows"]), L.ptr(hint["c0"]),
@@ -208,6 +208,18 @@ class _ItemsNormFn(torch.autograd.Function):
                ctypes.byref(meta.items), cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta),
                L.ptr(red), L.stream())
         return dconv, dgamma, dbeta, None, None, None
+
+
+def rounded_w32(mod: BaseConvNormAct, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 copy of `weight` rounded to the activation dtype (what the packed 16-bit weights of the dense kernels hold), cached per
+    parameter version like the packed weights (arch/conv.py: _packed; dropped by the forced re-pack of a training pass)."""
+    if dtype == torch.float32:
+        return weight.detach().float().contiguous()
+    key, ver = ("w32r", dtype), (weight._version, weight.data_ptr())
+    hit = mod._pack_cache.get(key)
+    if hit is None or hit[0] != ver:
+        hit = mod._pack_cache[key] = (ver, weight.detach().to(dtype).float().contiguous())
+    return hit[1]
 
 
 def items_block(mod: BaseConvNormAct, x2d: torch.Tensor, meta: PyramidMeta) -> torch.Tensor:

@@ -219,6 +219,45 @@ extern "C" int nndet_conv_out_sparse_forward(const NndetConv* c, const NndetItem
     return 0;
 }
 
+// Backward of the Scale layer at the K sampled anchors of the sparse regressor forward (k_ho_forward produced out = scale_l * raw):
+// vals[k][g] = grad[k][g] * scale_l (the gradient of the conv output, the input of k_ho_backward) and dscale[l] = sum over the
+// anchors of level l of grad . raw. One small block: K <= a few hundred. Replaces 13 element-wise / index launches in autograd.
+__global__ __launch_bounds__(256) void k_ho_scale_bwd(const float* __restrict__ g, const float* __restrict__ raw, const int32_t* __restrict__ lvl,
+                                                      int K, int G, HoLevels Lv, float* __restrict__ vals) {
+    __shared__ float ds[HO_MAX_LEVELS];
+    if (threadIdx.x < HO_MAX_LEVELS) ds[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int l = lvl[k];
+        const float sc = (l >= 0 && Lv.scale[l]) ? *Lv.scale[l] : (l >= 0 ? 1.f : 0.f);
+        float d = 0.f;
+        for (int j = 0; j < G; ++j) {
+            const float gv = g[(int64_t)k * G + j];
+            vals[(int64_t)k * G + j] = gv * sc;
+            d = fmaf(gv, raw[(int64_t)k * G + j], d);
+        }
+        if (l >= 0) atomicAdd(&ds[l], d);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < Lv.nlev && Lv.dscale[threadIdx.x]) *Lv.dscale[threadIdx.x] = ds[threadIdx.x];
+}
+
+extern "C" int nndet_conv_out_sparse_scale_backward(const NndetHeadLevels* levels, const float* grad, const float* raw, const int32_t* level,
+                                                    int32_t K, int32_t G, float* vals_out, void* stream) {
+    if (!levels || levels->nlev <= 0 || levels->nlev > HO_MAX_LEVELS || K < 0 || G <= 0 || G > 8) return NNDET_EINVAL;
+    if (K == 0) return 0;
+    if (!grad || !raw || !level || !vals_out) return NNDET_EINVAL;
+    HoLevels Lv;
+    memset(&Lv, 0, sizeof(Lv));
+    Lv.nlev = levels->nlev; Lv.G = G;
+    for (int l = 0; l < levels->nlev; ++l) {
+        Lv.scale[l] = reinterpret_cast<const float*>(levels->scale[l]); Lv.dscale[l] = reinterpret_cast<float*>(levels->dscale[l]);
+    }
+    k_ho_scale_bwd<<<1, 256, 0, as_stream(stream)>>>(grad, raw, level, K, G, Lv, vals_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int nndet_head_out_sparse_scatter(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t A, int32_t G,
                                              const int64_t* level_row0_host, const int64_t* idx, const float* val, int32_t K,
                                              const void* y, int32_t cout_p, void* dy_zeroed, int32_t* rows_out, int32_t* c0_out,
