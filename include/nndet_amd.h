@@ -424,6 +424,14 @@ int nndet_segbranch_forward(int32_t dtype, const void* x, int32_t N, int32_t D, 
 int nndet_segbranch_forward2(int32_t dtype, const void* x, const void* w_packed, const void* x2, const void* w2_packed, int32_t N, int32_t D,
                              int32_t H, int32_t W, int32_t c_p, const float* c0, const uint8_t* target, float* z_out, double* sums_out,
                              void* stream);
+/* All parameter gradients of the branch from the one-channel correlations (32 channels; every tensor fp32, contiguous):
+ * w_out [32][32][27], b_out [32] or NULL, w_lat [32][32] or NULL (then e_a, dw_lat NULL too), wd [32] = w_head[1] - w_head[0],
+ * e_x / e_a [32][27] = nndet_conv3d_backward_weight(cin_p == 1) of (d1, top-down term) / (d1, a_0), dsum [n_dsum] fp64 (its sum =
+ * sum(d1), as nndet_segbranch_backward leaves it) -> dw_out [32][32][27], db_out [32] or NULL, dw_lat [32][32], dw_head [2][32],
+ * db_head [2] or NULL (all WRITTEN). */
+int nndet_segbranch_param_grads(const float* w_out, const float* b_out, const float* w_lat, const float* wd, const float* e_x,
+                                const float* e_a, const double* dsum, int32_t n_dsum, float* dw_out, float* db_out, float* dw_lat,
+                                float* dw_head, float* db_head, void* stream);
 int nndet_segbranch_backward(int32_t dtype, const float* z, const uint8_t* target, int64_t nvox, const float* coeffs, void* d1_out,
                              double* dsum_out, void* stream);
 /* Scalar tail of the loss: sums [4] fp32 (what the forward entry points above produce, cast to fp32) ->

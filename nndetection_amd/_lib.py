@@ -123,6 +123,7 @@ SIGNATURES = {
     "nndet_segbranch_forward": (C.c_int, [_I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "nndet_segbranch_forward2": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nndet_segbranch_backward": (C.c_int, [_I32, _P, _P, _I64, _P, _P, _P, _P]),
+    "nndet_segbranch_param_grads": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "nndet_head_out_sparse_scatter": (C.c_int, [_I32, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, C.POINTER(C.c_int64), _P, _P, _I32,
                                                _P, _I32, _P, _P, _P, _P, _P]),
     "nndet_conv_out_sparse_scale_backward": (C.c_int, [C.POINTER(NndetHeadLevels), _P, _P, _P, _I32, _I32, _P, _P]),

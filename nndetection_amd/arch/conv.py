@@ -223,73 +223,60 @@ def _splitk_bytes(mod, desc, kind: int) -> int:
     return n
 
 
-def rank1_branch_backward(x_p, cin, weight, bias, head_weight, wd, d1, sum_d1, need_dx, lat=None):
-    """Backward of `conv3x3x3(x; weight) + bias` followed by a 2-class 1x1x1 head when the loss gradient is known as d1 = dL/d(l1 - l0)
-    per voxel (arch/segmenter.py: _SegBranchFn; the convolution output itself was never computed). With wd = w_head[1] - w_head[0]:
-        dx           = the ONE-input-channel convolution of d1 with Wf[cin][t] = sum_c wd[c] W[c][cin][2 - t]      (stem forward kernel)
-        E[cin][t]    = sum_p d1[p] x[p + t - 1][cin]                                                                (stem weight gradient)
-        dW[c][cin][t] = wd[c] E[cin][t],  dbias[c] = wd[c] sum(d1)
-        Gy[c]        = sum_p d1[p] y[p][c] = sum_{cin, t} W[c][cin][t] E[cin][t] + bias[c] sum(d1)  ->  dW_head = (-Gy, +Gy)
-    lat = (a_p, w_lat, need_da): the convolution's input was x + W_lat a (the decoder's 1x1x1 lateral, absorbed: x is the top-down
-    term alone). Then E above becomes E_x + W_lat E_a, and additionally
-        da              = the one-input-channel convolution of d1 with  sum_c W_lat[c][k] Wf[c][t]
-        dW_lat[c][k]    = sum_t wc[c][t] E_a[k][t],  wc[c][t] = sum_o wd[o] W[o][c][t]
-    Returns (dx_p or None, dW, dbias or None, Gy, stream of dW / Gy or None, da_p or None, dW_lat or None). E / dW / Gy run on the
-    weight-gradient stream like every other weight gradient."""
+def rank1_branch_backward(x_p, a_p, w_out, b_out, w_lat, w_head, b_head, wd, wf, wfa, d1, dsum, need_dx, need_da):
+    """Backward of the composed segmentation branch (arch/segmenter.py: _SegBranchFn) from d1 = dL/d(l1 - l0) per voxel. The level-0
+    map x (+ W_lat a), the output of `conv3x3x3(.; w_out) + b_out` and the logits were never computed; with wd = w_head[1] - w_head[0]:
+        dx  = the ONE-input-channel convolution of d1 with wf[cin][t] = sum_c wd[c] W_out[c][cin][2 - t]        (stem forward kernel)
+        da  = the same with wfa[k][t] = sum_c W_lat[c][k] wf[c][t]                                              (lateral absorbed)
+        E_x[cin][t] = sum_p d1[p] x[p + t - 1][cin], E_a likewise for a                                         (stem weight gradient)
+        every parameter gradient from E_x, E_a, sum(d1) in one small launch (csrc/segbranch.hip: k_segbranch_params).
+    Returns (dx_p, da_p, dW_out, db_out, dW_lat, dW_head, db_head); the parameter gradients are views of the per-step gradient pool
+    and are produced on the weight-gradient stream like every other weight gradient."""
     dev, dt = x_p.device, x_p.dtype
     N, D, H, W, cin_p = x_p.shape
-    cout = weight.shape[0]
-    w32 = weight.detach().float()
-    wf = torch.einsum("c,cidhw->idhw", wd[:cout], w32).flip(1, 2, 3).reshape(cin, 1, 3, 3, 3).contiguous()
+    cin = cout = w_out.shape[0]
     sd = L.NndetConv()
     sd.dtype, sd.transposed, sd.batch = L._DT[dt], 0, N
     sd.cin, sd.cout, sd.cin_p, sd.cout_p = 1, cin, 1, cin_p
     sd.in_d, sd.in_h, sd.in_w = D, H, W
     sd.out_d, sd.out_h, sd.out_w = D, H, W
     sd.k = (ctypes.c_int32 * 3)(3, 3, 3); sd.s = (ctypes.c_int32 * 3)(1, 1, 1); sd.p = (ctypes.c_int32 * 3)(1, 1, 1)
-    nw = weight.numel()
-    a_p, w_lat, need_da = lat if lat is not None else (None, None, False)
+    nw, nb = w_out.numel(), (cout if b_out is not None else 0)
     nl = w_lat.numel() if w_lat is not None else 0
-    gbuf = L.grad_pool.take(nw + (cout if bias is not None else 0) + nl, dev)
-    dw = gbuf[:nw].view(weight.shape)
-    dbias = gbuf[nw:nw + cout] if bias is not None else None
-    off = nw + (cout if bias is not None else 0)
-    dw_lat = gbuf[off:off + nl].view(w_lat.shape) if w_lat is not None else None
-    side = L.wgrad_streams.side(dev, weight)
+    nh, nhb = w_head.numel(), (2 if b_head is not None else 0)
+    gbuf = L.grad_pool.take(nw + nb + nl + nh + nhb, dev)
+    o = 0
+    dw = gbuf[o:o + nw].view(w_out.shape); o += nw
+    dbias = gbuf[o:o + nb] if nb else None; o += nb
+    dw_lat = gbuf[o:o + nl].view(w_lat.shape) if nl else None; o += nl
+    dw_head = gbuf[o:o + nh].view(w_head.shape); o += nh
+    db_head = gbuf[o:o + nhb] if nhb else None
+    side = L.wgrad_streams.side(dev, w_out)
     if side is not None:
-        L.wgrad_streams.side(dev, head_weight)               # its gradient is produced on that stream as well
+        L.wgrad_streams.side(dev, w_head)                    # their gradients are produced on that stream as well
         if w_lat is not None:
             L.wgrad_streams.side(dev, w_lat)
     dx_p = da_p = None
     if need_dx:
         dx_p = torch.empty_like(x_p)
         L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(d1), L.ptr(wf), None, None, L.ptr(dx_p), None, L.stream())
-    wl32 = w_lat.detach().float().reshape(w_lat.shape[0], w_lat.shape[1]) if w_lat is not None else None      # [c, k]
-    if need_da:
-        wfa = torch.einsum("ck,cdhw->kdhw", wl32, wf.view(cin, 3, 3, 3)).reshape(wl32.shape[1], 1, 3, 3, 3).contiguous()
+    if need_da and a_p is not None:
         da_p = torch.empty_like(a_p)
         L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(d1), L.ptr(wfa), None, None, L.ptr(da_p), None, L.stream())
     if side is not None:
-        for t in (x_p, d1, wd, sum_d1, w32) + ((a_p, wl32) if a_p is not None else ()):
+        for t in (x_p, d1, wd, dsum) + ((a_p,) if a_p is not None else ()):
             t.record_stream(side)
     cur = torch.cuda.current_stream(dev)
     raw = side.cuda_stream if side is not None else L.stream()
     with torch.cuda.stream(side if side is not None else cur):
-        e = torch.zeros((2 if a_p is not None else 1, cin, 1, 3, 3, 3), dtype=torch.float32, device=dev)
+        e = torch.zeros((2, cin, 27), dtype=torch.float32, device=dev)
         L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(x_p), L.ptr(e[0]), None, None, 0, raw)
-        ec = e[0].flip(2, 3, 4).view(cin, 3, 3, 3)                               # E_x[cin][t]
         if a_p is not None:
             L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(a_p), L.ptr(e[1]), None, None, 0, raw)
-            ea = e[1].flip(2, 3, 4).view(cin, 3, 3, 3)                           # E_a[k][t]
-            wc = torch.einsum("o,ocdhw->cdhw", wd[:cout], w32)                   # composed kernel [c][t]
-            dw_lat.copy_(torch.einsum("cdhw,kdhw->ck", wc, ea).view(w_lat.shape))
-            ec = ec + torch.einsum("ck,kdhw->cdhw", wl32, ea)                    # correlation with the convolution's full input
-        torch.mul(wd[:cout].view(cout, 1, 1, 1, 1), ec.view(1, cin, 3, 3, 3), out=dw)
-        gy = torch.einsum("cidhw,idhw->c", w32, ec)
-        if dbias is not None:
-            torch.mul(wd[:cout], sum_d1, out=dbias)
-            gy = gy + bias.detach().float() * sum_d1
-    return dx_p, dw, dbias, gy, side, da_p, dw_lat
+        L.call("nndet_segbranch_param_grads", L.ptr(w_out.detach()), L.ptr(b_out.detach()) if b_out is not None else None,
+               L.ptr(w_lat.detach()) if w_lat is not None else None, L.ptr(wd), L.ptr(e[0]), L.ptr(e[1]) if a_p is not None else None,
+               L.ptr(dsum), int(dsum.numel()), L.ptr(dw), L.ptr(dbias), L.ptr(dw_lat), L.ptr(dw_head), L.ptr(db_head), raw)
+    return dx_p, da_p, dw, dbias, dw_lat, dw_head, db_head
 
 
 class _ConvFn(torch.autograd.Function):

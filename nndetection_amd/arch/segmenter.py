@@ -118,6 +118,10 @@ class _SegBranchFn(torch.autograd.Function):
         wd = (wh[1] - wh[0]).contiguous()                                              # [cout]
         wc = torch.einsum("c,cidhw->dhwi", wd, w_out.detach().float()).reshape(27, cin)   # composed kernel, tap-major
         wq = wc.to(dt).contiguous()
+        # the flipped kernels of the backward pass (data gradients as one-input-channel convolutions of d1), made here where the host
+        # has time to spare: wf[cin][t] = wc[26 - t][cin]
+        wf = wc.flip(0).t().contiguous().view(cin, 1, 3, 3, 3)
+        wfa = wd                                                                        # (placeholder, replaced with the lateral)
         c0 = torch.zeros((), dtype=torch.float32, device=dev)
         if b_out is not None:
             c0 = c0 + (wd * b_out.detach().float()).sum()
@@ -132,35 +136,33 @@ class _SegBranchFn(torch.autograd.Function):
             ap, ka = phys(a0)
             if tuple(ap.shape) != tuple(xp.shape) or ap.dtype != dt or ka != 32 or tuple(w_lat.shape[:2]) != (cin, 32):
                 raise L.NndetError("fused segmentation branch: the absorbed lateral needs a 32 -> 32 1x1x1 convolution of a same-sized map")
-            wqa = torch.matmul(wc, w_lat.detach().float().reshape(cin, 32)).to(dt).contiguous()     # [27][k] = sum_c wc[t][c] W_lat[c][k]
+            wca = torch.matmul(wc, w_lat.detach().float().reshape(cin, 32))                 # [27][k] = sum_c wc[t][c] W_lat[c][k]
+            wqa = wca.to(dt).contiguous()
+            wfa = wca.flip(0).t().contiguous().view(32, 1, 3, 3, 3)
             L.call("nndet_segbranch_forward2", L.dtype_code(xp), L.ptr(ap), L.ptr(wqa), L.ptr(xp), L.ptr(wq), N, D, H, W, cp, L.ptr(c0),
                    L.ptr(target_u8), L.ptr(z), L.ptr(sums), L.stream())
         else:
             L.call("nndet_segbranch_forward", L.dtype_code(xp), L.ptr(xp), N, D, H, W, cp, L.ptr(wq), L.ptr(c0), L.ptr(target_u8), L.ptr(z),
                    L.ptr(sums), L.stream())
-        ctx.save_for_backward(xp, w_out, b_out if b_out is not None else wd, w_head, target_u8, z, wd,
-                              ap if ap is not None else wd, w_lat if w_lat is not None else wd)
+        ctx.save_for_backward(xp, w_out, b_out if b_out is not None else wd, w_head, b_head if b_head is not None else wd, target_u8, z, wd,
+                              ap if ap is not None else wd, w_lat if w_lat is not None else wd, wf, wfa)
         ctx.has_b_out, ctx.has_b_head, ctx.R, ctx.cin, ctx.has_lat = b_out is not None, b_head is not None, R, cin, ap is not None
         ctx.gacc = getattr(a0, "_nndet_gacc", None) if a0 is not None else None       # fused accumulation of a0's gradient (encoder.py)
         return sums.sum(0).float()
 
     @staticmethod
     def backward(ctx, g):
-        xp, w_out, b_out, w_head, tgt, z, wd, ap, w_lat = ctx.saved_tensors
+        xp, w_out, b_out, w_head, b_head, tgt, z, wd, ap, w_lat, wf, wfa = ctx.saved_tensors
         dev = xp.device
         nvox = z.numel()
         coeffs = g.detach().float().contiguous()
         d1 = torch.empty(xp.shape[:4] + (1,), dtype=xp.dtype, device=dev)
         dsum = torch.zeros((ctx.R,), dtype=torch.float64, device=dev)
         L.call("nndet_segbranch_backward", L.dtype_code(xp), L.ptr(z), L.ptr(tgt), nvox, L.ptr(coeffs), L.ptr(d1), L.ptr(dsum), L.stream())
-        sum_d1 = dsum.sum().float()
         from .conv import rank1_branch_backward
-        lat = (ap, w_lat, ctx.needs_input_grad[1]) if ctx.has_lat else None
-        dx_p, dw_out, db_out, gy, side, da_p, dw_lat = rank1_branch_backward(xp, ctx.cin, w_out, b_out if ctx.has_b_out else None, w_head,
-                                                                             wd, d1, sum_d1, ctx.needs_input_grad[0], lat)
-        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(dev)):
-            dw_head = torch.stack([-gy, gy]).view(w_head.shape).to(w_head.dtype)
-        db_head = torch.stack([-sum_d1, sum_d1]) if ctx.has_b_head else None
+        dx_p, da_p, dw_out, db_out, dw_lat, dw_head, db_head = rank1_branch_backward(
+            xp, ap if ctx.has_lat else None, w_out, b_out if ctx.has_b_out else None, w_lat if ctx.has_lat else None, w_head,
+            b_head if ctx.has_b_head else None, wd, wf, wfa, d1, dsum, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         da = None
         if da_p is not None:
             gacc = ctx.gacc
@@ -181,7 +183,7 @@ class _SegBranchFn(torch.autograd.Function):
                     gacc["ev"] = torch.cuda.Event()
                     gacc["ev"].record()
         return ((logical(dx_p, ctx.cin) if dx_p is not None else None), da, (dw_lat.to(w_lat.dtype) if ctx.has_lat else None),
-                dw_out.to(w_out.dtype), db_out, dw_head, db_head, None)
+                dw_out.to(w_out.dtype), db_out, dw_head.to(w_head.dtype), db_head, None)
 
 
 class _SegTail(torch.autograd.Function):

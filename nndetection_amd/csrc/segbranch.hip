@@ -192,6 +192,72 @@ __global__ __launch_bounds__(256) void k_segbranch_bwd(const float* __restrict__
     if (threadIdx.x == 0) atomicAdd(&dsum[blockIdx.x % SB_REPL], red);
 }
 
+// All parameter gradients of the branch from the one-channel correlations (tiny tensors, one workgroup): with Ec[c][t] = E[c][26 - t]
+// (E = what the stem weight-gradient kernel returns for (d1, tensor): sum_p tensor[p][c] d1[p + t - 1]),
+//   Ef[c][t]       = Ec_x[c][t] + sum_k W_lat[c][k] Ec_a[k][t]           (correlation of d1 with the convolution's full input)
+//   dW_out[o][c][t] = wd[o] Ef[c][t],  db_out[o] = wd[o] S,  S = sum(d1)
+//   Gy[o]          = sum_{c,t} W_out[o][c][t] Ef[c][t] + b_out[o] S       ->  dW_head = (-Gy, +Gy), db_head = (-S, +S)
+//   dW_lat[c][k]   = sum_t wc[c][t] Ec_a[k][t],  wc[c][t] = sum_o wd[o] W_out[o][c][t]
+// Replaces ~15 einsum / flip / mul launches of the autograd thread in front of the head trunks' backward chain.
+__global__ __launch_bounds__(256) void k_segbranch_params(const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                                          const float* __restrict__ w_lat, const float* __restrict__ wd,
+                                                          const float* __restrict__ e_x, const float* __restrict__ e_a,
+                                                          const double* __restrict__ dsum, int nrep, float* __restrict__ dw_out,
+                                                          float* __restrict__ db_out, float* __restrict__ dw_lat, float* __restrict__ dw_head,
+                                                          float* __restrict__ db_head) {
+    __shared__ float ef[32 * 27], eca[32 * 27], wc[32 * 27], swd[32], red[256];
+    __shared__ float S;
+    const int tid = threadIdx.x;
+    if (tid < 32) swd[tid] = wd[tid];
+    if (tid == 0) { double a = 0.0; for (int i = 0; i < nrep; ++i) a += dsum[i]; S = (float)a; }
+    for (int i = tid; i < 864; i += 256) eca[i] = e_a ? e_a[(i / 27) * 27 + 26 - i % 27] : 0.f;
+    __syncthreads();
+    for (int i = tid; i < 864; i += 256) {
+        const int c = i / 27, t = i % 27;
+        float v = e_x[c * 27 + 26 - t];
+        if (w_lat) for (int k = 0; k < 32; ++k) v = fmaf(w_lat[c * 32 + k], eca[k * 27 + t], v);
+        ef[i] = v;
+        float w = 0.f;
+        for (int o = 0; o < 32; ++o) w = fmaf(swd[o], w_out[(o * 32 + c) * 27 + t], w);
+        wc[i] = w;
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * 864; i += 256) dw_out[i] = swd[i / 864] * ef[i % 864];
+    if (tid < 32 && db_out) db_out[tid] = swd[tid] * S;
+    if (dw_lat)
+        for (int i = tid; i < 1024; i += 256) {
+            const int c = i >> 5, k = i & 31;
+            float v = 0.f;
+            for (int t = 0; t < 27; ++t) v = fmaf(wc[c * 27 + t], eca[k * 27 + t], v);
+            dw_lat[i] = v;
+        }
+    // Gy[o]: 8 threads per output channel o, 108 products each, reduced through LDS
+    {
+        const int o = tid >> 3, part = tid & 7;
+        float v = 0.f;
+        for (int i = part; i < 864; i += 8) v = fmaf(w_out[o * 864 + i], ef[i], v);
+        red[tid] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float g = 0.f;
+        for (int j = 0; j < 8; ++j) g += red[tid * 8 + j];
+        if (b_out) g = fmaf(b_out[tid], S, g);
+        dw_head[tid] = -g; dw_head[32 + tid] = g;
+    }
+    if (tid == 0 && db_head) { db_head[0] = -S; db_head[1] = S; }
+}
+
+extern "C" int nndet_segbranch_param_grads(const float* w_out, const float* b_out, const float* w_lat, const float* wd, const float* e_x,
+                                           const float* e_a, const double* dsum, int32_t n_dsum, float* dw_out, float* db_out,
+                                           float* dw_lat, float* dw_head, float* db_head, void* stream) {
+    if (!w_out || !wd || !e_x || !dsum || n_dsum <= 0 || !dw_out || !dw_head) return NNDET_EINVAL;
+    if ((w_lat == nullptr) != (e_a == nullptr) || (w_lat == nullptr) != (dw_lat == nullptr)) return NNDET_EINVAL;
+    k_segbranch_params<<<1, 256, 0, as_stream(stream)>>>(w_out, b_out, w_lat, wd, e_x, e_a, dsum, n_dsum, dw_out, db_out, dw_lat, dw_head, db_head);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int nndet_segbranch_replicas(void) { return SB_REPL; }
 
 static int segbranch_launch(int32_t dtype, const void* x, const void* w_packed, const void* x2, const void* w2_packed, int32_t N, int32_t D,
