@@ -502,15 +502,16 @@ int nndet_head_gather_backward(int32_t dtype, const NndetHeadLevels* levels, int
  *     head buffer, first channel a * G, values x the level's Scale (levels->scale, may be NULL); also written into dy_zeroed
  *     [rows][cout_p] (dtype, zero-filled by the caller), which thereby is the complete dense gradient; levels->dscale[l] += d(Scale)
  *     from y = the raw conv output. level_row0_host[l] = first row of level l (rows of level l: row0 + n * points + position).
- *   nndet_conv_out_sparse_backward: data gradient dx [rows][cin_p] (dtype; via dx32_zeroed, an fp32 scratch of the same shape), weight
+ *   nndet_conv_out_sparse_backward: data gradient dx_zeroed [rows][cin_p] (dtype, ZERO-FILLED by the caller; only the rows the entries
+ *     touch are written, via dx32_scratch, an fp32 scratch of the same shape that needs no initialisation), weight
  *     gradient dw [cout][cin][27] and dbias [cout] (fp32, ACCUMULATED with atomics) of the 3x3x3 / stride 1 / pad 1 convolution from the
  *     entries; x = the conv input (ragged, NndetItems), w_f32 = its weights [cout][cin][27] fp32. */
 int nndet_head_out_sparse_scatter(int32_t dtype, const NndetHeadLevels* levels, int32_t N, int32_t A, int32_t G,
                                   const int64_t* level_row0_host, const int64_t* idx, const float* val, int32_t K, const void* y,
                                   int32_t cout_p, void* dy_zeroed, int32_t* rows_out, int32_t* c0_out, float* vals_out, void* stream);
 int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetItems* items, const int32_t* rows, const int32_t* c0,
-                                   const float* vals, int32_t K, int32_t G, const void* x, const float* w_f32, float* dx32_zeroed,
-                                   void* dx, float* dw, float* dbias, void* stream);
+                                   const float* vals, int32_t K, int32_t G, const void* x, const float* w_f32, float* dx32_scratch,
+                                   void* dx_zeroed, float* dw, float* dbias, void* stream);
 /* Forward of such an output convolution at the K anchors idx[] only: out [K][G] = Scale_l * (conv(x)[row, a*G .. a*G+G-1] + bias),
  * raw_out [K][G] the unscaled values (for d(Scale)), rows_out / c0_out as nndet_head_out_sparse_scatter emits them and level_out the
  * pyramid level of each entry (-1 for unused slots, whose outputs are 0). Used for the regressor in training steps: nndet/arch/heads/comb.py:383-401 reads box_deltas at

@@ -191,8 +191,8 @@ class _RegSparseFn(torch.autograd.Function):
         gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
         dw = gbuf[:nw].view(weight.shape)
         dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
-        dx32 = torch.zeros((meta.rows, desc.cin_p), dtype=torch.float32, device=dev)
-        dx = torch.empty_like(t2d)
+        dx32 = torch.empty((meta.rows, desc.cin_p), dtype=torch.float32, device=dev)     # scratch: only the touched rows are used
+        dx = torch.zeros_like(t2d)
         L.call("nndet_conv_out_sparse_backward", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(rows), L.ptr(c0), L.ptr(vals),
                int(rows.numel()), G, L.ptr(t2d), L.ptr(w32), L.ptr(dx32), L.ptr(dx), L.ptr(dw), L.ptr(dbias), L.stream())
         return (dx, dw.to(weight.dtype), dbias, None, None) + dsc_out

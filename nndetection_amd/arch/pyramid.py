@@ -152,8 +152,8 @@ class _ItemsConvFn(torch.autograd.Function):
         if hint is not None:
             # sparse data + weight gradient of this output convolution (csrc/sparse_out.hip); dw / dbias are views of the zeroed pool
             w32 = rounded_w32(mod, weight, dt)                               # the values the forward kernel multiplied with
-            dx32 = torch.zeros((meta.rows, desc.cin_p), dtype=torch.float32, device=dev)
-            dx = torch.empty_like(x2d)
+            dx32 = torch.empty((meta.rows, desc.cin_p), dtype=torch.float32, device=dev)     # scratch: only the touched rows are used
+            dx = torch.zeros_like(x2d)
             L.call("nndet_conv_out_sparse_backward", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(hint["rows"]), L.ptr(hint["c0"]),
                    L.ptr(hint["vals"]), int(hint["rows"].numel()), int(hint["G"]), L.ptr(x2d), L.ptr(w32), L.ptr(dx32), L.ptr(dx),
                    L.ptr(dw), L.ptr(dbias), L.stream())

@@ -10,9 +10,9 @@
 //   k_ho_scatter : (anchor index, gradient values) entries -> (row of the ragged head buffer, first channel, values x level Scale),
 //                  writes them into the (zero-filled) DENSE gradient buffer as well, so that tensor stays a valid gradient for any
 //                  consumer that does not know about the sparse form; d(Scale) of the regressor (nndet/arch/layers/scale.py:21-43).
-//   k_ho_backward: per entry and tap: dX32[row + tap] += sum_g v_g W[c0+g][:, tap] (fp32 atomics), dW[c0+g][:, tap] += v_g X[row + tap],
-//                  dbias[c0+g] += v_g. One workgroup per entry, one thread per input channel.
-//   k_ho_convert : fp32 scratch -> activation dtype.
+//   k_ho_backward: one workgroup per (entry, tap), one thread per input channel, three passes over the SAME index set: zero the fp32
+//                  scratch rows the entries touch, dX32[row + tap] += sum_g v_g W[c0+g][:, tap] (fp32 atomics) with dW[c0+g][:, tap] += v_g
+//                  X[row + tap] and dbias[c0+g] += v_g, convert the touched rows into the (zero-filled) dense gradient.
 // Replaces, for these two layers only, nndet_head_gather_backward + nndet_conv3d_backward_data_items +
 // nndet_conv3d_backward_weight_items. Same mathematics; the values are not rounded to 16 bits on the way (closer to fp32).
 #include "common.h"
@@ -64,29 +64,41 @@ __global__ void k_ho_scatter(const int64_t* __restrict__ idx, const float* __res
     c0s[k] = c0;
 }
 
-// grid K, block 128 (thread = input channel, looped)
-template <typename T>
+// grid (K, 27), block 128 (thread = input channel, looped): one workgroup per (entry, tap) -- K x 27 ~ 1 000 ... 3 500 small workgroups
+// instead of K long ones (the per-entry loop over 27 taps ran 55 - 75 us on 42 ... 127 workgroups, on the critical chain between the
+// loss and the head trunks' backward pass). MODE 0: zero the fp32 scratch rows this (entry, tap) touches; MODE 1: accumulate;
+// MODE 2: convert the touched rows to the activation type (rows touched by several entries are written several times with the same
+// value). Only touched rows of the scratch are ever read, so it needs no dense fill and no dense conversion pass.
+template <typename T, int MODE>
 __global__ __launch_bounds__(128) void k_ho_backward(const int32_t* __restrict__ rows, const int32_t* __restrict__ c0s,
                                                      const float* __restrict__ vals, int G, const HoItems It, const T* __restrict__ x,
                                                      int cin, int cin_p, const float* __restrict__ w, int cout, float* __restrict__ dx32,
-                                                     float* __restrict__ dw, float* __restrict__ dbias) {
-    const int k = blockIdx.x;
+                                                     T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ dbias) {
+    const int k = blockIdx.x, t = blockIdx.y;
     const int row = rows[k];
     if (row < 0) return;                                                     // uniform
-    const int c0 = c0s[k];
-    float v[8];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) v[g] = (g < G && c0 + g < cout) ? vals[(int64_t)k * G + g] : 0.f;
     int it = 0;
     while (it + 1 < It.n && row >= It.row_off[it + 1]) ++it;
     const int D = It.dims[it][0], H = It.dims[it][1], W = It.dims[it][2];
     const int pos = row - (int)It.row_off[it];
     const int pd = pos / (H * W), ph = (pos / W) % H, pw = pos % W;
-    if (dbias && (int)threadIdx.x < G && c0 + (int)threadIdx.x < cout) atomicAdd(dbias + c0 + threadIdx.x, v[threadIdx.x]);
-    for (int t = 0; t < 27; ++t) {
-        const int qd = pd + t / 9 - 1, qh = ph + (t / 3) % 3 - 1, qw = pw + t % 3 - 1;
-        if ((unsigned)qd >= (unsigned)D || (unsigned)qh >= (unsigned)H || (unsigned)qw >= (unsigned)W) continue;       // zero padding
-        const int64_t qrow = It.row_off[it] + ((int64_t)qd * H + qh) * W + qw;
+    const int qd = pd + t / 9 - 1, qh = ph + (t / 3) % 3 - 1, qw = pw + t % 3 - 1;
+    const bool inside = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
+    const int c0 = c0s[k];
+    if constexpr (MODE == 1) {
+        if (t == 13 && dbias && (int)threadIdx.x < G && c0 + (int)threadIdx.x < cout)          // (the centre tap is always inside)
+            atomicAdd(dbias + c0 + threadIdx.x, vals[(int64_t)k * G + threadIdx.x]);
+    }
+    if (!inside) return;                                                     // zero padding (uniform)
+    const int64_t qrow = It.row_off[it] + ((int64_t)qd * H + qh) * W + qw;
+    if constexpr (MODE == 0) {
+        for (int ci = threadIdx.x; ci < cin_p; ci += blockDim.x) dx32[qrow * cin_p + ci] = 0.f;
+    } else if constexpr (MODE == 2) {
+        for (int ci = threadIdx.x; ci < cin_p; ci += blockDim.x) dx[qrow * cin_p + ci] = Elem<T>::st(dx32[qrow * cin_p + ci]);
+    } else {
+        float v[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v[g] = (g < G && c0 + g < cout) ? vals[(int64_t)k * G + g] : 0.f;
         for (int ci = threadIdx.x; ci < cin; ci += blockDim.x) {
             const float xv = Elem<T>::ld(x[qrow * cin_p + ci]);
             float acc = 0.f;
@@ -100,15 +112,6 @@ __global__ __launch_bounds__(128) void k_ho_backward(const int32_t* __restrict__
             }
             atomicAdd(dx32 + qrow * cin_p + ci, acc);
         }
-    }
-}
-
-template <typename T>
-__global__ void k_ho_convert(const float* __restrict__ src, T* __restrict__ dst, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 f = reinterpret_cast<const float4*>(src)[i];
-        dst[4 * i + 0] = Elem<T>::st(f.x); dst[4 * i + 1] = Elem<T>::st(f.y);
-        dst[4 * i + 2] = Elem<T>::st(f.z); dst[4 * i + 3] = Elem<T>::st(f.w);
     }
 }
 
@@ -289,35 +292,26 @@ extern "C" int nndet_head_out_sparse_scatter(int32_t dtype, const NndetHeadLevel
 
 extern "C" int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetItems* items, const int32_t* rows, const int32_t* c0,
                                               const float* vals, int32_t K, int32_t G, const void* x, const float* w_f32,
-                                              float* dx32_zeroed, void* dx, float* dw, float* dbias, void* stream) {
+                                              float* dx32_scratch, void* dx_zeroed, float* dw, float* dbias, void* stream) {
     if (!c || !items || items->n_items < 1 || items->n_items > NNDET_MAX_ITEMS || K < 0 || G <= 0 || G > 8) return NNDET_EINVAL;
     if (c->transposed || c->cin_p % 32 || c->cout_p % 32) return NNDET_EINVAL;
     for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 1 || c->p[i] != 1) return NNDET_EINVAL;
-    if (!x || !w_f32 || !dx32_zeroed || !dx || !dw) return NNDET_EINVAL;
+    if (!x || !w_f32 || !dx32_scratch || !dx_zeroed || !dw) return NNDET_EINVAL;
+    if (K == 0) return 0;
+    if (!rows || !c0 || !vals) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
     HoItems It;
-    memset(&It, 0, sizeof(It));
-    It.n = items->n_items;
-    int64_t total_rows = 0;
-    for (int i = 0; i < items->n_items; ++i) {
-        for (int a = 0; a < 3; ++a) It.dims[i][a] = items->dims[i][a];
-        It.row_off[i] = items->row_off[i];
-        const int64_t end = items->row_off[i] + (int64_t)items->dims[i][0] * items->dims[i][1] * items->dims[i][2];
-        if (end > total_rows) total_rows = end;
-    }
-    if (K > 0) {
-        if (!rows || !c0 || !vals) return NNDET_EINVAL;
-        if (c->dtype == NNDET_BF16) k_ho_backward<bf16_t><<<K, 128, 0, st>>>(rows, c0, vals, G, It, (const bf16_t*)x, c->cin, c->cin_p, w_f32, c->cout, dx32_zeroed, dw, dbias);
-        else if (c->dtype == NNDET_F16) k_ho_backward<f16_t><<<K, 128, 0, st>>>(rows, c0, vals, G, It, (const f16_t*)x, c->cin, c->cin_p, w_f32, c->cout, dx32_zeroed, dw, dbias);
-        else if (c->dtype == NNDET_F32) k_ho_backward<float><<<K, 128, 0, st>>>(rows, c0, vals, G, It, (const float*)x, c->cin, c->cin_p, w_f32, c->cout, dx32_zeroed, dw, dbias);
-        else return NNDET_EINVAL;
-        LAUNCH_CHECK();
-    }
-    const int64_t n4 = total_rows * c->cin_p / 4;
-    const unsigned nb = (unsigned)(ceil_div64(n4, 256) < 4096 ? ceil_div64(n4, 256) : 4096);
-    if (c->dtype == NNDET_BF16) k_ho_convert<bf16_t><<<nb, 256, 0, st>>>(dx32_zeroed, (bf16_t*)dx, n4);
-    else if (c->dtype == NNDET_F16) k_ho_convert<f16_t><<<nb, 256, 0, st>>>(dx32_zeroed, (f16_t*)dx, n4);
-    else k_ho_convert<float><<<nb, 256, 0, st>>>(dx32_zeroed, (float*)dx, n4);
+    ho_items(items, &It);
+    const dim3 grid(K, 27);
+#define HO_BWD(T_, MODE_) k_ho_backward<T_, MODE_><<<grid, 128, 0, st>>>(rows, c0, vals, G, It, (const T_*)x, c->cin, c->cin_p, w_f32, c->cout, \
+                                                                         dx32_scratch, (T_*)dx_zeroed, dw, dbias)
+#define HO_ALL(T_) do { HO_BWD(T_, 0); HO_BWD(T_, 1); HO_BWD(T_, 2); } while (0)
+    if (c->dtype == NNDET_BF16) HO_ALL(bf16_t);
+    else if (c->dtype == NNDET_F16) HO_ALL(f16_t);
+    else if (c->dtype == NNDET_F32) HO_ALL(float);
+    else return NNDET_EINVAL;
+#undef HO_ALL
+#undef HO_BWD
     LAUNCH_CHECK();
     return 0;
 }
