@@ -675,13 +675,16 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
 #pragma unroll
         for (int h = 0; h < NSTEP; ++h) {
             const int tp = h / SPT;
-            if (h % SPT == 0 && tp + WD < 27) {
+#ifndef IG3_DBG
+#define IG3_DBG 0       // timing experiments only (wrong results): 1 no weight loads in the tap loop, 2 no LDS fragment reads in it
+#endif
+            if (!(IG3_DBG & 1) && h % SPT == 0 && tp + WD < 27) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     af[(tp + WD) % (WD + 1)][i] =
                         __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff[i], tap_off(tp + WD), 0));
             }
-            if (h + 1 < NSTEP) lds_step(h + 1, bf[(h + 1) & 1]);
+            if (!(IG3_DBG & 2) && h + 1 < NSTEP) lds_step(h + 1, bf[(h + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -1136,8 +1139,8 @@ struct Plan {
 //      tools/probe_loop.hip where the NT = 8 loops stop at ~1000 (the weight buffer loads saturate the vector memory pipe).
 //      8 / 9 / 10: strided, 64 points per workgroup (halo 9^3 x 64 B = 46 KB at stride 2 -> 3 workgroups per CU instead of 1 at
 //      the 88 KB of the 128-point tile): 64 rows as 2 x 2 waves (8), 64 rows as 4 row waves x 64 points (9), 32 rows (10)
-static const int CFG_ROWS[11] = {32, 64, 64, 32, 32, 32, 64, 64, 64, 64, 32};
-static const int CFG_PTS[11] = {512, 256, 128, 128, 256, 512, 256, 512, 64, 64, 64};
+static const int CFG_ROWS[12] = {32, 64, 64, 32, 32, 32, 64, 64, 64, 64, 32, 128};
+static const int CFG_PTS[12] = {512, 256, 128, 128, 256, 512, 256, 512, 64, 64, 64, 512};
 
 static bool choose_tile(const int Lmax[3], const int in_step[3], const int span[3], int points, int maxp, int T[3], int H[3]) {
     double best = 1e300;
@@ -1316,6 +1319,9 @@ static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = f
             const char* nt_env = getenv("NNDET_IGEMM_NT");            // 8 / 16: force one variant (tests, experiments)
             const int force = nt_env ? atoi(nt_env) : 0;
             if (force == 8 || (force != 16 && cost(4, 1.0, 768) < cost(8, 1.6, 512))) { st[0] = 4; spec_cfg = 6; }
+            // experimental (NNDET_IGEMM_R128=1): 128 rows x 512 points per workgroup, ONE workgroup per CU with 512 registers per wave
+            const char* r128 = getenv("NNDET_IGEMM_R128");
+            if (r128 && atoi(r128) == 1 && a.Cy % 128 == 0 && spec_cfg == 7) spec_cfg = 11;
         }
         double pg = 1.0, ps = 1.0;
         for (int i = 0; i < 3; ++i) { pg *= (double)a.nt[i] * a.T[i]; ps *= (double)ceil_div(Lmax[i], st[i]) * st[i]; }
@@ -1336,7 +1342,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = f
     // SIMD (50 - 300 TFLOP/s, profiles/round3_v4_kernel_stats_by_grid.txt). Splitting the chunks over `ksplit` workgroups multiplies
     // the resident waves and divides the serial chain. NNDET_IGEMM_SPLITK=0 disables it, =N forces N (tests).
     P->ksplit = 1; P->splitk_bytes = 0;
-    const bool generic = P->cfg < 5 || P->cfg >= 8;              // k_igemm configurations (k_ig3 / k_ig3r have no split-K epilogue)
+    const bool generic = P->cfg < 5 || (P->cfg >= 8 && P->cfg <= 10);              // k_igemm configurations (k_ig3 / k_ig3r have no split-K epilogue)
     const int nchunk = a.Cx / KCb;
     const int64_t wgs = (int64_t)P->grid.x * P->grid.y * P->grid.z;
     const char* sk_env = getenv("NNDET_IGEMM_SPLITK");
@@ -1372,6 +1378,7 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
         case 5: k_ig3<T, 1, 2, 8, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
         case 6: k_ig3<T, 2, 2, 8, 3, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
         case 7: k_ig3<T, 2, 2, 16, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
+        case 11: k_ig3<T, 2, 4, 16, 1, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
         default: k_igemm<T, 1, 2, 4, 16, 4, false, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
     }
     LAUNCH_CHECK();
@@ -1404,7 +1411,7 @@ static int ensure_attrs() {
     rc |= set_lds_attr<float, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<float, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<float, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<float, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<float, 1, 2, 4, 16, 4>();
     rc |= set_lds_attr<bf16_t, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<bf16_t, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<bf16_t, 2, 1, 2, 16, 4, true>();
     rc |= set_lds_attr<float, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<float, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<float, 2, 1, 2, 16, 4, true>();
-    rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<bf16_t, 2, 2, 16, 2>();
+    rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<bf16_t, 2, 2, 16, 2>(); rc |= set_lds_attr3<bf16_t, 2, 4, 16, 1>();
     rc |= set_lds_attr3<float, 1, 2, 8, 2>(); rc |= set_lds_attr3<float, 2, 2, 8, 3>(); rc |= set_lds_attr3<float, 2, 2, 16, 2>();
     rc |= set_lds_attr<f16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<f16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<f16_t, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<f16_t, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<f16_t, 1, 2, 4, 16, 4>();
     rc |= set_lds_attr<f16_t, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<f16_t, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<f16_t, 2, 1, 2, 16, 4, true>();
@@ -1525,6 +1532,7 @@ static int launch_items(const Plan& P, const IgItems& it, hipStream_t st) {
         case 5: k_ig3<T, 1, 2, 8, 2, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
         case 6: k_ig3<T, 2, 2, 8, 3, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
         case 7: k_ig3<T, 2, 2, 16, 2, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
+        case 11: k_ig3<T, 2, 4, 16, 1, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
         default: return NNDET_EINVAL;
     }
     LAUNCH_CHECK();
@@ -1557,7 +1565,7 @@ int igemm_items_run(const NndetConv* c, const NndetItems* it, int kind, const vo
     Plan P;
     rc = build_plan(&cc, kind, &P, true);
     if (rc) return rc;
-    if (P.cfg < 5 || P.cfg > 7) return NNDET_EINVAL;
+    if ((P.cfg < 5 || P.cfg > 7) && P.cfg != 11) return NNDET_EINVAL;
     rc = ensure_attrs();
     if (rc) return rc;
     P.a.x = x; P.a.w = w; P.a.bias = bias; P.a.y = y; P.a.stats = stats; P.a.res = nullptr; P.a.ss = nullptr; P.a.ss_relu = 0;
