@@ -540,7 +540,17 @@ __device__ __forceinline__ float dpp_row_sum(float v) {   // sum over the 16 lan
     return v;
 }
 
-template <typename T, int WR, int MT, int NT, int MINW, bool AFF = false, bool ITEMS = false>
+// one wave-instruction of LDS-DMA: 64 lanes x 16 bytes from buffer offsets `voff` (out-of-range offsets write zeros: the conv padding)
+// to the 1 KB at LDS byte address lds_dst (wave-uniform). hipcc neither preserves M0 around asm nor counts the load in its vmcnt
+// bookkeeping: M0 is written in the same statement, and the completion is waited for by hand (s_waitcnt vmcnt(0) before the barrier).
+__device__ __forceinline__ void ig3_lds_dma16(__amdgpu_buffer_rsrc_t rs, int voff, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+
+// DMA (128-row configuration, ONE workgroup per CU): the halo of channel chunk kc + 1 goes global -> LDS by LDS-DMA into the second
+// 64 KB buffer WHILE the taps of chunk kc are multiplied -- one 1 KB piece per tap, issued from inside the tap loop (vmcnt is in-order:
+// pieces issued in one go in front of a tap's weight loads would be waited for together with them), weight fragments 4 taps ahead.
+template <typename T, int WR, int MT, int NT, int MINW, bool AFF = false, bool ITEMS = false, bool DMA = false>
 __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems IT) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
@@ -622,10 +632,40 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
     for (int i = 0; i < MT; ++i) voff[i] = ((row0 + (wr * MT + i) * 16 + li) * A.Cx + q * EPL) * (int)sizeof(T);
 
     const int nchunk = A.Cx / KC;
-    for (int kc = 0; kc < nchunk; ++kc) {
+    // DMA staging: wave wv moves pieces wv * NPC .. wv * NPC + NPC - 1 (1 KB each); LDS granule G = piece * 64 + lane holds halo row
+    // G / ROWP, voxel (G % ROWP) / 4, 16-byte part ((G % 4) ^ (row parity << 1)) -- the layout the VGPR staging below produces, with the
+    // swizzle applied to the SOURCE address because the LDS-DMA destination is lane-linear
+    constexpr int NPC = DMA ? (HV4 + 255) / 256 : 1;
+    constexpr int HBUF = 65536;
+    static_assert(!DMA || (HV4 * 16 <= HBUF && !AFF && sizeof(T) == 2), "LDS-DMA staging: 16-bit types, halo <= 64 KB, no affine on load");
+    int poff[NPC];
+    if constexpr (DMA) {
+        const int vox_bytes = A.Cx * (int)sizeof(T);
+#pragma unroll
+        for (int p = 0; p < NPC; ++p) {
+            const int G = (wv * NPC + p) * 64 + lane;
+            const int row = G / ROWP, col = G - row * ROWP;
+            const int hd = row / HH, hh = row - hd * HH, hw = col >> 2, part = (col & 3) ^ ((row & 1) << 1);
+            const int id = l0d - 1 + hd, ih = l0h - 1 + hh, iw = l0w - 1 + hw;
+            const bool ok = G < HV4 && (unsigned)id < (unsigned)I0 && (unsigned)ih < (unsigned)I1 && (unsigned)iw < (unsigned)I2;
+            poff[p] = ok ? ((id * I1 + ih) * I2 + iw) * vox_bytes + part * 16 : (int32_t)0x80000000;
+        }
+    }
+    auto dma_piece = [&](int p, int kc_, int buf) {
+        if constexpr (DMA)
+            ig3_lds_dma16(xrs, poff[p] < 0 ? poff[p] : poff[p] + kc_ * KC * (int)sizeof(T), (uint32_t)(buf * HBUF + (wv * NPC + p) * 1024));
+    };
+    if constexpr (DMA) {
+#pragma unroll
+        for (int p = 0; p < NPC; ++p) dma_piece(p, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    for (int kc = 0; kc < nchunk; ++kc) {
+        if constexpr (!DMA) __syncthreads();
         float asc[EPL], ash[EPL];              // deferred input norm: this thread stages part (cp & 3) of every halo voxel (AFF variants)
         if constexpr (AFF) load_affine<EPL>(A.ss, n, A.Cx, kc * KC + (cp & 3) * EPL, asc, ash);
+        if constexpr (!DMA) {
 #pragma unroll
         for (int s0 = 0; s0 < MAXP; s0 += 8) {
             u32x4 v[8];
@@ -644,11 +684,13 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
             }
         }
         __syncthreads();
+        }
+        const char* const hbase = smem + (DMA ? (kc & 1) * HBUF : 0);       // the halo buffer of this chunk
         const int wk = tap0_off + kc * KC * (int)sizeof(T);
         // Weight fragments are prefetched WD taps ahead into a ring of WD + 1 register sets. hipcc's scheduler sinks such
         // loads down to their first use (then every tap waits a full L2 round trip with vmcnt(0)), so the issue point is
         // pinned with sched_barrier: loads of tap tp + WD, barrier, LDS reads + MFMAs of tap tp.
-        constexpr int WD = 2;
+        constexpr int WD = DMA ? 4 : 2;
         u32x4 af[WD + 1][MT];
         constexpr int BORD[3] = {0, 1, 2};
         auto tap_off = [&](int tp) { return wk + ((tp / 9 * 3 + BORD[tp % 3]) * 3 + (tp / 3) % 3) * tap_step; };
@@ -664,7 +706,7 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
         auto lds_step = [&](int h, u32x4* dst) {
             const int tp = h / SPT, j0 = (h % SPT) * 4;
             const int a = tp / 9, c = (tp / 3) % 3, b = BORD[tp % 3];
-            const char* sb = smem + ((b & 1) ? sb1off : sb0off);
+            const char* sb = hbase + ((b & 1) ? sb1off : sb0off);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = j0 + jj;
@@ -684,6 +726,9 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
                     af[(tp + WD) % (WD + 1)][i] =
                         __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff[i], tap_off(tp + WD), 0));
             }
+            if constexpr (DMA) {                           // one piece of the NEXT chunk's halo per tap (NPC <= 16 < 27 taps)
+                if (h % SPT == 1 && tp < NPC && kc + 1 < nchunk) dma_piece(tp, kc + 1, (kc + 1) & 1);
+            }
             if (!(IG3_DBG & 2) && h + 1 < NSTEP) lds_step(h + 1, bf[(h + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -691,6 +736,10 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) M::mma(af[tp % (WD + 1)][i], bf[h & 1][jj], acc[i][(h % SPT) * 4 + jj]);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (DMA) {                               // the next chunk's halo has landed; everybody is done with this one
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
     }
 
@@ -1321,7 +1370,7 @@ static int build_plan(const NndetConv* c, int kind, Plan* P, bool force_spec = f
             if (force == 8 || (force != 16 && cost(4, 1.0, 768) < cost(8, 1.6, 512))) { st[0] = 4; spec_cfg = 6; }
             // experimental (NNDET_IGEMM_R128=1): 128 rows x 512 points per workgroup, ONE workgroup per CU with 512 registers per wave
             const char* r128 = getenv("NNDET_IGEMM_R128");
-            if (r128 && atoi(r128) == 1 && a.Cy % 128 == 0 && spec_cfg == 7) spec_cfg = 11;
+            if (r128 && atoi(r128) == 1 && a.Cy % 128 == 0 && spec_cfg == 7 && nndet_is16(c->dtype) && !c->in_affine) spec_cfg = 11;
         }
         double pg = 1.0, ps = 1.0;
         for (int i = 0; i < 3; ++i) { pg *= (double)a.nt[i] * a.T[i]; ps *= (double)ceil_div(Lmax[i], st[i]) * st[i]; }
@@ -1378,7 +1427,7 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
         case 5: k_ig3<T, 1, 2, 8, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
         case 6: k_ig3<T, 2, 2, 8, 3, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
         case 7: k_ig3<T, 2, 2, 16, 2, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
-        case 11: k_ig3<T, 2, 4, 16, 1, AFF><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
+        case 11: if constexpr (!AFF && sizeof(T) == 2) { k_ig3<T, 2, 4, 16, 1, false, false, true><<<P.grid, 256, 2 * 65536, st>>>(P.a, g_no_items); break; } else return NNDET_EINVAL;
         default: k_igemm<T, 1, 2, 4, 16, 4, false, AFF><<<P.grid, 256, P.lds, st>>>(P.a); break;
     }
     LAUNCH_CHECK();
@@ -1403,15 +1452,24 @@ static int set_lds_attr3() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     return rc;
 }
+template <typename T>
+static int set_lds_attr3_dma() {
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, 2, 4, 16, 1, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, 2, 4, 16, 1, false, true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+    return rc;
+}
 static int g_attr_done = 0;
 static int ensure_attrs() {
     if (g_attr_done) return 0;
     int rc = 0;
+    rc |= set_lds_attr3_dma<bf16_t>(); rc |= set_lds_attr3_dma<f16_t>();
     rc |= set_lds_attr<bf16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<bf16_t, 1, 2, 4, 16, 4>();
     rc |= set_lds_attr<float, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<float, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<float, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<float, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<float, 1, 2, 4, 16, 4>();
     rc |= set_lds_attr<bf16_t, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<bf16_t, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<bf16_t, 2, 1, 2, 16, 4, true>();
     rc |= set_lds_attr<float, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<float, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<float, 2, 1, 2, 16, 4, true>();
-    rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<bf16_t, 2, 2, 16, 2>(); rc |= set_lds_attr3<bf16_t, 2, 4, 16, 1>();
+    rc |= set_lds_attr3<bf16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<bf16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<bf16_t, 2, 2, 16, 2>();
     rc |= set_lds_attr3<float, 1, 2, 8, 2>(); rc |= set_lds_attr3<float, 2, 2, 8, 3>(); rc |= set_lds_attr3<float, 2, 2, 16, 2>();
     rc |= set_lds_attr<f16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<f16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<f16_t, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<f16_t, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<f16_t, 1, 2, 4, 16, 4>();
     rc |= set_lds_attr<f16_t, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<f16_t, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<f16_t, 2, 1, 2, 16, 4, true>();
@@ -1532,7 +1590,7 @@ static int launch_items(const Plan& P, const IgItems& it, hipStream_t st) {
         case 5: k_ig3<T, 1, 2, 8, 2, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
         case 6: k_ig3<T, 2, 2, 8, 3, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
         case 7: k_ig3<T, 2, 2, 16, 2, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
-        case 11: k_ig3<T, 2, 4, 16, 1, false, true><<<P.grid, 256, P.lds, st>>>(P.a, it); break;
+        case 11: if constexpr (sizeof(T) == 2) { k_ig3<T, 2, 4, 16, 1, false, true, true><<<P.grid, 256, 2 * 65536, st>>>(P.a, it); break; } else return NNDET_EINVAL;
         default: return NNDET_EINVAL;
     }
     LAUNCH_CHECK();
