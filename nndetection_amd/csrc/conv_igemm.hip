@@ -215,6 +215,9 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
     const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + wr * MT * 16 + li) * A.Cx + q * EPL;
     const int nchunk_all = A.Cx / KC;
     const int kc_begin = ks_i * nchunk_all / ksp, nchunk = (ks_i + 1) * nchunk_all / ksp;      // this workgroup's share of the chunks
+#ifndef IGP_DBG
+#define IGP_DBG 0       // timing experiments only (wrong results): 1 no weight loads in the tap loop, 2 no halo loads, 4 no LDS fragment reads
+#endif
     if constexpr (PIPE) {
         const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.w), 0, A.wbytes, 0x00020000);
         int voff[MT];
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 #pragma unroll
                 for (int b = 0; b < 8; ++b) {
                     const int o = goff[s0 + b];
+                    if (IGP_DBG & 2) v[b] = u32x4{(unsigned)o, 1u, 2u, 3u}; else
                     v[b] = *reinterpret_cast<const u32x4*>(xn + (o < 0 ? 0 : o) + kc * KC);
                 }
 #pragma unroll
@@ -251,15 +255,24 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
             u32x4 afr[3][MT], bf0[NH], bf1[NT - NH];
             auto load_w = [&](const IgTapX& t, u32x4* a_) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a_[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff[i], t.woff + kcoff, 0));
+                for (int i = 0; i < MT; ++i) {
+                    if (IGP_DBG & 1) a_[i] = u32x4{(unsigned)t.woff, (unsigned)voff[i], 2u, 3u}; else
+                    a_[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff[i], t.woff + kcoff, 0));
+                }
             };
             auto lds_h0 = [&](const IgTapX& t) {
 #pragma unroll
-                for (int j = 0; j < NH; ++j) bf0[j] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ t.flip) + t.toff));
+                for (int j = 0; j < NH; ++j) {
+                    if (IGP_DBG & 4) bf0[j] = u32x4{(unsigned)(boff[j] ^ t.flip), (unsigned)t.toff, 2u, 3u}; else
+                    bf0[j] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ t.flip) + t.toff));
+                }
             };
             auto lds_h1 = [&](const IgTapX& t) {
 #pragma unroll
-                for (int j = NH; j < NT; ++j) bf1[j - NH] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ t.flip) + t.toff));
+                for (int j = NH; j < NT; ++j) {
+                    if (IGP_DBG & 4) bf1[j - NH] = u32x4{(unsigned)(boff[j] ^ t.flip), (unsigned)t.toff, 2u, 3u}; else
+                    bf1[j - NH] = *reinterpret_cast<const u32x4*>(smem + ((boff[j] ^ t.flip) + t.toff));
+                }
             };
             load_w(cur, afr[0]);
             load_w(nxt, afr[1]);
