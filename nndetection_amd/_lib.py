@@ -295,6 +295,19 @@ class _GradPool:
 grad_pool = _GradPool()
 
 
+_aux_streams = {}
+
+
+def aux_stream(device):
+    """One auxiliary stream per device for work that has to leave the critical chain of the forward pass (arch/conv.py: the
+    materialising norm pass of an activation whose first consumer reads the pre-norm tensor)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _aux_streams.get(idx)
+    if st is None:
+        st = _aux_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
 class _WgradStreams:
     """Weight-gradient kernels on their own stream. Within a backward pass the data-gradient / norm-backward chain is the critical
     path; a weight gradient is only needed by the optimizer. Launched on a second stream the weight-gradient kernels fill the CUs the

@@ -158,6 +158,21 @@ def _pad1d(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
 DEFER_NORM = os.environ.get("NNDET_DEFER_NORM", "0") != "0"
 
 
+# Early consumer (NNDET_EARLY_CONSUMER=1 enables it; OFF by default: measured 0.8 % slower, see below): the full-resolution output of
+# encoder stage 0 is normalised in a 1.26 GB pass
+# (k_norm_apply, 0.22 ms) that sits on the serial chain of the forward pass between the stage's last convolution and the first
+# (stride-2) convolution of stage 1. With this on, that convolution reads the PRE-norm tensor and applies relu(x * scale + shift) while
+# staging (the AFF kernels of the deferred route: the same arithmetic, bit-identical inputs), and the materialising pass -- still
+# needed: the decoder, the segmentation branch and every backward kernel read the normalised tensor -- runs on an auxiliary stream next
+# to it. The producer tags its output with `_nndet_pre = (pre-norm tensor, scale/shift table, relu, event)`; the consumer and the
+# encoder make the current stream wait for the event before anything else can touch the normalised tensor.
+# Measured (one gpurun session, alternating, luna160 batch 4 bf16): 14.94 / 14.93 ms per step with it, 14.80 / 14.83 without
+# (profiles/round3_ab_early_consumer.txt) -- the stride-2 convolution and the norm pass are both HBM-heavy, side by side they take as
+# long as one after the other, and the staging arithmetic comes on top. Bit-identical results (tests/test_model_gpu.py).
+EARLY_CONSUMER = os.environ.get("NNDET_EARLY_CONSUMER", "0") != "0"
+_pre_event = [None]
+
+
 def deferred(x: torch.Tensor):
     """(scale_shift [N, C_p, 2] fp32, relu) if `x` is a DEFERRED activation -- the pre-norm output of a conv block whose
     InstanceNorm / GroupNorm (+ReLU) is applied by the CONSUMER convolution while it stages its input -- else None."""
@@ -285,7 +300,7 @@ class _ConvFn(torch.autograd.Function):
     sum / sum of squares of y accumulated by the conv epilogue (non-differentiable side output for _NormFn)."""
 
     @staticmethod
-    def forward(ctx, x, x_ss, x_relu, weight, bias, mod, residual, want_stats):
+    def forward(ctx, x, x_ss, x_relu, weight, bias, mod, residual, want_stats, pre=None):
         x_p, cin = phys(x)
         if cin != mod.in_channels:
             raise L.NndetError(f"expected {mod.in_channels} input channels, got {cin}")
@@ -294,6 +309,14 @@ class _ConvFn(torch.autograd.Function):
             if mod.transposed or desc.cin_p == 1 or tuple(x_ss.shape) != (desc.batch, desc.cin_p, 2):
                 raise L.NndetError("deferred input normalisation: unsupported consumer or coefficient table shape")
             desc.in_affine, desc.in_relu = x_ss.data_ptr(), int(x_relu)
+        x_bwd, desc_bwd = x_p, desc
+        if pre is not None:                      # early consumer: THIS launch reads the pre-norm tensor + table; backward sees the plain input
+            pre_p, _ = phys(pre[0])
+            if x_ss is not None or tuple(pre_p.shape) != tuple(x_p.shape) or pre_p.dtype != x_p.dtype or tuple(pre[1].shape) != (desc.batch, desc.cin_p, 2):
+                raise L.NndetError("early consumer: the pre-norm tensor does not match the input")
+            desc = _desc(x_p, mod.in_channels, mod.out_channels, mod.k, mod.s, mod.p, mod.transposed)
+            desc.in_affine, desc.in_relu = pre[1].data_ptr(), int(pre[2])
+            x_p = pre_p
         dev, dt = x_p.device, x_p.dtype
         N, cout, cout_p = desc.batch, desc.cout, desc.cout_p
         stem = desc.cin_p == 1
@@ -315,10 +338,10 @@ class _ConvFn(torch.autograd.Function):
                    L.ptr(ws), sk, L.stream())
         else:
             L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats), L.stream())
-        ctx.desc, ctx.mod, ctx.has_bias, ctx.has_res = desc, mod, bias is not None, residual is not None
+        ctx.desc, ctx.mod, ctx.has_bias, ctx.has_res = desc_bwd, mod, bias is not None, residual is not None
         ctx.gacc = None if mod.transposed else getattr(x, "_nndet_gacc", None)   # fused accumulation of the input gradient (encoder.py)
         ctx.x_ss = x_ss                      # (tiny) keeps the table alive for the weight gradient
-        ctx.save_for_backward(x_p, weight)
+        ctx.save_for_backward(x_bwd, weight)
         out = logical(y, cout)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -347,7 +370,7 @@ class _ConvFn(torch.autograd.Function):
             side = ctx.wg_side
             raw = side.cuda_stream if side is not None else L.stream()
             dx_p = _rank1_backward(ctx, dconv, weight, x_p, desc, dw, dbias, side, raw)
-            return (logical(dx_p, desc.cin) if dx_p is not None else None), None, None, dw.to(weight.dtype), dbias, None, None, None
+            return (logical(dx_p, desc.cin) if dx_p is not None else None), None, None, dw.to(weight.dtype), dbias, None, None, None, None
         if ctx.needs_input_grad[0]:
             if desc.cin_p == 1:
                 raise L.NndetError("gradient w.r.t. the 1-channel input image is not implemented (never needed in training)")
@@ -403,7 +426,7 @@ class _ConvFn(torch.autograd.Function):
         L.call("nndet_conv3d_backward_weight", ctypes.byref(desc), L.ptr(x_p), L.ptr(dconv), L.ptr(dw),
                None if bias_from_dgrad else L.ptr(dbias), L.ptr(ws), ws_bytes, raw)
         # d(residual) = grad_out: the same NDHWC buffer is handed to both consumers (no copy, no add kernel)
-        return dx, None, None, dw.to(weight.dtype), dbias, None, (logical(dconv, cout) if ctx.has_res else None), None
+        return dx, None, None, dw.to(weight.dtype), dbias, None, (logical(dconv, cout) if ctx.has_res else None), None, None
 
 
 class _NormFn(torch.autograd.Function):
@@ -423,7 +446,7 @@ class _NormFn(torch.autograd.Function):
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         mean_rstd = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
         code = L.dtype_code(y_p)
-        if materialize:
+        if materialize and materialize != 2:
             out_p = torch.empty_like(y_p)
             L.call("nndet_norm_apply", code, L.ptr(y_p), L.ptr(stats), L.ptr(g32), L.ptr(b32), N, spatial, cout, cout_p,
                    mod.norm_groups, float(mod.norm_eps), int(mod.relu), L.ptr(out_p), L.ptr(mean_rstd), L.stream())
@@ -433,7 +456,21 @@ class _NormFn(torch.autograd.Function):
             ss = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
             L.call("nndet_norm_finalize", L.ptr(stats), L.ptr(g32), L.ptr(b32), N, spatial, cout, cout_p, mod.norm_groups,
                    float(mod.norm_eps), L.ptr(mean_rstd), L.ptr(ss), L.stream())
-            out = logical(y_p.view(y_p.shape), cout)          # an alias of y's storage (no kernel)
+            if materialize == 2:                              # early consumer: materialise on the auxiliary stream (see EARLY_CONSUMER)
+                out_p = torch.empty_like(y_p)
+                cur, aux = torch.cuda.current_stream(dev), L.aux_stream(dev)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                aux.wait_event(ev)
+                L.call("nndet_affine_apply", code, L.ptr(y_p), L.ptr(ss), N, spatial, cout_p, int(mod.relu), L.ptr(out_p), aux.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(aux)
+                for t in (y_p, ss, out_p):
+                    t.record_stream(aux)
+                _pre_event[0] = done
+                out = logical(out_p, cout)
+            else:
+                out = logical(y_p.view(y_p.shape), cout)      # an alias of y's storage (no kernel)
         ctx.mod, ctx.code, ctx.dims = mod, code, (N, spatial, cout, cout_p)
         ctx.save_for_backward(y_p, mean_rstd, g32, b32)
         if ss is not None:
@@ -549,6 +586,8 @@ class BaseConvNormAct(nn.Sequential):
             self.relu = True
         self._pack_cache = {}
         self.defer_output = False        # set by our containers: the norm + ReLU of the output is applied by the consumer convs
+        self.early_output = False        # set by the encoder: the output's first consumer reads the pre-norm tensor (see EARLY_CONSUMER)
+        self.early_input = False         # ... and this is that consumer
         if initializer is not None:
             self.apply(initializer)
 
@@ -558,6 +597,7 @@ class BaseConvNormAct(nn.Sequential):
         our own convolutions consume) the result is one: its norm + ReLU is applied by the consumers on load."""
         has_norm = self.norm_groups > 0
         d = deferred(x)
+        pre = getattr(x, "_nndet_pre", None) if d is None else None
         if d is None:
             x = L.autocast_input(x)
             if residual is not None and residual.dtype != x.dtype:
@@ -570,14 +610,25 @@ class BaseConvNormAct(nn.Sequential):
         if d is not None and (self.transposed or self.in_channels == 1):
             x, d = materialize(x), None
         x_ss, x_relu = d if d is not None else (None, False)
-        y, stats = _ConvFn.apply(x, x_ss, x_relu, self.conv.weight, self.conv.bias, self, residual, has_norm)
+        if pre is not None:
+            use = (self.early_input and x.is_cuda and not self.transposed and self.in_channels != 1 and pre[0].dtype == x.dtype
+                   and pre[0].shape == x.shape)
+            if not use:                          # not the consumer this was meant for: only order behind the materialising pass
+                torch.cuda.current_stream(x.device).wait_event(pre[3])
+                pre = None
+        y, stats = _ConvFn.apply(x, x_ss, x_relu, self.conv.weight, self.conv.bias, self, residual, has_norm, pre)
+        if pre is not None:
+            torch.cuda.current_stream(x.device).wait_event(pre[3])    # from here on the normalised tensor is complete for this stream
         if not has_norm:
             return y
         defer = bool(self.defer_output) and DEFER_NORM and y.is_cuda
-        out, ss = _NormFn.apply(y, self.norm.weight, self.norm.bias, stats, self, not defer)
+        early = (not defer) and bool(self.early_output) and EARLY_CONSUMER and y.is_cuda
+        out, ss = _NormFn.apply(y, self.norm.weight, self.norm.bias, stats, self, 2 if early else (not defer))
         if defer:
             mark_padded(out)
             out._nndet_deferred = (ss, self.relu)
+        elif early:
+            out._nndet_pre = (y, ss, self.relu, _pre_event[0])
         return out
 
 

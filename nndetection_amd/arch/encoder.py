@@ -40,7 +40,12 @@ class Encoder(nn.Module):
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         outputs = []
         for sid, module in enumerate(self.stages):
-            x = module(x)
+            pre = getattr(x, "_nndet_pre", None)
+            x_in, x = x, module(x)
+            if pre is not None:                  # (set_early_consumer: whatever the stage did with the tag, order this stream behind the
+                if x_in.is_cuda:                 #  materialising pass before the tensor is handed to anybody else)
+                    torch.cuda.current_stream(x_in.device).wait_event(pre[3])
+                del x_in._nndet_pre
             if sid in self.out_stages:
                 outputs.append(x)
                 if self.fuse_grad_accum and sid + 1 < self.num_stages and torch.is_grad_enabled() and x.requires_grad:
@@ -57,6 +62,18 @@ class Encoder(nn.Module):
         consumer whose backward runs second ADDS its data gradient into the first one's buffer (nndet_conv3d_backward_data_acc) and
         returns no gradient of its own. Only the detector switches it on, and only when both consumers are our convolutions."""
         self.fuse_grad_accum = bool(on)
+
+    def set_early_consumer(self, on: bool) -> None:
+        """Stage 0's output is normalised on an auxiliary stream while the first convolution of stage 1 already reads the pre-norm
+        tensor (arch/conv.py: EARLY_CONSUMER): the 1.26 GB norm pass leaves the serial chain of the forward pass. Only the detector
+        switches it on."""
+        if self.num_stages < 2:
+            return
+        last0 = [m for m in self.stages[0].modules() if hasattr(m, "early_output")]
+        first1 = [m for m in self.stages[1].modules() if hasattr(m, "early_input")]
+        if last0 and first1:
+            last0[-1].early_output = bool(on)
+            first1[0].early_input = bool(on)
 
     def set_defer_outputs(self, on: bool) -> None:
         """Hand the stage outputs on as DEFERRED activations (pre-norm tensor + coefficients, arch/conv.py). Only the detector

@@ -43,6 +43,8 @@ class BaseRetinaNet(nn.Module):
             self.encoder.set_defer_outputs(True)     # the decoder's lateral convs apply the encoder's norm + ReLU on load
             if hasattr(self.encoder, "set_fuse_grad_accum"):
                 self.encoder.set_fuse_grad_accum(os.environ.get("NNDET_FUSE_GRAD_ACC", "1") != "0")
+            if hasattr(self.encoder, "set_early_consumer"):
+                self.encoder.set_early_consumer(True)    # (arch/conv.py: only with NNDET_EARLY_CONSUMER=1, measured slower)
             if hasattr(self.encoder, "stage_hook") and hasattr(self.decoder, "early_lateral") and \
                     list(getattr(self.encoder, "out_stages", [])) == list(range(self.decoder.num_level)):
                 self.encoder.stage_hook = self.decoder.early_lateral      # laterals start under the deeper encoder stages

@@ -388,6 +388,51 @@ def test_segmentation_branch_fusion_in_train_step(golden_dir, dtype, monkeypatch
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_early_consumer_of_the_stage0_output(golden_dir, dtype, monkeypatch):
+    """arch/conv.py EARLY_CONSUMER: the first convolution of encoder stage 1 reads the PRE-norm output of stage 0 (norm + ReLU applied
+    while staging, `in_affine`) while the normalised tensor is written on an auxiliary stream. Same arithmetic on the same values: the
+    losses and every parameter gradient agree with the plain route to the noise of the statistics' atomics, the stage-0 output is
+    the same tensor bit for bit, the tag does not leak out of the encoder, and the affine launch really is the one that runs."""
+    from nndetection_amd.arch import conv as C
+    from nndetection_amd import _lib as L
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    x = torch.from_numpy(gn["x"]).cuda().to(dtype)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    res = {}
+    for on in (True, False, True):
+        monkeypatch.setattr(C, "EARLY_CONSUMER", on)
+        net.zero_grad(set_to_none=True)
+        calls.clear()
+        with torch.no_grad():
+            feats = net.encoder(x)
+        torch.cuda.synchronize()
+        assert ("nndet_affine_apply" in calls) == on
+        assert all(not hasattr(f, "_nndet_pre") for f in feats)
+        f0 = feats[0].detach().float().cpu().clone()
+        losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+        (sum(losses.values()) * (256.0 if dtype == torch.float16 else 1.0)).backward()
+        torch.cuda.synchronize()
+        res.setdefault(on, []).append((f0, {k: float(v.detach()) for k, v in losses.items()},
+                                       {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    tol = 2e-5 if dtype == torch.float32 else (3e-2 if dtype == torch.bfloat16 else 4e-3)
+    ltol = 1e-6 if dtype == torch.float32 else (2e-3 if dtype == torch.bfloat16 else 3e-4)
+    ref = res[False][0]
+    for f0, ls, gr in res[True]:
+        assert torch.equal(f0, ref[0])
+        for k, v in ref[1].items():
+            assert abs(ls[k] - v) <= ltol * max(1.0, abs(v)), (k, ls[k], v)
+        assert set(gr) == set(ref[2])
+        for n, g0 in ref[2].items():
+            d = float((gr[n] - g0).abs().max())
+            assert d <= tol * (float(g0.abs().max()) + 1e-12) + 1e-7, (n, d, float(g0.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_fused_input_gradient_accumulation(golden_dir, dtype, monkeypatch):
     """Encoder stage outputs feed the next stage and the decoder lateral. With set_fuse_grad_accum the second data gradient is added
     into the first one's buffer (nndet_conv3d_backward_data_acc) instead of autograd adding two tensors: same gradients (fp32: the
