@@ -97,6 +97,72 @@ SEG_BRANCH = os.environ.get("NNDET_SEG_BRANCH", "1") != "0"
 SEG_LATERAL = os.environ.get("NNDET_SEG_LATERAL", "1") != "0"
 
 
+# ---- the last top-down step absorbed as well (NNDET_SEG_UP) ----------------------------------------------------------------------------
+# With the lateral absorbed, the branch's second input is u = up_1(x_1) + b_up + b_lat: a k = s = 2 transposed convolution of the
+# half-resolution map x_1 (64 channels), written (629 MB at 160x160x96, batch 4), read once by the branch, and in the backward pass its
+# gradient written and read twice. conv3(u; wc) is linear in x_1: for the output voxel p = 2 m + pi (pi = its parity class) tap t reads
+# u[p + t - 1] = u[2 (m + delta) + par], so
+#     conv3(u; wc)[2 m + pi] = sum_{delta in {-1,0,1}^3, i} Wc[pi][i][delta] x_1[m + delta][i]  +  sum_{t: p + t - 1 inside} B[t]
+#     Wc[pi][i][delta] = sum_{t -> (delta, par)} sum_k wc[t][k] W_up[i][k][par],      B[t] = wc[t] . (b_up + b_lat)
+# -- ONE 3x3x3 / stride-1 convolution 64 -> 8 (one output channel per parity class) at HALF resolution on the existing MFMA kernels, plus
+# a bias that depends on the border class of p only (27 values). Per axis: pi = 0: t = 0 -> (delta -1, par 1), 1 -> (0, 0), 2 -> (0, 1);
+# pi = 1: t = 0 -> (0, 0), 1 -> (0, 1), 2 -> (+1, 0). Backward, from d1 = dL/dz: dz_up[m][pi] = d1[2 m + pi] (space-to-depth),
+# dx_1 and dWc are that convolution's data / weight gradient, and with S[t] = sum of d1 over the voxels whose tap t stays inside:
+#     dW_up[i][k][par] = sum_{(pi, delta) -> (t, par)} wc[t][k] dWc[pi][i][delta]
+#     d(b_up)[k] = d(b_lat)[k] = sum_t wc[t][k] S[t]
+#     Ec_u[t][k] = sum_p d1[p] u[p + t - 1][k] = sum_{(pi, delta) -> (t, par), i} W_up[i][k][par] dWc[pi][i][delta] + S[t] (b_up + b_lat)[k]
+# (Ec_u is what k_segbranch_params needs of u for the gradients of decoder.out.P0 and the head). u never exists.
+SEG_UP = os.environ.get("NNDET_SEG_UP", "1") != "0"
+
+
+def _up_tap_map(dtype=torch.float32, device=None) -> torch.Tensor:
+    """M[pi][t][delta + 1][par] = 1 where tap t of an output voxel of parity pi reads the transposed convolution's output of kernel
+    position par at the half-resolution offset delta (one axis)."""
+    m = torch.zeros((2, 3, 3, 2), dtype=dtype, device=device)
+    for pi, t, e, par in ((0, 0, 0, 1), (0, 1, 1, 0), (0, 2, 1, 1), (1, 0, 1, 0), (1, 1, 1, 1), (1, 2, 2, 0)):
+        m[pi, t, e, par] = 1.0
+    return m
+
+
+def _border_matrix(dtype=torch.float32, device=None) -> torch.Tensor:
+    """K[t][cls] = 1 if tap t of a voxel of border class cls (0: first plane, 1: inside, 2: last plane; one axis) stays inside."""
+    k = torch.ones((3, 3), dtype=dtype, device=device)
+    k[0, 0] = 0.0
+    k[2, 2] = 0.0
+    return k
+
+
+def up_compose(wc: torch.Tensor, w_up: torch.Tensor, bsum: Optional[torch.Tensor]):
+    """wc [27, C] (tap-major composed kernel), w_up [I, C, 2, 2, 2] (ConvTranspose3d layout), bsum [C] or None ->
+    Wc [8, I, 3, 3, 3] (output channel = parity class (pd * 2 + ph) * 2 + pw) and the border-class bias cb [3, 3, 3]."""
+    C = wc.shape[1]
+    M = _up_tap_map(wc.dtype, wc.device)
+    wc4 = wc.reshape(3, 3, 3, C)
+    Wc = torch.einsum("adxp,beyq,cfzr,defk,ikpqr->abcixyz", M, M, M, wc4, w_up.to(wc.dtype)).reshape(8, w_up.shape[0], 3, 3, 3)
+    cb = None
+    if bsum is not None:
+        K = _border_matrix(wc.dtype, wc.device)
+        cb = torch.einsum("ad,be,cf,abc->def", K, K, K, (wc4 * bsum.to(wc.dtype)).sum(-1))
+    return Wc, cb
+
+
+def up_param_grads(wc: torch.Tensor, w_up: torch.Tensor, bsum: Optional[torch.Tensor], dWc: torch.Tensor, cls_sums: torch.Tensor):
+    """dWc [8, I, 3, 3, 3] (weight gradient of the composed convolution), cls_sums [3, 3, 3] (sum of d1 per border class) ->
+    (dW_up [I, C, 2, 2, 2], dbsum [C], Ec_u [27, C]); see the derivation above."""
+    C, I = wc.shape[1], w_up.shape[0]
+    M = _up_tap_map(wc.dtype, wc.device)
+    K = _border_matrix(wc.dtype, wc.device)
+    wc4 = wc.reshape(3, 3, 3, C)
+    d7 = dWc.to(wc.dtype).reshape(2, 2, 2, I, 3, 3, 3)
+    S = torch.einsum("ad,be,cf,def->abc", K, K, K, cls_sums.to(wc.dtype))
+    dw_up = torch.einsum("adxp,beyq,cfzr,defk,abcixyz->ikpqr", M, M, M, wc4, d7)
+    ec = torch.einsum("adxp,beyq,cfzr,ikpqr,abcixyz->defk", M, M, M, w_up.to(wc.dtype), d7)
+    dbsum = torch.einsum("defk,def->k", wc4, S)
+    if bsum is not None:
+        ec = ec + S.unsqueeze(-1) * bsum.to(wc.dtype)
+    return dw_up, dbsum, ec.reshape(27, C)
+
+
 class _SegBranchFn(torch.autograd.Function):
     """x = the decoder's level-0 map BEFORE decoder.out.P0 [N, 32, D, H, W] (16-bit), w_out [32, 32, 3, 3, 3] / b_out of that
     convolution, w_head [2, 32, 1, 1, 1] / b_head of the segmenter's output conv, target uint8 -> fp32 [4] = (sum CE, tp, fp, fn).

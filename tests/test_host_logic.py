@@ -332,3 +332,47 @@ def test_fused_sgd_version_counters_are_advanced_by_hand():
         except (RuntimeError, NotImplementedError):
             return                                                        # no CPU kernel in this build
         assert float(p[0]) != 1.0 and p._version in (v, v + 1)
+
+
+def test_absorbed_top_down_step_algebra():
+    """arch/segmenter.py (NNDET_SEG_UP): conv3(up(x1) + b; wc) as one half-resolution 3x3x3 convolution with 8 parity output channels
+    plus a border-class bias, and its parameter gradients from that convolution's weight gradient -- against plain torch in fp64."""
+    import torch.nn.functional as F
+    from nndetection_amd.arch.segmenter import up_compose, up_param_grads
+    torch.manual_seed(3)
+    dd = torch.float64
+    N, I, C, D2, H2, W2 = 2, 6, 5, 3, 4, 2
+    x1 = torch.randn(N, I, D2, H2, W2, dtype=dd, requires_grad=True)
+    w_up = torch.randn(I, C, 2, 2, 2, dtype=dd, requires_grad=True)
+    bsum = torch.randn(C, dtype=dd, requires_grad=True)
+    wc = torch.randn(27, C, dtype=dd, requires_grad=True)
+    G = torch.randn(N, 1, 2 * D2, 2 * H2, 2 * W2, dtype=dd)
+    u = F.conv_transpose3d(x1, w_up, bias=bsum, stride=2)
+    u.retain_grad()
+    zr = F.conv3d(u, wc.t().reshape(1, C, 3, 3, 3), padding=1)
+    (zr * G).sum().backward()
+    # ---- forward
+    Wc, cb = up_compose(wc.detach(), w_up.detach(), bsum.detach())
+    zup = F.conv3d(x1.detach(), Wc, padding=1)                               # [N, 8, D2, H2, W2]
+    z = zup.reshape(N, 2, 2, 2, D2, H2, W2).permute(0, 4, 1, 5, 2, 6, 3).reshape(N, 1, 2 * D2, 2 * H2, 2 * W2).clone()
+
+    def cls(n):
+        c = torch.ones(n, dtype=torch.long); c[0] = 0; c[-1] = 2
+        return c
+    cd, ch, cw = cls(2 * D2), cls(2 * H2), cls(2 * W2)
+    z += cb[cd][:, ch][:, :, cw]
+    assert torch.allclose(z, zr.detach(), rtol=1e-10, atol=1e-10)
+    # ---- backward from d1 = G
+    d1 = G[:, 0]
+    dzs = d1.reshape(N, D2, 2, H2, 2, W2, 2).permute(0, 2, 4, 6, 1, 3, 5).reshape(N, 8, D2, H2, W2)
+    dx1 = torch.nn.grad.conv3d_input(x1.shape, Wc, dzs, padding=1)
+    dWc = torch.nn.grad.conv3d_weight(x1.detach(), Wc.shape, dzs, padding=1)
+    csum = torch.zeros(3, 3, 3, dtype=dd)
+    csum.index_put_((cd[:, None, None].expand(2 * D2, 2 * H2, 2 * W2), ch[None, :, None].expand(2 * D2, 2 * H2, 2 * W2),
+                     cw[None, None, :].expand(2 * D2, 2 * H2, 2 * W2)), d1.sum(0), accumulate=True)
+    dw_up, dbsum, ec = up_param_grads(wc.detach(), w_up.detach(), bsum.detach(), dWc, csum)
+    assert torch.allclose(dx1, x1.grad, rtol=1e-10, atol=1e-10)
+    assert torch.allclose(dw_up, w_up.grad, rtol=1e-10, atol=1e-10)
+    assert torch.allclose(dbsum, bsum.grad, rtol=1e-10, atol=1e-10)
+    # Ec_u[t][k] = sum_p d1[p] u[p + t - 1][k] = the gradient of the composed kernel wc
+    assert torch.allclose(ec, wc.grad, rtol=1e-10, atol=1e-10)
