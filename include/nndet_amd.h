@@ -424,6 +424,20 @@ int nndet_segbranch_forward(int32_t dtype, const void* x, int32_t N, int32_t D, 
 int nndet_segbranch_forward2(int32_t dtype, const void* x, const void* w_packed, const void* x2, const void* w2_packed, int32_t N, int32_t D,
                              int32_t H, int32_t W, int32_t c_p, const float* c0, const uint8_t* target, float* z_out, double* sums_out,
                              void* stream);
+/* ... and with the last top-down step absorbed as well (nndet/arch/decoder/base.py:272-304,405-413: u = ConvTranspose3d(k = s = 2)(x_1)):
+ * conv3(u; wc) is one 3x3x3 / stride-1 convolution 64 -> 8 of the HALF-resolution map x_1 -- one output channel per parity class of the
+ * output voxel, run by nndet_conv3d_forward on composed weights (nndetection_amd/arch/segmenter.py: up_compose) -- plus a bias that
+ * depends on the voxel's border class only. x = a_0 with w_packed = wc . W_lat as above; zup [N, D/2, H/2, W/2, 32] (dtype) = that
+ * convolution's output (channel (pd * 2 + ph) * 2 + pw of voxel m belongs to output voxel 2 m + (pd, ph, pw)); cb [27] fp32 = the
+ * bias of border class (cd * 3 + ch) * 3 + cw (0: first plane of the axis, 1: inside, 2: last plane). D, H, W even. u never exists. */
+int nndet_segbranch_forward_up(int32_t dtype, const void* x, const void* w_packed, const void* zup, const float* cb, int32_t N, int32_t D,
+                               int32_t H, int32_t W, int32_t c_p, const float* c0, const uint8_t* target, float* z_out, double* sums_out,
+                               void* stream);
+/* Backward side of that: d1 [N, D, H, W] (dtype) -> dzs_out [N, D/2, H/2, W/2, 32] (dtype; channel (pd * 2 + ph) * 2 + pw of voxel m =
+ * d1[2 m + (pd, ph, pw)], channels 8 .. 31 zero: the output gradient of the composed convolution) and csum_out fp64
+ * [nndet_segbranch_replicas()][27] (zeroed by the caller): the sum of d1 per border class. */
+int nndet_segbranch_s2d(int32_t dtype, const void* d1, int32_t N, int32_t D, int32_t H, int32_t W, void* dzs_out, double* csum_out,
+                        void* stream);
 /* All parameter gradients of the branch from the one-channel correlations (32 channels; every tensor fp32, contiguous):
  * w_out [32][32][27], b_out [32] or NULL, w_lat [32][32] or NULL (then e_a, dw_lat NULL too), wd [32] = w_head[1] - w_head[0],
  * e_x / e_a [32][27] = nndet_conv3d_backward_weight(cin_p == 1) of (d1, top-down term) / (d1, a_0), dsum [n_dsum] fp64 (its sum =

@@ -122,6 +122,8 @@ SIGNATURES = {
     "nndet_segbranch_replicas": (C.c_int, []),
     "nndet_segbranch_forward": (C.c_int, [_I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "nndet_segbranch_forward2": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nndet_segbranch_forward_up": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nndet_segbranch_s2d": (C.c_int, [_I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "nndet_segbranch_backward": (C.c_int, [_I32, _P, _P, _I64, _P, _P, _P, _P]),
     "nndet_segbranch_param_grads": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "nndet_head_out_sparse_scatter": (C.c_int, [_I32, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, C.POINTER(C.c_int64), _P, _P, _I32,

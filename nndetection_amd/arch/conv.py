@@ -238,7 +238,7 @@ def _splitk_bytes(mod, desc, kind: int) -> int:
     return n
 
 
-def rank1_branch_backward(x_p, a_p, w_out, b_out, w_lat, w_head, b_head, wd, wf, wfa, d1, dsum, need_dx, need_da):
+def rank1_branch_backward(x_p, a_p, w_out, b_out, w_lat, w_head, b_head, wd, wf, wfa, d1, dsum, need_dx, need_da, e_x_fn=None):
     """Backward of the composed segmentation branch (arch/segmenter.py: _SegBranchFn) from d1 = dL/d(l1 - l0) per voxel. The level-0
     map x (+ W_lat a), the output of `conv3x3x3(.; w_out) + b_out` and the logits were never computed; with wd = w_head[1] - w_head[0]:
         dx  = the ONE-input-channel convolution of d1 with wf[cin][t] = sum_c wd[c] W_out[c][cin][2 - t]        (stem forward kernel)
@@ -247,8 +247,11 @@ def rank1_branch_backward(x_p, a_p, w_out, b_out, w_lat, w_head, b_head, wd, wf,
         every parameter gradient from E_x, E_a, sum(d1) in one small launch (csrc/segbranch.hip: k_segbranch_params).
     Returns (dx_p, da_p, dW_out, db_out, dW_lat, dW_head, db_head); the parameter gradients are views of the per-step gradient pool
     and are produced on the weight-gradient stream like every other weight gradient."""
-    dev, dt = x_p.device, x_p.dtype
-    N, D, H, W, cin_p = x_p.shape
+    # x_p None (the top-down step absorbed too, arch/segmenter.py: NNDET_SEG_UP): the correlation E_x of d1 with the never-formed
+    # top-down term comes from `e_x_fn(raw stream)`, called inside the weight-gradient stream context; no dx.
+    ref_p = x_p if x_p is not None else a_p
+    dev, dt = ref_p.device, ref_p.dtype
+    N, D, H, W, cin_p = ref_p.shape
     cin = cout = w_out.shape[0]
     sd = L.NndetConv()
     sd.dtype, sd.transposed, sd.batch = L._DT[dt], 0, N
@@ -272,20 +275,23 @@ def rank1_branch_backward(x_p, a_p, w_out, b_out, w_lat, w_head, b_head, wd, wf,
         if w_lat is not None:
             L.wgrad_streams.side(dev, w_lat)
     dx_p = da_p = None
-    if need_dx:
+    if need_dx and x_p is not None:
         dx_p = torch.empty_like(x_p)
         L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(d1), L.ptr(wf), None, None, L.ptr(dx_p), None, L.stream())
     if need_da and a_p is not None:
         da_p = torch.empty_like(a_p)
         L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(d1), L.ptr(wfa), None, None, L.ptr(da_p), None, L.stream())
     if side is not None:
-        for t in (x_p, d1, wd, dsum) + ((a_p,) if a_p is not None else ()):
+        for t in (d1, wd, dsum) + ((x_p,) if x_p is not None else ()) + ((a_p,) if a_p is not None else ()):
             t.record_stream(side)
     cur = torch.cuda.current_stream(dev)
     raw = side.cuda_stream if side is not None else L.stream()
     with torch.cuda.stream(side if side is not None else cur):
         e = torch.zeros((2, cin, 27), dtype=torch.float32, device=dev)
-        L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(x_p), L.ptr(e[0]), None, None, 0, raw)
+        if x_p is not None:
+            L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(x_p), L.ptr(e[0]), None, None, 0, raw)
+        else:
+            e[0].copy_(e_x_fn(side, raw))
         if a_p is not None:
             L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(d1), L.ptr(a_p), L.ptr(e[1]), None, None, 0, raw)
         L.call("nndet_segbranch_param_grads", L.ptr(w_out.detach()), L.ptr(b_out.detach()) if b_out is not None else None,

@@ -168,6 +168,9 @@ class UFPNModular(nn.Module):
     # convolution ALONE with both biases (b_up + b_lat: the add of two [C] vectors is differentiable, so both get their gradient), and
     # the segmentation branch reads the encoder's level-0 map itself.
     absorb_lat0 = False
+    # ... and the last top-down step itself (arch/segmenter.py: NNDET_SEG_UP): then up.P1 is not run either, level 0 of the returned
+    # list is x_1 (the half-resolution map) tagged with the three modules, and the branch composes them.
+    absorb_up0 = False
 
     def _out0(self, x0: torch.Tensor) -> torch.Tensor:
         if self.defer_out0:
@@ -183,6 +186,10 @@ class UFPNModular(nn.Module):
         """x_0 of a pass that absorbs the lateral: up_1(x_1) + b_up + b_lat, tagged with (lateral module, its input)."""
         from .conv import _ConvFn
         up, lat = self.up["P1"], self.lateral["P0"][0]
+        if self.absorb_up0:
+            x1._nndet_pre_lat = (lat, inp0)
+            x1._nndet_pre_up = up
+            return x1
         biases = [b for b in (up.conv.bias, lat.conv.bias) if b is not None]
         bias = (biases[0] + biases[1]) if len(biases) == 2 else (biases[0] if biases else None)
         x0, _ = _ConvFn.apply(x1, None, False, up.conv.weight, bias, up, None, False)

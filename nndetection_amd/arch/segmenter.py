@@ -115,52 +115,55 @@ SEG_LATERAL = os.environ.get("NNDET_SEG_LATERAL", "1") != "0"
 SEG_UP = os.environ.get("NNDET_SEG_UP", "1") != "0"
 
 
-def _up_tap_map(dtype=torch.float32, device=None) -> torch.Tensor:
-    """M[pi][t][delta + 1][par] = 1 where tap t of an output voxel of parity pi reads the transposed convolution's output of kernel
-    position par at the half-resolution offset delta (one axis)."""
-    m = torch.zeros((2, 3, 3, 2), dtype=dtype, device=device)
-    for pi, t, e, par in ((0, 0, 0, 1), (0, 1, 1, 0), (0, 2, 1, 1), (1, 0, 1, 0), (1, 1, 1, 1), (1, 2, 2, 0)):
-        m[pi, t, e, par] = 1.0
-    return m
+_up_consts = {}
 
 
-def _border_matrix(dtype=torch.float32, device=None) -> torch.Tensor:
-    """K[t][cls] = 1 if tap t of a voxel of border class cls (0: first plane, 1: inside, 2: last plane; one axis) stays inside."""
-    k = torch.ones((3, 3), dtype=dtype, device=device)
-    k[0, 0] = 0.0
-    k[2, 2] = 0.0
-    return k
+def _up_tables(dtype, device):
+    """T [8 * 27, 27 * 8]: T[(pi, delta), (t, par)] = 1 where tap t (3 axes) of an output voxel of parity class pi reads the transposed
+    convolution's kernel position par at the half-resolution offset delta; K3 [27, 27]: K3[t, cls] = 1 if tap t of a voxel of border
+    class cls stays inside the volume. Built once per (dtype, device)."""
+    key = (dtype, str(device))
+    hit = _up_consts.get(key)
+    if hit is None:
+        m = torch.zeros((2, 3, 3, 2), dtype=torch.float64)            # one axis: [pi][t][delta + 1][par]
+        for pi, t, e, par in ((0, 0, 0, 1), (0, 1, 1, 0), (0, 2, 1, 1), (1, 0, 1, 0), (1, 1, 1, 1), (1, 2, 2, 0)):
+            m[pi, t, e, par] = 1.0
+        T = torch.einsum("adxp,beyq,cfzr->abcxyzdefpqr", m, m, m).reshape(8 * 27, 27 * 8)
+        k = torch.ones((3, 3), dtype=torch.float64)                    # one axis: [t][cls]
+        k[0, 0] = 0.0
+        k[2, 2] = 0.0
+        K3 = torch.einsum("ad,be,cf->abcdef", k, k, k).reshape(27, 27)
+        hit = _up_consts[key] = (T.to(dtype=dtype, device=device), K3.to(dtype=dtype, device=device))
+    return hit
 
 
 def up_compose(wc: torch.Tensor, w_up: torch.Tensor, bsum: Optional[torch.Tensor]):
     """wc [27, C] (tap-major composed kernel), w_up [I, C, 2, 2, 2] (ConvTranspose3d layout), bsum [C] or None ->
-    Wc [8, I, 3, 3, 3] (output channel = parity class (pd * 2 + ph) * 2 + pw) and the border-class bias cb [3, 3, 3]."""
-    C = wc.shape[1]
-    M = _up_tap_map(wc.dtype, wc.device)
-    wc4 = wc.reshape(3, 3, 3, C)
-    Wc = torch.einsum("adxp,beyq,cfzr,defk,ikpqr->abcixyz", M, M, M, wc4, w_up.to(wc.dtype)).reshape(8, w_up.shape[0], 3, 3, 3)
+    Wc [8, I, 3, 3, 3] (output channel = parity class (pd * 2 + ph) * 2 + pw) and the border-class bias cb [27]."""
+    I, C = w_up.shape[0], wc.shape[1]
+    T, K3 = _up_tables(wc.dtype, wc.device)
+    A = torch.matmul(wc, w_up.to(wc.dtype).permute(1, 2, 3, 4, 0).reshape(C, 8 * I))          # [t, (par, i)] = sum_k wc[t, k] W_up[i, k, par]
+    Wc = torch.matmul(T, A.reshape(27 * 8, I)).reshape(8, 27, I).permute(0, 2, 1).reshape(8, I, 3, 3, 3)
     cb = None
     if bsum is not None:
-        K = _border_matrix(wc.dtype, wc.device)
-        cb = torch.einsum("ad,be,cf,abc->def", K, K, K, (wc4 * bsum.to(wc.dtype)).sum(-1))
+        cb = torch.matmul(torch.mv(wc, bsum.to(wc.dtype)), K3)           # cb[cls] = sum_t B[t] K3[t, cls]
     return Wc, cb
 
 
 def up_param_grads(wc: torch.Tensor, w_up: torch.Tensor, bsum: Optional[torch.Tensor], dWc: torch.Tensor, cls_sums: torch.Tensor):
-    """dWc [8, I, 3, 3, 3] (weight gradient of the composed convolution), cls_sums [3, 3, 3] (sum of d1 per border class) ->
+    """dWc [8, I, 3, 3, 3] (weight gradient of the composed convolution), cls_sums [27] (sum of d1 per border class) ->
     (dW_up [I, C, 2, 2, 2], dbsum [C], Ec_u [27, C]); see the derivation above."""
-    C, I = wc.shape[1], w_up.shape[0]
-    M = _up_tap_map(wc.dtype, wc.device)
-    K = _border_matrix(wc.dtype, wc.device)
-    wc4 = wc.reshape(3, 3, 3, C)
-    d7 = dWc.to(wc.dtype).reshape(2, 2, 2, I, 3, 3, 3)
-    S = torch.einsum("ad,be,cf,def->abc", K, K, K, cls_sums.to(wc.dtype))
-    dw_up = torch.einsum("adxp,beyq,cfzr,defk,abcixyz->ikpqr", M, M, M, wc4, d7)
-    ec = torch.einsum("adxp,beyq,cfzr,ikpqr,abcixyz->defk", M, M, M, w_up.to(wc.dtype), d7)
-    dbsum = torch.einsum("defk,def->k", wc4, S)
+    I, C = w_up.shape[0], wc.shape[1]
+    T, K3 = _up_tables(wc.dtype, wc.device)
+    d = dWc.to(wc.dtype).reshape(8, I, 27).permute(0, 2, 1).reshape(8 * 27, I)
+    dA = torch.matmul(T.t(), d).reshape(27, 8, I)                        # [t, par, i] = sum_{(pi, delta) -> (t, par)} dWc[pi][i][delta]
+    S = torch.mv(K3, cls_sums.to(wc.dtype).reshape(27))                  # S[t] = sum over the classes whose tap t stays inside
+    dw_up = torch.einsum("tk,tpi->ikp", wc, dA).reshape(I, C, 2, 2, 2)
+    ec = torch.einsum("tpi,ikp->tk", dA, w_up.to(wc.dtype).reshape(I, C, 8))
+    dbsum = torch.mv(wc.t(), S)
     if bsum is not None:
         ec = ec + S.unsqueeze(-1) * bsum.to(wc.dtype)
-    return dw_up, dbsum, ec.reshape(27, C)
+    return dw_up, dbsum, ec
 
 
 class _SegBranchFn(torch.autograd.Function):
@@ -173,7 +176,10 @@ class _SegBranchFn(torch.autograd.Function):
     z = conv3(a0; wc . W_lat) + conv3(x; wc) + c0 (nndet_segbranch_forward2)."""
 
     @staticmethod
-    def forward(ctx, x, a0, w_lat, w_out, b_out, w_head, b_head, target_u8):
+    def forward(ctx, x, a0, w_lat, w_out, b_out, w_head, b_head, target_u8, w_up=None, b_up=None, b_lat=None):
+        ctx.up = w_up is not None
+        if ctx.up:
+            return _SegBranchFn._forward_up(ctx, x, a0, w_lat, w_out, b_out, w_head, b_head, target_u8, w_up, b_up, b_lat)
         xp, cin = phys(x)
         dev, dt = xp.device, xp.dtype
         N, D, H, W, cp = xp.shape
@@ -216,8 +222,143 @@ class _SegBranchFn(torch.autograd.Function):
         ctx.gacc = getattr(a0, "_nndet_gacc", None) if a0 is not None else None       # fused accumulation of a0's gradient (encoder.py)
         return sums.sum(0).float()
 
+    # ---- the top-down step absorbed too: x = x_1 [N, I, D/2, H/2, W/2] (see the derivation above SEG_UP)
+    @staticmethod
+    def _up_desc(x1p, cin1):
+        import ctypes
+        sd = L.NndetConv()
+        N, D2, H2, W2, cp1 = x1p.shape
+        sd.dtype, sd.transposed, sd.batch = L._DT[x1p.dtype], 0, N
+        sd.cin, sd.cout, sd.cin_p, sd.cout_p = cin1, 8, cp1, 32
+        sd.in_d, sd.in_h, sd.in_w = D2, H2, W2
+        sd.out_d, sd.out_h, sd.out_w = D2, H2, W2
+        sd.k = (ctypes.c_int32 * 3)(3, 3, 3); sd.s = (ctypes.c_int32 * 3)(1, 1, 1); sd.p = (ctypes.c_int32 * 3)(1, 1, 1)
+        return sd
+
+    @staticmethod
+    def _forward_up(ctx, x1, a0, w_lat, w_out, b_out, w_head, b_head, target_u8, w_up, b_up, b_lat):
+        import ctypes
+        x1p, cin1 = phys(x1)
+        ap, ka = phys(a0)
+        dev, dt = ap.device, ap.dtype
+        N, D, H, W, cp = ap.shape
+        cout = w_out.shape[0]
+        cin = 32
+        if (cp != 32 or ka != 32 or tuple(w_out.shape[1:]) != (32, 3, 3, 3) or tuple(w_head.shape[:2]) != (2, cout) or dt == torch.float32
+                or x1p.dtype != dt or tuple(x1p.shape[:4]) != (N, D // 2, H // 2, W // 2) or (D | H | W) & 1
+                or tuple(w_up.shape) != (cin1, cin, 2, 2, 2) or tuple(w_lat.shape[:2]) != (cin, 32)):
+            raise L.NndetError("fused segmentation branch with the top-down step: 16 bits, even dims, a k = s = 2 transposed convolution C1 -> 32")
+        wh = w_head.detach().reshape(2, cout).float()
+        wd = (wh[1] - wh[0]).contiguous()
+        wc = torch.einsum("c,cidhw->dhwi", wd, w_out.detach().float()).reshape(27, cin).contiguous()
+        c0 = torch.zeros((), dtype=torch.float32, device=dev)
+        if b_out is not None:
+            c0 = c0 + (wd * b_out.detach().float()).sum()
+        if b_head is not None:
+            c0 = c0 + (b_head.detach()[1] - b_head.detach()[0]).float()
+        c0 = c0.reshape(1).contiguous()
+        wca = torch.matmul(wc, w_lat.detach().float().reshape(cin, 32))
+        wqa = wca.to(dt).contiguous()
+        wfa = wca.flip(0).t().contiguous().view(32, 1, 3, 3, 3)
+        bs = [b.detach().float() for b in (b_up, b_lat) if b is not None]
+        bsum = (bs[0] + bs[1]) if len(bs) == 2 else (bs[0] if bs else torch.zeros((cin,), dtype=torch.float32, device=dev))
+        w_up32 = w_up.detach().float().contiguous()
+        Wc, cb = up_compose(wc, w_up32, bsum)
+        Wc, cb = Wc.contiguous(), cb.contiguous()
+        sd = _SegBranchFn._up_desc(x1p, cin1)
+        lib = L.load()
+        pk = []
+        for mode in (0, 1):
+            buf = torch.empty((int(lib.nndet_packed_weight_elems(ctypes.byref(sd), mode)),), dtype=dt, device=dev)
+            L.call("nndet_pack_weight", ctypes.byref(sd), mode, L.ptr(Wc), L.ptr(buf), L.stream())
+            pk.append(buf)
+        zup = torch.empty((N, D // 2, H // 2, W // 2, 32), dtype=dt, device=dev)
+        L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(x1p), L.ptr(pk[0]), None, None, L.ptr(zup), None, L.stream())
+        z = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
+        R = int(lib.nndet_segbranch_replicas())
+        sums = torch.zeros((R, 4), dtype=torch.float64, device=dev)
+        L.call("nndet_segbranch_forward_up", L.dtype_code(ap), L.ptr(ap), L.ptr(wqa), L.ptr(zup), L.ptr(cb), N, D, H, W, cp, L.ptr(c0),
+               L.ptr(target_u8), L.ptr(z), L.ptr(sums), L.stream())
+        ctx.save_for_backward(x1p, w_out, b_out if b_out is not None else wd, w_head, b_head if b_head is not None else wd, target_u8, z, wd,
+                              ap, w_lat, wfa, wc, w_up32, bsum, pk[1], w_up)
+        ctx.has_b_out, ctx.has_b_head, ctx.R, ctx.cin, ctx.cin1 = b_out is not None, b_head is not None, R, cin, cin1
+        ctx.has_b_up, ctx.has_b_lat = b_up is not None, b_lat is not None
+        ctx.b_refs = [b for b in (b_up, b_lat) if b is not None]             # (parameters: their gradients come from the weight-gradient stream)
+        ctx.gacc = getattr(a0, "_nndet_gacc", None)
+        return sums.sum(0).float()
+
+    @staticmethod
+    def _backward_up(ctx, g):
+        import ctypes
+        (x1p, w_out, b_out, w_head, b_head, tgt, z, wd, ap, w_lat, wfa, wc, w_up32, bsum, pk1, w_up) = ctx.saved_tensors
+        dev, dt = ap.device, ap.dtype
+        N, D, H, W, _ = ap.shape
+        coeffs = g.detach().float().contiguous()
+        d1 = torch.empty(ap.shape[:4] + (1,), dtype=dt, device=dev)
+        dsum = torch.zeros((ctx.R,), dtype=torch.float64, device=dev)
+        L.call("nndet_segbranch_backward", L.dtype_code(ap), L.ptr(z), L.ptr(tgt), z.numel(), L.ptr(coeffs), L.ptr(d1), L.ptr(dsum), L.stream())
+        dzs = torch.empty((N, D // 2, H // 2, W // 2, 32), dtype=dt, device=dev)
+        csum = torch.zeros((ctx.R, 27), dtype=torch.float64, device=dev)
+        L.call("nndet_segbranch_s2d", L.dtype_code(ap), L.ptr(d1), N, D, H, W, L.ptr(dzs), L.ptr(csum), L.stream())
+        sd = _SegBranchFn._up_desc(x1p, ctx.cin1)
+        dx1_p = None
+        if ctx.needs_input_grad[0]:
+            dx1_p = torch.empty_like(x1p)
+            L.call("nndet_conv3d_backward_data", ctypes.byref(sd), L.ptr(dzs), L.ptr(pk1), L.ptr(dx1_p), L.stream())
+        out = {}
+
+        def e_x_fn(side, raw):                       # runs inside the weight-gradient stream context (arch/conv.py)
+            if side is not None:
+                for t in (x1p, dzs, csum, wc, w_up32, bsum):
+                    t.record_stream(side)
+                L.wgrad_streams.side(dev, w_up)
+                for b in ctx.b_refs:
+                    L.wgrad_streams.side(dev, b)
+            dWc = torch.zeros((8, ctx.cin1, 3, 3, 3), dtype=torch.float32, device=dev)
+            ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(sd))
+            ws = L.workspace(ws_bytes, dev, raw_stream=raw if side is not None else None)
+            L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(x1p), L.ptr(dzs), L.ptr(dWc), None, L.ptr(ws), ws_bytes, raw)
+            dw_up, dbsum, ec = up_param_grads(wc, w_up32, bsum, dWc, csum.sum(0).float())
+            out["dw_up"], out["dbsum"] = dw_up, dbsum
+            return ec.flip(0).t()                   # Ec[t][k] -> the kernels' E[k][26 - t]
+
+        from .conv import rank1_branch_backward
+        _, da_p, dw_out, db_out, dw_lat, dw_head, db_head = rank1_branch_backward(
+            None, ap, w_out, b_out if ctx.has_b_out else None, w_lat, w_head, b_head if ctx.has_b_head else None, wd, None, wfa, d1, dsum,
+            False, ctx.needs_input_grad[1], e_x_fn=e_x_fn)
+        da = _SegBranchFn._a0_grad(ctx, da_p, dev)
+        dbs = out["dbsum"]
+        return ((logical(dx1_p, ctx.cin1) if dx1_p is not None else None), da, dw_lat.to(w_lat.dtype), dw_out.to(w_out.dtype), db_out,
+                dw_head.to(w_head.dtype), db_head, None, out["dw_up"].to(w_up.dtype), dbs if ctx.has_b_up else None,
+                dbs if ctx.has_b_lat else None)
+
+    @staticmethod
+    def _a0_grad(ctx, da_p, dev):
+        """The gradient of a0 through the fused-accumulation protocol of the encoder outputs (encoder.py: set_fuse_grad_accum)."""
+        if da_p is None:
+            return None
+        gacc = ctx.gacc
+        if gacc is not None and gacc["buf"] is not None and gacc["buf"].shape == da_p.shape and gacc["buf"].dtype == da_p.dtype:
+            # another consumer of a0 wrote its gradient first (not the usual order: this node is the last one created): add
+            if gacc.get("ev") is not None:
+                torch.cuda.current_stream(dev).wait_event(gacc["ev"])
+                gacc["buf"].record_stream(torch.cuda.current_stream(dev))
+            gacc["buf"].add_(da_p)
+            ps = gacc.get("stream")
+            if ps is not None and ps != torch.cuda.current_stream(dev):
+                ev2 = torch.cuda.Event(); ev2.record(); ps.wait_event(ev2)
+            gacc["buf"] = None
+            return None
+        if gacc is not None:                       # first consumer: the other one adds into this buffer (conv.py: _ConvFn.backward)
+            gacc["buf"] = da_p
+            gacc["ev"] = torch.cuda.Event()
+            gacc["ev"].record()
+        return logical(da_p, 32)
+
     @staticmethod
     def backward(ctx, g):
+        if ctx.up:
+            return _SegBranchFn._backward_up(ctx, g)
         xp, w_out, b_out, w_head, b_head, tgt, z, wd, ap, w_lat, wf, wfa = ctx.saved_tensors
         dev = xp.device
         nvox = z.numel()
@@ -229,27 +370,9 @@ class _SegBranchFn(torch.autograd.Function):
         dx_p, da_p, dw_out, db_out, dw_lat, dw_head, db_head = rank1_branch_backward(
             xp, ap if ctx.has_lat else None, w_out, b_out if ctx.has_b_out else None, w_lat if ctx.has_lat else None, w_head,
             b_head if ctx.has_b_head else None, wd, wf, wfa, d1, dsum, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        da = None
-        if da_p is not None:
-            gacc = ctx.gacc
-            if gacc is not None and gacc["buf"] is not None and gacc["buf"].shape == da_p.shape and gacc["buf"].dtype == da_p.dtype:
-                # another consumer of a0 wrote its gradient first (not the usual order: this node is the last one created): add
-                if gacc.get("ev") is not None:
-                    torch.cuda.current_stream(dev).wait_event(gacc["ev"])
-                    gacc["buf"].record_stream(torch.cuda.current_stream(dev))
-                gacc["buf"].add_(da_p)
-                ps = gacc.get("stream")
-                if ps is not None and ps != torch.cuda.current_stream(dev):
-                    ev2 = torch.cuda.Event(); ev2.record(); ps.wait_event(ev2)
-                gacc["buf"] = None
-            else:
-                da = logical(da_p, 32)
-                if gacc is not None:                       # first consumer: the other one adds into this buffer (conv.py: _ConvFn.backward)
-                    gacc["buf"] = da_p
-                    gacc["ev"] = torch.cuda.Event()
-                    gacc["ev"].record()
+        da = _SegBranchFn._a0_grad(ctx, da_p, dev)
         return ((logical(dx_p, ctx.cin) if dx_p is not None else None), da, (dw_lat.to(w_lat.dtype) if ctx.has_lat else None),
-                dw_out.to(w_out.dtype), db_out, dw_head.to(w_head.dtype), db_head, None)
+                dw_out.to(w_out.dtype), db_out, dw_head.to(w_head.dtype), db_head, None, None, None, None)
 
 
 class _SegTail(torch.autograd.Function):
@@ -306,8 +429,14 @@ class DiCESegmenterFgBg(nn.Module):
         pre = getattr(pred_seg.get("seg_input"), "_nndet_pre_out", None) if "seg_input" in pred_seg else None
         if pre is not None:                                       # the decoder skipped its output convolution: the whole branch here
             lat = getattr(pred_seg["seg_input"], "_nndet_pre_lat", None)      # (lateral module, its input): absorbed as well
-            s = _SegBranchFn.apply(pred_seg["seg_input"], lat[1] if lat else None, lat[0].conv.weight if lat else None,
-                                   pre.conv.weight, pre.conv.bias, self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
+            up = getattr(pred_seg["seg_input"], "_nndet_pre_up", None) if lat else None   # ... and the last top-down step: seg_input is x_1
+            if up is not None:
+                s = _SegBranchFn.apply(pred_seg["seg_input"], lat[1], lat[0].conv.weight, pre.conv.weight, pre.conv.bias,
+                                       self.conv_out.conv.weight, self.conv_out.conv.bias, tgt, up.conv.weight, up.conv.bias,
+                                       lat[0].conv.bias)
+            else:
+                s = _SegBranchFn.apply(pred_seg["seg_input"], lat[1] if lat else None, lat[0].conv.weight if lat else None,
+                                       pre.conv.weight, pre.conv.bias, self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
         elif "seg_input" in pred_seg:
             s = _SegHeadFused.apply(pred_seg["seg_input"], self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
         else:

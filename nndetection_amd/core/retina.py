@@ -89,11 +89,12 @@ class BaseRetinaNet(nn.Module):
         if hasattr(self.decoder, "defer_out0"):                # decoder.out.P0 + segmentation head + loss as one 32 -> 1 convolution?
             self.decoder.defer_out0 = self._seg_branch_ok(inp)
             self.decoder.absorb_lat0 = self.decoder.defer_out0 and self._seg_lateral_ok()
+            self.decoder.absorb_up0 = self.decoder.absorb_lat0 and self._seg_up_ok(inp)
         try:
             features_maps_all = self.decoder(self.encoder(inp))
         finally:
             if hasattr(self.decoder, "defer_out0"):
-                self.decoder.defer_out0 = self.decoder.absorb_lat0 = False
+                self.decoder.defer_out0 = self.decoder.absorb_lat0 = self.decoder.absorb_up0 = False
         feature_maps_head = [features_maps_all[i] for i in self.decoder_levels]
         tail_ev = getattr(self.decoder, "tail_event", None)    # level 0 (the segmenter's input) comes from the decoder's side stream
         if getattr(self, "_seg_side", None) is not None:       # train_step: the segmentation branch forks HERE (before the head is queued)
@@ -148,6 +149,20 @@ class BaseRetinaNet(nn.Module):
         m, up = blk[0], getattr(self.decoder, "up", {})
         return bool(m.norm_groups == 0 and not m.transposed and m.k == (1, 1, 1) and m.s == (1, 1, 1) and m.in_channels == 32
                     and m.out_channels == 32 and not getattr(m, "relu", False) and "P1" in up and up["P1"].norm_groups == 0)
+
+    def _seg_up_ok(self, inp: Tensor) -> bool:
+        """... and the last top-down step (arch/segmenter.py: SEG_UP): a plain k = s = 2 transposed convolution onto the 32 channels of
+        level 0 whose input (decoder level 1) nobody else reads, even patch dims."""
+        from ..arch import segmenter as S
+        up = getattr(self.decoder, "up", {})
+        if not S.SEG_UP or "P1" not in up or inp.dim() != 5 or any(int(d) % 2 for d in inp.shape[2:]):
+            return False
+        m = up["P1"]
+        used = getattr(self.decoder, "used_levels", None)
+        return bool(getattr(m, "transposed", False) and m.norm_groups == 0 and m.k == (2, 2, 2) and m.s == (2, 2, 2) and m.p == (0, 0, 0)
+                    and m.out_channels == 32 and m.in_channels % 32 == 0 and not getattr(m, "relu", False)
+                    and 1 not in tuple(self.decoder_levels) and used is not None and 1 not in used
+                    and getattr(self.decoder, "skip_unused_out", True))
 
     def _seg_rank1_ok(self) -> bool:
         """True if decoder level 0 is produced by one of our plain 3x3x3 / stride-1 convolutions (no norm) and read by the segmenter

@@ -40,14 +40,20 @@ __device__ __forceinline__ float sb_softplus(float x) { return fmaxf(x, 0.f) + l
 // it), 76 MFMAs per 256 outputs; the kernel is bound by the 629 MB read of x (halo re-reads come from L2).
 // TWO: a second 32-channel input x2 with its own composed weights wq2, accumulated into the same tap products (K = 64): the decoder's
 // lateral convolution absorbed as well (z = conv3(a0; wc . W_lat) + conv3(up; wc) + c0, see nndet_segbranch_forward2).
-template <typename T, bool TWO>
+// UP: a third term that is already reduced to one value per voxel -- the absorbed top-down step (arch/segmenter.py: NNDET_SEG_UP):
+// zup [N, D/2, H/2, W/2, 32] holds, in channel (pd * 2 + ph) * 2 + pw of the half-resolution voxel m, the contribution to the output
+// voxel 2 m + (pd, ph, pw); cb[27] is the bias of the voxel's border class (cd * 3 + ch) * 3 + cw (0 first plane, 1 inside, 2 last).
+template <typename T, bool TWO, bool UP = false>
 __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ x, const uint32_t* __restrict__ wq, const T* __restrict__ x2,
                                                           const uint32_t* __restrict__ wq2, const float* __restrict__ c0p,
                                                           const uint8_t* __restrict__ target, int N, int D, int H, int W,
-                                                          float* __restrict__ z, double* __restrict__ sums) {
+                                                          float* __restrict__ z, double* __restrict__ sums,
+                                                          const T* __restrict__ zup = nullptr, const float* __restrict__ cbp = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* u = reinterpret_cast<float*>(smem);
     __shared__ double red[4];
+    __shared__ float scb[27];
+    if constexpr (UP) { if (threadIdx.x < 27) scb[threadIdx.x] = cbp[threadIdx.x]; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, q = lane >> 4;
@@ -73,13 +79,21 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
     // B operands of one tile: 16 bytes of voxel (group g = wave + 4 k, column li), channels 8 q ..; out-of-volume voxels read zeros
     // (the conv padding). The loads of tile i + 1 are issued BEFORE tile i is processed: a tile is ~1 us of work against ~2 us of
     // memory latency, and only two workgroups share a CU.
-    auto load_tile = [&](int tile, u32x4* bv) {
+    auto load_tile = [&](int tile, u32x4* bv, float& zu) {
         const int n = tile / per_img;
         int tt = tile - n * per_img;
         const int tw_i = tt % ntw; tt /= ntw;
         const int th_i = tt % nth;
         const int td_i = tt / nth;
         const int d0 = td_i * SB_TD, h0 = th_i * SB_TH, w0 = tw_i * SB_TW;
+        if constexpr (UP) {                                             // this thread's output voxel of that tile: its value of the third term
+            const int od = d0 + od_l, oh = h0 + oh_l, ow = w0 + ow_l;
+            zu = 0.f;
+            if (od < D && oh < H && ow < W) {
+                const int64_t m = (((int64_t)n * (D >> 1) + (od >> 1)) * (H >> 1) + (oh >> 1)) * (W >> 1) + (ow >> 1);
+                zu = Elem<T>::ld(zup[m * 32 + (((od & 1) * 2 + (oh & 1)) * 2 + (ow & 1))]);
+            }
+        }
         const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(x)) + (int64_t)n * img_bytes,
                                                            0, img_bytes, 0x00020000);
         const auto xrs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(TWO ? x2 : x)) + (int64_t)n * img_bytes,
@@ -106,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
     const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
     const int t_begin = xcd * t8 + lw, t_end = min((xcd + 1) * t8, ntiles);
     u32x4 bv[NB], bn[NB];
-    if (t_begin < t_end) load_tile(t_begin, bv);
+    float zu = 0.f, zun = 0.f;
+    if (t_begin < t_end) load_tile(t_begin, bv, zu);
     for (int tile = t_begin; tile < t_end; tile += nx) {
         const int n = tile / per_img;
         int tt = tile - n * per_img;
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
         const int td_i = tt / nth;
         const int d0 = td_i * SB_TD, h0 = th_i * SB_TH, w0 = tw_i * SB_TW;
         const int next = tile + nx;
-        if (next < t_end) load_tile(next, bn);
+        if (next < t_end) load_tile(next, bn, zun);
         // (LDS-only barriers: __syncthreads() would also wait for the loads of the NEXT tile that were just issued)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous tile's reads of u are done
 #pragma unroll
@@ -146,7 +161,11 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
         const int od = d0 + od_l, oh = h0 + oh_l, ow = w0 + ow_l;
         if (od < D && oh < H && ow < W) {
             const int64_t idx = (((int64_t)n * D + od) * H + oh) * W + ow;
-            const float zv = (s0 + s1) + (s2 + c0);
+            float zv = (s0 + s1) + (s2 + c0);
+            if constexpr (UP) {
+                const int cd = od == 0 ? 0 : (od == D - 1 ? 2 : 1), ch = oh == 0 ? 0 : (oh == H - 1 ? 2 : 1), cw = ow == 0 ? 0 : (ow == W - 1 ? 2 : 1);
+                zv += zu + scb[(cd * 3 + ch) * 3 + cw];
+            }
             z[idx] = zv;
             const bool t = target[idx] > 0;
             const float p1 = 1.f / (1.f + expf(-zv));
@@ -155,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_segbranch_fwd(const T* __restrict__ 
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) bv[k] = bn[k];
+        zu = zun;
     }
     double dsum[4] = {(double)ce, (double)tp, (double)fp, (double)fn};
 #pragma unroll
@@ -190,6 +210,63 @@ __global__ __launch_bounds__(256) void k_segbranch_bwd(const float* __restrict__
     if ((threadIdx.x & 63) == 0) atomicAdd(&red, s);
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&dsum[blockIdx.x % SB_REPL], red);
+}
+
+// NNDET_SEG_UP, backward side: the space-to-depth copy of d1 that the composed half-resolution convolution takes as its output
+// gradient -- dzs[n][m][(pd * 2 + ph) * 2 + pw] = d1[n][2 m + (pd, ph, pw)], channels 8 .. 31 zero -- and the sum of d1 per border class
+// (27 sums; csum [SB_REPL][27], zeroed by the caller), from which the host forms S[t] = sum of d1 over the voxels whose tap t stays
+// inside the volume. One thread per half-resolution voxel; D, H, W even.
+template <typename T>
+__global__ __launch_bounds__(256) void k_segbranch_s2d(const T* __restrict__ d1, int N, int D, int H, int W, T* __restrict__ dzs,
+                                                       double* __restrict__ csum) {
+    __shared__ double bins[27];
+    if (threadIdx.x < 27) bins[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
+    const int64_t total = (int64_t)N * D2 * H2 * W2;
+    float inner = 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < total; m += (int64_t)gridDim.x * 256) {
+        const int mw = (int)(m % W2);
+        int64_t r = m / W2;
+        const int mh = (int)(r % H2); r /= H2;
+        const int md = (int)(r % D2);
+        const int n = (int)(r / D2);
+        uint32_t pk[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int od = 2 * md + a, oh = 2 * mh + b;
+                const int64_t v = (((int64_t)n * D + od) * H + oh) * W + 2 * mw;
+                const uint32_t two = *reinterpret_cast<const uint32_t*>(d1 + v);        // (pw = 0, 1): 4-byte aligned, W even
+                pk[a * 2 + b] = two;
+                const float v0 = H16<T>::lo(two), v1 = H16<T>::hi(two);
+                const int cd = od == 0 ? 0 : (od == D - 1 ? 2 : 1), ch = oh == 0 ? 0 : (oh == H - 1 ? 2 : 1);
+                const int c0 = mw == 0 ? 0 : 1, c1 = mw == W2 - 1 ? 2 : 1;               // ow = 2 mw: first or inside; 2 mw + 1: inside or last
+                if (cd == 1 && ch == 1 && c0 == 1) inner += v0; else atomicAdd(&bins[(cd * 3 + ch) * 3 + c0], (double)v0);
+                if (cd == 1 && ch == 1 && c1 == 1) inner += v1; else atomicAdd(&bins[(cd * 3 + ch) * 3 + c1], (double)v1);
+            }
+        u32x4* dst = reinterpret_cast<u32x4*>(dzs + m * 32);
+        dst[0] = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        dst[1] = u32x4{0u, 0u, 0u, 0u}; dst[2] = u32x4{0u, 0u, 0u, 0u}; dst[3] = u32x4{0u, 0u, 0u, 0u};
+    }
+    const double sv = wave_sum_f64((double)inner);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&bins[13], sv);
+    __syncthreads();
+    if (threadIdx.x < 27 && bins[threadIdx.x] != 0.0) atomicAdd(&csum[(blockIdx.x % SB_REPL) * 27 + threadIdx.x], bins[threadIdx.x]);
+}
+
+extern "C" int nndet_segbranch_s2d(int32_t dtype, const void* d1, int32_t N, int32_t D, int32_t H, int32_t W, void* dzs_out, double* csum_out,
+                                   void* stream) {
+    if (!d1 || !dzs_out || !csum_out || N <= 0 || D < 2 || H < 2 || W < 2 || (D | H | W) & 1 || !nndet_is16(dtype)) return NNDET_EINVAL;
+    const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2);
+    int64_t nb = ceil_div64(total, 256 * 2);
+    if (nb > 4096) nb = 4096;
+    hipStream_t st = as_stream(stream);
+    if (dtype == NNDET_BF16) k_segbranch_s2d<bf16_t><<<(unsigned)nb, 256, 0, st>>>((const bf16_t*)d1, N, D, H, W, (bf16_t*)dzs_out, csum_out);
+    else k_segbranch_s2d<f16_t><<<(unsigned)nb, 256, 0, st>>>((const f16_t*)d1, N, D, H, W, (f16_t*)dzs_out, csum_out);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 // All parameter gradients of the branch from the one-channel correlations (tiny tensors, one workgroup): with Ec[c][t] = E[c][26 - t]
@@ -262,9 +339,10 @@ extern "C" int nndet_segbranch_replicas(void) { return SB_REPL; }
 
 static int segbranch_launch(int32_t dtype, const void* x, const void* w_packed, const void* x2, const void* w2_packed, int32_t N, int32_t D,
                             int32_t H, int32_t W, int32_t c_p, const float* c0, const uint8_t* target, float* z_out, double* sums_out,
-                            void* stream) {
+                            void* stream, const void* zup = nullptr, const float* cb = nullptr) {
     if (!x || !w_packed || !c0 || !target || !z_out || !sums_out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || c_p != 32) return NNDET_EINVAL;
     if ((x2 == nullptr) != (w2_packed == nullptr)) return NNDET_EINVAL;
+    if ((zup == nullptr) != (cb == nullptr) || (zup && (x2 || ((D | H | W) & 1)))) return NNDET_EINVAL;
     if (!nndet_is16(dtype)) return NNDET_EINVAL;                       // the fp32 path keeps the separate layers
     if ((int64_t)D * H * W * 64 >= (1LL << 31)) return NNDET_EINVAL;    // 32-bit buffer offsets per image
     const int64_t ntiles = (int64_t)ceil_div(D, SB_TD) * ceil_div(H, SB_TH) * ceil_div(W, SB_TW) * N;
@@ -275,13 +353,19 @@ static int segbranch_launch(int32_t dtype, const void* x, const void* w_packed, 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         attr_done = 1;
     }
     hipStream_t st = as_stream(stream);
 #define SB_GO(T_, TWO_) k_segbranch_fwd<T_, TWO_><<<nb, 256, SB_LDS, st>>>((const T_*)x, (const uint32_t*)w_packed, (const T_*)x2, \
                                                                            (const uint32_t*)w2_packed, c0, target, N, D, H, W, z_out, sums_out)
-    if (dtype == NNDET_BF16) { if (x2) SB_GO(bf16_t, true); else SB_GO(bf16_t, false); }
+#define SB_GO3(T_) k_segbranch_fwd<T_, false, true><<<nb, 256, SB_LDS, st>>>((const T_*)x, (const uint32_t*)w_packed, nullptr, nullptr, c0, target, \
+                                                                           N, D, H, W, z_out, sums_out, (const T_*)zup, cb)
+    if (zup) { if (dtype == NNDET_BF16) SB_GO3(bf16_t); else SB_GO3(f16_t); }
+    else if (dtype == NNDET_BF16) { if (x2) SB_GO(bf16_t, true); else SB_GO(bf16_t, false); }
     else { if (x2) SB_GO(f16_t, true); else SB_GO(f16_t, false); }
+#undef SB_GO3
 #undef SB_GO
     LAUNCH_CHECK();
     return 0;
@@ -298,6 +382,13 @@ extern "C" int nndet_segbranch_forward2(int32_t dtype, const void* x, const void
                                         double* sums_out, void* stream) {
     if (!x2 || !w2_packed) return NNDET_EINVAL;
     return segbranch_launch(dtype, x, w_packed, x2, w2_packed, N, D, H, W, c_p, c0, target, z_out, sums_out, stream);
+}
+
+extern "C" int nndet_segbranch_forward_up(int32_t dtype, const void* x, const void* w_packed, const void* zup, const float* cb, int32_t N,
+                                          int32_t D, int32_t H, int32_t W, int32_t c_p, const float* c0, const uint8_t* target, float* z_out,
+                                          double* sums_out, void* stream) {
+    if (!zup || !cb) return NNDET_EINVAL;
+    return segbranch_launch(dtype, x, w_packed, nullptr, nullptr, N, D, H, W, c_p, c0, target, z_out, sums_out, stream, zup, cb);
 }
 
 extern "C" int nndet_segbranch_backward(int32_t dtype, const float* z, const uint8_t* target, int64_t nvox, const float* coeffs,

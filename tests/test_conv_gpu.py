@@ -387,6 +387,87 @@ def test_segmentation_branch_as_one_convolution(shape, dtype, lateral, monkeypat
         assert e_ref <= 1.25 * e_tworef + 0.25 * tol, f"{name}: fused {e_ref:.3e} vs two-layer {e_tworef:.3e} from fp32"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 8, 10, 12), (1, 16, 24, 32), (1, 6, 18, 34)], ids=["ragged", "tiles", "odd-tiles"])
+def test_segmentation_branch_absorbs_the_top_down_step(shape, dtype, monkeypatch):
+    """NNDET_SEG_UP: with the lateral absorbed, the last top-down step up.P1 (ConvTranspose3d k = s = 2, 64 -> 32) goes into the branch as
+    well -- conv3(up(x1) + b; wc) as ONE half-resolution 3x3x3 convolution 64 -> 8 (nndet_conv3d_forward on composed weights) + a
+    border-class bias (nndet_segbranch_forward_up); backward through nndet_segbranch_s2d and that convolution's data / weight gradient.
+    Losses and the gradients of x1, a0 and of ALL parameters (up.P1 weight + bias, lateral weight + bias, out.P0, head) against plain
+    PyTorch fp32 of the four layers and against the route that forms the top-down term (nndet_segbranch_forward2)."""
+    from nndetection_amd.arch import Generator, ConvInstanceRelu, DiCESegmenterFgBg
+    from nndetection_amd import _lib as L
+    torch.manual_seed(17)
+    N, D, H, W = shape
+    mk = lambda: (ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=False, add_act=False),
+                  DiCESegmenterFgBg(Generator(ConvInstanceRelu, 3), seg_classes=1, in_channels=[32], decoder_levels=[0], dice_kwargs={"batch_dice": True}),
+                  ConvInstanceRelu(3, 32, 32, 1, stride=1, padding=0, add_norm=False, add_act=False),
+                  ConvInstanceRelu(3, 64, 32, 2, stride=2, padding=0, add_norm=False, add_act=False, transposed=True))
+    conv, seg, latm, upm = mk()
+    with torch.no_grad():
+        conv.conv.weight.copy_(torch.randn_like(conv.conv.weight) / 29.4); conv.conv.bias.copy_(torch.randn(32) * 0.2)
+        seg.conv_out.conv.weight.copy_(torch.randn_like(seg.conv_out.conv.weight) * 0.3); seg.conv_out.conv.bias.copy_(torch.tensor([0.2, -0.1]))
+        latm.conv.weight.copy_(torch.randn_like(latm.conv.weight) / 5.7); latm.conv.bias.copy_(torch.randn(32) * 0.3)
+        upm.conv.weight.copy_(torch.randn_like(upm.conv.weight) / 8.0); upm.conv.bias.copy_(torch.randn(32) * 0.3)
+    x10, a00 = torch.randn(N, 64, D // 2, H // 2, W // 2), torch.randn(N, 32, D, H, W).relu()
+    tgt = (torch.rand(N, D, H, W) > 0.75).float()
+    xr, ar = x10.to(dtype).float().requires_grad_(True), a00.to(dtype).float().requires_grad_(True)
+    P = {"w": conv.conv.weight, "b": conv.conv.bias, "ws": seg.conv_out.conv.weight, "bs": seg.conv_out.conv.bias, "wl": latm.conv.weight,
+         "bl": latm.conv.bias, "wu": upm.conv.weight, "bu": upm.conv.bias}
+    R = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    x0r = F.conv3d(ar, R["wl"], R["bl"]) + F.conv_transpose3d(xr, R["wu"], R["bu"], stride=2)
+    sl = F.conv3d(F.conv3d(x0r, R["w"], R["b"], padding=1), R["ws"], R["bs"])
+    t = (tgt > 0).long()
+    p = torch.softmax(sl, 1)
+    oh = torch.zeros_like(p).scatter_(1, t[:, None], 1)
+    ax = [0, 2, 3, 4]
+    tp = (p * oh).sum(ax); fp = (p * (1 - oh)).sum(ax); fn = ((1 - p) * oh).sum(ax)
+    ce = 0.5 * F.cross_entropy(sl, t)
+    dice = 0.5 * (1 - ((2 * tp + 1e-5) / (2 * tp + fp + fn + 1e-5))[1:].mean())
+    ((ce + dice) * 64.0).backward()
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    res = {}
+    for up_mode in (True, False):
+        cg, sg, lg, ug = mk()
+        for m_, r_ in ((cg, conv), (sg, seg), (lg, latm), (ug, upm)):
+            m_.load_state_dict(r_.state_dict())
+        cg, sg, lg, ug = cg.cuda(), sg.cuda(), lg.cuda(), ug.cuda()
+        xg = x10.cuda().to(dtype).requires_grad_(True)
+        ag = a00.cuda().to(dtype).requires_grad_(True)
+        calls.clear()
+        if up_mode:
+            xin = xg * 1.0                                       # (a non-leaf, like the decoder's level-1 map)
+            xin._nndet_pre_out, xin._nndet_pre_lat, xin._nndet_pre_up = cg, (lg, ag * 1.0), ug      # what UFPNModular attaches
+            out = sg.compute_loss(sg([xin], fused=True), tgt.cuda())
+            assert "nndet_segbranch_forward_up" in calls and "nndet_segbranch_forward2" not in calls
+        else:
+            from nndetection_amd.arch.conv import _ConvFn
+            u, _ = _ConvFn.apply(xg * 1.0, None, False, ug.conv.weight, ug.conv.bias + lg.conv.bias, ug, None, False)
+            u._nndet_pre_out, u._nndet_pre_lat = cg, (lg, ag * 1.0)
+            out = sg.compute_loss(sg([u], fused=True), tgt.cuda())
+            assert "nndet_segbranch_forward2" in calls and "nndet_segbranch_forward_up" not in calls
+        ((out["seg_ce"] + out["seg_dice"]) * 64.0).backward()
+        torch.cuda.synchronize()
+        if up_mode:
+            assert "nndet_segbranch_s2d" in calls
+        res[up_mode] = [out["seg_ce"].detach().cpu(), out["seg_dice"].detach().cpu(), xg.grad.float().cpu(), ag.grad.float().cpu(),
+                        cg.conv.weight.grad.cpu(), cg.conv.bias.grad.cpu(), sg.conv_out.conv.weight.grad.cpu(), sg.conv_out.conv.bias.grad.cpu(),
+                        lg.conv.weight.grad.cpu(), lg.conv.bias.grad.cpu(), ug.conv.weight.grad.cpu(), ug.conv.bias.grad.cpu()]
+    refs = [ce.detach(), dice.detach(), xr.grad, ar.grad, R["w"].grad, R["b"].grad, R["ws"].grad, R["bs"].grad, R["wl"].grad, R["bl"].grad,
+            R["wu"].grad, R["bu"].grad]
+    ltol = 2e-3 if dtype == torch.bfloat16 else 3e-4
+    tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3
+    for i, name in enumerate(("seg_ce", "seg_dice")):
+        assert abs(float(res[True][i]) - float(refs[i])) <= ltol, (name, float(res[True][i]), float(refs[i]))
+    names = ("dx1", "da0", "dW", "db", "dW_seg", "db_seg", "dW_lat", "db_lat", "dW_up", "db_up")
+    for name, a, d_, r in zip(names, res[True][2:], res[False][2:], refs[2:]):
+        e_ref, e_two, e_tworef = relerr(a, r), relerr(a, d_), relerr(d_, r)
+        assert e_ref <= tol, f"{name}: absorbed top-down step vs fp32 {e_ref:.3e} (the route that forms it: {e_tworef:.3e})"
+        assert e_two <= 1.05 * (e_ref + e_tworef) + 1e-6, f"{name}: vs the route that forms the top-down term {e_two:.3e}"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_segloss(dtype):
     from nndetection_amd.arch import Generator, ConvInstanceRelu, DiCESegmenterFgBg

@@ -360,7 +360,7 @@ def test_absorbed_top_down_step_algebra():
         c = torch.ones(n, dtype=torch.long); c[0] = 0; c[-1] = 2
         return c
     cd, ch, cw = cls(2 * D2), cls(2 * H2), cls(2 * W2)
-    z += cb[cd][:, ch][:, :, cw]
+    z += cb.reshape(3, 3, 3)[cd][:, ch][:, :, cw]
     assert torch.allclose(z, zr.detach(), rtol=1e-10, atol=1e-10)
     # ---- backward from d1 = G
     d1 = G[:, 0]
@@ -370,7 +370,7 @@ def test_absorbed_top_down_step_algebra():
     csum = torch.zeros(3, 3, 3, dtype=dd)
     csum.index_put_((cd[:, None, None].expand(2 * D2, 2 * H2, 2 * W2), ch[None, :, None].expand(2 * D2, 2 * H2, 2 * W2),
                      cw[None, None, :].expand(2 * D2, 2 * H2, 2 * W2)), d1.sum(0), accumulate=True)
-    dw_up, dbsum, ec = up_param_grads(wc.detach(), w_up.detach(), bsum.detach(), dWc, csum)
+    dw_up, dbsum, ec = up_param_grads(wc.detach(), w_up.detach(), bsum.detach(), dWc, csum.reshape(27))
     assert torch.allclose(dx1, x1.grad, rtol=1e-10, atol=1e-10)
     assert torch.allclose(dw_up, w_up.grad, rtol=1e-10, atol=1e-10)
     assert torch.allclose(dbsum, bsum.grad, rtol=1e-10, atol=1e-10)

@@ -353,38 +353,45 @@ def test_segmentation_branch_fusion_in_train_step(golden_dir, dtype, monkeypatch
     real = L.call
     monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
     res = {}
-    # (whole branch incl. the level-0 lateral, nndet_segbranch_forward2) / (output conv + head only) / the separate layers
-    for mode in ((True, True), (True, False), (False, False)):
-        monkeypatch.setattr(S, "SEG_BRANCH", mode[0]); monkeypatch.setattr(S, "SEG_LATERAL", mode[1])
+    # (whole branch incl. the level-0 lateral and the last top-down step, nndet_segbranch_forward_up) / (... without the top-down step,
+    # nndet_segbranch_forward2) / (output conv + head only) / the separate layers
+    for mode in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
+        monkeypatch.setattr(S, "SEG_BRANCH", mode[0]); monkeypatch.setattr(S, "SEG_LATERAL", mode[1]); monkeypatch.setattr(S, "SEG_UP", mode[2])
         net.zero_grad(set_to_none=True)
         calls.clear()
         losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
         (sum(losses.values()) * (256.0 if dtype == torch.float16 else 1.0)).backward()
         torch.cuda.synchronize()
         lp = dtype != torch.float32
-        assert ("nndet_segbranch_forward2" in calls) == (mode == (True, True) and lp), (mode, dtype)
-        assert ("nndet_segbranch_forward" in calls) == (mode == (True, False) and lp), (mode, dtype)
+        # (this model's head reads decoder level 1, so its last top-down step cannot be absorbed: the first two modes coincide here;
+        # tests/test_parity_full_gpu.py::test_luna160_absorbed_top_down_step runs the route on the architecture that allows it)
+        up_ok = net._seg_up_ok(x)
+        assert not up_ok
+        assert ("nndet_segbranch_forward_up" in calls) == (mode == (True, True, True) and lp and up_ok), (mode, dtype)
+        assert ("nndet_segbranch_forward2" in calls) == (mode[:2] == (True, True) and lp and not (mode[2] and up_ok)), (mode, dtype)
+        assert ("nndet_segbranch_forward" in calls) == (mode == (True, False, False) and lp), (mode, dtype)
         assert ("nndet_segbranch_backward" in calls) == (mode[0] and lp)
         res[mode] = ({k: float(v.detach()) for k, v in losses.items()},
                      {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
-    res[False] = res[(False, False)]
+    res[False] = res[(False, False, False)]
     # (fp32: the same kernels both times, only the atomics' summation order differs)
     tol = 2e-5 if dtype == torch.float32 else (3e-2 if dtype == torch.bfloat16 else 4e-3)
     ltol = 1e-6 if dtype == torch.float32 else (2e-3 if dtype == torch.bfloat16 else 3e-4)
-    for mode in ((True, True), (True, False)):
+    for mode in ((True, True, True), (True, True, False), (True, False, False)):
         for k, v in res[False][0].items():
             assert abs(res[mode][0][k] - v) <= ltol * max(1.0, abs(v)), (mode, k, res[mode][0][k], v)
         assert set(res[mode][1]) == set(res[False][1]) and "decoder.out.P0.0.conv.weight" in res[mode][1] \
-            and "decoder.lateral.P0.0.conv.weight" in res[mode][1]
+            and "decoder.lateral.P0.0.conv.weight" in res[mode][1] and "decoder.up.P1.conv.weight" in res[mode][1] \
+            and "decoder.up.P1.conv.bias" in res[mode][1]
         for n, g0 in res[False][1].items():
             d = float((res[mode][1][n] - g0).abs().max())
             assert d <= tol * (float(g0.abs().max()) + 1e-12) + 1e-7, (mode, n, d, float(g0.abs().max()))
-    monkeypatch.setattr(S, "SEG_BRANCH", True); monkeypatch.setattr(S, "SEG_LATERAL", True)
+    monkeypatch.setattr(S, "SEG_BRANCH", True); monkeypatch.setattr(S, "SEG_LATERAL", True); monkeypatch.setattr(S, "SEG_UP", True)
     calls.clear()
     with torch.no_grad():
         _, pred = net.train_step(x, _cuda_targets(tg), evaluation=True)
     assert "nndet_segbranch_forward" not in calls and pred["pred_seg"].shape[1] == 2
-    assert net.decoder.defer_out0 is False and net.decoder.absorb_lat0 is False
+    assert net.decoder.defer_out0 is False and net.decoder.absorb_lat0 is False and net.decoder.absorb_up0 is False
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
