@@ -68,6 +68,10 @@ class UFPNModular(nn.Module):
     # 0.33 ms at 160x160x96, and their backward passes) run next to the MFMA-bound head instead of in front of it. `tail_event` tells
     # the consumer of level 0 when it is ready. NNDET_DECODER_TAIL=0: everything on the caller's stream.
     split_tail = os.environ.get("NNDET_DECODER_TAIL", "1") != "0"
+    # ... and, when nothing but level 0 reads level 1 either (the detection head starts at level 2 and out.P1 is skipped), lateral P1 and
+    # the top-down step up.P2 that forms x_1 as well: 0.07 + 0.23 ms of HBM-bound launches leave the chain in front of the head.
+    # NNDET_DECODER_TAIL1=0: level 1 stays on the caller's stream.
+    split_tail1 = os.environ.get("NNDET_DECODER_TAIL1", "1") != "0"
     _tail_streams: dict = {}
     # The lateral 1x1x1 convolutions only need their own encoder stage. Issued from a hook of the encoder as soon as that stage's
     # output exists (the detector installs it), the HBM-bound full- and half-resolution laterals (0.28 + 0.30 ms at 160x160x96) run on
@@ -121,6 +125,8 @@ class UFPNModular(nn.Module):
                     cur.wait_event(ev)
                     lat.record_stream(cur)
         absorb = self._absorbing(inp_seq[0])
+        tail1 = bool(split and self.split_tail1 and self.num_level >= 4 and self.skip_unused_out and self.used_levels is not None
+                     and 1 not in self.used_levels and fpn[1] is None)
         if split:
             dev = inp_seq[0].device
             main = torch.cuda.current_stream(dev)
@@ -133,21 +139,28 @@ class UFPNModular(nn.Module):
                 with torch.cuda.stream(side):
                     fpn[0] = self.lateral["P0"](inp_seq[0])
         for l, fm in enumerate(inp_seq):
-            if fpn[l] is None and not (l == 0 and absorb):
+            if fpn[l] is None and not (l == 0 and absorb) and not (l == 1 and tail1):
                 fpn[l] = self.lateral[f"P{l}"](fm)
         xs: List[Optional[torch.Tensor]] = [None] * self.num_level
         x = fpn[self.num_level - 1]
         xs[self.num_level - 1] = x
-        for level in range(self.num_level - 2, 0 if split else -1, -1):
+        for level in range(self.num_level - 2, (1 if tail1 else 0) if split else -1, -1):
             # x_l = lateral_l + up_{l+1}(x_{l+1})  (decoder/base.py:405-413): the add is the epilogue of the transposed conv
             x = self._top_down0(x, inp_seq[0]) if (level == 0 and absorb) else self.up[f"P{level + 1}"](x, residual=fpn[level])
             xs[level] = x
         outs: List[Optional[torch.Tensor]] = [None] * self.num_level
         if split:
             ev = torch.cuda.Event()
-            ev.record(main)                                      # x_1 is ready
+            ev.record(main)                                      # x_1 (tail1: x_2 and the encoder outputs) is ready
             side.wait_event(ev)
-            xs[1].record_stream(side)
+            if tail1:
+                xs[2].record_stream(side)
+                inp_seq[1].record_stream(side)
+                with torch.cuda.stream(side):
+                    fpn[1] = self.lateral["P1"](inp_seq[1])
+                    xs[1] = self.up["P2"](xs[2], residual=fpn[1])
+            else:
+                xs[1].record_stream(side)
             with torch.cuda.stream(side):
                 xs[0] = self._top_down0(xs[1], inp_seq[0]) if absorb else self.up["P1"](xs[1], residual=fpn[0])
                 outs[0] = self._out0(xs[0])
