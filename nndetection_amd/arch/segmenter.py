@@ -166,6 +166,43 @@ def up_param_grads(wc: torch.Tensor, w_up: torch.Tensor, bsum: Optional[torch.Te
     return dw_up, dbsum, ec
 
 
+def _compose_up_branch(params, dt):
+    """Everything of the absorbed branch that depends on the parameters only (a few dozen small launches): the composed kernels, the
+    constant, the border-class bias and the two packed copies of the half-resolution convolution's weights. On the CURRENT stream."""
+    import ctypes
+    w_lat, w_out, b_out, w_head, b_head, w_up, b_up, b_lat = params
+    dev = w_out.device
+    cout, cin, cin1 = w_out.shape[0], w_out.shape[1], w_up.shape[0]
+    wh = w_head.detach().reshape(2, cout).float()
+    wd = (wh[1] - wh[0]).contiguous()
+    wc = torch.einsum("c,cidhw->dhwi", wd, w_out.detach().float()).reshape(27, cin).contiguous()
+    c0 = torch.zeros((), dtype=torch.float32, device=dev)
+    if b_out is not None:
+        c0 = c0 + (wd * b_out.detach().float()).sum()
+    if b_head is not None:
+        c0 = c0 + (b_head.detach()[1] - b_head.detach()[0]).float()
+    c0 = c0.reshape(1).contiguous()
+    wca = torch.matmul(wc, w_lat.detach().float().reshape(cin, 32))
+    wqa = wca.to(dt).contiguous()
+    wfa = wca.flip(0).t().contiguous().view(32, 1, 3, 3, 3)
+    bs = [b.detach().float() for b in (b_up, b_lat) if b is not None]
+    bsum = (bs[0] + bs[1]) if len(bs) == 2 else (bs[0] if bs else torch.zeros((cin,), dtype=torch.float32, device=dev))
+    w_up32 = w_up.detach().float().contiguous()
+    Wc, cb = up_compose(wc, w_up32, bsum)
+    Wc, cb = Wc.contiguous(), cb.contiguous()
+    sd = L.NndetConv()                              # (packing depends on the channel counts / kernel only)
+    sd.dtype, sd.transposed, sd.batch = L._DT[dt], 0, 1
+    sd.cin, sd.cout, sd.cin_p, sd.cout_p = cin1, 8, (cin1 + 31) // 32 * 32, 32
+    sd.k = (ctypes.c_int32 * 3)(3, 3, 3); sd.s = (ctypes.c_int32 * 3)(1, 1, 1); sd.p = (ctypes.c_int32 * 3)(1, 1, 1)
+    lib = L.load()
+    pk = []
+    for mode in (0, 1):
+        buf = torch.empty((int(lib.nndet_packed_weight_elems(ctypes.byref(sd), mode)),), dtype=dt, device=dev)
+        L.call("nndet_pack_weight", ctypes.byref(sd), mode, L.ptr(Wc), L.ptr(buf), L.stream())
+        pk.append(buf)
+    return {"wd": wd, "wc": wc, "c0": c0, "wqa": wqa, "wfa": wfa, "bsum": bsum, "w_up32": w_up32, "cb": cb, "pk": pk}
+
+
 class _SegBranchFn(torch.autograd.Function):
     """x = the decoder's level-0 map BEFORE decoder.out.P0 [N, 32, D, H, W] (16-bit), w_out [32, 32, 3, 3, 3] / b_out of that
     convolution, w_head [2, 32, 1, 1, 1] / b_head of the segmenter's output conv, target uint8 -> fp32 [4] = (sum CE, tp, fp, fn).
@@ -248,30 +285,11 @@ class _SegBranchFn(torch.autograd.Function):
                 or x1p.dtype != dt or tuple(x1p.shape[:4]) != (N, D // 2, H // 2, W // 2) or (D | H | W) & 1
                 or tuple(w_up.shape) != (cin1, cin, 2, 2, 2) or tuple(w_lat.shape[:2]) != (cin, 32)):
             raise L.NndetError("fused segmentation branch with the top-down step: 16 bits, even dims, a k = s = 2 transposed convolution C1 -> 32")
-        wh = w_head.detach().reshape(2, cout).float()
-        wd = (wh[1] - wh[0]).contiguous()
-        wc = torch.einsum("c,cidhw->dhwi", wd, w_out.detach().float()).reshape(27, cin).contiguous()
-        c0 = torch.zeros((), dtype=torch.float32, device=dev)
-        if b_out is not None:
-            c0 = c0 + (wd * b_out.detach().float()).sum()
-        if b_head is not None:
-            c0 = c0 + (b_head.detach()[1] - b_head.detach()[0]).float()
-        c0 = c0.reshape(1).contiguous()
-        wca = torch.matmul(wc, w_lat.detach().float().reshape(cin, 32))
-        wqa = wca.to(dt).contiguous()
-        wfa = wca.flip(0).t().contiguous().view(32, 1, 3, 3, 3)
-        bs = [b.detach().float() for b in (b_up, b_lat) if b is not None]
-        bsum = (bs[0] + bs[1]) if len(bs) == 2 else (bs[0] if bs else torch.zeros((cin,), dtype=torch.float32, device=dev))
-        w_up32 = w_up.detach().float().contiguous()
-        Wc, cb = up_compose(wc, w_up32, bsum)
-        Wc, cb = Wc.contiguous(), cb.contiguous()
+        params = (w_lat, w_out, b_out, w_head, b_head, w_up, b_up, b_lat)
+        pre = _compose_up_branch(params, dt)
+        wd, wc, c0, wqa, wfa, bsum, w_up32, cb, pk = (pre[k] for k in ("wd", "wc", "c0", "wqa", "wfa", "bsum", "w_up32", "cb", "pk"))
         sd = _SegBranchFn._up_desc(x1p, cin1)
         lib = L.load()
-        pk = []
-        for mode in (0, 1):
-            buf = torch.empty((int(lib.nndet_packed_weight_elems(ctypes.byref(sd), mode)),), dtype=dt, device=dev)
-            L.call("nndet_pack_weight", ctypes.byref(sd), mode, L.ptr(Wc), L.ptr(buf), L.stream())
-            pk.append(buf)
         zup = torch.empty((N, D // 2, H // 2, W // 2, 32), dtype=dt, device=dev)
         L.call("nndet_conv3d_forward", ctypes.byref(sd), L.ptr(x1p), L.ptr(pk[0]), None, None, L.ptr(zup), None, L.stream())
         z = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
