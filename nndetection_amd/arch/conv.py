@@ -327,7 +327,14 @@ class _ConvFn(torch.autograd.Function):
         N, cout, cout_p = desc.batch, desc.cout, desc.cout_p
         stem = desc.cin_p == 1
         w_arg = weight.detach().float().contiguous() if stem else _packed(mod, 0, weight, desc, dt)
-        y = torch.empty((N, desc.out_d, desc.out_h, desc.out_w, cout_p), dtype=dt, device=dev)
+        y = None
+        dst = getattr(mod, "_out_buf", None)      # (arch/decoder.py: the head levels' outputs are written straight into the ragged batch buffer)
+        if dst is not None:
+            mod._out_buf = None
+            if tuple(dst.shape) == (N, desc.out_d, desc.out_h, desc.out_w, cout_p) and dst.dtype == dt and dst.device == dev and dst.is_contiguous():
+                y = dst
+        if y is None:
+            y = torch.empty((N, desc.out_d, desc.out_h, desc.out_w, cout_p), dtype=dt, device=dev)
         stats = L.arena_zeros((L.STATS_REPLICAS, N, cout_p, 2), torch.float64, dev) if want_stats else None
         b_p = _padded_bias(mod, bias, cout_p)
         r_p = None

@@ -166,12 +166,44 @@ class UFPNModular(nn.Module):
                 outs[0] = self._out0(xs[0])
                 self.tail_event = torch.cuda.Event()
                 self.tail_event.record(side)
+        self._ragged_out(xs, 1 if split else 0)
         for level in range(1 if split else 0, self.num_level):
             if self.skip_unused_out and self.used_levels is not None and level not in self.used_levels:
                 outs[level] = None
             else:
                 outs[level] = self._out0(xs[0]) if level == 0 else self.out[f"P{level}"](xs[level])
         return outs
+
+    # The detection head batches its levels as ONE ragged [rows, C_p] buffer, level-major (arch/pyramid.py: cat_levels). When the
+    # levels it reads are a contiguous run of equally wide out convolutions, those write their outputs straight into consecutive
+    # slices of one allocation and the concatenation becomes a view (45 MB copied per step otherwise). NNDET_RAGGED_OUT=0: off.
+    ragged_out = os.environ.get("NNDET_RAGGED_OUT", "1") != "0"
+
+    def _ragged_out(self, xs, first: int) -> None:
+        from .conv import BaseConvNormAct
+        from ..layout import cpad
+        if not (self.ragged_out and self.skip_unused_out and self.used_levels is not None):
+            return
+        lv = sorted(l for l in self.used_levels if l >= max(first, 1))
+        if len(lv) < 2 or lv != list(range(lv[0], lv[0] + len(lv))) or any(xs[l] is None or not xs[l].is_cuda for l in lv):
+            return
+        mods = []
+        for l in lv:
+            blk = self.out[f"P{l}"]
+            m = blk[0] if len(list(blk.children())) == 1 else None
+            if not isinstance(m, BaseConvNormAct) or m.transposed or m.s != (1, 1, 1) or m.k != (3, 3, 3) or m.p != (1, 1, 1) or m.norm_groups:
+                return
+            mods.append(m)
+        cp = cpad(mods[0].out_channels)
+        if any(cpad(m.out_channels) != cp for m in mods) or xs[lv[0]].dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            return
+        rows = [xs[l].shape[0] * xs[l].shape[2] * xs[l].shape[3] * xs[l].shape[4] for l in lv]
+        base = torch.empty((sum(rows), cp), dtype=xs[lv[0]].dtype, device=xs[lv[0]].device)
+        r0 = 0
+        for l, m, nr in zip(lv, mods, rows):
+            x = xs[l]
+            m._out_buf = base[r0:r0 + nr].view(x.shape[0], x.shape[2], x.shape[3], x.shape[4], cp)
+            r0 += nr
 
     # Set by the detector for ONE forward pass (core/retina.py): a training step without prediction whose segmentation branch
     # computes decoder.out.P0 + output conv + loss as one composed 32 -> 1 convolution (arch/segmenter.py: _SegBranchFn) gets the

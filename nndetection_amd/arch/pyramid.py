@@ -82,6 +82,16 @@ class _CatLevelsFn(torch.autograd.Function):
         ps = [phys(f)[0] for f in fmaps]
         ctx.meta, ctx.c = meta, fmaps[0].shape[1]
         cp = ps[0].shape[4]
+        # consecutive slices of one allocation (arch/decoder.py: _ragged_out): the concatenation is a view
+        p0 = ps[0]
+        if p0.is_cuda and all(p.is_contiguous() and p.dtype == p0.dtype and p.shape[4] == cp for p in ps):
+            st, off, ok = p0.untyped_storage().data_ptr(), p0.data_ptr(), True
+            for p in ps:
+                ok = ok and p.untyped_storage().data_ptr() == st and p.data_ptr() == off
+                off += p.numel() * p.element_size()
+            if ok and off - p0.data_ptr() <= p0.untyped_storage().nbytes() - (p0.data_ptr() - st):
+                total = sum(p.numel() for p in ps) // cp
+                return torch.empty((0,), dtype=p0.dtype, device=p0.device).set_(p0.untyped_storage(), p0.storage_offset(), (total, cp), (cp, 1))
         return torch.cat([p.reshape(-1, cp) for p in ps], dim=0)
 
     @staticmethod

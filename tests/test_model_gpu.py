@@ -439,6 +439,35 @@ def test_early_consumer_of_the_stage0_output(golden_dir, dtype, monkeypatch):
             assert d <= tol * (float(g0.abs().max()) + 1e-12) + 1e-7, (n, d, float(g0.abs().max()))
 
 
+def test_head_levels_are_written_into_the_ragged_batch_buffer(golden_dir, monkeypatch):
+    """arch/decoder.py `_ragged_out`: the out convolutions of the levels the detection head reads write into consecutive slices of ONE
+    allocation, so `cat_levels` (the head's ragged [rows, C_p] batch) is a view instead of a 45 MB copy -- same values as the
+    concatenation of separately allocated outputs, gradients flow to every level."""
+    from nndetection_amd.arch import decoder as D
+    from nndetection_amd.arch.pyramid import cat_levels
+    from nndetection_amd.layout import phys
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    x = torch.from_numpy(gn["x"]).cuda().to(torch.bfloat16)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(D.UFPNModular, "ragged_out", on)
+        net.zero_grad(set_to_none=True)
+        outs = net.decoder(net.encoder(x))
+        torch.cuda.current_stream().wait_event(net.decoder.tail_event) if net.decoder.tail_event is not None else None
+        fm = [outs[l] for l in net.decoder_levels]
+        t2d, meta = cat_levels(fm)
+        assert (t2d.data_ptr() == phys(fm[0])[0].data_ptr()) == on           # a view of the first level's buffer / a fresh copy
+        (t2d.float() * torch.linspace(-1, 1, t2d.shape[1], device="cuda")).sum().backward()
+        torch.cuda.synchronize()
+        res[on] = (t2d.detach().float().cpu(), {n: p.grad.detach().float().cpu() for n, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1]) and len(res[True][1]) > 20
+    for n, g in res[False][1].items():
+        assert float((res[True][1][n] - g).abs().max()) <= 2e-2 * float(g.abs().max()) + 1e-7, n      # (same kernels; atomics' order only)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_fused_input_gradient_accumulation(golden_dir, dtype, monkeypatch):
     """Encoder stage outputs feed the next stage and the decoder lateral. With set_fuse_grad_accum the second data gradient is added
