@@ -338,6 +338,7 @@ class _SegBranchFn(torch.autograd.Function):
             L.call("nndet_conv3d_backward_weight", ctypes.byref(sd), L.ptr(x1p), L.ptr(dzs), L.ptr(dWc), None, L.ptr(ws), ws_bytes, raw)
             dw_up, dbsum, ec = up_param_grads(wc, w_up32, bsum, dWc, csum.sum(0).float())
             out["dw_up"], out["dbsum"] = dw_up, dbsum
+            out["dbsum2"] = dbsum.clone() if (ctx.has_b_up and ctx.has_b_lat) else dbsum     # two parameters never share one gradient tensor
             return ec.flip(0).t()                   # Ec[t][k] -> the kernels' E[k][26 - t]
 
         from .conv import rank1_branch_backward
@@ -348,7 +349,7 @@ class _SegBranchFn(torch.autograd.Function):
         dbs = out["dbsum"]
         return ((logical(dx1_p, ctx.cin1) if dx1_p is not None else None), da, dw_lat.to(w_lat.dtype), dw_out.to(w_out.dtype), db_out,
                 dw_head.to(w_head.dtype), db_head, None, out["dw_up"].to(w_up.dtype), dbs if ctx.has_b_up else None,
-                dbs if ctx.has_b_lat else None)
+                out["dbsum2"] if ctx.has_b_lat else None)
 
     @staticmethod
     def _a0_grad(ctx, da_p, dev):
