@@ -364,6 +364,14 @@ static int pw_plan(const NndetConv* c, int kind, const void* x, const void* w, c
     const size_t lds_per_rowtile = (size_t)ncls * nkc * 1024;
     if (lds_per_rowtile * 2 > 64 * 1024) return 1;      // weights of even a 32-row block do not fit: generic kernel
     A.npts = (int64_t)c->batch * A.L[0] * A.L[1] * A.L[2];
+    {   // Small pyramid levels (< 50 000 lattice points per batch: levels 3 - 5 of the 160x160x96 patch) go to the implicit-GEMM kernel: here
+        // every workgroup stages up to 66 KB of weight fragments for a handful of points (33 - 70 us launches for 16 us of traffic), there
+        // the 64-point tiles + split-K spread the layer over the chip. Measured on the step: 13.98 -> 13.89 ms (three alternations,
+        // profiles/round3_ab_pw_minpts.txt). NNDET_PW_MINPTS overrides the threshold (0: every pointwise layer stays here).
+        const char* mp = getenv("NNDET_PW_MINPTS");                  // (read per call: tests flip it)
+        const int64_t minpts = mp ? atoll(mp) : 50000;
+        if (A.npts < minpts) return 1;
+    }
     const int64_t nstrided = A.npts * ncls;
     if (A.npts >= (1LL << 31) || nstrided * (A.Cx > A.Cy ? A.Cx : A.Cy) * esz >= (1LL << 62)) return 1;
     A.ntiles = (int32_t)ceil_div64(A.npts, 16);

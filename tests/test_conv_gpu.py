@@ -40,6 +40,7 @@ CONVS = [
 ]
 SPEC3 = ["c32_k3", "c64_k3", "c128_k3", "head_cls", "head_reg", "c32_k3_tiles", "c64_k3_tiles"]   # 3x3x3 stride 1
 STRIDED = ["c32to64_s2", "c32to32_s2", "c64_s221", "up_222", "up_221"]                             # strided gathers (fwd or dgrad)
+POINTWISE = ["lateral", "seg_out", "up_222", "up_221", "up_222_c32", "lateral_c64", "lateral_256to128"]   # k_pw's layers (1x1x1, k = s transposed)
 
 
 def _mk(name, dtype, norm=None, act=False):
@@ -85,12 +86,15 @@ def _ref_forward(m, x, cfg, dtype, norm, act):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name,spec", [(c[0], "lib") for c in CONVS] + [(n, v) for v in ("generic", "ig3-nt8", "ig3-nt16") for n in SPEC3] +
-                         [(n, v) for v in ("strided-0", "strided-1", "strided-2") for n in STRIDED])
+                         [(n, v) for v in ("strided-0", "strided-1", "strided-2") for n in STRIDED] + [(n, "pw") for n in POINTWISE])
 def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
     """spec: "lib" = the library's own kernel choice; "generic" = k_igemm only (NNDET_IGEMM_SPEC=0); "ig3-nt8" / "ig3-nt16" =
     force the compile-time-tile kernel k_ig3 for every 3x3x3 stride-1 convolution (forward and backward-data,
-    NNDET_IGEMM_SPEC=2) with 8 / 16 point tiles per wave for the 64-row layers (NNDET_IGEMM_NT)."""
-    if spec.startswith("strided"):                      # tile variants of the strided implicit-GEMM configurations (NNDET_IGEMM_STRIDED)
+    NNDET_IGEMM_SPEC=2) with 8 / 16 point tiles per wave for the 64-row layers (NNDET_IGEMM_NT); "pw" = the pointwise kernel k_pw
+    whatever the size (NNDET_PW_MINPTS=0: by default layers this small go to the implicit-GEMM kernel)."""
+    if spec == "pw":
+        monkeypatch.setenv("NNDET_PW_MINPTS", "0")
+    elif spec.startswith("strided"):                      # tile variants of the strided implicit-GEMM configurations (NNDET_IGEMM_STRIDED)
         monkeypatch.setenv("NNDET_IGEMM_STRIDED", spec[8:])
     elif spec == "generic":
         monkeypatch.setenv("NNDET_IGEMM_SPEC", "0")
@@ -571,8 +575,12 @@ def test_full_size_layer_against_torch_gpu():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
-def test_transposed_conv_with_fused_residual(dtype):
-    """decoder top-down step x_l = lateral_l + up(x_{l+1}) (nndet/arch/decoder/base.py:405-413) from one kernel."""
+@pytest.mark.parametrize("route", ["lib", "pw"])
+def test_transposed_conv_with_fused_residual(dtype, route, monkeypatch):
+    """decoder top-down step x_l = lateral_l + up(x_{l+1}) (nndet/arch/decoder/base.py:405-413) from one kernel ("pw": the pointwise
+    kernel whatever the size, "lib": the library's choice -- the implicit-GEMM kernel for a layer this small)."""
+    if route == "pw":
+        monkeypatch.setenv("NNDET_PW_MINPTS", "0")
     m, x, cfg = _mk("up_222", dtype)
     res = torch.randn(2, 32, 8, 10, 12)
     rd = lambda t_: t_.detach().to(dtype).float().clone()
