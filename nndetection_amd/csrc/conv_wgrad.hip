@@ -601,7 +601,15 @@ static int wg_dispatch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st, i
 
 // number of spatial slices (= workgroups per channel-block pair) for a problem with `pairs` block pairs
 static int wgrad_slices(int pairs, int total_tiles) {
-    int S = 512 / pairs;    // ~2 persistent workgroups per CU over all block pairs
+    // 384 persistent workgroups over all block pairs = 1.5 per CU (two fit): inside the training step these kernels run on the
+    // lowest-priority stream NEXT to the data-gradient chain, and with every slot of every CU taken by a long-running weight-gradient
+    // workgroup the chain's kernels wait for slots -- 512: 13.84 / 13.86 ms per step, 448: 13.86 / 13.76, 384: 13.74 / 13.77, 352: 14.19,
+    // 256: 14.2, 128: 18.1 (profiles/round3_ab_wgrad_wgs.txt; 192x192x128 patches: 23.14 -> 23.02). NNDET_WGRAD_WGS overrides (<= 512:
+    // the workspace bound).
+    const char* we = getenv("NNDET_WGRAD_WGS");
+    int total = we ? atoi(we) : 384;
+    if (total < 8 || total > 512) total = 384;
+    int S = total / pairs;
     if (S < 1) S = 1;
     if (S > total_tiles) S = total_tiles;
     return S;
