@@ -376,3 +376,26 @@ def test_absorbed_top_down_step_algebra():
     assert torch.allclose(dbsum, bsum.grad, rtol=1e-10, atol=1e-10)
     # Ec_u[t][k] = sum_p d1[p] u[p + t - 1][k] = the gradient of the composed kernel wc
     assert torch.allclose(ec, wc.grad, rtol=1e-10, atol=1e-10)
+
+
+def test_which_steps_may_absorb_the_top_down_step():
+    """core/retina.py `_seg_up_ok` / `_seg_lateral_ok`: the last top-down step may only go into the segmentation branch when decoder
+    level 1 has no other reader (the head starts at level 2, out.P1 is skipped), up.P1 is a plain k = s = 2 transposed convolution onto
+    32 channels and the patch dimensions are even."""
+    from nndetection_amd.plans import get_plan
+    from nndetection_amd.ptmodule import build_model
+    from nndetection_amd.arch import segmenter as S
+    luna = build_model(get_plan("luna160"))
+    assert luna._seg_lateral_ok()
+    assert luna._seg_up_ok(torch.zeros(1, 1, 160, 160, 96))
+    assert luna._seg_up_ok(torch.zeros(1, 1, 192, 64, 32))
+    assert not luna._seg_up_ok(torch.zeros(1, 1, 160, 160, 95))           # odd depth: the parity classes would be ragged
+    assert not luna._seg_up_ok(torch.zeros(1, 160, 160, 96))              # not a 5-D batch
+    old = S.SEG_UP
+    try:
+        S.SEG_UP = False
+        assert not luna._seg_up_ok(torch.zeros(1, 1, 160, 160, 96))
+    finally:
+        S.SEG_UP = old
+    toy = build_model(get_plan("toy64"))                                    # its detection head reads level 1
+    assert 1 in tuple(toy.decoder_levels) and not toy._seg_up_ok(torch.zeros(1, 1, 64, 64, 64))
