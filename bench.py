@@ -206,6 +206,30 @@ def step_algorithmic_work(net, plan, batch, esz):
     return flops * batch, byts * batch
 
 
+def executed_flops_skipped(net, plan, batch, dtype_name):
+    """FLOPs of the reference's graph that a TRAINING step of this implementation does not execute as dense convolutions:
+    the regressor's output convolution (evaluated at the sampled positives only: forward + both gradients), the dense gradients of the
+    classifier's output convolution (sparse at the sampled anchors), and -- 16-bit route -- decoder.out.P0 + lateral.P0 + up.P1, which
+    the segmentation branch absorbs into one composed convolution. None when a switch that changes this is set."""
+    import math
+    from nndetection_amd.arch import heads as H, segmenter as S
+    if not (H.SPARSE_OUT and H.SPARSE_REG):
+        return None
+    P = tuple(plan["patch_size"])
+    strides = net.encoder.get_strides()
+    size = [tuple(int(math.ceil(P[a] / st[a])) for a in range(3)) for st in strides]
+    conv_fl = lambda m, sp: 2.0 * math.prod(sp) * math.prod(m.k) * m.in_channels * m.out_channels
+    fl, what = 0.0, []
+    for l in net.decoder_levels:
+        fl += 3 * conv_fl(net.head.regressor.conv_out, size[l]) + 2 * conv_fl(net.head.classifier.conv_out, size[l])
+    what.append("head.regressor.conv_out (x3), head.classifier.conv_out gradients (x2)")
+    if dtype_name in ("bf16", "f16") and S.SEG_BRANCH and S.SEG_LATERAL and S.SEG_UP and os.environ.get("NNDET_SEG_FUSED", "1") != "0":
+        fl += 3 * conv_fl(net.decoder.out["P0"][0], size[0]) + 3 * conv_fl(net.decoder.lateral["P0"][0], size[0])
+        fl += 3 * conv_fl(net.decoder.up["P1"], size[1])
+        what.append("decoder.out.P0, decoder.lateral.P0, decoder.up.P1 (x3 each)")
+    return {"flops": fl * batch, "what": "; ".join(what)}
+
+
 def head_trunk_roofline(plan, batch, dtype, device, iters=30):
     """The launch with the most TIME per training step: the shared 128 -> 128 head-trunk convolution over ALL pyramid levels of all
     images as one ragged batch (k_ig3<..., ITEMS>, arch/pyramid.py): 4 such forward launches + 4 data gradients per step."""
@@ -383,9 +407,10 @@ def _det_randperm(n, *a, **k):
 _det_randperm.nndet_reversed_arange = True     # the device sampler then selects what this permutation selects (parity_check)
 
 
-def cpu_baseline(plan, device=None):
+def cpu_baseline(plan, device=None, batch=2):
     """The CPU oracle (plain PyTorch fp32 restatement of the reference, oracle/retina_torch.py; kind "port") on this host:
-    ONE patch forward + ATSS + losses + backward (a bounded sample of the same workload). The thread count is chosen by a
+    a batch of TWO patches forward + ATSS + losses + backward (a bounded sample of the same workload; two, not one, so that the
+    batch-level hard-negative mining and batch_dice of the parity check below couple images as they do at the benchmarked batch). The thread count is chosen by a
     short sweep over {physical cores, 64, 32, 16} on a proxy (the full-resolution 32->32 3x3x3 convolution, forward + backward:
     the layer type that dominates the CPU time), after one warm-up call; 256 SMT threads oversubscribe oneDNN badly (round 1
     measured 0.008 patches/s that way). The same patch / weights then go through the HIP fp32 kernels and the four losses are
@@ -409,7 +434,7 @@ def cpu_baseline(plan, device=None):
     torch.set_num_threads(best)
     torch.manual_seed(0)
     net = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
-    x, tg = synth_batch(plan, 1, torch.float32, "cpu", 0)
+    x, tg = synth_batch(plan, batch, torch.float32, "cpu", 0)
     orig = torch.randperm
     torch.randperm = _det_randperm                          # the sampler's permutation, fixed for the parity comparison
     try:
@@ -417,9 +442,10 @@ def cpu_baseline(plan, device=None):
         losses, _ = net.train_step(x, tg, evaluation=False)
         sum(losses.values()).backward()
         dt = time.perf_counter() - t0
-        out = {"value": round(1.0 / dt, 4), "unit": "patches/s", "cores": best, "threads": best, "logical_cpus": logical,
+        out = {"value": round(batch / dt, 4), "unit": "patches/s", "cores": best, "threads": best, "logical_cpus": logical,
                "kind": "port", "thread_sweep_proxy_s": sweep,
-               "sample": "1 patch %dx%dx%d fp32: forward + ATSS + losses + backward of the CPU oracle (%.1f s, %d threads)" % (*P, dt, best)}
+               "sample": "one batch of %d patches %dx%dx%d fp32: forward + ATSS + losses + backward of the CPU oracle (%.1f s, %d threads)"
+                         % (batch, *P, dt, best)}
         parity = None
         if device is not None:
             from nndetection_amd.ptmodule import build_model
@@ -432,13 +458,81 @@ def cpu_baseline(plan, device=None):
             lc = {k: float(v) for k, v in losses.items()}
             lgv = {k: float(v) for k, v in lg.items()}
             diff = max(abs(lc[k] - lgv[k]) for k in lc)
-            parity = {"what": "losses of the HIP fp32 kernels vs the CPU oracle on the cpu_baseline patch (same weights, same sampler permutation)",
+            parity = {"what": "losses of the HIP fp32 kernels vs the CPU oracle on the cpu_baseline batch of %d patches (same weights, same sampler permutation)" % batch,
+                      "patches": batch,
                       "losses_cpu_oracle": {k: round(v, 6) for k, v in lc.items()}, "losses_hip_fp32": {k: round(v, 6) for k, v in lgv.items()},
                       "max_abs_diff": diff, "tolerance": 1e-4, "ok": bool(diff <= 1e-4 and set(lc) == set(lgv))}
             del hip
     finally:
         torch.randperm = orig
     return out, parity
+
+
+def torch_rocm_baseline_child(plan_name, batch, warmup=3, steps=10):
+    """stock PyTorch-ROCm on THIS GPU -- the oracle's module tree (plain torch.nn Conv3d / ConvTranspose3d /
+    InstanceNorm3d / GroupNorm / ReLU, i.e. MIOpen + ATen kernels, the layers the reference builds) with the reference's training
+    arithmetic: torch.autocast(float16) + torch.amp.GradScaler (scripts/train.py:277-278 precision=16), losses as the reference
+    computes them, torch.optim.SGD(nesterov). Runs in a child process (own MIOpen state, bounded by a timeout) and prints one JSON
+    object. The ATSS assignment (numpy in the oracle) is computed ONCE on the host before the timed loop and handed in as device
+    tensors: the baseline's time contains no target assignment at all (that favours the baseline). Checker / context leg only."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # no exhaustive per-shape kernel search inside a bounded leg
+    os.environ.setdefault("MIOPEN_LOG_LEVEL", "1")
+    from oracle.retina_torch import OracleRetinaUNet
+    from nndetection_amd.plans import MODEL_CFG_V001, TRAINER_CFG_V001, get_plan
+    plan = get_plan(plan_name)
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    net = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
+    x, tg = synth_batch(plan, batch, torch.float32, "cpu", 1000)
+    assigned = tuple(t.to(dev) for t in net.assign(x.shape, tg))
+    net.to(dev)
+    x = x.to(dev)
+    tgd = {"target_boxes": None, "target_classes": None, "target_seg": tg["target_seg"].to(dev)}
+    opt = torch.optim.SGD(net.parameters(), lr=TRAINER_CFG_V001["initial_lr"], momentum=0.9, nesterov=True, weight_decay=3e-5)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.float16):
+            losses, _ = net.train_step(x, tgd, evaluation=False, assigned=assigned)
+            loss = sum(losses.values())
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    t_first = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t_first
+    for _ in range(max(0, warmup - 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"value": round(batch * steps / dt, 3), "unit": "patches/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+                      "warmup": warmup, "batch": batch, "first_step_s": round(t_first, 1), "final_loss": round(float(last.detach()), 5),
+                      "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                      "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "torch": torch.__version__}), flush=True)
+
+
+def torch_rocm_baseline(plan_name, batch, timeout_s=240):
+    """Runs `torch_rocm_baseline_child` in a subprocess; a failure or a timeout costs the leg, never the headline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--torch-baseline-child", "--plan", plan_name, "--batch", str(batch)]
+    base = {"kind": "stock PyTorch-ROCm (MIOpen / ATen) on this GPU: the oracle's torch.nn module tree, fp16 autocast + GradScaler + "
+                    "torch.optim.SGD(nesterov), batch %d; target assignment precomputed and excluded; checker leg, outside the timed region" % batch}
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, timeout=timeout_s, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return dict(base, **json.loads(line))
+        return dict(base, error="rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+    except Exception as e:                                        # noqa: BLE001
+        return dict(base, error="%s: %s" % (type(e).__name__, str(e)[:200]))
 
 
 def inference_rate(net, x, iters=5):
@@ -468,7 +562,13 @@ def main():
     ap.add_argument("--no-routes", action="store_true", help="skip the short plugin / fp32 / fp16 comparison runs")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes for roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / NMS / CPU legs (only the timed steps)")
+    ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm leg (torch_rocm_baseline)")
+    ap.add_argument("--torch-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.torch_baseline_child:
+        from nndetection_amd.plans import get_plan as _gp
+        torch_rocm_baseline_child(args.plan, args.batch or _gp(args.plan)["batch_size"])
+        return
     MEASURE_PMC[0] = not args.no_pmc
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -544,6 +644,41 @@ def main():
                                 "floor_ms_mfma": round(fl / (peak_tf * 1e12) * 1e3, 3), "floor_ms_hbm": round(by / 8e12 * 1e3, 3),
                                 "note": "convolutions only: each reads its input and writes its output once, forward + data gradient + weight gradient; "
                                         "norm / ReLU / loss / optimizer passes count as zero algorithmic bytes"}
+        sr = out["step_roofline"]
+        skipped = executed_flops_skipped(net, plan, batch, args.dtype)
+        if skipped is not None:
+            ex = fl - skipped["flops"]
+            sr["executed_flops_per_step"] = int(ex)
+            sr["mfma_frac_executed"] = round(ex / (ms_step * 1e-3) / 1e12 / peak_tf, 4)
+            sr["executed_note"] = ("algorithmic FLOPs minus the dense layers this implementation does not run in a training step: " + skipped["what"] +
+                                   " (the kernels that replace them -- composed 32(+32)->1 and half-resolution convolutions, <= 170 sparse rows -- are not added back, "
+                                   "so this is a lower bound of what the matrix cores execute)")
+        if not args.no_pmc and not args.no_extras and world == 1:
+            # the step's REAL HBM traffic: two rocprofv3 --pmc passes over a short run of this same script (tools/step_traffic.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            try:
+                import step_traffic
+                extra = ["--plan", args.plan, "--dtype", args.dtype] + (["--batch", str(batch)] if args.batch else []) + (["--via-plugin"] if args.via_plugin else [])
+                st = step_traffic.measure(4, 2, extra) if os.environ.get("NNDET_BENCH_PMC", "1") != "0" else None
+            except Exception as e:                                           # noqa: BLE001
+                st = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+            if st is not None and "hbm_bytes_per_step" in st:
+                sr["traffic"] = st["hbm_bytes_per_step"]
+                sr["traffic_over_algorithmic"] = round(st["hbm_bytes_per_step"] / by, 3)
+                sr["traffic_GBs"] = round(st["hbm_bytes_per_step"] / (ms_step * 1e-3) / 1e9, 1)
+                sr["traffic_hbm_frac"] = round(st["hbm_bytes_per_step"] / (ms_step * 1e-3) / 1e9 / 8000.0, 4)
+                sr["traffic_source"] = st
+            else:
+                sr["traffic"] = None
+                sr["traffic_source"] = st
+                pj = os.path.join(ROOT, "profiles", "round4_step_traffic.json")
+                if os.path.isfile(pj) and args.plan == "luna160" and batch == 4 and args.dtype == "bf16":
+                    with open(pj) as f:
+                        cj = json.load(f)
+                    if "hbm_bytes_per_step" in cj:
+                        sr["traffic"] = cj["hbm_bytes_per_step"]
+                        sr["traffic_over_algorithmic"] = round(cj["hbm_bytes_per_step"] / by, 3)
+                        sr["traffic_source"] = dict(st or {}, fallback="profiles/round4_step_traffic.json (committed PMC summary, NOT re-measured in this run)")
         if not args.no_extras:
             x_inf = route.batch["data"].to(dtype) if args.via_plugin else route.x
             out["inference"] = inference_rate(net, x_inf)
@@ -571,6 +706,11 @@ def main():
             if not args.no_cpu_baseline and world == 1:                      # the CPU leg only at N = 1 (rank 0)
                 torch.cuda.empty_cache()
                 out["cpu_baseline"], out["parity_check"] = cpu_baseline(plan, device)
+            if not args.no_torch_baseline and world == 1:
+                torch.cuda.empty_cache()
+                out["torch_rocm_baseline"] = torch_rocm_baseline(args.plan, batch)
+                if "value" in out["torch_rocm_baseline"]:
+                    out["torch_rocm_baseline"]["headline_over_this"] = round(out["value"] / out["torch_rocm_baseline"]["value"], 2)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -182,24 +182,45 @@ class OracleRetinaUNet(nn.Module):
         num_pos, num_neg, pool = bx.hnm_counts(positive.numel(), negative.numel(), batch_size,
                                                sk["batch_size_per_image"], sk["positive_fraction"],
                                                sk.get("min_neg", 0), sk.get("pool_size", 10))
-        perm1 = torch.randperm(positive.numel())[:num_pos]
+        perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
         pos_mask = torch.zeros_like(labels_cat, dtype=torch.uint8); pos_mask[positive[perm1]] = 1
         _, pool_idx = probs[negative].topk(pool, sorted=True)
         negp = negative[pool_idx]
-        perm2 = torch.randperm(negp.numel())[:num_neg]
+        perm2 = torch.randperm(negp.numel(), device=negp.device)[:num_neg]
         neg_mask = torch.zeros_like(labels_cat, dtype=torch.uint8); neg_mask[negp[perm2]] = 1
         return torch.where(pos_mask)[0], torch.where(neg_mask)[0]
 
-    def train_step(self, images, targets, evaluation: bool = False):
-        pred, anchors, npl, seg = self(images)
-        B = images.shape[0]
+    def assign(self, images_shape, targets):
+        """ATSS target assignment of a batch with the numpy restatement (retina.py:228-290): (labels, matched boxes, anchors), each
+        concatenated over the batch. Split from `train_step` so that bench.py's same-GPU leg (stock torch modules on the GPU) can
+        compute it once on the host and hand the device copies in."""
+        P = tuple(images_shape[2:])
+        st = [[1, 1, 1]]
+        for s_ in self.plan_arch["strides"]:
+            st.append([a * b for a, b in zip(st[-1], s_)])
+        fm = [tuple(-(-P[a] // st[l][a]) for a in range(3)) for l in self.decoder_levels]
+        anchors, npl = self.anchors(P, fm)
         labels, matched = [], []
         for gb, gc in zip(targets["target_boxes"], targets["target_classes"]):
-            _, m = bx.atss_match(gb.numpy(), anchors, npl, self.A, self.model_cfg["matcher_kwargs"]["num_candidates"])
-            lab, mb = bx.assign_targets(m, gb.numpy(), gc.numpy(), anchors.shape[0])
+            gb, gc = gb.detach().cpu().numpy(), gc.detach().cpu().numpy()
+            _, m = bx.atss_match(gb, anchors, npl, self.A, self.model_cfg["matcher_kwargs"]["num_candidates"])
+            lab, mb = bx.assign_targets(m, gb, gc, anchors.shape[0])
             labels.append(torch.from_numpy(lab)); matched.append(torch.from_numpy(mb))
-        labels_cat = torch.cat(labels); matched_cat = torch.cat(matched)
-        anchors_t = torch.from_numpy(anchors).repeat(B, 1)
+        return torch.cat(labels), torch.cat(matched), torch.from_numpy(anchors).repeat(len(labels), 1)
+
+    def train_step(self, images, targets, evaluation: bool = False, assigned=None):
+        pred, anchors, npl, seg = self(images)
+        B = images.shape[0]
+        if assigned is None:
+            labels, matched = [], []
+            for gb, gc in zip(targets["target_boxes"], targets["target_classes"]):
+                _, m = bx.atss_match(gb.numpy(), anchors, npl, self.A, self.model_cfg["matcher_kwargs"]["num_candidates"])
+                lab, mb = bx.assign_targets(m, gb.numpy(), gc.numpy(), anchors.shape[0])
+                labels.append(torch.from_numpy(lab)); matched.append(torch.from_numpy(mb))
+            labels_cat = torch.cat(labels); matched_cat = torch.cat(matched)
+            anchors_t = torch.from_numpy(anchors).repeat(B, 1)
+        else:
+            labels_cat, matched_cat, anchors_t = assigned
         logits, deltas = pred["box_logits"], pred["box_deltas"]
         with torch.no_grad():
             pos, neg = self.select_indices(labels_cat, logits, B)

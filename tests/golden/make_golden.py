@@ -455,6 +455,12 @@ if __name__ == "__main__":
         golden_net("toy64", lite=True)        # BASELINE.json configs[0]: the reference's own CPU-runnable case
     if "luna160" in which:
         golden_net("luna160", lite=True, batch=1)   # BASELINE.json configs[1] (the benchmarked plan), one 160x160x96 patch, fp32
+    if "lidc192" in which:
+        golden_net("lidc192", lite=True, batch=1)   # BASELINE.json configs[3] (192x192x128), one patch, fp32 (round 4)
+    if "luna160_b4" in which:
+        # BASELINE.json configs[1] at the BENCHMARKED batch (c002.py:52): the batch-level hard-negative mining (sampler.py:237-270) and
+        # batch_dice couple the four patches (round 4; ~40 GB peak: the two models run one after the other)
+        golden_net("luna160", lite=True, batch=4, tag="luna160_b4")
     if "postproc" in which:
         golden_postproc()
     if "luna160_fp64" in which:
