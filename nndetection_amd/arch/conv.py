@@ -57,10 +57,25 @@ def _desc(x_p: torch.Tensor, cin: int, cout: int, k, s, p, transposed: bool) -> 
     return d
 
 
+# Everything cached from a parameter is keyed on (its autograd version, its address, PARAM_GENERATION[0]). Fused optimizer kernels
+# (torch._fused_sgd_ / torch.optim.*(fused=True)) write parameters WITHOUT advancing `_version`; whoever installs such an optimizer
+# registers `bump_param_generation` as an optimizer step post-hook (ptmodule.amd_fuse_sgd does), so that the caches are invalidated by
+# the step itself and correctness does not depend on the unconditional re-pack of a training-mode forward (NNDET_REPACK_EVERY_STEP).
+PARAM_GENERATION = [0]
+
+
+def bump_param_generation(*_args, **_kwargs) -> None:
+    PARAM_GENERATION[0] += 1
+
+
+def _pver(t: torch.Tensor):
+    return (t._version, t.data_ptr(), PARAM_GENERATION[0])
+
+
 def _packed(mod, mode: int, weight: torch.Tensor, desc: L.NndetConv, dtype: torch.dtype) -> torch.Tensor:
     """Packed + cast weights, cached per (mode, dtype) until the parameter changes (optimizer step)."""
     key = (mode, dtype)
-    ver = (weight._version, weight.data_ptr())
+    ver = _pver(weight)
     hit = mod._pack_cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -79,7 +94,7 @@ def _padded_bias(mod, bias: Optional[torch.Tensor], cout_p: int) -> Optional[tor
         return None
     if bias.numel() == cout_p and bias.dtype == torch.float32:
         return bias.detach()
-    key, ver = ("bias", cout_p), (bias._version, bias.data_ptr())
+    key, ver = ("bias", cout_p), _pver(bias)
     hit = mod._pack_cache.get(key)
     if hit is None or hit[0] != ver:
         hit = mod._pack_cache[key] = (ver, _pad1d(bias, cout_p))
@@ -108,16 +123,18 @@ def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1), force: bool 
     (nndetection_amd.optim advances it by hand; a foreign optimizer may not)."""
     jobs = []
     for mod in model.modules():
-        if not isinstance(mod, BaseConvNormAct) or mod.in_channels == 1:
+        if not isinstance(mod, BaseConvNormAct):
+            continue
+        if force:                                                    # EVERY block, the 1-channel stem included (ADVICE r3): its forward
+            mod._pack_cache.pop(("bias", cpad(mod.out_channels)), None)      # reads the padded-bias cache too (_ConvFn.forward)
+            mod._pack_cache.pop(("w32r", dtype), None)               # (arch/pyramid.py: rounded_w32)
+        if mod.in_channels == 1:
             continue
         w = mod.conv.weight
         if not w.is_cuda:
             return 0
-        if force:
-            mod._pack_cache.pop(("bias", cpad(mod.out_channels)), None)
-            mod._pack_cache.pop(("w32r", dtype), None)               # (arch/pyramid.py: rounded_w32)
         _padded_bias(mod, mod.conv.bias, cpad(mod.out_channels))
-        ver = (w._version, w.data_ptr())
+        ver = _pver(w)
         for mode in modes:
             hit = mod._pack_cache.get((mode, dtype))
             if hit is not None and hit[0] == ver and not force:

@@ -225,7 +225,8 @@ def rounded_w32(mod: BaseConvNormAct, weight: torch.Tensor, dtype: torch.dtype) 
     parameter version like the packed weights (arch/conv.py: _packed; dropped by the forced re-pack of a training pass)."""
     if dtype == torch.float32:
         return weight.detach().float().contiguous()
-    key, ver = ("w32r", dtype), (weight._version, weight.data_ptr())
+    from .conv import _pver
+    key, ver = ("w32r", dtype), _pver(weight)
     hit = mod._pack_cache.get(key)
     if hit is None or hit[0] != ver:
         hit = mod._pack_cache[key] = (ver, weight.detach().to(dtype).float().contiguous())

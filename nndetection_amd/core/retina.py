@@ -86,6 +86,11 @@ class BaseRetinaNet(nn.Module):
                 if getattr(self, "_grad_numel", None) is None:
                     self._grad_numel = sum(p.numel() + 64 for p in self.parameters() if p.requires_grad)
                 L.grad_pool.begin(self._grad_numel, inp.device)
+                # side channels of the PREVIOUS backward pass (sparse-gradient hints, the factorised segmentation gradient): entries
+                # nobody consumed would pin large tensors across steps
+                L.grad_hints.d.clear()
+                from ..arch.conv import _rank1_grads
+                _rank1_grads.clear()
         if hasattr(self.decoder, "defer_out0"):                # decoder.out.P0 + segmentation head + loss as one 32 -> 1 convolution?
             self.decoder.defer_out0 = self._seg_branch_ok(inp)
             self.decoder.absorb_lat0 = self.decoder.defer_out0 and self._seg_lateral_ok()

@@ -18,9 +18,17 @@ def _bump_versions(tensors) -> None:
     here the packed / cast convolution weights (arch/conv.py: _packed) -- so the counters are advanced by hand after the launch."""
     setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
     if setter is not None:
-        setter(tuple(tensors), tuple(t._version + 1 for t in tensors))
-    else:                                                      # older torch: an in-place no-op that does bump
-        torch._foreach_add_(list(tensors), 0.0)
+        try:
+            setter(tuple(tensors), tuple(t._version + 1 for t in tensors))
+            return
+        except TypeError:                                      # a torch build whose private setter takes (Tensor, int)
+            try:
+                for t in tensors:
+                    setter(t, t._version + 1)
+                return
+            except TypeError:
+                pass
+    torch._foreach_add_(list(tensors), 0.0)                    # an in-place no-op that does bump
 
 
 class SGDNesterov:

@@ -317,6 +317,26 @@ def amd_fuse_sgd(opt) -> bool:
         g["fused"], g["foreach"] = True, False
     opt.defaults["fused"], opt.defaults["foreach"] = True, False
     opt._step_supports_amp_scaling = True
+    # torch._fused_sgd_ does not advance the parameters' version counters: invalidate everything cached from a parameter (packed /
+    # cast weights, padded biases) by the step itself -- not only by the re-pack of the next training-mode forward
+    if not getattr(opt, "_nndet_generation_hook", False):
+        from .arch.conv import bump_param_generation
+        opt.register_step_post_hook(bump_param_generation)
+        opt._nndet_generation_hook = True
+    # this edits a CONSTRUCTED optimizer (the reference builds it; we only see the instance): re-validate what torch.optim.SGD's
+    # constructor would have checked for fused=True, also for groups added later
+    if not getattr(opt, "_nndet_add_group_checked", False):
+        orig_add = opt.add_param_group
+
+        def add_param_group(group, _orig=orig_add):
+            ps = group["params"] if isinstance(group, dict) else group
+            ps = [ps] if isinstance(ps, torch.Tensor) else list(ps)
+            if not all(q.is_cuda and q.dtype == torch.float32 for q in ps):
+                raise ValueError("amd_fuse_sgd switched this optimizer to fused=True: new parameters must be fp32 tensors on the GPU")
+            return _orig(group)
+
+        opt.add_param_group = add_param_group
+        opt._nndet_add_group_checked = True
     return True
 
 

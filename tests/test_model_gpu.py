@@ -782,3 +782,38 @@ def test_stream_overlap_does_not_change_training(golden_dir, monkeypatch, dtype)
             d = float((g1[n] - g0[n]).abs().max())
             assert d <= gtol * (float(g0[n].abs().max()) + 1e-9), (it, n, d, float(g0[n].abs().max()))
         opt.step()
+
+
+def test_foreign_fused_optimizer_invalidates_every_parameter_cache():
+    """`amd_fuse_sgd` switches the reference's torch.optim.SGD to fused=True, and torch._fused_sgd_ writes the
+    parameters WITHOUT advancing their version counters. Everything cached from a parameter -- packed / cast weights, padded biases,
+    the STEM's (1 input channel) padded bias included -- must be invalidated by the optimizer step itself (the step post-hook bumps
+    `arch.conv.PARAM_GENERATION`), not only by the unconditional re-pack of a training-mode `BaseRetinaNet.forward`: here the blocks
+    are called directly (no prepack_all) and must see the updated parameters after every step."""
+    import torch.nn.functional as F
+    from nndetection_amd.arch.conv import ConvInstanceRelu, PARAM_GENERATION
+    from nndetection_amd.ptmodule import amd_fuse_sgd
+    torch.manual_seed(0)
+    stem = ConvInstanceRelu(3, 1, 20, 3, stride=1, padding=1, add_norm=False, add_act=False).cuda()     # bias=True: conv.py:113
+    conv = ConvInstanceRelu(3, 32, 40, 3, stride=1, padding=1, add_norm=False, add_act=False).cuda()
+    assert stem.conv.bias is not None and conv.conv.bias is not None
+    params = list(stem.parameters()) + list(conv.parameters())
+    opt = torch.optim.SGD(params, lr=0.5, momentum=0.9, nesterov=True)
+    assert amd_fuse_sgd(opt) and opt.param_groups[0]["fused"]
+    x1 = torch.randn(1, 1, 12, 10, 8, device="cuda")
+    x2 = torch.randn(1, 32, 12, 10, 8, device="cuda")
+    for it in range(3):
+        y1, y2 = stem(x1), conv(x2)
+        r1 = F.conv3d(x1, stem.conv.weight, stem.conv.bias, padding=1)
+        r2 = F.conv3d(x2, conv.conv.weight, conv.conv.bias, padding=1)
+        assert float((y1 - r1).abs().max()) <= 2e-5 * float(r1.abs().max()), ("stem", it)
+        assert float((y2 - r2).abs().max()) <= 2e-5 * float(r2.abs().max()), ("conv", it)
+        opt.zero_grad()
+        (y1.square().mean() + y2.square().mean()).backward()
+        gen, v = PARAM_GENERATION[0], [p._version for p in params]
+        before = [p.detach().clone() for p in params]
+        opt.step()
+        assert PARAM_GENERATION[0] == gen + 1, "the step post-hook did not run"
+        assert all(float((p.detach() - b).abs().max()) > 0 for p, b in zip(params, before)), "the step changed every parameter"
+    with pytest.raises(ValueError):
+        opt.add_param_group({"params": [torch.zeros(3, requires_grad=True)]})           # CPU tensor into a fused optimizer

@@ -28,6 +28,9 @@ for s in $STAGES; do
     ablib) # A/B of two builds of the library in one session: nndetection_amd/csrc/libnndet_amd_prev.so (git archive <rev> + build.sh) vs the current one
            for v in cur prev cur prev; do lib=$PWD/nndetection_amd/csrc/libnndet_amd.so; [ $v = prev ] && lib=$PWD/nndetection_amd/csrc/libnndet_amd_prev.so
              NNDET_AMD_LIB=$lib timeout 600 python bench.py --steps 60 --warmup 15 --no-extras > gpurun_out/ablib_$v.txt 2>&1; echo "lib=$v $(grep -o '"value": [0-9.]*' gpurun_out/ablib_$v.txt | head -1) $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ablib_$v.txt | head -1)" | tee -a gpurun_out/ablib.txt; done;;
+    r4parity) timeout 1500 python -m pytest tests/test_parity_full_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "b4 or lidc192" > gpurun_out/t_r4parity.txt 2>&1; tail -30 gpurun_out/t_r4parity.txt;;
+    r4model) timeout 900 python -m pytest tests/test_model_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "foreign_fused or optimizer_steps" > gpurun_out/t_r4model.txt 2>&1; tail -15 gpurun_out/t_r4model.txt;;
+    steptraffic) timeout 600 python tools/step_traffic.py --steps 5 --warmup 3 > gpurun_out/step_traffic_stdout.txt 2>&1; cat gpurun_out/step_traffic_stdout.txt; head -20 gpurun_out/step_traffic.txt;;
     suite) timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_suite.txt 2>&1; tail -8 gpurun_out/t_suite.txt;;
   esac
 done
