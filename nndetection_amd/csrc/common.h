@@ -61,6 +61,26 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 // Everything the kernels need to know about a 16-bit storage type T (bf16_t / f16_t): packed conversion of two floats, the two
 // halves of a packed pair as floats, 1.0 twice, the 16x16x32 MFMA. The kernels are written once against H16<T>.
+// ---- float64 accumulators of the fp32 (parity) convolution kernels: v_mfma_f64_16x16x4_f64 leaves row q + 4 r of the 16 x 16 result
+// in register r of lane (q = lane / 16, li = lane % 16) (tools/probe_mfma64.hip); the epilogues are written for the fp32 MFMA layout,
+// row 4 q + r. Rounds to fp32 (the ONE rounding of the exactly accumulated sum) and transposes the 4 x 4 (q, r) index across the four
+// 16-lane rows of the wave: destination (q, r) takes register q of lane (r, li). All 64 lanes must be active.
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 f64acc_rows_to_f32(const f64x4_t& c) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int q = lane >> 4, li = lane & 15;
+    const int v0 = __float_as_int((float)c[0]), v1 = __float_as_int((float)c[1]), v2 = __float_as_int((float)c[2]), v3 = __float_as_int((float)c[3]);
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int src = (r * 16 + li) * 4;
+        const int g0 = __builtin_amdgcn_ds_bpermute(src, v0), g1 = __builtin_amdgcn_ds_bpermute(src, v1);
+        const int g2 = __builtin_amdgcn_ds_bpermute(src, v2), g3 = __builtin_amdgcn_ds_bpermute(src, v3);
+        o[r] = __int_as_float(q == 0 ? g0 : (q == 1 ? g1 : (q == 2 ? g2 : g3)));
+    }
+    return o;
+}
+
 template <typename T> struct H16;
 template <> struct H16<bf16_t> {
     static constexpr uint32_t ONE2 = 0x3f803f80u;

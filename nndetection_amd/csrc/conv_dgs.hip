@@ -18,6 +18,9 @@
 
 template <typename T> struct DgMma {     // the 16-bit storage types (bf16_t, f16_t)
     static constexpr int KC = 32, EPL = 8;
+    typedef f32x4 acc_t;
+    __device__ static __forceinline__ acc_t zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ static __forceinline__ f32x4 f32(const acc_t& c) { return c; }
     __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) { c = H16<T>::mma(a, b, c); }
     __device__ static __forceinline__ void store4(T* p, float a, float b, float c, float d) {
         uint2 v; v.x = H16<T>::pack2(a, b); v.y = H16<T>::pack2(c, d);
@@ -29,14 +32,17 @@ template <typename T> struct DgMma {     // the 16-bit storage types (bf16_t, f1
         v[2] = H16<T>::lo(u.y); v[3] = H16<T>::hi(u.y);
     }
 };
-template <> struct DgMma<float> {
+template <> struct DgMma<float> {          // the parity path accumulates in float64 (conv_igemm.hip: Mma<float>)
     static constexpr int KC = 16, EPL = 4;
-    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+    typedef f64x4_t acc_t;
+    __device__ static __forceinline__ acc_t zero() { return f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+    __device__ static __forceinline__ f32x4 f32(const acc_t& c) { return f64acc_rows_to_f32(c); }
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
         const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[0], (double)fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[1], (double)fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[2], (double)fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[3], (double)fb[3], c, 0, 0, 0);
     }
     __device__ static __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
     __device__ static __forceinline__ void load4(const float* p, float* v) {
@@ -63,7 +69,7 @@ struct DgsArgs {
 #define DGS_TH 8
 #define DGS_TW 8
 template <typename T, int MT, int MAXP, int G>
-__global__ __launch_bounds__(256, MT == 2 ? 3 : 1) void k_dgs(const DgsArgs A) {
+__global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? 3 : 1) void k_dgs(const DgsArgs A) {
     using M = DgMma<T>;
     constexpr int KC = M::KC, EPL = M::EPL, NT = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 1) void k_dgs(const DgsArgs A) {
     // in L2 until the other class of the workgroup is done (microseconds later, 12 MB of half-written lines in flight per XCD against
     // 4 MB of L2); the group keeps both accumulator sets and stores the two halves back to back.
     for (int cg = 0; cg < A.ncls; cg += G) {
-        f32x4 acc[G][MT][NT];
+        typename M::acc_t acc_k[G][MT][NT];
         bool live[G];
         // bf16 + residual (the fused gradient accumulation): the group's residual pieces are fetched NOW, 16 bytes per lane in the
         // layout of the epilogue's stores, and wait under the group's MFMA steps; the epilogue turns them back into the MFMA layout
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 1) void k_dgs(const DgsArgs A) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < NT; ++j) acc_k[g][i][j] = M::zero();
             if (!live[g]) continue;
             const int nstep = C.ntap * nchunk;                                   // (tap, chunk) steps, chunk fastest
             u32x4 af[MT], afn[MT];
@@ -189,10 +195,17 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 1) void k_dgs(const DgsArgs A) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) M::mma(af[i], bf[j], acc[g][i][j]);
+                    for (int j = 0; j < NT; ++j) M::mma(af[i], bf[j], acc_k[g][i][j]);
             }
         }
         // ---- the group's outputs: o = s * i + c
+        f32x4 acc[G][MT][NT];                       // (uniform control flow here: DgMma<float>::f32 exchanges values between lanes)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[g][i][j] = M::f32(acc_k[g][i][j]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int ld = l0d + wv, lh = l0h + 2 * j + (li >> 3), lw = l0w + (li & 7);

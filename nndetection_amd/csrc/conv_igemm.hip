@@ -32,18 +32,31 @@ typedef unsigned int v4u_t __attribute__((__vector_size__(16)));
 template <typename T> struct Mma {     // the 16-bit storage types (bf16_t, f16_t)
     static constexpr int KC = 32;   // channels per 64-byte chunk
     static constexpr int EPL = 8;   // elements per 16-byte fragment
+    typedef f32x4 acc_t;
+    __device__ static __forceinline__ acc_t zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
     __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) { c = H16<T>::mma(a, b, c); }
+    __device__ static __forceinline__ f32x4 f32(const acc_t& c) { return c; }
 };
+// fp32 activations = the PARITY path (north_star: outputs within 1e-4 of the reference). Round 4: products of fp32 values are exact in
+// float64 and the sum runs in float64 on v_mfma_f64_16x16x4_f64, so every convolution output is the exactly accumulated sum rounded ONCE
+// to fp32 -- closer to a float64 evaluation of the network than the reference's own fp32 (oneDNN) kernels are
+// (tests/test_parity_full_gpu.py: *_arbitrated_by_fp64, net_*_grad64.npz). Operand layout as the fp32 MFMA (A: row = lane % 16,
+// k = lane / 16; B likewise); the float64 RESULT layout differs: register r of lane (q = lane / 16, li) holds row q + 4 r
+// (tools/probe_mfma64.hip, profiles/round4_probe_mfma64.txt), the fp32 one row 4 q + r. `f32()` rounds and moves the values to the
+// fp32 layout the epilogues are written for (16 ds_bpermute per tile, once per output); it must be called with all 64 lanes active.
 template <> struct Mma<float> {
     static constexpr int KC = 16;
     static constexpr int EPL = 4;
-    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+    typedef f64x4_t acc_t;
+    __device__ static __forceinline__ acc_t zero() { return f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
         const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[0], (double)fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[1], (double)fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[2], (double)fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[3], (double)fb[3], c, 0, 0, 0);
     }
+    __device__ static __forceinline__ f32x4 f32(const acc_t& c) { return f64acc_rows_to_f32(c); }
 };
 
 // stores 4 consecutive channels and returns (through a..d) the values as stored (i.e. rounded to T)
@@ -130,7 +143,7 @@ struct IgItems {
 // same loop was 25 % slower than the plain one, which is why it is a per-configuration choice
 // (profiles/round1_micro_v8_generic_pinned_rejected.txt).
 template <typename T, int WR, int MT, int NT, int MAXP, int MINW, bool PIPE = false, bool AFF = false>
-__global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : MINW)) void k_igemm(const IgArgs A) {     // (fp32: float64 accumulators, all 512 registers)
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -206,11 +219,11 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
         const int brow = (pd * A.in_step[0]) * HH + ph * A.in_step[1];
         boff[j] = ((brow * HW + pw * (A.deint ? 1 : A.in_step[2])) * 64 + q * 16) ^ (((brow >> A.swzsh) & A.swz) << 5);
     }
-    f32x4 acc[MT][NT];
+    typename M::acc_t acc_k[MT][NT];          // (float64 for fp32 activations, see Mma<float>)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc_k[i][j] = M::zero();
 
     const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + wr * MT * 16 + li) * A.Cx + q * EPL;
     const int nchunk_all = A.Cx / KC;
@@ -288,14 +301,14 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < NH; ++j) M::mma(afr[u][i], bf0[j], acc[i][j]);
+                        for (int j = 0; j < NH; ++j) M::mma(afr[u][i], bf0[j], acc_k[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                     lds_h0(nxt);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = NH; j < NT; ++j) M::mma(afr[u][i], bf1[j - NH], acc[i][j]);
+                        for (int j = NH; j < NT; ++j) M::mma(afr[u][i], bf1[j - NH], acc_k[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                     cur = nxt; nxt = nn;
                 }
@@ -350,11 +363,16 @@ __global__ __launch_bounds__(256, MINW) void k_igemm(const IgArgs A) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) M::mma(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) M::mma(af[i], bf[j], acc_k[i][j]);
         }
     }
 
     // ---------------- epilogue: lane holds rows row0 + i*16 + q*4 + {0..3} of voxel (tile j, li)
+    f32x4 acc[MT][NT];                              // (uniform control flow here: Mma<float>::f32 exchanges values between lanes)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = M::f32(acc_k[i][j]);
     if (A.part) {                                  // split-K: raw partial sums, everything else in k_ig_splitk_reduce (uniform branch)
         float* pb = A.part + ((int64_t)ks_i * A.N + n) * A.O[0] * A.O[1] * A.O[2] * A.Cy;
 #pragma unroll
@@ -564,7 +582,7 @@ __device__ __forceinline__ void ig3_lds_dma16(__amdgpu_buffer_rsrc_t rs, int vof
 // 64 KB buffer WHILE the taps of chunk kc are multiplied -- one 1 KB piece per tap, issued from inside the tap loop (vmcnt is in-order:
 // pieces issued in one go in front of a tap's weight loads would be waited for together with them), weight fragments 4 taps ahead.
 template <typename T, int WR, int MT, int NT, int MINW, bool AFF = false, bool ITEMS = false, bool DMA = false>
-__global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems IT) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : MINW)) void k_ig3(const IgArgs A, const IgItems IT) {
     using M = Mma<T>;
     constexpr int KC = M::KC, EPL = M::EPL;
     constexpr int TD = NT / WR, TH = 8, TW = 8;
@@ -628,11 +646,11 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
     const int sb0off = lanevox * 64 + ((q ^ (par << 1)) << 4);      // the two swizzle phases of this lane's base address
     const int sb1off = lanevox * 64 + ((q ^ (par << 1) ^ 2) << 4);
 
-    f32x4 acc[MT][NT];
+    typename M::acc_t acc_k[MT][NT];          // (float64 for fp32 activations, see Mma<float>)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc_k[i][j] = M::zero();
 
     // weights: buffer loads (SRD of the packed weight tensor in SGPRs) = per-lane 32-bit offset of each of the MT fragments
     // + a SCALAR offset per (tap, chunk): no per-tap vector address arithmetic, no 64-bit lane addresses to keep live
@@ -747,7 +765,7 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) M::mma(af[tp % (WD + 1)][i], bf[h & 1][jj], acc[i][(h % SPT) * 4 + jj]);
+                for (int jj = 0; jj < 4; ++jj) M::mma(af[tp % (WD + 1)][i], bf[h & 1][jj], acc_k[i][(h % SPT) * 4 + jj]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (DMA) {                               // the next chunk's halo has landed; everybody is done with this one
@@ -757,6 +775,11 @@ __global__ __launch_bounds__(256, MINW) void k_ig3(const IgArgs A, const IgItems
     }
 
     // ---------------- epilogue: buffer stores, 32-bit lane offset + scalar offset per point tile j
+    f32x4 acc[MT][NT];                              // (uniform control flow here: Mma<float>::f32 exchanges values between lanes)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = M::f32(acc_k[i][j]);
     float ssum[MT][4], ssq[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i)

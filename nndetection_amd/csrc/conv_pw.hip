@@ -16,6 +16,9 @@
 
 template <typename T> struct PwMma {     // the 16-bit storage types (bf16_t, f16_t)
     static constexpr int KC = 32, EPL = 8;
+    typedef f32x4 acc_t;
+    __device__ static __forceinline__ acc_t zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ static __forceinline__ f32x4 f32(const acc_t& c) { return c; }
     __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) { c = H16<T>::mma(a, b, c); }
     __device__ static __forceinline__ void store4(T* p, const f32x4& v) {
         uint2 u;
@@ -27,14 +30,17 @@ template <typename T> struct PwMma {     // the 16-bit storage types (bf16_t, f1
         return f32x4{H16<T>::lo(u.x), H16<T>::hi(u.x), H16<T>::lo(u.y), H16<T>::hi(u.y)};
     }
 };
-template <> struct PwMma<float> {
+template <> struct PwMma<float> {          // the parity path accumulates in float64 (conv_igemm.hip: Mma<float>)
     static constexpr int KC = 16, EPL = 4;
-    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+    typedef f64x4_t acc_t;
+    __device__ static __forceinline__ acc_t zero() { return f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+    __device__ static __forceinline__ f32x4 f32(const acc_t& c) { return f64acc_rows_to_f32(c); }
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
         const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[0], (double)fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[1], (double)fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[2], (double)fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[3], (double)fb[3], c, 0, 0, 0);
     }
     __device__ static __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
     __device__ static __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -164,12 +170,13 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
                     f32x4 acc[MT];
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        typename M::acc_t ak = M::zero();
 #pragma unroll
                         for (int kc = 0; kc < NKC; ++kc) {
                             const u32x4 a = *reinterpret_cast<const u32x4*>(smem + ((c * MT + i) * NKC + kc) * 1024 + lane * 16);
-                            M::mma(a, b[u][kc], acc[i]);
+                            M::mma(a, b[u][kc], ak);
                         }
+                        acc[i] = M::f32(ak);             // (wave-uniform control flow: PwMma<float>::f32 exchanges values between lanes)
                     }
                     const bool pv = pt[u] >= 0;
                     int64_t o = pv ? pt[u] : 0;
@@ -222,9 +229,9 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
                 const int64_t p = (int64_t)(t0 + u) * 16 + li;
                 const bool ok = p < A.npts;
                 const int64_t pc = ok ? p : 0;
-                f32x4 acc[MT];
+                typename M::acc_t acc_k[MT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < MT; ++i) acc_k[i] = M::zero();
                 for (int c0 = 0; c0 < A.ncls; c0 += 4) {     // 4 kernel positions in flight
                     u32x4 b[4][NKC];
 #pragma unroll
@@ -247,10 +254,13 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
 #pragma unroll
                             for (int kc = 0; kc < NKC; ++kc) {
                                 const u32x4 a = *reinterpret_cast<const u32x4*>(smem + (((c0 + cc) * MT + i) * NKC + kc) * 1024 + lane * 16);
-                                M::mma(a, b[cc][kc], acc[i]);
+                                M::mma(a, b[cc][kc], acc_k[i]);
                             }
                     }
                 }
+                f32x4 acc[MT];                               // (wave-uniform control flow here)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = M::f32(acc_k[i]);
                 if constexpr (sizeof(T) == 2 && MT % 2 == 0) {      // paired 16-byte stores (see the scatter branch)
                     typedef unsigned int pw_v2u __attribute__((ext_vector_type(2)));
 #pragma unroll

@@ -102,9 +102,13 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemArgs A) {
     const int skd = slot / 9, skh = (slot / 3) % 3, skw = slot % 3;
     const bool active = slot < 27 && skd < A.k[0] && skh < A.k[1] && skw < A.k[2];
     const int tap = (skd * A.k[1] + skh) * A.k[2] + skw;              // index into the weight's flattened kernel volume
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // (parity path: the 256 products of a chunk are summed in fp32, the chunks of this workgroup in fp64 -- one fp32 chain over
+    // the ~150 chunks x 256 voxels a workgroup walks at 160x160x96 x batch 4 was 2e-3 of the largest element off the reference,
+    // tests/test_parity_full_gpu.py::test_luna160_b4_fp32_vs_reference_golden)
+    double A0 = 0.0, A1 = 0.0, A2 = 0.0, A3 = 0.0;
     const int64_t nchunks = (A.total + 255) / 256;
     for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         const int64_t v = ch * 256 + threadIdx.x;
         const bool valid = v < A.total;
         int64_t t2 = valid ? v : 0;
@@ -145,14 +149,15 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const StemArgs A) {
                 const float4 d = *reinterpret_cast<const float4*>(dr + i * STEM_DYS_STRIDE);
                 a0 = fmaf(x1, d.x, a0); a1 = fmaf(x1, d.y, a1); a2 = fmaf(x1, d.z, a2); a3 = fmaf(x1, d.w, a3);
             }
+            A0 += (double)a0; A1 += (double)a1; A2 += (double)a2; A3 += (double)a3;
         }
     }
     if (active) {
         const int c = c0 + cg * 4;
-        if (c + 0 < A.cout) atomicAdd(A.dw + (int64_t)(c + 0) * taps + tap, a0);
-        if (c + 1 < A.cout) atomicAdd(A.dw + (int64_t)(c + 1) * taps + tap, a1);
-        if (c + 2 < A.cout) atomicAdd(A.dw + (int64_t)(c + 2) * taps + tap, a2);
-        if (c + 3 < A.cout) atomicAdd(A.dw + (int64_t)(c + 3) * taps + tap, a3);
+        if (c + 0 < A.cout) atomicAdd(A.dw + (int64_t)(c + 0) * taps + tap, (float)A0);
+        if (c + 1 < A.cout) atomicAdd(A.dw + (int64_t)(c + 1) * taps + tap, (float)A1);
+        if (c + 2 < A.cout) atomicAdd(A.dw + (int64_t)(c + 2) * taps + tap, (float)A2);
+        if (c + 3 < A.cout) atomicAdd(A.dw + (int64_t)(c + 3) * taps + tap, (float)A3);
     }
 }
 

@@ -71,6 +71,9 @@ template <typename T> struct WF {        // the 16-bit storage types (bf16_t, f1
         v = u32x4{ua.x, ua.y, ub.x, ub.y};
     }
     __device__ __forceinline__ void set_ones() { v = u32x4{H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2}; }   // 1.0 x 8
+    typedef f32x4 acc_t;
+    __device__ static __forceinline__ acc_t zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ static __forceinline__ int row(int q, int rr) { return q * 4 + rr; }      // row of register rr of lane row q in a 16 x 16 result
     __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) { c = H16<T>::mma(a.v, b.v, c); }
 };
 template <> struct WF<float> {
@@ -83,9 +86,15 @@ template <> struct WF<float> {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 1.f;
     }
-    __device__ static __forceinline__ void mma(const WF& a, const WF& b, f32x4& c) {
+    // the parity path accumulates in float64 (conv_igemm.hip: Mma<float>): a weight gradient is a sum over up to 4e7 voxels, one fp32
+    // accumulator chain per workgroup slice was tens of thousands of roundings long. v_mfma_f64_16x16x4_f64 leaves row q + 4 rr in
+    // register rr of lane row q (tools/probe_mfma64.hip): the epilogues index the partial-sum tile through row().
+    typedef f64x4_t acc_t;
+    __device__ static __forceinline__ acc_t zero() { return f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+    __device__ static __forceinline__ int row(int q, int rr) { return q + 4 * rr; }
+    __device__ static __forceinline__ void mma(const WF& a, const WF& b, acc_t& c) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.v[j], (double)b.v[j], c, 0, 0, 0);
     }
 };
 
@@ -169,13 +178,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
     for (int ks = 0; ks < KS; ++ks) qrowb[ks] = qrow0[ks] * QROW;
     const int wstep = A.step[2] * RB;
 
-    f32x4 acc[NTS][2 * RBK][2];
+    typename WF<T>::acc_t acc[NTS][2 * RBK][2];
 #pragma unroll
     for (int t = 0; t < NTS; ++t)
 #pragma unroll
         for (int i = 0; i < 2 * RBK; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = WF<T>::zero();
 
     const T* pbase = reinterpret_cast<const T*>(A.p);
     const T* qbase_ptr = reinterpret_cast<const T*>(A.q);
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + q * 4 + rr) * 32 + j * 16 + li] = acc[ts][2 * b + i][j][rr];
+                        for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + WF<T>::row(q, rr)) * 32 + j * 16 + li] = (float)acc[ts][2 * b + i][j][rr];
             }
         }
     }
@@ -379,13 +388,13 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgIt
         tapw[ts] = __builtin_amdgcn_readfirstlane(valid ? tt : -1);
     }
 
-    f32x4 acc[NTS][2][2];
+    typename WF<T>::acc_t acc[NTS][2][2];
 #pragma unroll
     for (int t = 0; t < NTS; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = WF<T>::zero();
 
     const int tiles_per_n = A.nt[0] * A.nt[1] * A.nt[2];
     const int p_img = A.PL[0] * A.PL[1] * A.PL[2] * A.Cp * (int)sizeof(T), q_img = A.QD[0] * A.QD[1] * A.QD[2] * A.Cq * (int)sizeof(T);
@@ -517,8 +526,8 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgIt
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int r = r0 + i * 16 + q * 4 + rr;
-                if (r < A.R) atomicAdd(A.dbias + r, acc[NTS - 1][i][0][rr]);
+                const int r = r0 + i * 16 + WF<T>::row(q, rr);
+                if (r < A.R) atomicAdd(A.dbias + r, (float)acc[NTS - 1][i][0][rr]);
             }
     }
     float* part = A.part + ((int64_t)blockIdx.x * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgIt
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + q * 4 + rr) * 32 + j * 16 + li] = acc[ts][i][j][rr];
+                    for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + WF<T>::row(q, rr)) * 32 + j * 16 + li] = (float)acc[ts][i][j][rr];
         }
     }
 }

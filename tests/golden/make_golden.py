@@ -204,15 +204,26 @@ def golden_net(name, lite=False, batch=None, tag=None):
     torch.randperm = det_randperm
     try:
         tgr = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in tg.items()}
+        picks = {}
+        _rsel, _osel = ref.head.select_indices, ora.select_indices
+        ref.head.select_indices = lambda *a, **k: picks.setdefault("ref", _rsel(*a, **k))
+        ora.select_indices = lambda *a, **k: picks.setdefault("ora", _osel(*a, **k))
         lr, pr = ref.train_step(x, tgr, evaluation=True, batch_num=0)
         sum(lr.values()).backward()
         tgo = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in tg.items()}
         lo, po = ora.train_step(x, tgo, evaluation=True)
         sum(lo.values()).backward()
+        for i in (0, 1):
+            assert torch.equal(picks["ref"][i].sort()[0], picks["ora"][i].sort()[0]), "oracle and reference sampled different anchors"
     finally:
         torch.randperm = orig
     g = {} if lite else {"x": x.numpy(), "target_seg": tg["target_seg"].numpy().astype(np.uint8)}
     g["x_checksum"] = np.float64(x.double().sum().item())
+    # the anchors the reference's hard-negative sampler picked (comb.py:247-276; indices into the batch-concatenated anchors, ascending):
+    # the negatives sit at the boundary of a top-k pool of millions of nearly equal scores, so any change of the last bit of a logit can
+    # swap one -- the full-size GPU tests replay these picks and report how many their own sampler run shares (round 4)
+    g["sampled_pos"] = picks["ref"][0].sort()[0].numpy().astype(np.int64)
+    g["sampled_neg"] = picks["ref"][1].sort()[0].numpy().astype(np.int64)
     for i, (b, c) in enumerate(zip(tg["target_boxes"], tg["target_classes"])):
         g[f"gt_boxes_{i}"], g[f"gt_classes_{i}"] = b.numpy(), c.numpy()
     print(f"  [{name}] reference losses:", {k: float(v) for k, v in lr.items()})
@@ -290,6 +301,69 @@ def golden_fp64(name="luna160", batch=1):
         print(f"  [{name} fp64] image {b}: reference fp32 boxes vs fp64: max {max(err_ref):.3e}, median {np.median(err_ref):.3e}; "
               f"max |score| diff {np.abs(g[f'det_scores64_{b}'] - rs).max():.2e}; largest decoded size {max(size):.1f}")
     np.savez_compressed(os.path.join(OUT, f"net_{name}_fp64.npz"), **g)
+
+
+def golden_grad64(name, batch, tag=None, lean=False):
+    """float64 arbitration of the parameter GRADIENTS (round 4): the oracle network evaluated in float64 on the fixture's inputs with
+    the anchors the fp32 run sampled (which anchors the hard-negative miner picks depends on near-ties of 4.7 M scores; the picks of
+    the fp32 oracle run -- identical to the reference's, that is what net_<tag>_golden.npz pins -- are replayed). Stores the 92
+    gradient norms, the four gradient slices of the fp32 fixture and the losses. A heavily cancelling sum like d(gamma) of a
+    full-resolution InstanceNorm (millions of sign-alternating terms) turns the 1e-5 relative differences two fp32 evaluations of a
+    50-layer network have per element into 1e-3 of the sum: tests/test_parity_full_gpu.py measures the HIP fp32 gradients AND the
+    reference's against this file."""
+    plan = get_plan(name)
+    plan["batch_size"] = batch
+    x, tg = synth_inputs(plan)
+    picks = {}
+    orig = torch.randperm
+    torch.randperm = det_randperm
+    try:
+        o32 = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
+        fill_state(o32)
+        sel = o32.select_indices
+        def rec(*a, **k):
+            picks["idx"] = sel(*a, **k)
+            return picks["idx"]
+        o32.select_indices = rec
+        with torch.no_grad():
+            l32, _ = o32.train_step(x, {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in tg.items()})
+        del o32
+        o64 = OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001)
+        fill_state(o64)
+        o64 = o64.double()
+        o64.select_indices = lambda *a, **k: picks["idx"]
+        if lean:        # recompute the full-resolution stage in the backward pass instead of keeping its four 2.5 GB (batch 4) tensors
+            from torch.utils.checkpoint import checkpoint
+            st0 = o64.encoder.stages[0].convs
+            fwd0 = st0.forward
+            st0.forward = lambda inp: checkpoint(fwd0, inp, use_reentrant=False)
+            # torch's float64 conv3d on the CPU unfolds the WHOLE batch into one [Cin * 27, N * D * H * W] matrix (68 GB for the
+            # full-resolution 32 -> 32 layer at batch 4): run every convolution image by image
+            for m in o64.modules():
+                if isinstance(m, (torch.nn.Conv3d, torch.nn.ConvTranspose3d)):
+                    m.forward = (lambda f: (lambda inp: torch.cat([f(inp[i:i + 1]) for i in range(inp.shape[0])], 0)))(m.forward)
+        tg64 = {"target_boxes": [t.clone() for t in tg["target_boxes"]], "target_classes": [t.clone() for t in tg["target_classes"]],
+                "target_seg": tg["target_seg"].clone()}
+        assigned = tuple(t.double() if t.is_floating_point() else t for t in o64.assign(x.shape, tg64))
+        l64, _ = o64.train_step(x.double(), tg64, assigned=assigned)
+        sum(l64.values()).backward()
+    finally:
+        torch.randperm = orig
+    g = {"batch": np.int64(batch)}
+    for k in l64:
+        g[f"loss_{k}"] = np.float64(l64[k].item())
+        print(f"  [{name} fp64] loss {k}: fp64 {l64[k].item():.9f} fp32 oracle {l32[k].item():.9f}")
+    names = [k for k, _ in o64.named_parameters()]
+    g["grad_names"] = np.asarray(names)
+    g["grad_norms"] = np.asarray([(p.grad.norm().item() if p.grad is not None else -1.0) for _, p in o64.named_parameters()], np.float64)
+    for k in ("encoder.stages.0.convs.0.0.conv.weight", "head.regressor.conv_out.conv.bias",
+              "decoder.up.P1.conv.weight", "segmenter.conv_out.conv.weight"):
+        g["grad::" + k] = dict(o64.named_parameters())[k].grad.numpy().reshape(-1)[:512].copy()
+    ref = np.load(os.path.join(OUT, f"net_{tag or name}_golden.npz"))
+    dev = np.abs(ref["grad_norms"].astype(np.float64) - g["grad_norms"]) / np.maximum(np.abs(g["grad_norms"]), 1e-12)
+    worst = np.argsort(-dev)[:5]
+    print(f"  [{name} fp64] reference fp32 gradient norms vs fp64: " + ", ".join(f"{names[i]} {dev[i]:.2e}" for i in worst))
+    np.savez_compressed(os.path.join(OUT, f"net_{tag or name}_grad64.npz"), **g)
 
 
 def golden_postproc():
@@ -461,6 +535,12 @@ if __name__ == "__main__":
         # BASELINE.json configs[1] at the BENCHMARKED batch (c002.py:52): the batch-level hard-negative mining (sampler.py:237-270) and
         # batch_dice couple the four patches (round 4; ~40 GB peak: the two models run one after the other)
         golden_net("luna160", lite=True, batch=4, tag="luna160_b4")
+    if "lidc192_grad64" in which:
+        golden_grad64("lidc192", 1)
+    if "luna160_grad64" in which:
+        golden_grad64("luna160", 1)
+    if "luna160_b4_grad64" in which:
+        golden_grad64("luna160", 4, tag="luna160_b4", lean=True)
     if "postproc" in which:
         golden_postproc()
     if "luna160_fp64" in which:
