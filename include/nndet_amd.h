@@ -114,6 +114,15 @@ int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* anchors, int
 int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const int32_t* img_off_host, int32_t B,
                                    const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
                                    int32_t k, int64_t* matches, void* workspace, size_t workspace_bytes, void* stream);
+/* nndet_atss3d_match_batched_f32 that also writes the anchors' TRAINING LABELS: labels_out [B,M] = gt_classes[matched GT] + 1, 0 for an
+ * unmatched anchor -- what BaseRetinaNet.assign_targets_to_anchors forms from the matches with a clamp / gather / compare / multiply
+ * chain over [B, M] tensors (nndet/core/retina.py:262-287; ATSS produces no BETWEEN_THRESHOLDS = -2). gt_classes [G] float (NULL: all
+ * class 0). The matched BOXES are not gathered at all: nndet_detloss_matched_f32 reads them through `matches` at the <= 42 sampled
+ * positives (the reference's matched_gt_boxes is a [B, M, 6] gather, 114 MB per step at 160x160x96 / batch 4). */
+int nndet_atss3d_assign_batched_f32(const float* gt, const float* gt_classes, int64_t G, const int32_t* img_off_host, int32_t B,
+                                    const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
+                                    int32_t k, int64_t* matches, float* labels_out, void* workspace, size_t workspace_bytes,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Box decode + clip -- replaces decode_single (nndet/core/boxes/coder.py:90-155, weights = 1) followed
@@ -570,6 +579,16 @@ int nndet_detloss_compact_f32(const float* logits, const float* deltas_compact, 
                               int32_t neg_cap, const int64_t* counts, const float* labels, const float* matched_gt, const float* anchors,
                               int64_t m_anchors, int32_t C, float eps, float clip, float reg_weight, int32_t reg_mean, float cls_weight,
                               int32_t cls_mean, float* losses_out, float* g_deltas_out, float* g_logits_out, void* stream);
+/* nndet_detloss_f32 / nndet_detloss_compact_f32 with the matched GT boxes given INDIRECTLY: gt_all [G][6] = the GT boxes of the batch
+ * concatenated, matches [B * m_anchors] = the ATSS output (index local to the image, -1 unmatched), gt_base_host [B] (HOST array) = first
+ * row of each image in gt_all; B <= 64. deltas_compact != 0: deltas are the [pos_cap][6] rows of the sampled positives. Replaces the
+ * `matched_gt_boxes[sampled_pos_inds]` read of DetectionHeadHNM.compute_loss (nndet/arch/heads/comb.py:383-391) without the dense
+ * [B * M, 6] tensor behind it. */
+int nndet_detloss_matched_f32(const float* logits, const float* deltas, int32_t deltas_compact, const int64_t* pos, int32_t pos_cap,
+                              const int64_t* neg, int32_t neg_cap, const int64_t* counts, const float* labels, const float* gt_all,
+                              const int64_t* matches, const int32_t* gt_base_host, int32_t B, const float* anchors, int64_t m_anchors,
+                              int32_t C, float eps, float clip, float reg_weight, int32_t reg_mean, float cls_weight, int32_t cls_mean,
+                              float* losses_out, float* g_deltas_out, float* g_logits_out, void* stream);
 
 #ifdef __cplusplus
 }

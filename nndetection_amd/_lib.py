@@ -69,6 +69,7 @@ SIGNATURES = {
     "nndet_atss3d_workspace_bytes": (_SZ, [_I64, _I64, _I32, _I32]),
     "nndet_atss3d_match_f32": (C.c_int, [_P, _I64, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _SZ, _P]),
     "nndet_atss3d_match_batched_f32": (C.c_int, [_P, _I64, C.POINTER(C.c_int32), _I32, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _SZ, _P]),
+    "nndet_atss3d_assign_batched_f32": (C.c_int, [_P, _P, _I64, C.POINTER(C.c_int32), _I32, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _P, _SZ, _P]),
     "nndet_decode_clip3d_f32": (C.c_int, [_P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P]),
     "nndet_postprocess3d_workspace_bytes": (_SZ, [_I32, _I64, _I32, _I32]),
     "nndet_postprocess3d_f32": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _I32, _F, _F, _F, _F, _I32, _F, _I32, _F, _I32, _F, _I32,
@@ -84,6 +85,8 @@ SIGNATURES = {
                                        _P, _SZ, _P]),
     "nndet_detloss_f32": (C.c_int, [_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _I32, _F, _I32, _P, _P, _P, _P]),
     "nndet_detloss_compact_f32": (C.c_int, [_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _I32, _F, _I32, _P, _P, _P, _P]),
+    "nndet_detloss_matched_f32": (C.c_int, [_P, _P, _I32, _P, _I32, _P, _I32, _P, _P, _P, _P, C.POINTER(C.c_int32), _I32, _P, _I64, _I32, _F, _F, _F,
+                                            _I32, _F, _I32, _P, _P, _P, _P]),
     "nndet_detloss_scatter_f32": (C.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "nndet_wbc3d_workspace_bytes": (_SZ, [_I64]),
     "nndet_wbc3d_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _I32, _F, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -212,12 +212,25 @@ class _DetLossFn(torch.autograd.Function):
         losses = torch.empty((2,), dtype=torch.float32, device=dev)
         g_d = torch.empty((P, 6), dtype=torch.float32, device=dev)
         g_l = torch.empty((P + Q, C), dtype=torch.float32, device=dev)
-        lab, gt, an = labels.detach().float().contiguous(), matched_gt.detach().float().contiguous(), anchors.detach().float().contiguous()
+        lab, an = labels.detach().float().contiguous(), anchors.detach().float().contiguous()
         ctx.compact = bool(cfg.get("compact", False))        # box_deltas = the [P, 6] rows of the sampled positives (_RegSparseFn)
-        L.call("nndet_detloss_compact_f32" if ctx.compact else "nndet_detloss_f32", L.ptr(lg), L.ptr(dl), L.ptr(pos), P, L.ptr(neg), Q,
-               L.ptr(counts), L.ptr(lab), L.ptr(gt), L.ptr(an),
-               an.shape[0], C, float(cfg["eps"]), float(cfg["clip"]), float(cfg["reg_w"]), int(cfg["reg_mean"]), float(cfg["cls_w"]),
-               int(cfg["cls_mean"]), L.ptr(losses), L.ptr(g_d), L.ptr(g_l), L.stream())
+        if hasattr(matched_gt, "materialize"):               # core.retina.MatchedBoxes: GT boxes + ATSS matches, no [B, M, 6] gather
+            mb = matched_gt
+            nb = len(mb)
+            base = (ctypes.c_int32 * nb)(*[min(o, max(mb.gt_all.shape[0] - 1, 0)) for o in mb.offsets[:nb]])
+            gta = mb.gt_all.detach().float().contiguous()
+            if gta.shape[0] == 0:                            # no object in the whole batch: nothing is positive, nothing is read
+                gta = torch.zeros((1, 6), dtype=torch.float32, device=dev)
+            L.call("nndet_detloss_matched_f32", L.ptr(lg), L.ptr(dl), int(ctx.compact), L.ptr(pos), P, L.ptr(neg), Q, L.ptr(counts), L.ptr(lab),
+                   L.ptr(gta), L.ptr(mb.matches.contiguous()), base, nb, L.ptr(an), an.shape[0], C, float(cfg["eps"]), float(cfg["clip"]),
+                   float(cfg["reg_w"]), int(cfg["reg_mean"]), float(cfg["cls_w"]), int(cfg["cls_mean"]), L.ptr(losses), L.ptr(g_d), L.ptr(g_l),
+                   L.stream())
+        else:
+            gt = matched_gt.detach().float().contiguous()
+            L.call("nndet_detloss_compact_f32" if ctx.compact else "nndet_detloss_f32", L.ptr(lg), L.ptr(dl), L.ptr(pos), P, L.ptr(neg), Q,
+                   L.ptr(counts), L.ptr(lab), L.ptr(gt), L.ptr(an),
+                   an.shape[0], C, float(cfg["eps"]), float(cfg["clip"]), float(cfg["reg_w"]), int(cfg["reg_mean"]), float(cfg["cls_w"]),
+                   int(cfg["cls_mean"]), L.ptr(losses), L.ptr(g_d), L.ptr(g_l), L.stream())
         ctx.save_for_backward(pos, neg, g_d, g_l)
         ctx.shapes = (tuple(box_logits.shape), box_logits.dtype, tuple(box_deltas.shape), box_deltas.dtype)
         # two 0-dim outputs (not one [2] tensor the caller indexes: autograd would then build the incoming gradient with two zero
@@ -341,6 +354,8 @@ class GIoURegressor(nn.Module):
 
 class DetectionHeadHNMNative(nn.Module):
     """classifier + regressor + hard-negative sampling; loss on decoded boxes (comb.py:351-405)."""
+
+    accepts_matched_boxes = True      # compute_loss takes core.retina.MatchedBoxes in place of the list of [M, 6] tensors
 
     def __init__(self, classifier, regressor, coder, sampler, log_num_anchors=None):
         super().__init__()
@@ -500,6 +515,8 @@ class DetectionHeadHNMNative(nn.Module):
         box_logits, box_deltas = prediction["box_logits"], prediction["box_deltas"]
         if box_logits.is_cuda and self._use_sync_free():
             return self._compute_loss_sync_free(box_logits, box_deltas, target_labels, matched_gt_boxes, anchors)
+        if hasattr(matched_gt_boxes, "materialize"):                 # core.retina.MatchedBoxes: the reference's list for this route
+            matched_gt_boxes = matched_gt_boxes.materialize()
         if isinstance(box_deltas, DeferredDeltas):
             box_deltas = box_deltas.materialize()
         losses = {}
@@ -540,13 +557,17 @@ class DetectionHeadHNMNative(nn.Module):
             # one launch for both losses and their gradients instead of ~250 element-wise ones (csrc/boxes.hip: k_detloss)
             same = all(a is anchors[0] for a in anchors)
             an = anchors[0] if same else torch.cat(anchors, dim=0)
-            gt = _cat_rows(matched_gt_boxes)
+            indirect = hasattr(matched_gt_boxes, "materialize") and same
+            gt = matched_gt_boxes if indirect else _cat_rows(matched_gt_boxes.materialize() if hasattr(matched_gt_boxes, "materialize")
+                                                              else matched_gt_boxes)
             cfg = {"eps": self.regressor.eps, "clip": getattr(self.coder, "bbox_xform_clip", math.log(1000. / 16)),
                    "reg_w": self.regressor.loss_weight, "reg_mean": self.regressor.reduction == "mean",
                    "cls_w": self.classifier.loss_weight, "cls_mean": self.classifier.reduction == "mean",
                    "compact": deferred is not None}
             reg_l, cls_l = _DetLossFn.apply(box_logits, box_deltas, pos, neg, counts, labels, gt, an, cfg)
             return {"reg": reg_l, "cls": cls_l}, pos, neg
+        if hasattr(matched_gt_boxes, "materialize"):
+            matched_gt_boxes = matched_gt_boxes.materialize()
         n_pos, n_neg = counts[0], counts[1]
         pos_ok, neg_ok = pos >= 0, neg >= 0
         pos_c, neg_c = pos.clamp(min=0), neg.clamp(min=0)

@@ -158,7 +158,12 @@ def up_param_grads(wc: torch.Tensor, w_up: torch.Tensor, bsum: Optional[torch.Te
     d = dWc.to(wc.dtype).reshape(8, I, 27).permute(0, 2, 1).reshape(8 * 27, I)
     dA = torch.matmul(T.t(), d).reshape(27, 8, I)                        # [t, par, i] = sum_{(pi, delta) -> (t, par)} dWc[pi][i][delta]
     S = torch.mv(K3, cls_sums.to(wc.dtype).reshape(27))                  # S[t] = sum over the classes whose tap t stays inside
-    dw_up = torch.einsum("tk,tpi->ikp", wc, dA).reshape(I, C, 2, 2, 2)
+    # .contiguous(): einsum hands back a PERMUTED view of its [C, 8 I] product. A gradient that does not obey autograd's layout contract
+    # is not adopted by AccumulateGrad but CLONED -- on the parameter's stream, which the engine orders behind this node's stream only,
+    # not behind the weight-gradient stream this runs on: the clone then reads the tensor before it is written (round 4: at batch 4
+    # decoder.up.P1.conv.weight.grad came out as zeros / stale memory in some runs; found by
+    # tests/test_parity_full_gpu.py::test_luna160_b4_benchmarked_route_vs_fp32_and_reference).
+    dw_up = torch.einsum("tk,tpi->ikp", wc, dA).reshape(I, C, 2, 2, 2).contiguous()
     ec = torch.einsum("tpi,ikp->tk", dA, w_up.to(wc.dtype).reshape(I, C, 8))
     dbsum = torch.mv(wc.t(), S)
     if bsum is not None:

@@ -50,9 +50,11 @@ class ATSSMatcher:
         return mq, matches
 
     def match_batch(self, boxes: Sequence[Tensor], anchors: Tensor, num_anchors_per_level: Sequence[int],
-                    num_anchors_per_loc: int) -> Tuple[Tensor, Tensor, Sequence[int]]:
+                    num_anchors_per_loc: int, classes: Sequence[Tensor] = None):
         """All images of a batch against their shared anchors in ONE pass (nndet_atss3d_match_batched_f32).
-        -> (gt_all [G,6] concatenated, matches [B, M] with indices local to the image / -1, offsets [B+1])."""
+        -> (gt_all [G,6] concatenated, matches [B, M] with indices local to the image / -1, offsets [B+1]).
+        With `classes` (per image, as `boxes`): the kernel also writes the anchors' training labels (class of the matched GT + 1, 0 =
+        background; nndet/core/retina.py:262-287) and a fourth value `labels` [B, M] fp32 is returned."""
         M, B = anchors.shape[0], len(boxes)
         dev = anchors.device
         offs_img = [0]
@@ -71,6 +73,16 @@ class ATSSMatcher:
         matches = torch.empty((B, M), dtype=torch.int64, device=dev)
         ws_bytes = L.load().nndet_atss3d_workspace_bytes(max(G, 1), M, Lv, k)
         ws = L.workspace(ws_bytes, dev)
+        if classes is not None:
+            cl = [c.detach().to(dev, torch.float32).reshape(-1) for c, b in zip(classes, boxes) if b.numel() > 0]
+            gt_cls = (cl[0] if len(cl) == 1 else torch.cat(cl, 0)).contiguous() if cl else None
+            if gt_cls is not None and gt_cls.numel() != G:
+                raise L.NndetError("ATSS: one class per ground-truth box expected")
+            labels = torch.empty((B, M), dtype=torch.float32, device=dev)
+            L.call("nndet_atss3d_assign_batched_f32", L.ptr(gt) if G else None, L.ptr(gt_cls) if gt_cls is not None else None, G,
+                   (ctypes.c_int32 * (B + 1))(*offs_img), B, L.ptr(an), M, (ctypes.c_int64 * (Lv + 1))(*offs), Lv, k, L.ptr(matches),
+                   L.ptr(labels), L.ptr(ws), ws_bytes, L.stream())
+            return gt, matches, offs_img, labels
         L.call("nndet_atss3d_match_batched_f32", L.ptr(gt) if G else None, G, (ctypes.c_int32 * (B + 1))(*offs_img), B,
                L.ptr(an), M, (ctypes.c_int64 * (Lv + 1))(*offs), Lv, k, L.ptr(matches), L.ptr(ws), ws_bytes, L.stream())
         return gt, matches, offs_img

@@ -17,6 +17,38 @@ from . import boxes as box_utils
 REPACK_EVERY_STEP = os.environ.get("NNDET_REPACK_EVERY_STEP", "1") != "0"
 
 
+class MatchedBoxes:
+    """The reference's `matched_gt_boxes` (one [M, 6] tensor per image: the GT box each anchor was matched to, retina.py:262-287)
+    WITHOUT the gather: the GT boxes of the batch, the ATSS matches [B, M] (index local to the image, -1 = none) and the first GT row of
+    each image. The detection loss reads the boxes of the <= 42 sampled positives through the matches (nndet_detloss_matched_f32);
+    `materialize()` gives the reference's list for any other consumer (114 MB per step at 160x160x96, batch 4)."""
+
+    def __init__(self, gt_all: Tensor, matches: Tensor, offsets):
+        self.gt_all, self.matches, self.offsets = gt_all, matches, [int(o) for o in offsets]
+
+    def __len__(self):
+        return self.matches.shape[0]
+
+    def tensors(self):
+        return [self.gt_all, self.matches]
+
+    def materialize(self) -> List[Tensor]:
+        B, M = self.matches.shape
+        if self.gt_all.shape[0] == 0:
+            return [torch.zeros((M, 6), dtype=torch.float32, device=self.matches.device) for _ in range(B)]
+        last = self.gt_all.shape[0] - 1
+        base = torch.tensor([min(o, last) for o in self.offsets[:-1]], dtype=torch.int64, device=self.matches.device)[:, None]
+        boxes = self.gt_all[self.matches.clamp(min=0) + base]
+        for b in range(B):
+            if self.offsets[b + 1] == self.offsets[b]:
+                boxes[b].zero_()
+        return list(boxes.unbind(0))
+
+
+# NNDET_LAZY_TARGETS=0: labels / matched boxes of the batched target assignment as the clamp / gather / compare chain of round 3
+LAZY_TARGETS = os.environ.get("NNDET_LAZY_TARGETS", "1") != "0"
+
+
 class BaseRetinaNet(nn.Module):
     def __init__(self, dim: int, encoder, decoder, head, num_classes: int, anchor_generator, matcher,
                  decoder_levels: tuple = (2, 3, 4, 5), score_thresh: float = None, detections_per_img: int = 100,
@@ -184,6 +216,9 @@ class BaseRetinaNet(nn.Module):
             self._seg_rank1_cached = bool(ok)
         return ok
 
+    def _lazy_targets_ok(self) -> bool:
+        return bool(getattr(self.head, "accepts_matched_boxes", False))
+
     # Target assignment (ATSS on the anchors + GT boxes) does not depend on the network: with the anchors of the previous step with
     # the same image shape (the generator caches them) it runs on a side stream UNDER the forward pass instead of between the
     # forward and the backward pass (0.3-0.45 ms of small launches per step). The segmentation branch (fused output conv + loss,
@@ -225,7 +260,7 @@ class BaseRetinaNet(nn.Module):
                 side = self._aux(images.device, 0)
                 side.wait_stream(main)                   # the targets (and everything of the previous step) are ready
                 with torch.cuda.stream(side):
-                    pre = self.assign_targets_to_anchors(cached, target_boxes, target_classes)
+                    pre = self.assign_targets_to_anchors(cached, target_boxes, target_classes, lazy=self._lazy_targets_ok())
             elif cached is not None:
                 self._lazy_fork = torch.cuda.Event()
                 self._lazy_fork.record(main)             # the target tensors are ready here; the forward pass is queued behind it
@@ -250,16 +285,16 @@ class BaseRetinaNet(nn.Module):
                 side = self._aux(images.device, 0)
                 side.wait_event(self._lazy_fork)
                 with torch.cuda.stream(side):
-                    pre = self.assign_targets_to_anchors(cached, target_boxes, target_classes)
+                    pre = self.assign_targets_to_anchors(cached, target_boxes, target_classes, lazy=self._lazy_targets_ok())
                     for t in list(target_boxes) + list(target_classes):
                         t.record_stream(side)
         if pre is not None and len(anchors) == len(cached) and all(a is c for a, c in zip(anchors, cached)):
             main.wait_stream(self._aux(images.device, 0))
             labels, matched_gt_boxes = pre
-            for t in list(labels) + list(matched_gt_boxes):
+            for t in list(labels) + (matched_gt_boxes.tensors() if isinstance(matched_gt_boxes, MatchedBoxes) else list(matched_gt_boxes)):
                 t.record_stream(main)
         else:
-            labels, matched_gt_boxes = self.assign_targets_to_anchors(anchors, target_boxes, target_classes)
+            labels, matched_gt_boxes = self.assign_targets_to_anchors(anchors, target_boxes, target_classes, lazy=self._lazy_targets_ok())
         if overlap:
             if not hasattr(self, "_anchors_by_shape"):
                 self._anchors_by_shape = {}
@@ -293,13 +328,14 @@ class BaseRetinaNet(nn.Module):
         return losses, prediction
 
     @torch.no_grad()
-    def assign_targets_to_anchors(self, anchors: List[Tensor], target_boxes: List[Tensor], target_classes: List[Tensor]):
-        """retina.py:228-290 with the fused ATSS kernel as matcher."""
+    def assign_targets_to_anchors(self, anchors: List[Tensor], target_boxes: List[Tensor], target_classes: List[Tensor], lazy: bool = False):
+        """retina.py:228-290 with the fused ATSS kernel as matcher. `lazy` (train_step, when the head accepts it): the labels come
+        straight out of the ATSS kernel and the matched boxes stay a `MatchedBoxes` (no [B, M, 6] gather)."""
         labels, matched_gt_boxes = [], []
         npl = None
         if len(anchors) > 1 and all(a is anchors[0] for a in anchors) and hasattr(self.proposal_matcher, "match_batch") \
                 and len(anchors) <= 64:
-            return self._assign_targets_batched(anchors[0], target_boxes, target_classes)
+            return self._assign_targets_batched(anchors[0], target_boxes, target_classes, lazy=lazy and LAZY_TARGETS)
         for anchors_per_image, gt_boxes, gt_classes in zip(anchors, target_boxes, target_classes):
             if npl is None:
                 npl = self.anchor_generator.get_num_acnhors_per_level()
@@ -322,10 +358,14 @@ class BaseRetinaNet(nn.Module):
             matched_gt_boxes.append(matched_gt_boxes_per_image)
         return labels, matched_gt_boxes
 
-    def _assign_targets_batched(self, anchors: Tensor, target_boxes: List[Tensor], target_classes: List[Tensor]):
+    def _assign_targets_batched(self, anchors: Tensor, target_boxes: List[Tensor], target_classes: List[Tensor], lazy: bool = False):
         """Same result as the per-image loop above, with one ATSS pass over the shared anchors for the whole batch."""
         dev, B, M = anchors.device, len(target_boxes), anchors.shape[0]
         npl = self.anchor_generator.get_num_acnhors_per_level()
+        if lazy:
+            gt_all, matches, offs, labels = self.proposal_matcher.match_batch(
+                target_boxes, anchors, npl, self.anchor_generator.num_anchors_per_location()[0], classes=target_classes)
+            return list(labels.unbind(0)), MatchedBoxes(gt_all, matches, offs)
         gt_all, matches, offs = self.proposal_matcher.match_batch(
             target_boxes, anchors, npl, self.anchor_generator.num_anchors_per_location()[0])
         if gt_all.shape[0] == 0:

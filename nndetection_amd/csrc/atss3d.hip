@@ -151,9 +151,13 @@ __global__ void k_atss_thr(int G, int ncand, const double* __restrict__ sums, fl
 }
 
 // per anchor arg-max over the GTs of ONE image. grid (total_blocks, B), block 256
+// labels (optional): the anchor's training label as BaseRetinaNet.assign_targets_to_anchors forms it (core/retina.py:262-287 of the
+// reference): class of the matched GT + 1, 0 for an unmatched anchor -- written here instead of by a clamp / gather / compare / multiply
+// chain over the [B, M] match tensor.
 __global__ __launch_bounds__(256) void k_atss_assign(AtssArgs A, const float* __restrict__ gt,
                                                      const float* __restrict__ anchors, const u64* __restrict__ kth,
-                                                     const float* __restrict__ thr, int64_t* __restrict__ matches) {
+                                                     const float* __restrict__ thr, int64_t* __restrict__ matches,
+                                                     const float* __restrict__ gt_cls, float* __restrict__ labels) {
     __shared__ float g_s[GT_TILE][6];
     __shared__ u64 p_s[GT_TILE];
     __shared__ float t_s[GT_TILE];
@@ -188,7 +192,10 @@ __global__ __launch_bounds__(256) void k_atss_assign(AtssArgs A, const float* __
             }
         }
     }
-    if (valid) matches[(int64_t)img * A.M + a] = (int64_t)bi;
+    if (valid) {
+        matches[(int64_t)img * A.M + a] = (int64_t)bi;
+        if (labels) labels[(int64_t)img * A.M + a] = bi >= 0 ? (gt_cls ? gt_cls[gbeg + bi] : 0.f) + 1.f : 0.f;
+    }
 }
 
 __global__ void k_fill_i64(int64_t* p, int64_t n, int64_t v) {
@@ -214,9 +221,9 @@ extern "C" size_t nndet_atss3d_workspace_bytes(int64_t G, int64_t M, int32_t L, 
     return w.total;
 }
 
-extern "C" int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const int32_t* img_off_host, int32_t B,
-                                              const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
-                                              int32_t k, int64_t* matches, void* workspace, size_t workspace_bytes, void* stream) {
+static int atss_batched(const float* gt, const float* gt_cls, int64_t G, const int32_t* img_off_host, int32_t B,
+                        const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
+                        int32_t k, int64_t* matches, float* labels, void* workspace, size_t workspace_bytes, void* stream) {
     hipStream_t st = as_stream(stream);
     if (G < 0 || M < 0 || L <= 0 || L > MAXL || k <= 0 || !level_offsets_host || B <= 0 || B > MAXB || !img_off_host) return NNDET_EINVAL;
     if (M == 0) return 0;
@@ -225,6 +232,7 @@ extern "C" int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const 
     if (G == 0) {  // Matcher.__call__ fast path (matcher/base.py:51-56) for every image
         k_fill_i64<<<(unsigned)ceil_div64(M * B, 256), 256, 0, st>>>(matches, M * B, -1);
         LAUNCH_CHECK();
+        if (labels) HIP_TRY(hipMemsetAsync(labels, 0, (size_t)M * B * sizeof(float), st));
         return 0;
     }
     if (!gt || !workspace) return NNDET_EINVAL;
@@ -270,9 +278,23 @@ extern "C" int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const 
     LAUNCH_CHECK();
     k_atss_thr<<<ceil_div((int)G, 64), 64, 0, st>>>((int)G, ncand, w.sums, w.thr);
     LAUNCH_CHECK();
-    k_atss_assign<<<dim3(nblk, B), 256, 0, st>>>(A, gt, anchors, w.prefix, w.thr, matches);
+    k_atss_assign<<<dim3(nblk, B), 256, 0, st>>>(A, gt, anchors, w.prefix, w.thr, matches, gt_cls, labels);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const int32_t* img_off_host, int32_t B,
+                                              const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
+                                              int32_t k, int64_t* matches, void* workspace, size_t workspace_bytes, void* stream) {
+    return atss_batched(gt, nullptr, G, img_off_host, B, anchors, M, level_offsets_host, L, k, matches, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nndet_atss3d_assign_batched_f32(const float* gt, const float* gt_classes, int64_t G, const int32_t* img_off_host, int32_t B,
+                                               const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
+                                               int32_t k, int64_t* matches, float* labels_out, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+    if (!labels_out) return NNDET_EINVAL;
+    return atss_batched(gt, gt_classes, G, img_off_host, B, anchors, M, level_offsets_host, L, k, matches, labels_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* anchors, int64_t M,

@@ -307,6 +307,11 @@ struct DetLossArgs {
     int64_t m_anchors;
     int32_t P, Q, C, reg_mean, cls_mean;
     int32_t compact;        // deltas are [P][6] rows in the order of pos (nndet_detloss_compact_f32) instead of [B * M][6]
+    // matched GT boxes either as the dense [B * M][6] tensor `gt` (the reference's matched_gt_boxes, retina.py:262-287) or INDIRECT:
+    // `matches` [B * M] (index of the matched GT local to the image, the ATSS kernel's output) + `gt` = the concatenated GT boxes
+    // [G][6] + gt_base[image] = first GT row of the image: the [B, M, 6] gather (114 MB per step at 160x160x96, batch 4) is never made
+    const int64_t* matches;
+    int32_t gt_base[65];
     float eps, clip, reg_w, cls_w;
     float* losses; float* g_deltas; float* g_logits;
 };
@@ -333,7 +338,8 @@ __global__ __launch_bounds__(256) void k_detloss(const DetLossArgs A) {
             const float pcx = d[0] * w + cx, pcy = d[1] * h + cy, pcz = d[4] * dd_ + cz;
             const float pw = expf(dw) * w, ph = expf(dh) * h, pd = expf(dz) * dd_;
             const float p[6] = {pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph, pcz - 0.5f * pd, pcz + 0.5f * pd};
-            const float* t = A.gt + idx * 6;
+            const float* t = A.matches ? A.gt + (int64_t)(A.gt_base[idx / A.m_anchors] + (A.matches[idx] > 0 ? A.matches[idx] : 0)) * 6
+                                       : A.gt + idx * 6;
             const Box pb = ldbox(p), tb = ldbox(t);
             reg_part += giou_val(pb, vol3(pb), tb, vol3(tb), A.eps);
             float G[6];
@@ -401,7 +407,7 @@ extern "C" int nndet_detloss_f32(const float* logits, const float* deltas, const
     DetLossArgs a;
     a.logits = logits; a.deltas = deltas; a.pos = pos; a.neg = neg; a.counts = counts; a.labels = labels; a.gt = matched_gt;
     a.anchors = anchors; a.m_anchors = m_anchors; a.P = pos_cap; a.Q = neg_cap; a.C = C; a.reg_mean = reg_mean; a.cls_mean = cls_mean;
-    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight; a.compact = 0;
+    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight; a.compact = 0; a.matches = nullptr;
     a.losses = losses_out; a.g_deltas = g_deltas_out; a.g_logits = g_logits_out;
     k_detloss<<<1, 256, 0, as_stream(stream)>>>(a);
     LAUNCH_CHECK();
@@ -419,7 +425,31 @@ extern "C" int nndet_detloss_compact_f32(const float* logits, const float* delta
     DetLossArgs a;
     a.logits = logits; a.deltas = deltas_compact; a.pos = pos; a.neg = neg; a.counts = counts; a.labels = labels; a.gt = matched_gt;
     a.anchors = anchors; a.m_anchors = m_anchors; a.P = pos_cap; a.Q = neg_cap; a.C = C; a.reg_mean = reg_mean; a.cls_mean = cls_mean;
-    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight; a.compact = 1;
+    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight; a.compact = 1; a.matches = nullptr;
+    a.losses = losses_out; a.g_deltas = g_deltas_out; a.g_logits = g_logits_out;
+    k_detloss<<<1, 256, 0, as_stream(stream)>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// Same losses with the matched GT boxes given INDIRECTLY (see DetLossArgs.matches): gt_all [G][6] = the batch's GT boxes concatenated,
+// matches [B * m_anchors] = nndet_atss3d_*_batched_f32's output, gt_base_host [B] = first row of each image in gt_all.
+// deltas_compact != 0: `deltas` are the [pos_cap][6] rows of the sampled positives (as nndet_detloss_compact_f32).
+extern "C" int nndet_detloss_matched_f32(const float* logits, const float* deltas, int32_t deltas_compact, const int64_t* pos, int32_t pos_cap,
+                                         const int64_t* neg, int32_t neg_cap, const int64_t* counts, const float* labels,
+                                         const float* gt_all, const int64_t* matches, const int32_t* gt_base_host, int32_t B,
+                                         const float* anchors, int64_t m_anchors, int32_t C, float eps, float clip, float reg_weight,
+                                         int32_t reg_mean, float cls_weight, int32_t cls_mean, float* losses_out, float* g_deltas_out,
+                                         float* g_logits_out, void* stream) {
+    if (!logits || !deltas || !pos || !neg || !counts || !labels || !gt_all || !matches || !gt_base_host || !anchors || !losses_out ||
+        !g_deltas_out || !g_logits_out)
+        return NNDET_EINVAL;
+    if (pos_cap < 1 || neg_cap < 0 || C < 1 || m_anchors < 1 || B < 1 || B > 64) return NNDET_EINVAL;
+    DetLossArgs a;
+    a.logits = logits; a.deltas = deltas; a.pos = pos; a.neg = neg; a.counts = counts; a.labels = labels; a.gt = gt_all;
+    a.anchors = anchors; a.m_anchors = m_anchors; a.P = pos_cap; a.Q = neg_cap; a.C = C; a.reg_mean = reg_mean; a.cls_mean = cls_mean;
+    a.eps = eps; a.clip = clip; a.reg_w = reg_weight; a.cls_w = cls_weight; a.compact = deltas_compact ? 1 : 0; a.matches = matches;
+    for (int b = 0; b < 65; ++b) a.gt_base[b] = b < B ? gt_base_host[b] : 0;
     a.losses = losses_out; a.g_deltas = g_deltas_out; a.g_logits = g_logits_out;
     k_detloss<<<1, 256, 0, as_stream(stream)>>>(a);
     LAUNCH_CHECK();

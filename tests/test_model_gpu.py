@@ -817,3 +817,44 @@ def test_foreign_fused_optimizer_invalidates_every_parameter_cache():
         assert all(float((p.detach() - b).abs().max()) > 0 for p, b in zip(params, before)), "the step changed every parameter"
     with pytest.raises(ValueError):
         opt.add_param_group({"params": [torch.zeros(3, requires_grad=True)]})           # CPU tensor into a fused optimizer
+
+
+def test_lazy_target_assignment_equals_the_gathered_one(golden_dir, monkeypatch):
+    """Round 4: the batched ATSS kernel writes the anchors' labels itself (nndet_atss3d_assign_batched_f32) and the
+    matched boxes stay a `MatchedBoxes` (GT boxes + matches; the detection loss reads <= 42 rows through nndet_detloss_matched_f32)
+    instead of the clamp / gather / compare / multiply chain over [B, M] tensors and the [B, M, 6] gather of
+    nndet/core/retina.py:262-287. Same labels and boxes bit for bit -- incl. an image without objects and non-zero classes -- and the
+    same losses / gradients of a training step."""
+    from nndetection_amd.core import retina as R
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    x = torch.from_numpy(gn["x"]).cuda()
+    with torch.no_grad():
+        _, anchors, _ = net(x)
+    boxes = [b.cuda() for b in tg["target_boxes"]]
+    classes = [torch.arange(b.shape[0], dtype=torch.float32).cuda() % 3 for b in boxes]      # classes 0, 1, 2, ...
+    for variant in ("as is", "first image empty"):
+        bx_ = [boxes[0][:0]] + boxes[1:] if variant == "first image empty" else boxes
+        cl_ = [classes[0][:0]] + classes[1:] if variant == "first image empty" else classes
+        lab0, mb0 = net.assign_targets_to_anchors(anchors, bx_, cl_, lazy=False)
+        lab1, mb1 = net.assign_targets_to_anchors(anchors, bx_, cl_, lazy=True)
+        assert isinstance(mb1, R.MatchedBoxes) and not isinstance(mb0, R.MatchedBoxes)
+        for a, b in zip(lab0, lab1):
+            assert torch.equal(a, b), variant
+        for a, b, l in zip(mb0, mb1.materialize(), lab0):
+            assert torch.equal(a[l > 0], b[l > 0]), variant               # (rows of unmatched anchors are never read: index 0 in both)
+        assert sum(int((l > 0).sum()) for l in lab0) > 0
+    res = {}
+    for lazy in (True, False):
+        monkeypatch.setattr(R, "LAZY_TARGETS", lazy)
+        net.zero_grad(set_to_none=True)
+        losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        res[lazy] = ({k: float(v.detach()) for k, v in losses.items()},
+                     {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    for n, g in res[False][1].items():
+        assert float((res[True][1][n] - g).abs().max()) <= 1e-6 * float(g.abs().max()) + 1e-12, n
