@@ -71,6 +71,7 @@ def synth_plugin_batch(plan, batch, device, seed):
 
 
 _TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+NBATCH = int(os.environ.get("NNDET_BENCH_NBATCH", "3"))     # distinct synthetic batches a route cycles through
 
 
 class Route:
@@ -92,23 +93,29 @@ class Route:
             self.mod = StandaloneRetinaUNetV001AMD(copy.deepcopy(MODEL_CFG_V001), cfg, pl_plan).to(device)
             self.net = self.mod.model
             self.opt, self.sched = self.mod.configure_optimizers()
-            self.batch = synth_plugin_batch(plan, batch, device, seed=1000 + rank)
+            # NBATCH distinct synthetic batches, resident in HBM, visited round-robin (not one identical batch every step)
+            self.batches = [synth_plugin_batch(plan, batch, device, seed=1000 + rank + 17 * i) for i in range(NBATCH)]
+            self.batch = self.batches[0]
             self.ctx = (lambda: torch.autocast("cuda", dtype=dt)) if dtype_name != "f32" else contextlib.nullcontext
         else:
             self.net = build_model(plan).to(device)
             self.opt, self.sched = configure_optimizer(self.net)
-            self.x, self.tg = synth_batch(plan, batch, dt, device, seed=1000 + rank)
+            self.data = [synth_batch(plan, batch, dt, device, seed=1000 + rank + 17 * i) for i in range(NBATCH)]
+            self.x, self.tg = self.data[0]
+        self.it = 0
         self.scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14) if dtype_name == "f16" else None
         self.ddp = ddp_factory(self.net) if ddp_factory is not None else None
         torch.manual_seed(1234 + rank)
 
     def step(self):
+        self.it += 1
         if self.via_plugin:
             with self.ctx():
-                out = self.mod.training_step(self.batch, 0)
+                out = self.mod.training_step(self.batches[self.it % NBATCH], self.it)
             loss = out["loss"]
         else:
-            losses, _ = self.net.train_step(self.x, self.tg, evaluation=False, batch_num=0)
+            x, tg = self.data[self.it % NBATCH]
+            losses, _ = self.net.train_step(x, tg, evaluation=False, batch_num=self.it)
             loss = sum(losses.values())
         if self.ddp is not None:
             self.ddp.begin_step()
@@ -624,6 +631,7 @@ def main():
                                    ", RetinaUNetV001 train step (fwd + ATSS + losses + bwd + SGD), %dx%dx%d patches" % tuple(plan["patch_size"]),
                        "plan": args.plan, "batch_per_gpu": batch, "global_batch": batch * world,
                        "parallelism": "dp%d" % world, "params": sum(p.numel() for p in net.parameters()),
+                       "distinct_batches": NBATCH,
                        "route": "plugin training_step (batch dict -> device-side targets -> train_step)" if args.via_plugin else
                                 "BaseRetinaNet.train_step on prepared targets",
                        "loss_scaling": "torch.amp.GradScaler (sync-free: fused SGD takes scale / found_inf on the device)" if route.scaler is not None else None},
