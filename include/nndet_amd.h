@@ -56,6 +56,13 @@ size_t nndet_nms3d_workspace_bytes(int64_t n);
 int nndet_nms3d_f32(const float* boxes, const float* scores, int64_t n, float iou_threshold,
                     int64_t* keep_out, int64_t* n_keep_out, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* 2D boxes [n,4] (x1, y1, x2, y2): nndet._C.nms dispatches on dets.size(1) (nms_kernel / devIoU, nndet/csrc/cuda/nms.cu:22-34,54-96,172-180;
+ * the Python wrapper sends 2D boxes to torchvision.ops.nms, nndet/core/boxes/nms.py:70-72 -- same rule). Same outputs / workspace as
+ * nndet_nms3d_f32; decisions are bit-identical to devIoU: the boxes are widened to (x1, y1, x2, y2, 0, 1), whose 3D IoU multiplies the
+ * 2D intersection and areas by exactly 1.0f. */
+int nndet_nms2d_f32(const float* boxes, const float* scores, int64_t n, float iou_threshold,
+                    int64_t* keep_out, int64_t* n_keep_out, void* workspace, size_t workspace_bytes,
+                    void* stream);
 /* Same, but the caller supplies the order (descending score) -- the mask + scan part only.
  * `order` [n] int32 indices into boxes. Used by batched post-processing that already sorted. */
 int nndet_nms3d_sorted_f32(const float* boxes, const int32_t* order, int64_t n, float iou_threshold,
@@ -118,11 +125,21 @@ int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const int32_t* im
  * unmatched anchor -- what BaseRetinaNet.assign_targets_to_anchors forms from the matches with a clamp / gather / compare / multiply
  * chain over [B, M] tensors (nndet/core/retina.py:262-287; ATSS produces no BETWEEN_THRESHOLDS = -2). gt_classes [G] float (NULL: all
  * class 0). The matched BOXES are not gathered at all: nndet_detloss_matched_f32 reads them through `matches` at the <= 42 sampled
- * positives (the reference's matched_gt_boxes is a [B, M, 6] gather, 114 MB per step at 160x160x96 / batch 4). */
+ * positives (the reference's matched_gt_boxes is a [B, M, 6] gather, 114 MB per step at 160x160x96 / batch 4).
+ * center_in_gt != 0 (ATSSMatcher(center_in_gt=True), nndet/core/boxes/matcher/atss.py:101-107; RetinaUNetV001 sets it False): a candidate
+ * only becomes a positive of a GT box if the anchor's centre lies inside that box, more than min_dist (the reference: 0.01) from every
+ * face (center_in_boxes, nndet/core/boxes/ops.py:290-311). */
 int nndet_atss3d_assign_batched_f32(const float* gt, const float* gt_classes, int64_t G, const int32_t* img_off_host, int32_t B,
                                     const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
-                                    int32_t k, int64_t* matches, float* labels_out, void* workspace, size_t workspace_bytes,
-                                    void* stream);
+                                    int32_t k, int32_t center_in_gt, float min_dist, int64_t* matches, float* labels_out,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+/* IoU-threshold matcher -- replaces IoUMatcher.compute_matches (nndet/core/boxes/matcher/iou.py:43-107; the matcher of the reference's
+ * skeleton module, RetinaUNetV001 configures ATSS): matches [M] = index of the GT with the highest IoU (ties: lowest index),
+ * -1 (BELOW_LOW_THRESHOLD) if that IoU < low_threshold, -2 (BETWEEN_THRESHOLDS) if low <= IoU < high_threshold. With
+ * allow_low_quality_matches every GT also claims its best anchor (ties: lowest anchor index; two GTs on one anchor: the higher GT index,
+ * as the reference's sequential assignment); workspace: G * 8 bytes then. G == 0 -> all -1. The [G, M] IoU matrix is never formed. */
+int nndet_iou_match3d_f32(const float* gt, int64_t G, const float* anchors, int64_t M, float low_threshold, float high_threshold,
+                          int32_t allow_low_quality_matches, int64_t* matches, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Box decode + clip -- replaces decode_single (nndet/core/boxes/coder.py:90-155, weights = 1) followed

@@ -59,6 +59,7 @@ SIGNATURES = {
     "nndet_arch": (C.c_char_p, []),
     "nndet_nms3d_workspace_bytes": (_SZ, [_I64]),
     "nndet_nms3d_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
+    "nndet_nms2d_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
     "nndet_nms3d_sorted_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
     "nndet_iou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
     "nndet_giou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
@@ -69,7 +70,9 @@ SIGNATURES = {
     "nndet_atss3d_workspace_bytes": (_SZ, [_I64, _I64, _I32, _I32]),
     "nndet_atss3d_match_f32": (C.c_int, [_P, _I64, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _SZ, _P]),
     "nndet_atss3d_match_batched_f32": (C.c_int, [_P, _I64, C.POINTER(C.c_int32), _I32, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _SZ, _P]),
-    "nndet_atss3d_assign_batched_f32": (C.c_int, [_P, _P, _I64, C.POINTER(C.c_int32), _I32, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _P, _P, _P, _SZ, _P]),
+    "nndet_iou_match3d_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _F, _I32, _P, _P, _SZ, _P]),
+    "nndet_atss3d_assign_batched_f32": (C.c_int, [_P, _P, _I64, C.POINTER(C.c_int32), _I32, _P, _I64, C.POINTER(C.c_int64), _I32, _I32, _I32, _F, _P, _P,
+                                                  _P, _SZ, _P]),
     "nndet_decode_clip3d_f32": (C.c_int, [_P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P]),
     "nndet_postprocess3d_workspace_bytes": (_SZ, [_I32, _I64, _I32, _I32]),
     "nndet_postprocess3d_f32": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _I32, _F, _F, _F, _F, _I32, _F, _I32, _F, _I32, _F, _I32,

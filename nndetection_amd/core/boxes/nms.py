@@ -18,17 +18,18 @@ def _nms_raw(boxes: Tensor, scores: Tensor, iou_threshold: float):
     if ws_bytes == 0:
         raise L.NndetError("nndet_nms3d_workspace_bytes failed")
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=b.device)
-    L.call("nndet_nms3d_f32", L.ptr(b), L.ptr(s), n, float(iou_threshold), L.ptr(keep), L.ptr(n_keep),
-           L.ptr(ws), ws_bytes, L.stream())
+    L.call("nndet_nms2d_f32" if b.shape[1] == 4 else "nndet_nms3d_f32", L.ptr(b), L.ptr(s), n, float(iou_threshold), L.ptr(keep),
+           L.ptr(n_keep), L.ptr(ws), ws_bytes, L.stream())
     return keep, n_keep
 
 
 def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
-    """keep indices (int64, decreasing score), same contract as nndet._C.nms. Only 3D boxes on GPU."""
+    """keep indices (int64, decreasing score), same contract as nndet._C.nms: [N, 6] boxes (x1, y1, x2, y2, z1, z2) or [N, 4]
+    (the reference sends 2D boxes to torchvision.ops.nms, nms.py:70-72; its own 2D kernel is nms.cu:54-96)."""
     if boxes.shape[0] == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)   # cpu/nms.cpp:24-26
-    if boxes.shape[1] != 6:
-        raise L.NndetError("only 3D boxes are supported by the MI355X NMS")
+    if boxes.shape[1] not in (4, 6):
+        raise L.NndetError("NMS takes [N, 4] or [N, 6] boxes")
     keep, n_keep = _nms_raw(boxes, scores, iou_threshold)
     return keep[: int(n_keep.item())]     # the one host sync (the reference syncs on the mask D2H instead)
 

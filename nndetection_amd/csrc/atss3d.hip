@@ -26,7 +26,17 @@ struct AtssArgs {
     int64_t M;
     int32_t B;                   // images in the batch (they share the anchors)
     int32_t img_off[MAXB + 1];   // GT offsets per image into the concatenated GT list
+    int32_t center_in_gt;        // atss.py:101-107: a positive's centre must lie inside its GT box, further than min_dist from every face
+    float min_dist;
 };
+
+// center_in_boxes (nndet/core/boxes/ops.py:290-311) of the anchor's centre (box_center, ops.py:314-327) and GT box g: the smallest of
+// the six centre-to-face distances must exceed eps. Same fp32 expressions, no contraction (-ffp-contract=off).
+__device__ __forceinline__ bool ctr_in_box(const float* g, const float* a, float eps) {
+    const float cx = (a[2] + a[0]) / 2.f, cy = (a[3] + a[1]) / 2.f, cz = (a[5] + a[4]) / 2.f;
+    const float m = fminf(fminf(fminf(cx - g[0], cy - g[1]), fminf(g[2] - cx, g[3] - cy)), fminf(cz - g[4], g[5] - cz));
+    return m > eps;
+}
 
 __device__ __forceinline__ float ctr_dist(const float* g, const float* a) {
     float gx = (g[2] + g[0]) / 2.f, gy = (g[3] + g[1]) / 2.f, gz = (g[5] + g[4]) / 2.f;
@@ -187,7 +197,9 @@ __global__ __launch_bounds__(256) void k_atss_assign(AtssArgs A, const float* __
                 const u64 key = ((u64)__float_as_uint(ctr_dist(g_s[g], ab)) << 32) | (u64)(uint32_t)a;
                 if (key <= p_s[g]) {
                     const float v = iou3(g_s[g], ab);
-                    if (v >= t_s[g] && v > best) { best = v; bi = g0 + g - gbeg; }   // index local to the image
+                    if (v >= t_s[g] && v > best && (!A.center_in_gt || ctr_in_box(g_s[g], ab, A.min_dist))) {
+                        best = v; bi = g0 + g - gbeg;                                // index local to the image
+                    }
                 }
             }
         }
@@ -223,7 +235,8 @@ extern "C" size_t nndet_atss3d_workspace_bytes(int64_t G, int64_t M, int32_t L, 
 
 static int atss_batched(const float* gt, const float* gt_cls, int64_t G, const int32_t* img_off_host, int32_t B,
                         const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
-                        int32_t k, int64_t* matches, float* labels, void* workspace, size_t workspace_bytes, void* stream) {
+                        int32_t k, int64_t* matches, float* labels, void* workspace, size_t workspace_bytes, void* stream,
+                        int32_t center_in_gt = 0, float min_dist = 0.01f) {
     hipStream_t st = as_stream(stream);
     if (G < 0 || M < 0 || L <= 0 || L > MAXL || k <= 0 || !level_offsets_host || B <= 0 || B > MAXB || !img_off_host) return NNDET_EINVAL;
     if (M == 0) return 0;
@@ -241,7 +254,7 @@ static int atss_batched(const float* gt, const float* gt_cls, int64_t G, const i
     atss_layout(G, L, (char*)workspace, &w);
     if (w.total > workspace_bytes) return NNDET_EWORKSPACE;
     AtssArgs A;
-    A.L = L; A.G = (int32_t)G; A.M = M; A.B = B;
+    A.L = L; A.G = (int32_t)G; A.M = M; A.B = B; A.center_in_gt = center_in_gt; A.min_dist = min_dist;
     for (int b = 0; b <= B; ++b) {
         A.img_off[b] = img_off_host[b];
         if (b && img_off_host[b] < img_off_host[b - 1]) return NNDET_EINVAL;
@@ -291,10 +304,11 @@ extern "C" int nndet_atss3d_match_batched_f32(const float* gt, int64_t G, const 
 
 extern "C" int nndet_atss3d_assign_batched_f32(const float* gt, const float* gt_classes, int64_t G, const int32_t* img_off_host, int32_t B,
                                                const float* anchors, int64_t M, const int64_t* level_offsets_host, int32_t L,
-                                               int32_t k, int64_t* matches, float* labels_out, void* workspace, size_t workspace_bytes,
-                                               void* stream) {
+                                               int32_t k, int32_t center_in_gt, float min_dist, int64_t* matches, float* labels_out,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
     if (!labels_out) return NNDET_EINVAL;
-    return atss_batched(gt, gt_classes, G, img_off_host, B, anchors, M, level_offsets_host, L, k, matches, labels_out, workspace, workspace_bytes, stream);
+    return atss_batched(gt, gt_classes, G, img_off_host, B, anchors, M, level_offsets_host, L, k, matches, labels_out, workspace, workspace_bytes, stream,
+                        center_in_gt ? 1 : 0, min_dist);
 }
 
 extern "C" int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* anchors, int64_t M,
@@ -303,4 +317,84 @@ extern "C" int nndet_atss3d_match_f32(const float* gt, int64_t G, const float* a
     if (G < 0 || G > 0x7fffffff) return NNDET_EINVAL;
     const int32_t off[2] = {0, (int32_t)G};
     return nndet_atss3d_match_batched_f32(gt, G, off, 1, anchors, M, level_offsets_host, L, k, matches, workspace, workspace_bytes, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------ IoU-threshold matcher
+// IoUMatcher.compute_matches (nndet/core/boxes/matcher/iou.py:43-107; the matcher of the reference's skeleton module -- RetinaUNetV001
+// uses ATSS): per anchor the GT with the highest IoU (ties: lowest GT index), BELOW_LOW_THRESHOLD (-1) if that IoU < low,
+// BETWEEN_THRESHOLDS (-2) if low <= IoU < high; with allow_low_quality_matches every GT additionally claims the anchor it overlaps most
+// (ties: lowest anchor index; two GTs claiming one anchor: the higher GT index wins, as the reference's in-order index assignment).
+// The [G, M] IoU matrix is never written: pass 1 keeps, per GT, the key (IoU bits << 32 | ~anchor) of its best anchor by atomicMax.
+__global__ __launch_bounds__(256) void k_ioum_assign(const float* __restrict__ gt, int G, const float* __restrict__ anchors, int64_t M,
+                                                     float low, float high, int64_t* __restrict__ matches, u64* __restrict__ best_key) {
+    __shared__ float g_s[GT_TILE][6];
+    __shared__ u64 k_s[GT_TILE];
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = a < M;
+    float ab[6] = {0, 0, 0, 0, 0, 0};
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ab[q] = anchors[a * 6 + q];
+    }
+    float best = -1.f;
+    int bi = 0;
+    for (int g0 = 0; g0 < G; g0 += GT_TILE) {
+        const int ng = min(GT_TILE, G - g0);
+        __syncthreads();
+        if ((int)threadIdx.x < ng * 6) (&g_s[0][0])[threadIdx.x] = gt[g0 * 6 + threadIdx.x];
+        if ((int)threadIdx.x < ng) k_s[threadIdx.x] = 0ull;
+        __syncthreads();
+        if (valid) {
+            for (int g = 0; g < ng; ++g) {
+                const float v = iou3(g_s[g], ab);
+                if (v > best) { best = v; bi = g0 + g; }                       // first maximum: lowest GT index (NaN never wins)
+                if (best_key && v >= 0.f) atomicMax(&k_s[g], ((u64)__float_as_uint(v) << 32) | (u64)(~(uint32_t)a));
+            }
+        }
+        __syncthreads();
+        if (best_key && (int)threadIdx.x < ng && k_s[threadIdx.x]) atomicMax(&best_key[g0 + threadIdx.x], k_s[threadIdx.x]);
+    }
+    if (valid) {
+        int64_t m = bi;
+        if (best < low) m = -1;                                                 // (an all-NaN column keeps best = -1 -> below)
+        else if (best < high) m = -2;
+        matches[a] = m;
+    }
+}
+
+__global__ void k_ioum_lowq(int G, const u64* __restrict__ best_key, int64_t* __restrict__ matches) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int g = 0; g < G; ++g) {
+            const u64 k = best_key[g];
+            if (k) matches[(int64_t)(~(uint32_t)(k & 0xffffffffull))] = (int64_t)g;
+        }
+}
+
+extern "C" int nndet_iou_match3d_f32(const float* gt, int64_t G, const float* anchors, int64_t M, float low_threshold, float high_threshold,
+                                     int32_t allow_low_quality_matches, int64_t* matches, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    hipStream_t st = as_stream(stream);
+    if (G < 0 || G > 0x7fffffff || M < 0 || M >= (1LL << 32) || low_threshold > high_threshold) return NNDET_EINVAL;
+    if (M == 0) return 0;
+    if (!matches || !anchors) return NNDET_EINVAL;
+    if (G == 0) {                                                              // Matcher.__call__ fast path (matcher/base.py:51-56)
+        k_fill_i64<<<(unsigned)ceil_div64(M, 256), 256, 0, st>>>(matches, M, -1);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (!gt) return NNDET_EINVAL;
+    u64* keys = nullptr;
+    if (allow_low_quality_matches) {
+        if (!workspace || workspace_bytes < (size_t)G * 8) return NNDET_EWORKSPACE;
+        keys = reinterpret_cast<u64*>(workspace);
+        HIP_TRY(hipMemsetAsync(keys, 0, (size_t)G * 8, st));
+    }
+    k_ioum_assign<<<(unsigned)ceil_div64(M, 256), 256, 0, st>>>(gt, (int)G, anchors, M, low_threshold, high_threshold, matches, keys);
+    LAUNCH_CHECK();
+    if (keys) {
+        k_ioum_lowq<<<1, 64, 0, st>>>((int)G, keys, matches);
+        LAUNCH_CHECK();
+    }
+    return 0;
 }

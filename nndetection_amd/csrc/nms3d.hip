@@ -71,6 +71,17 @@ __global__ void k_gather_boxes(const float* __restrict__ boxes, const int32_t* _
     out[i] = boxes[(int64_t)order[r] * 6 + k];
 }
 
+// 2D boxes (x1, y1, x2, y2) -> (x1, y1, x2, y2, 0, 1): the 3D IoU of two such boxes IS devIoU of nndet/csrc/cuda/nms.cu:22-34 bit for bit
+// (the third factor of the intersection and of both volumes is exactly 1.0f, and the products keep the reference's order), so the 2D
+// kernel of the reference (nms.cu:54-96) needs no second mask kernel here.
+__global__ void k_gather_boxes2d(const float* __restrict__ boxes, const int32_t* __restrict__ order, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = *reinterpret_cast<const float4*>(boxes + (int64_t)order[i] * 4);
+    float* o = out + i * 6;
+    o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = 0.f; o[5] = 1.f;
+}
+
 // grid (col_blocks, ceil(col_blocks/4)), block 256 = 4 waves; wave w handles row block 4*by + w.
 // labels (may be NULL): bit only between boxes of the same label (per-class clustering of wbc3d.hip); nan_hits: a NaN IoU sets the
 // bit as well (`!(iou <= thr)`: the box leaves the pool, wbc.py:122,141) -- NMS itself uses `iou > thr` (nms.cu:126).
@@ -314,11 +325,15 @@ static int nms_layout(int64_t n, char* base, NmsWs* ws) {
 
 // order == NULL: `boxes` already are in score order (no gather); n_valid: see k_nms_compact
 static int nms_core(const float* boxes, const int32_t* order, int64_t n, float thr, int64_t* keep_out,
-                    int64_t* n_keep_out, NmsWs& ws, hipStream_t st, const int64_t* n_valid = nullptr) {
+                    int64_t* n_keep_out, NmsWs& ws, hipStream_t st, const int64_t* n_valid = nullptr, int box_dim = 6) {
     const int cb = (int)ceil_div64(n, 64);
     { const int arc = nms_scan_attr(); if (arc) return arc; }
     const float* sboxes = boxes;
-    if (order) {
+    if (order && box_dim == 4) {
+        k_gather_boxes2d<<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(boxes, order, n, ws.sboxes);
+        LAUNCH_CHECK();
+        sboxes = ws.sboxes;
+    } else if (order) {
         k_gather_boxes<<<(unsigned)ceil_div64(n * 6, 256), 256, 0, st>>>(boxes, order, n, ws.sboxes);
         LAUNCH_CHECK();
         sboxes = ws.sboxes;
@@ -364,6 +379,26 @@ extern "C" int nndet_nms3d_f32(const float* boxes, const float* scores, int64_t 
     HIP_TRY((rocprim::radix_sort_pairs_desc<rocprim::default_config, const float*, float*, const int32_t*, int32_t*>(
         ws.sort_tmp, tmp, scores, ws.keys_out, ws.vals_in, ws.order, (size_t)n, 0, 32, st, false)));
     return nms_core(boxes, ws.order, n, thr, keep_out, n_keep_out, ws, st);
+}
+
+// 2D boxes [n, 4] (x1, y1, x2, y2): nndet._C.nms accepts them too (nms_kernel / devIoU, nndet/csrc/cuda/nms.cu:22-34,54-96; the Python
+// dispatcher routes 2D to torchvision.ops.nms, nndet/core/boxes/nms.py:70-72 -- same rule: suppress iff IoU > thr, descending score order).
+extern "C" int nndet_nms2d_f32(const float* boxes, const float* scores, int64_t n, float thr, int64_t* keep_out,
+                               int64_t* n_keep_out, void* workspace, size_t workspace_bytes, void* stream) {
+    hipStream_t st = as_stream(stream);
+    if (n < 0 || !n_keep_out) return NNDET_EINVAL;
+    if (n == 0) return (int)hipMemsetAsync(n_keep_out, 0, 8, st);
+    if (!boxes || !scores || !keep_out || !workspace) return NNDET_EINVAL;
+    NmsWs ws;
+    int rc = nms_layout(n, (char*)workspace, &ws);
+    if (rc) return rc;
+    if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
+    k_iota<<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(ws.vals_in, n);
+    LAUNCH_CHECK();
+    size_t tmp = ws.sort_tmp_bytes;
+    HIP_TRY((rocprim::radix_sort_pairs_desc<rocprim::default_config, const float*, float*, const int32_t*, int32_t*>(
+        ws.sort_tmp, tmp, scores, ws.keys_out, ws.vals_in, ws.order, (size_t)n, 0, 32, st, false)));
+    return nms_core(boxes, ws.order, n, thr, keep_out, n_keep_out, ws, st, nullptr, 4);
 }
 
 extern "C" int nndet_nms3d_sorted_f32(const float* boxes, const int32_t* order, int64_t n, float thr,

@@ -19,6 +19,7 @@ import numpy as np
 F32 = np.float32
 INF = 100.0  # nndet/core/boxes/matcher/atss.py uses INF = 100 as the "not a candidate" fill value
 BELOW_LOW_THRESHOLD = -1  # nndet/core/boxes/matcher/base.py:14
+BETWEEN_THRESHOLDS = -2   # nndet/core/boxes/matcher/base.py:15
 BBOX_XFORM_CLIP = float(np.log(1000.0 / 16))  # torchvision BoxCoder default: 4.135166...
 
 
@@ -127,9 +128,17 @@ def anchors_for_image(image_size, fmap_sizes, width, height, depth) -> Tuple[np.
 # --------------------------------------------------------------------------------------
 # ATSS matcher
 # --------------------------------------------------------------------------------------
+def center_in_boxes(center, boxes, eps=0.01):
+    """nndet/core/boxes/ops.py:290-311: min over the six centre-to-face distances > eps (row i of `center` against row i of `boxes`)."""
+    center, boxes = _f(center), _f(boxes)
+    ax = np.stack([center[:, 0] - boxes[:, 0], center[:, 1] - boxes[:, 1], boxes[:, 2] - center[:, 0], boxes[:, 3] - center[:, 1],
+                   center[:, 2] - boxes[:, 4], boxes[:, 5] - center[:, 2]], 1)
+    return ax.min(1) > F32(eps)
+
+
 def atss_match(boxes, anchors, num_anchors_per_level: Sequence[int], num_anchors_per_loc: int,
-               num_candidates: int = 4) -> Tuple[np.ndarray, np.ndarray]:
-    """ATSSMatcher.compute_matches (center_in_gt=False), nndet/core/boxes/matcher/atss.py:48-122,
+               num_candidates: int = 4, center_in_gt: bool = False, min_dist: float = 0.01) -> Tuple[np.ndarray, np.ndarray]:
+    """ATSSMatcher.compute_matches (center_in_gt=False: V001; True: atss.py:101-107), nndet/core/boxes/matcher/atss.py:48-122,
     with Matcher.__call__'s no-GT fast path (matcher/base.py:51-56).
 
     Tie rule (the reference's torch.topk leaves ties implementation-defined): candidates are the
@@ -153,12 +162,61 @@ def atss_match(boxes, anchors, num_anchors_per_level: Sequence[int], num_anchors
     std = cov.astype(np.float64).std(1, ddof=1) if cov.shape[1] > 1 else np.full((G,), np.nan)
     thr = mean.astype(F32) + std.astype(F32)                     # atss.py:97-99: fp32 mean + fp32 std
     is_pos = cov >= thr[:, None]
+    if center_in_gt:
+        ac = np.stack([(anchors[:, 2] + anchors[:, 0]) / F32(2), (anchors[:, 3] + anchors[:, 1]) / F32(2),
+                       (anchors[:, 5] + anchors[:, 4]) / F32(2)], 1).astype(F32)                   # box_center, ops.py:314-327
+        inside = center_in_boxes(ac[cand.reshape(-1)], np.repeat(boxes, cand.shape[1], 0), min_dist).reshape(cand.shape)
+        is_pos = is_pos & inside
     best = np.full((G, M), -INF, F32)
     for g in range(G):
         sel = cand[g][is_pos[g]]
         best[g, sel] = iou[g, sel]
     matches = best.argmax(0).astype(np.int64)                    # first max -> lowest GT index on ties
     matches[best.max(0) == -INF] = BELOW_LOW_THRESHOLD
+    return iou, matches
+
+
+def nms2d(boxes, scores, thr):
+    """2D NMS: devIoU + nms_kernel + the host scan of nndet/csrc/cuda/nms.cu:22-34,54-96,203-215 (what nndet._C.nms does for [N, 4]
+    boxes; the Python wrapper uses torchvision.ops.nms, same rule) -- greedy over descending score (ties: lower index first),
+    suppress iff IoU > thr. -> kept indices into the input order."""
+    b, s = _f(boxes).reshape(-1, 4), _f(scores)
+    order = np.argsort(-s.astype(np.float64), kind="stable")
+    b = b[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    alive = np.ones(len(b), bool)
+    keep = []
+    for i in range(len(b)):
+        if not alive[i]:
+            continue
+        keep.append(order[i])
+        bottom, top = np.maximum(b[i, 0], b[i + 1:, 0]), np.minimum(b[i, 2], b[i + 1:, 2])
+        left, right = np.maximum(b[i, 1], b[i + 1:, 1]), np.minimum(b[i, 3], b[i + 1:, 3])
+        inter = np.maximum(right - left, F32(0)) * np.maximum(top - bottom, F32(0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / (area[i] + area[i + 1:] - inter)
+        alive[i + 1:] &= ~(iou > F32(thr))
+    return np.asarray(keep, np.int64)
+
+
+def iou_match(boxes, anchors, low: float, high: float, allow_low_quality_matches: bool):
+    """IoUMatcher.compute_matches, nndet/core/boxes/matcher/iou.py:43-107 (+ the no-GT fast path, matcher/base.py:51-56).
+    Ties (torch.max leaves the index of equal maxima implementation-defined): lowest GT index per anchor, lowest anchor index per GT;
+    two GTs claiming the same anchor through the low-quality rule: the later (higher) GT index, as the in-order assignment."""
+    boxes, anchors = _f(boxes).reshape(-1, 6), _f(anchors)
+    G, M = boxes.shape[0], anchors.shape[0]
+    if G == 0:
+        return np.zeros((0,), F32), np.full((M,), BELOW_LOW_THRESHOLD, np.int64)
+    iou = box_iou(boxes, anchors)
+    vals, matches = iou.max(0), iou.argmax(0).astype(np.int64)
+    all_matches = matches.copy()
+    below, between = vals < F32(low), (vals >= F32(low)) & (vals < F32(high))
+    matches[below] = BELOW_LOW_THRESHOLD
+    matches[between] = BETWEEN_THRESHOLDS
+    if allow_low_quality_matches:
+        best = iou.argmax(1)
+        for g in range(G):
+            matches[best[g]] = g
     return iou, matches
 
 

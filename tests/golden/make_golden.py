@@ -90,6 +90,16 @@ def golden_boxes():
     a_or, npl = bx.anchors_for_image((48, 40, 24), [(12, 10, 6), (6, 5, 3), (3, 3, 3)], W, W, W)
     eq(a_or, g["anchors"], "anchors")
     assert npl == list(g["anchors_per_level"])
+    # ---- 2D NMS (round 4): the reference's CPU path nms_cpu on [N, 4] boxes (box_iou_union_2d), nndet/core/boxes/nms.py:31-53
+    from nndet.core.boxes.nms import nms_cpu
+    c2 = rng.uniform(0, 60, (600, 2)); s2 = rng.uniform(4, 20, (600, 2))
+    b2 = np.stack([c2[:, 0] - s2[:, 0] / 2, c2[:, 1] - s2[:, 1] / 2, c2[:, 0] + s2[:, 0] / 2, c2[:, 1] + s2[:, 1] / 2], 1).astype(np.float32)
+    sc2 = ((rng.permutation(600) + 1) / 601).astype(np.float32)
+    g["nms2d_boxes"], g["nms2d_scores"] = b2, sc2
+    for thr in (0.1, 0.5):
+        k2 = nms_cpu(torch.from_numpy(b2), torch.from_numpy(sc2), thr).numpy()
+        g[f"nms2d_keep_{thr}"] = k2
+        eq(bx.nms2d(b2, sc2, thr), k2, f"nms2d thr {thr}")
     # ---- ATSS (tie-free GT placement: centres off the anchor-centre lattice)
     gt = np.asarray([[5.3, 7.1, 17.9, 22.2, 3.7, 12.4],
                      [20.6, 11.3, 41.1, 30.9, 6.2, 21.7],
@@ -102,6 +112,25 @@ def golden_boxes():
     eq(m_or, g["atss_matches"], "atss matches")
     eq(iou_or, mq.numpy(), "atss match_quality_matrix")
     print("    positives per gt:", [(g["atss_matches"] == i).sum() for i in range(4)])
+    # center_in_gt=True (the reference's default, atss.py:101-107; V001 sets it False): anchor centres must lie inside the GT box
+    # (its own GT set: three more boxes whose above-threshold candidates partly / all have their centre outside)
+    gt_c = np.concatenate([gt, np.asarray([[9.3, 10.2, 13.6, 14.9, 5.1, 8.4], [22.2, 14.1, 28.9, 30.3, 8.2, 13.7], [25.2, 17.1, 26.9, 30.3, 9.2, 10.7]], np.float32)], 0)
+    matcher_c = rb.ATSSMatcher(num_candidates=4, similarity_fn=rb.box_iou, center_in_gt=True)
+    _, matches_c = matcher_c(torch.from_numpy(gt_c), anc[0], num_anchors_per_level=npl, num_anchors_per_loc=27)
+    _, matches_n = matcher(torch.from_numpy(gt_c), anc[0], num_anchors_per_level=npl, num_anchors_per_loc=27)
+    g["atss_gt_center_in_gt"], g["atss_matches_center_in_gt"] = gt_c, matches_c.numpy()
+    _, mc_or = bx.atss_match(gt_c, a_or, npl, 27, 4, center_in_gt=True)
+    eq(mc_or, g["atss_matches_center_in_gt"], "atss matches (center_in_gt)")
+    assert 0 < (g["atss_matches_center_in_gt"] >= 0).sum() < (matches_n.numpy() >= 0).sum(), "the centre test must remove some positives"
+    print("    positives per gt with / without center_in_gt:", [((g["atss_matches_center_in_gt"] == i).sum(), (matches_n.numpy() == i).sum())
+                                                                 for i in range(len(gt_c))])
+    # ---- IoUMatcher (round 4; the skeleton module's matcher, nndet/core/boxes/matcher/iou.py:20-107)
+    for low, high, lq in ((0.3, 0.5, False), (0.4, 0.6, True)):
+        im = rb.IoUMatcher(low_threshold=low, high_threshold=high, allow_low_quality_matches=lq, similarity_fn=rb.box_iou)
+        _, mi = im(torch.from_numpy(gt_c), anc[0], num_anchors_per_level=npl, num_anchors_per_loc=27)
+        g[f"ioumatch_{low}_{high}_{int(lq)}"] = mi.numpy()
+        eq(bx.iou_match(gt_c, a_or, low, high, lq)[1], mi.numpy(), f"IoUMatcher low {low} high {high} low-quality {lq}")
+        print(f"    IoUMatcher({low}, {high}, {lq}): matched {(mi >= 0).sum().item()}, between {(mi == -2).sum().item()}")
     mq0, m0 = matcher(torch.zeros(0, 6), anc[0], num_anchors_per_level=npl, num_anchors_per_loc=27)
     assert mq0.numel() == 0 and (m0 == -1).all()
     lab_or, mb_or = bx.assign_targets(m_or, gt, np.asarray([0, 0, 0, 0], np.float32), a_or.shape[0])
