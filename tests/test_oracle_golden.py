@@ -66,6 +66,22 @@ def test_batched_nms_and_edges(g):
     assert list(bx.nms(one, np.asarray([0.3], np.float32), 0.5)) == [0]
 
 
+def test_atss_center_in_gt_iou_matcher_and_2d_nms(g):
+    """Round 4: what the reference's matcher / native API offers beyond RetinaUNetV001 -- ATSSMatcher(center_in_gt=True)
+    (matcher/atss.py:101-107), IoUMatcher (matcher/iou.py:43-107), 2D NMS (nms.cu:22-34,54-96 / nms_cpu on [N, 4] boxes)."""
+    npl = [int(v) for v in g["anchors_per_level"]]
+    gt_c = g["atss_gt_center_in_gt"]
+    _, m = bx.atss_match(gt_c, g["anchors"], npl, 27, 4, center_in_gt=True)
+    biteq(m, g["atss_matches_center_in_gt"])
+    _, m_plain = bx.atss_match(gt_c, g["anchors"], npl, 27, 4)
+    assert (m_plain >= 0).sum() > (m >= 0).sum() > 0
+    for low, high, lq in ((0.3, 0.5, False), (0.4, 0.6, True)):
+        biteq(bx.iou_match(gt_c, g["anchors"], low, high, lq)[1], g[f"ioumatch_{low}_{high}_{int(lq)}"])
+    assert bx.iou_match(gt_c[:0], g["anchors"], 0.3, 0.5, True)[1].tolist() == [-1] * len(g["anchors"])
+    for thr in (0.1, 0.5):
+        biteq(bx.nms2d(g["nms2d_boxes"], g["nms2d_scores"], thr), g[f"nms2d_keep_{thr}"])
+
+
 def test_decode_clip(g):
     d = bx.decode_single(g["dec_rel"], g["anchors"])
     assert np.abs(d - g["dec_boxes"]).max() < 1e-4      # exp() is library dependent
