@@ -681,3 +681,37 @@ def test_full_size_bf16_kernels_against_fp32_kernels(name, lp, monkeypatch):
         tol = (2.0 ** -7 if lp == torch.bfloat16 else 2.0 ** -10) * float(b.abs().max())
         nbad = int((err > tol).sum())
         assert nbad == 0, f"{name} {what}: {nbad} elements off by more than {tol:.4f} (max {float(err.max()):.4f})"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+def test_batched_weight_packing_equals_single(dtype):
+    """nndet_pack_weights_batched (round 4: tiles transposed through LDS) against nndet_pack_weight (element-wise gather), bit for bit,
+    for every kind of layer of the network: 3x3x3 with padded channel counts (27 -> 32, 162 -> 192), 1x1x1, transposed k = s = 2 and
+    (2, 2, 1), a 320-channel layer, both orientations (forward / data gradient)."""
+    import ctypes
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch.conv import ConvInstanceRelu
+    specs = [(32, 32, 3, 1, False), (128, 27, 3, 1, False), (128, 162, 3, 1, False), (64, 64, 1, 1, False), (32, 2, 1, 1, False),
+             (128, 64, (2, 2, 2), (2, 2, 2), True), (128, 128, (2, 2, 1), (2, 2, 1), True), (320, 320, 3, 1, False), (256, 320, 3, 2, False)]
+    mods, convs, modes, ws, outs, refs = [], [], [], [], [], []
+    for cin, cout, k, s_, tr in specs:
+        m = ConvInstanceRelu(3, cin, cout, k, stride=s_, padding=0 if tr or k == 1 else 1, transposed=tr, add_norm=False, add_act=False).cuda()
+        with torch.no_grad():
+            m.conv.weight.copy_(torch.randn_like(m.conv.weight))
+        for mode in (0, 1):
+            d = L.NndetConv()
+            d.dtype, d.transposed, d.batch = L._DT[dtype], int(tr), 1
+            d.cin, d.cout, d.cin_p, d.cout_p = cin, cout, (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+            d.k = (ctypes.c_int32 * 3)(*m.k); d.s = (ctypes.c_int32 * 3)(*m.s); d.p = (ctypes.c_int32 * 3)(*m.p)
+            n = L.load().nndet_packed_weight_elems(ctypes.byref(d), mode)
+            w32 = m.conv.weight.detach().float().contiguous()
+            ref = torch.full((n,), 7.0, device="cuda").to(dtype)
+            L.call("nndet_pack_weight", ctypes.byref(d), mode, L.ptr(w32), L.ptr(ref), L.stream())
+            out = torch.full((n,), 9.0, device="cuda").to(dtype)                       # (every element must be written, padding included)
+            mods.append(m); convs.append(d); modes.append(mode); ws.append(w32); outs.append(out); refs.append(ref)
+    n = len(convs)
+    L.call("nndet_pack_weights_batched", (L.NndetConv * n)(*convs), (ctypes.c_int32 * n)(*modes), (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws]),
+           (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), n, L.stream())
+    torch.cuda.synchronize()
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o, r), (specs[i // 2], modes[i], int((o != r).sum()))
