@@ -396,6 +396,13 @@ class _ConvFn(torch.autograd.Function):
         dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
         dx = None
         bias_from_dgrad = False
+        if _rank1_grads and dconv.data_ptr() not in _rank1_grads and getattr(mod, "_nndet_rank1_consumer", False):
+            # The segmentation head handed on a FACTORISED gradient (an unwritten tensor registered under its address, see
+            # rank1_register) and something between the two nodes -- a tensor hook, gradient checkpointing, a wrapper that clones or
+            # accumulates gradients -- gave this node another tensor: its content is undefined. Fail loudly instead of training on it.
+            _rank1_grads.clear()
+            raise L.NndetError("the factorised gradient of the fused segmentation head reached decoder.out.P0 as a COPY (a hook / "
+                               "checkpointing / gradient accumulation in between?); set NNDET_SEG_RANK1=0 for the dense gradient")
         if dconv.data_ptr() in _rank1_grads:               # factorised output gradient (fused segmentation head): see _rank1_backward
             side = ctx.wg_side
             raw = side.cuda_stream if side is not None else L.stream()

@@ -214,6 +214,8 @@ class BaseRetinaNet(nn.Module):
                   and mods[0].norm_groups == 0 and not mods[0].transposed and mods[0].k == (3, 3, 3) and mods[0].s == (1, 1, 1)
                   and mods[0].p == (1, 1, 1) and mods[0].out_channels % 32 == 0 and mods[0].in_channels % 32 == 0)
             self._seg_rank1_cached = bool(ok)
+            if ok:
+                mods[0]._nndet_rank1_consumer = True     # (arch/conv.py: a COPY of the factorised gradient arriving there is an error)
         return ok
 
     def _lazy_targets_ok(self) -> bool:

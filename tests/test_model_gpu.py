@@ -806,8 +806,8 @@ def test_foreign_fused_optimizer_invalidates_every_parameter_cache():
         y1, y2 = stem(x1), conv(x2)
         r1 = F.conv3d(x1, stem.conv.weight, stem.conv.bias, padding=1)
         r2 = F.conv3d(x2, conv.conv.weight, conv.conv.bias, padding=1)
-        assert float((y1 - r1).abs().max()) <= 2e-5 * float(r1.abs().max()), ("stem", it)
-        assert float((y2 - r2).abs().max()) <= 2e-5 * float(r2.abs().max()), ("conv", it)
+        assert float((y1 - r1).detach().abs().max()) <= 2e-5 * float(r1.detach().abs().max()), ("stem", it)
+        assert float((y2 - r2).detach().abs().max()) <= 2e-5 * float(r2.detach().abs().max()), ("conv", it)
         opt.zero_grad()
         (y1.square().mean() + y2.square().mean()).backward()
         gen, v = PARAM_GENERATION[0], [p._version for p in params]
@@ -861,3 +861,40 @@ def test_lazy_target_assignment_equals_the_gathered_one(golden_dir, monkeypatch)
         assert abs(res[True][0][k] - v) <= 1e-6 * max(1.0, abs(v)), (k, res[True][0][k], v)
     for n, g in res[False][1].items():
         assert float((res[True][1][n] - g).abs().max()) <= 1e-4 * float(g.abs().max()) + 1e-12, n
+
+
+def test_copied_factorised_gradient_fails_loudly(golden_dir, monkeypatch):
+    """VERDICT r3 ("works, tested, will not scale past this model"): the fused segmentation head hands its input gradient on in factorised
+    form through an unwritten tensor registered under its address. If anything between the head and decoder.out.P0 replaces that tensor
+    (here: a tensor hook that clones the gradient) the receiving node must raise -- not train on undefined memory."""
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch import segmenter as S
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    monkeypatch.setattr(S, "SEG_BRANCH", False)                  # the rank-1 route (the composed branch does not use the side channel)
+    x = torch.from_numpy(gn["x"]).cuda().to(torch.bfloat16)
+    orig = net.segmenter.forward
+
+    def hooked(fm, fused=False):
+        out = orig(fm, fused=fused)
+        if "seg_input" in out:
+            src = out["seg_input"]
+            y = src * 1.0                                         # an extra autograd node whose backward hands on a fresh tensor
+            for a in ("_nndet_rank1_ok", "_nndet_padded"):
+                if hasattr(src, a):
+                    setattr(y, a, getattr(src, a))
+            out["seg_input"] = y
+        return out
+
+    losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+    sum(losses.values()).backward()                               # the normal route works
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    net.zero_grad(set_to_none=True)
+    monkeypatch.setattr(net.segmenter, "forward", hooked)
+    losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+    with pytest.raises((L.NndetError, RuntimeError), match="factorised gradient"):
+        sum(losses.values()).backward()
+    torch.cuda.synchronize()
