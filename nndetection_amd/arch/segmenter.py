@@ -352,6 +352,10 @@ class _SegBranchFn(torch.autograd.Function):
             False, ctx.needs_input_grad[1], e_x_fn=e_x_fn)
         da = _SegBranchFn._a0_grad(ctx, da_p, dev)
         dbs = out["dbsum"]
+        for t_, p_ in ((out["dw_up"], w_up), (dbs, None), (out["dbsum2"], None)):
+            # produced on the weight-gradient stream: autograd must ADOPT these tensors (see up_param_grads), never clone them
+            if not t_.is_contiguous() or (p_ is not None and tuple(t_.shape) != tuple(p_.shape)):
+                raise L.NndetError("a parameter gradient of the absorbed segmentation branch violates autograd's layout contract")
         return ((logical(dx1_p, ctx.cin1) if dx1_p is not None else None), da, dw_lat.to(w_lat.dtype), dw_out.to(w_out.dtype), db_out,
                 dw_head.to(w_head.dtype), db_head, None, out["dw_up"].to(w_up.dtype), dbs if ctx.has_b_up else None,
                 out["dbsum2"] if ctx.has_b_lat else None)
