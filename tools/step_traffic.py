@@ -104,6 +104,8 @@ def measure(steps=5, warmup=3, bench_args=(), timeout_s=240, keep_table=None):
                "launches_per_step": round(sum(f["launches"] for f in fam.values()), 1), "steps_profiled": int(nstep),
                "families": {k: {"read_MB": round(v["read"] / 1e6, 1), "write_MB": round(v["write"] / 1e6, 1),
                                 "launches_per_step": round(v["launches"], 1)} for k, v in sorted(fam.items(), key=lambda kv: -(kv[1]["read"] + kv[1]["write"]))},
+               "kernels": {k[:160]: {"read_MB": round(v["read"] / 1e6, 1), "write_MB": round(v["write"] / 1e6, 1), "launches_per_step": round(v["launches"], 2)}
+                           for k, v in sorted(kern.items(), key=lambda kv: -(kv[1]["read"] + kv[1]["write"]))[:24]},
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps %d --warmup %d --no-extras`, all dispatches / %d steps; "
                          "KB units, FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md)" % (steps, warmup, int(nstep))}
         if keep_table:
@@ -135,4 +137,4 @@ if __name__ == "__main__":
     r = measure(a.steps, a.warmup, a.bench_args, keep_table=a.table)
     with open(a.out, "w") as f:
         json.dump(r, f, indent=1)
-    print(json.dumps({k: v for k, v in (r or {}).items() if k != "families"}))
+    print(json.dumps({k: v for k, v in (r or {}).items() if k not in ("families", "kernels")}))
