@@ -85,11 +85,16 @@ __global__ void k_gather_boxes2d(const float* __restrict__ boxes, const int32_t*
 // grid (col_blocks, ceil(col_blocks/4)), block 256 = 4 waves; wave w handles row block 4*by + w.
 // labels (may be NULL): bit only between boxes of the same label (per-class clustering of wbc3d.hip); nan_hits: a NaN IoU sets the
 // bit as well (`!(iou <= thr)`: the box leaves the pool, wbc.py:122,141) -- NMS itself uses `iou > thr` (nms.cu:126).
+// blockIdx.z = image of a batch (round 4: the fused post-processing runs the NMS of all images of a batch in the same launches instead
+// of one image after the other -- every launch of this file is latency-bound at N <= 10 000): boxes / mask advance by the strides.
 __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, int64_t n, float thr,
                                                   u64* __restrict__ mask, int col_blocks,
-                                                  const int32_t* __restrict__ labels = nullptr, int nan_hits = 0) {
+                                                  const int32_t* __restrict__ labels = nullptr, int nan_hits = 0,
+                                                  int64_t bs_boxes = 0, int64_t bs_mask = 0) {
     __shared__ float cbox[64 * 6];
     __shared__ int32_t clab[64];
+    boxes += (int64_t)blockIdx.z * bs_boxes;
+    mask += (int64_t)blockIdx.z * bs_mask;
     const int cb = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int rb = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -138,8 +143,11 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ __launch_bounds__(1024) void k_nms_scan_super(const u64* __restrict__ mask, int64_t n, int col_blocks,
                                                          int c0, int c1, u64* __restrict__ remv,
-                                                         u64* __restrict__ keepbits) {
+                                                         u64* __restrict__ keepbits, int64_t bs_mask = 0) {
     extern __shared__ __attribute__((aligned(16))) char nms_smem[];
+    mask += (int64_t)blockIdx.x * bs_mask;                           // blockIdx.x = image of a batch (one workgroup each)
+    remv += (int64_t)blockIdx.x * col_blocks;
+    keepbits += (int64_t)blockIdx.x * col_blocks;
     u64* rows = reinterpret_cast<u64*>(nms_smem);                    // [NMS_SCAN_NBUF][64 rows][64 words]
     __shared__ u64 remv_l[64];
     __shared__ u64 keep_l;
@@ -226,7 +234,10 @@ __global__ __launch_bounds__(1024) void k_nms_scan_super(const u64* __restrict__
 
 // grid (ceil((col_blocks - c1)/256), c1 - c0), block 256: thread = one later column word, block row = chunk.
 __global__ __launch_bounds__(256) void k_nms_propagate(const u64* __restrict__ mask, int col_blocks, int c0, int c1,
-                                                       const u64* __restrict__ keepbits, u64* __restrict__ remv) {
+                                                       const u64* __restrict__ keepbits, u64* __restrict__ remv, int64_t bs_mask = 0) {
+    mask += (int64_t)blockIdx.z * bs_mask;                           // blockIdx.z = image of a batch
+    keepbits += (int64_t)blockIdx.z * col_blocks;
+    remv += (int64_t)blockIdx.z * col_blocks;
     const int c = c0 + blockIdx.y;
     const int j = c1 + blockIdx.x * 256 + threadIdx.x;
     const u64 keep = keepbits[c];
@@ -243,9 +254,14 @@ __global__ __launch_bounds__(256) void k_nms_propagate(const u64* __restrict__ m
 // *n_valid are real boxes, the rest is padding up to the launch capacity (never reported).
 __global__ __launch_bounds__(1024) void k_nms_compact(const u64* __restrict__ keepbits, int col_blocks,
                                                       const int32_t* __restrict__ order, int64_t* __restrict__ keep_out,
-                                                      int64_t* __restrict__ n_keep, const int64_t* __restrict__ n_valid) {
+                                                      int64_t* __restrict__ n_keep, const int64_t* __restrict__ n_valid,
+                                                      int64_t bs_keep = 0) {
     __shared__ int wsum[16];
     __shared__ int running;
+    keepbits += (int64_t)blockIdx.x * col_blocks;                    // blockIdx.x = image of a batch (order == NULL then)
+    keep_out += (int64_t)blockIdx.x * bs_keep;
+    n_keep += blockIdx.x;
+    if (n_valid) n_valid += blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) running = 0;
     __syncthreads();
@@ -427,6 +443,42 @@ int nms_presorted_run(const float* boxes, int64_t n_cap, const int64_t* n_valid_
     if (rc) return rc;
     if (ws.total > workspace_bytes) return NNDET_EWORKSPACE;
     return nms_core(boxes, nullptr, n_cap, thr, keep_out, n_keep_out, ws, st, n_valid_dev);
+}
+
+// The same for the B images of a batch at once: boxes [B, n_cap, 6] (each image in score order, zero rows behind its *n_valid),
+// n_valid_dev / n_keep_out [B], keep_out [B, n_cap]. Image = an extra grid dimension of every launch; workspace B x the single one.
+size_t nms_presorted_batched_workspace_bytes(int64_t n_cap, int B) {
+    if (n_cap <= 0 || B <= 0) return 256;
+    const int64_t cb = ceil_div64(n_cap, 64);
+    return align_up((size_t)B * n_cap * cb * 8, 256) + 2 * align_up((size_t)B * cb * 8, 256);
+}
+int nms_presorted_batched_run(const float* boxes, int64_t n_cap, int B, const int64_t* n_valid_dev, float thr, int64_t* keep_out,
+                              int64_t* n_keep_out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (n_cap <= 0 || B <= 0 || B > 65535 || !boxes || !keep_out || !n_keep_out || !workspace || !n_valid_dev) return NNDET_EINVAL;
+    if (nms_presorted_batched_workspace_bytes(n_cap, B) > workspace_bytes) return NNDET_EWORKSPACE;
+    const int cb = (int)ceil_div64(n_cap, 64);
+    { const int arc = nms_scan_attr(); if (arc) return arc; }
+    char* base = (char*)workspace;
+    u64* mask = (u64*)base;
+    u64* remv = (u64*)(base + align_up((size_t)B * n_cap * cb * 8, 256));
+    u64* keepbits = (u64*)((char*)remv + align_up((size_t)B * cb * 8, 256));
+    const int64_t bs_mask = n_cap * cb;
+    HIP_TRY(hipMemsetAsync(remv, 0, (size_t)B * cb * 8, st));
+    HIP_TRY(hipMemsetAsync(keep_out, 0xFF, (size_t)B * n_cap * 8, st));
+    k_nms_mask<<<dim3(cb, ceil_div(cb, 4), B), 256, 0, st>>>(boxes, n_cap, thr, mask, cb, nullptr, 0, n_cap * 6, bs_mask);
+    LAUNCH_CHECK();
+    for (int c0 = 0; c0 < cb; c0 += 64) {
+        const int c1 = c0 + 64 < cb ? c0 + 64 : cb;
+        k_nms_scan_super<<<B, 1024, NMS_SCAN_LDS, st>>>(mask, n_cap, cb, c0, c1, remv, keepbits, bs_mask);
+        LAUNCH_CHECK();
+        if (c1 < cb) {
+            k_nms_propagate<<<dim3(ceil_div(cb - c1, 256), c1 - c0, B), 256, 0, st>>>(mask, cb, c0, c1, keepbits, remv, bs_mask);
+            LAUNCH_CHECK();
+        }
+    }
+    k_nms_compact<<<B, 1024, 0, st>>>(keepbits, cb, nullptr, keep_out, n_keep_out, n_valid_dev, n_cap);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 // Mask + greedy scan only (wbc3d.hip): sboxes [n, 6] in descending score order, slabels (may be NULL) their labels. Returns the

@@ -17,6 +17,9 @@
 #include <rocprim/rocprim.hpp>
 
 size_t nms_presorted_workspace_bytes(int64_t n_cap);
+size_t nms_presorted_batched_workspace_bytes(int64_t n_cap, int B);
+int nms_presorted_batched_run(const float* boxes, int64_t n_cap, int B, const int64_t* n_valid_dev, float thr, int64_t* keep_out,
+                              int64_t* n_keep_out, void* workspace, size_t workspace_bytes, hipStream_t st);
 int nms_presorted_run(const float* boxes, int64_t n_cap, const int64_t* n_valid_dev, float thr, int64_t* keep_out,
                       int64_t* n_keep_out, void* workspace, size_t workspace_bytes, hipStream_t st);
 
@@ -244,8 +247,10 @@ static int pp_layout(int B, int K, char* base, PpWs* w) {
         nullptr, tmp, nullptr, nullptr, (unsigned)BK, (unsigned)B, nullptr, nullptr, 0, 64, (hipStream_t)0, false);
     if (e != hipSuccess) return (int)e;
     size_t o_tmp = take(tmp > 0 ? tmp : 256);
-    const size_t nms_b = nms_presorted_workspace_bytes(K);
+    // (round 4) the NMS of all B images runs in the same launches: B x the single-image workspace (NNDET_PP_BATCHED_NMS=0: one by one)
+    size_t nms_b = nms_presorted_workspace_bytes(K);
     if (nms_b == 0) return NNDET_EINVAL;
+    { const size_t bb = nms_presorted_batched_workspace_bytes(K, B); if (bb > nms_b) nms_b = bb; }
     size_t o_nms = take(nms_b);
     w->prefix = (u64*)(base + o_p); w->krem = (int*)(base + o_k); w->cnt = (int*)(base + o_c); w->hist = (unsigned*)(base + o_h);
     w->seg_off = (int*)(base + o_so);
@@ -354,10 +359,16 @@ static int pp_run(const float* scores, int32_t scores_are_probs, const float* de
     LAUNCH_CHECK();
     k_pp_offset_boxes<<<dim3(ceil_div(K, 256), B), 256, 0, st>>>(K, w.cboxes, w.clabels, w.n_valid, w.maxc, w.nboxes);
     LAUNCH_CHECK();
-    for (int b = 0; b < B; ++b) {
-        rc = nms_presorted_run(w.nboxes + (size_t)b * K * 6, K, w.n_valid + b, nms_thresh, w.keep + (size_t)b * K, w.n_keep + b,
-                               w.nms_ws, w.nms_ws_bytes, st);
+    static const int batched_nms = getenv("NNDET_PP_BATCHED_NMS") ? atoi(getenv("NNDET_PP_BATCHED_NMS")) : 1;
+    if (batched_nms && B > 1) {
+        rc = nms_presorted_batched_run(w.nboxes, K, B, w.n_valid, nms_thresh, w.keep, w.n_keep, w.nms_ws, w.nms_ws_bytes, st);
         if (rc) return rc;
+    } else {
+        for (int b = 0; b < B; ++b) {
+            rc = nms_presorted_run(w.nboxes + (size_t)b * K * 6, K, w.n_valid + b, nms_thresh, w.keep + (size_t)b * K, w.n_keep + b,
+                                   w.nms_ws, w.nms_ws_bytes, st);
+            if (rc) return rc;
+        }
     }
     k_pp_gather<<<B, 256, 0, st>>>(K, max_det, w.keep, w.n_keep, w.cboxes, w.cscores, w.clabels, w.cidx, out_boxes, out_scores,
                                    out_labels, out_index, out_counts);
