@@ -83,37 +83,43 @@ __global__ __launch_bounds__(256) void k_pp_pick(int B, u64* __restrict__ prefix
     radix_pick_wave(prefix + i, krem + i, hist + (int64_t)i * 256, shift, threadIdx.x & 63);
 }
 
-// every key <= the K-th smallest goes into the candidate list (exactly K per image: keys are distinct)
+// every key <= the K-th smallest goes into the candidate list (exactly K per image: keys are distinct).
+// ONE global atomic per workgroup (round 4): the K = 10 000 returning adds per image onto the same counter serialise in L2 at ~30 ns
+// each -- 250-330 us for a 19 MB pass whose histogram twin takes 14 us; the hits are sparse (1 in ~150), so aggregating per wave does
+// not help. Threads rank their hits with an LDS atomic, thread 0 reserves the block's slots.
 __global__ __launch_bounds__(256) void k_pp_collect(PpArgs A, const u64* __restrict__ kth, int* __restrict__ cnt, u64* __restrict__ cand) {
+    __shared__ int lcnt, lbase;
     const int b = blockIdx.y;
     const u64 lim = kth[b];
     const float* s = A.scores + (int64_t)b * A.MC;
     const int64_t i0 = ((int64_t)blockIdx.x * 256) * PP_ITEMS + threadIdx.x;
+    if (threadIdx.x == 0) lcnt = 0;
+    __syncthreads();
+    u64 keys[PP_ITEMS];
+    unsigned hits = 0;
 #pragma unroll
     for (int t = 0; t < PP_ITEMS; ++t) {
         const int64_t i = i0 + (int64_t)t * 256;
-        bool hit = false;
-        u64 mykey = 0;
+        keys[t] = 0;
         if (i < A.MC) {
-            const u64 key = pp_key(pp_score(A, s[i]), (uint32_t)i);
-            hit = key <= lim;
-            mykey = key;
-        }
-        // ONE atomic per wave and item instead of one per candidate (round 4: the K = 10 000 adds per image onto the same counter
-        // serialised in L2 -- 250 us for a 19 MB pass): the first hit lane reserves the wave's slots, the others take their rank
-        const u64 m = __ballot(hit);
-        if (m) {
-            const int lane = threadIdx.x & 63;
-            const int leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&cnt[b], __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (hit) {
-                const int pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
-                if (pos < A.K) cand[(int64_t)b * A.K + pos] = mykey;
-            }
+            keys[t] = pp_key(pp_score(A, s[i]), (uint32_t)i);
+            if (keys[t] <= lim) hits |= 1u << t;
         }
     }
+    int lofs = 0;
+    if (hits) lofs = atomicAdd(&lcnt, __popc(hits));
+    __syncthreads();
+    if (lcnt == 0) return;
+    if (threadIdx.x == 0) lbase = atomicAdd(&cnt[b], lcnt);
+    __syncthreads();
+    if (!hits) return;
+    int pos = lbase + lofs;
+#pragma unroll
+    for (int t = 0; t < PP_ITEMS; ++t)
+        if (hits & (1u << t)) {
+            if (pos < A.K) cand[(int64_t)b * A.K + pos] = keys[t];
+            ++pos;
+        }
 }
 
 // Sort of the K <= 16 384 candidate keys of an image, ascending (= descending score, ties by index): ONE workgroup per image, bitonic
