@@ -50,6 +50,7 @@ typedef _Float16 f16_t;
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
 }
@@ -90,6 +91,10 @@ template <> struct H16<bf16_t> {
     __device__ static __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, const f32x4& c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
+    // 32 x 32 x 16: lane l holds A[m = l % 32][k = 8 (l / 32) + 0..7], B[k][n = l % 32]; D register r = row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32
+    __device__ static __forceinline__ f32x16_t mma32(const u32x4& a, const u32x4& b, const f32x16_t& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
 };
 template <> struct H16<f16_t> {
     static constexpr uint32_t ONE2 = 0x3c003c00u;
@@ -99,6 +104,9 @@ template <> struct H16<f16_t> {
     __device__ static __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, const f32x4& c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
+    __device__ static __forceinline__ f32x16_t mma32(const u32x4& a, const u32x4& b, const f32x16_t& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
 };
 template <> struct H16<float> {   // never used: keeps discarded `if constexpr (sizeof(T) == 2)` branches well-formed
     static constexpr uint32_t ONE2 = 0;
@@ -106,6 +114,7 @@ template <> struct H16<float> {   // never used: keeps discarded `if constexpr (
     __device__ static __forceinline__ float lo(uint32_t) { return 0.f; }
     __device__ static __forceinline__ float hi(uint32_t) { return 0.f; }
     __device__ static __forceinline__ f32x4 mma(const u32x4&, const u32x4&, const f32x4& c) { return c; }
+    __device__ static __forceinline__ f32x16_t mma32(const u32x4&, const u32x4&, const f32x16_t& c) { return c; }
 };
 
 // run `F<T>` for the activation type a dtype code names (NNDET_F32 / NNDET_BF16 / NNDET_F16)

@@ -39,7 +39,9 @@ struct WgArgs {
     int64_t sr, sk;
     int32_t ntap, total_tiles;
     uint32_t mH2, mH1;    // magic multipliers for / H[2], / H[1] (0 = divisor 1)
+    uint32_t m_tpn, m_nt2, m_nt12;   // k_wgrad3d: / (tiles per image), / nt[2], / (nt[1] * nt[2])
     int32_t lTH;          // log2(TH)
+    int32_t dbg;          // timing experiments only (NNDET_WGRAD3_DBG; wrong results): 1 = stage the first tile only, 2 = no MFMA phase, 4 = no commit (k_wgrad3), 16 = no MFMA phase in the second point half (k_wgrad3d)
     WgTap taps[27];
 };
 
@@ -50,6 +52,7 @@ struct WgItems {
     int32_t dims[NNDET_MAX_ITEMS][3];
     int32_t tile_begin[NNDET_MAX_ITEMS];
     int64_t row_off[NNDET_MAX_ITEMS];
+    uint32_t m_nt2[NNDET_MAX_ITEMS], m_nt12[NNDET_MAX_ITEMS];   // k_wgrad3d: magic multipliers for / nt2, / (nt1 * nt2) of the item's (4, 8, 8) tiling
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -335,8 +338,18 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 //     LDS round trip was exposed, 25 % MFMA utilisation);
 //   * 256 registers per wave -> two workgroups per CU.
 // Work split as in k_wgrad: the 4 waves take taps wv, wv + 4, ... (7 slots, 27 of 28 used), all 8 contraction steps.
-template <typename T, int MINW, bool AFF = false, int QDEPTH = 2, bool ITEMS = false>
+//
+// M32 (round 4, 16-bit types): the same tiles and tap split on v_mfma_f32_32x32x16 instead of four 16x16x32 per (step, tap). The SQ
+// counters of the 16x16x32 form (profiles/round4_wgrad3_pmc.txt): MFMA pipe busy 41 % of the kernel, 44 % of the wave cycles are
+// issue stalls, 4 instructions issued per MFMA -- with 16-cycle MFMAs a wave has 4 issue slots per MFMA and spends them on the two
+// transpose reads, their waits and the pipeline's bookkeeping. One 32x32x16 does the work of two of them from the SAME 2 + 2 operand
+// registers (a contraction step is 16 points = two lattice rows; lane groups 0 / 1 fetch channel blocks 0 / 1 of the first row,
+// 2 / 3 of the second: 256 contiguous bytes per half wave, conflict-free without any padding rule), so the instruction count per
+// FLOP halves and the accumulators stay 7 x 16 registers. (Halving the LDS reads instead -- one 12-point read per halo row feeding
+// the three W taps through v_alignbit -- was measured first: +2 %, the reads were never the bound; 256 B / clock, not 128.)
+template <typename T, int MINW, bool AFF = false, int QDEPTH = 2, bool ITEMS = false, bool M32 = false>
 __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgItems IT) {
+    static_assert(!M32 || sizeof(T) == 2, "the 32x32x16 variant is for the 16-bit storage types");
     constexpr int RB = 32 * (int)sizeof(T), PPV = RB / 16;
     constexpr int KS = 8, NTS = 7, TD = 4, TH = 8, HD = TD + 2, HH = TH + 2, HW = 10;
     constexpr int PROW = 8 * RB + RB / 2, QROW = HW * RB + RB / 2;     // bytes per row of 8 points / per halo row (with bank padding)
@@ -388,13 +401,22 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgIt
         tapw[ts] = __builtin_amdgcn_readfirstlane(valid ? tt : -1);
     }
 
-    typename WF<T>::acc_t acc[NTS][2][2];
+    typename WF<T>::acc_t acc[M32 ? 1 : NTS][2][2];
 #pragma unroll
-    for (int t = 0; t < NTS; ++t)
+    for (int t = 0; t < (M32 ? 1 : NTS); ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = WF<T>::zero();
+    f32x16_t acc32[M32 ? NTS : 1];
+#pragma unroll
+    for (int t = 0; t < (M32 ? NTS : 1); ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[t][r] = 0.f;
+    // M32 fragment bases: lane group q = (row q >> 1 of the step's two lattice rows, channel block q & 1)
+    const int lane32 = (q & 1) * 16 * (int)sizeof(T) + (li >> 2) * RB + (li & 3) * 8;
+    const char* const p_lane32 = sp + (q >> 1) * PROW + lane32;
+    const int q_lane32 = PBYTES + (q >> 1) * QROW + lane32;
 
     const int tiles_per_n = A.nt[0] * A.nt[1] * A.nt[2];
     const int p_img = A.PL[0] * A.PL[1] * A.PL[2] * A.Cp * (int)sizeof(T), q_img = A.QD[0] * A.QD[1] * A.QD[2] * A.Cq * (int)sizeof(T);
@@ -471,7 +493,36 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgIt
     // wave 3's last slot would recompute tap 0 and discard it (27 taps on 28 slots): it accumulates sum_p dY[p][r] instead
     const bool do_bias = A.dbias != nullptr && blockIdx.z == 0 && wv == 3;
     // pinned software pipeline over the 56 (contraction step, tap slot) pairs
+    auto compute32 = [&]() {
+        if constexpr (M32) {
+            constexpr int KS2 = 16, U = KS2 * NTS, QD_ = 3;       // 16 steps of 16 points; prefetch distance in MFMAs
+            auto tr2 = [&](const char* b0) -> u32x4 {
+                const uint2 a = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0)));
+                const uint2 b = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 4 * RB)));
+                return u32x4{a.x, a.y, b.x, b.y};
+            };
+            u32x4 pf[2], qf[QD_ + 1];
+            auto load_q = [&](int u) -> u32x4 {
+                const int ks = u / NTS, ts = u % NTS;             // lattice rows 2 ks, 2 ks + 1: slice ks >> 2, rows (ks & 3) * 2 + (q >> 1)
+                if (ts == NTS - 1 && do_bias) return u32x4{H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2};
+                return tr2(smem + (q_lane32 + tapoff[ts]) + (((ks >> 2) * HH) + (ks & 3) * 2) * QROW);
+            };
+            pf[0] = tr2(p_lane32);
+#pragma unroll
+            for (int u0 = 0; u0 < QD_; ++u0) qf[u0] = load_q(u0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ks = u / NTS, ts = u % NTS;
+                if (u + QD_ < U) qf[(u + QD_) % (QD_ + 1)] = load_q(u + QD_);
+                if (ts == 0 && ks + 1 < KS2) pf[(ks + 1) & 1] = tr2(p_lane32 + (ks + 1) * 2 * PROW);
+                __builtin_amdgcn_sched_barrier(0);
+                acc32[ts] = H16<T>::mma32(pf[ks & 1], qf[u % (QD_ + 1)], acc32[ts]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
     auto compute = [&]() {
+        if constexpr (M32) { compute32(); return; }
         constexpr int U = KS * NTS, QD_ = QDEPTH;   // LDS fragment prefetch distance (steps of 4 MFMAs)
         WF<T> pf[2][2], qf[QD_ + 1][2];
         auto load_p = [&](int ks, WF<T>* d) {
@@ -515,11 +566,31 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgIt
     for (; base + (int)blockIdx.x < A.total_tiles; base += gridDim.x) {
         const int nb = base + gridDim.x;
         const bool has_next = nb + (int)blockIdx.x < A.total_tiles;
-        if (has_next) issue(tile_of(nb));           // in flight during the MFMA phase
-        compute();
+        if (has_next && !(A.dbg & 1)) issue(tile_of(nb));           // in flight during the MFMA phase
+        if (!(A.dbg & 2)) compute();
         __syncthreads();                            // every wave is done reading the tile
-        if (has_next) commit();
+        if (has_next && !(A.dbg & 5)) commit();
         __syncthreads();
+    }
+    float* part = A.part + ((int64_t)blockIdx.x * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
+    if constexpr (M32) {
+        const int n = lane & 31, mh = (lane >> 5) * 4;
+        if (do_bias && n == 0) {             // column 0 of the ones-GEMM
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = r0 + (r >> 2) * 8 + mh + (r & 3);
+                if (m < A.R) atomicAdd(A.dbias + m, acc32[NTS - 1][r]);
+            }
+        }
+#pragma unroll
+        for (int ts = 0; ts < NTS; ++ts) {
+            if (tapw[ts] >= 0) {
+                float* pt = part + (int64_t)tapw[ts] * 1024;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pt[((r >> 2) * 8 + mh + (r & 3)) * 32 + n] = acc32[ts][r];
+            }
+        }
+        return;
     }
     if (do_bias && li == 0) {                // column 0 of the ones-GEMM: rows r0 + i*16 + 4q + rr
 #pragma unroll
@@ -530,7 +601,6 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgIt
                 if (r < A.R) atomicAdd(A.dbias + r, (float)acc[NTS - 1][i][0][rr]);
             }
     }
-    float* part = A.part + ((int64_t)blockIdx.x * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
 #pragma unroll
     for (int ts = 0; ts < NTS; ++ts) {
         if (tapw[ts] >= 0) {
@@ -541,6 +611,467 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(const WgArgs A, const WgIt
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) pt[(i * 16 + WF<T>::row(q, rr)) * 32 + j * 16 + li] = (float)acc[ts][i][j][rr];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3x3, stride 1: LDS-DMA form
+// k_wgrad3d (round 4, 16-bit types): k_wgrad3's tiles and tap split with the staging taken off the critical path.
+// Timing k_wgrad3 with phases switched off (NNDET_WGRAD3_DBG, profiles/round4_wgrad3_phases.txt): MFMA phase alone 0.45 ms, staging
+// alone 0.30 ms, together 0.65 ms for the full-resolution 32 -> 32 layer -- the two add up although two workgroups share a CU:
+// every tile pays ~250 instructions of address arithmetic, 14 buffer loads into 56 staging registers, a commit pass of 14
+// ds_write_b128 and two barriers. Here
+//   * the NEXT tile goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, as in k_ig3r) into a second buffer while the MFMAs
+//     of the current one run: no staging registers, no commit pass, ONE barrier per tile; 54 pieces of 1 KB per tile, 6-7 per wave,
+//     one issued every 8th MFMA. Lanes outside the tensor use an out-of-range offset and the hardware writes the zero padding;
+//   * 8 waves: wave = (tap class wv & 3 as before, point half wv >> 2): 7 tap slots x 8 steps of 16 points = 56 v_mfma_32x32x16
+//     per wave and tile, 112 accumulator registers, two waves per SIMD at 256 registers. Each half writes its own partial slice;
+//   * LDS rows are unpadded (the destination of a DMA piece is lane-linear): the half wave of a transpose read fetches channel
+//     blocks 0 / 1 of four consecutive voxels = 256 contiguous bytes, conflict-free at any row pitch.
+// 2 x (16 KB dY tile + 38 KB X halo) = 108 KB of LDS: one workgroup per CU. No deferred input norm (the data never passes
+// through registers): those launches stay on k_wgrad3.
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint32_t lds_dst) {
+    // M0 is written in the same statement that reads it; hipcc does not count this load: waited for by hand (vmcnt(0) before the barrier)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rs), "s"(soff), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_uniform_rsrc(const char* p, int num_records) {
+    // the descriptor must sit in SGPRs: pin the (workgroup-uniform) address there whatever the divergence analysis concluded
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(((uint64_t)hi << 32) | lo), 0, num_records, 0x00020000);
+}
+
+#ifndef WG3D_GAP
+#define WG3D_GAP 1
+#endif
+#ifndef WG3D_QD
+#define WG3D_QD 3      // LDS fragment prefetch distance in MFMAs
+#endif
+template <typename T, bool ITEMS>
+__global__ __launch_bounds__(512, 2) void k_wgrad3d(const WgArgs A, const WgItems IT) {
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    constexpr int RB = 64, NTS = 7, TD = 4, TH = 8, HD = TD + 2, HH = TH + 2, HW = 10;
+    constexpr int PROW = 8 * RB, QROW = HW * RB;                   // unpadded rows
+    constexpr int PBYTES = 32 * PROW, QPIECES = (HD * HH * HW * 4 + 63) / 64, BUF = PBYTES + QPIECES * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int tq = wv & 3, half = wv >> 2;
+    const int r0 = blockIdx.y * 32, k0 = blockIdx.z * 32;
+
+    int tapoff[NTS], tapw[NTS];
+#pragma unroll
+    for (int ts = 0; ts < NTS; ++ts) {
+        const int t = tq + ts * 4;
+        const bool valid = t < 27;
+        const int tt = valid ? t : 0;
+        const int a = tt / 9, b = (tt / 3) % 3, c = tt % 3;
+        tapoff[ts] = __builtin_amdgcn_readfirstlane((a * HH + b) * QROW + c * RB);
+        tapw[ts] = __builtin_amdgcn_readfirstlane(valid ? tt : -1);
+    }
+    f32x16_t acc[NTS];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // fragment bases: lane group q = (row q >> 1 of the step's two lattice rows, channel block q & 1)
+    const int lane32 = (q & 1) * 32 + (li >> 2) * RB + (li & 3) * 8;
+    const int p_lane = (q >> 1) * PROW + lane32;
+    const int q_lane = PBYTES + (q >> 1) * QROW + lane32;
+
+    // ---- DMA geometry. The waves of the FIRST point half issue all 54 pieces (the SIMD favours its older wave: they finish their MFMAs
+    // ~1500 cycles before their SIMD partners and would idle at the barrier; measured with s_memtime, profiles/round4_wgrad3d_phases.txt).
+    // P piece pp = tq * 4 + i: voxels pp * 16 + (lane >> 2) = slice pp >> 2 = tq, rows i * 2 + (lane >> 5), column (lane >> 2) & 7.
+    // Q piece qp = tq + 4 j: granule G = qp * 64 + lane = halo voxel G >> 2 (row-major over 6 x 10 x 10), part G & 3.
+    constexpr int NPP = 4, NQ = (QPIECES + 3) / 4, NPC = NPP + NQ;
+    const int p_pw = (lane >> 2) & 7, p_hb = lane >> 5, part = lane & 3;
+    uint32_t qsel[NQ];          // bit hd | bit 6 + hh | bit 16 + hw; bit 31 = no such granule
+    int qcoord[NQ];             // hd << 16 | hh << 8 | hw
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int G = (tq + 4 * j) * 64 + lane;
+        const int vox = G >> 2;
+        const int row = vox / HW, hw = vox - row * HW;
+        const int hd = row / HH, hh = row - hd * HH;
+        const bool valid = vox < HD * HH * HW;
+        qsel[j] = valid ? (1u << hd) | (1u << (6 + hh)) | (1u << (16 + hw)) : 0x80000000u;
+        qcoord[j] = (hd << 16) | (hh << 8) | hw;
+    }
+    // per-item strides (bytes) and the lane parts of the offsets that depend on them
+    int PL0 = A.PL[0], PL1 = A.PL[1], PL2 = A.PL[2];
+    int p_rowb = 0, p_slab = 0, q_rowb = 0, q_slab = 0, p_voff = 0, n_cur = -1;
+    int qrel[NQ];
+    auto set_dims = [&](int d0, int d1, int d2) {
+        PL0 = d0; PL1 = d1; PL2 = d2;
+        p_rowb = d2 * A.Cp * 2; p_slab = d1 * p_rowb;
+        q_rowb = d2 * A.Cq * 2; q_slab = d1 * q_rowb;
+        p_voff = p_hb * p_rowb + p_pw * A.Cp * 2 + part * 16;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+            qrel[j] = (qcoord[j] >> 16) * q_slab + ((qcoord[j] >> 8) & 255) * q_rowb + (qcoord[j] & 255) * A.Cq * 2 + part * 16;
+    };
+    if constexpr (!ITEMS) set_dims(A.PL[0], A.PL[1], A.PL[2]);
+
+    // scalars of the tile being staged (no divisions: magic multipliers from the host)
+    __amdgpu_buffer_rsrc_t prs, qrs;
+    int l0d = 0, l0h = 0, l0w = 0;
+    uint32_t qmask = 0;
+    bool p_okw = false;
+    auto mdivu = [](uint32_t n, uint32_t m) -> uint32_t { return m ? __umulhi(n, m) : n; };
+    auto decode = [&](int tile) {
+        int n, tt, nt1 = A.nt[1], nt2 = A.nt[2];
+        uint32_t m2 = A.m_nt2, m12 = A.m_nt12;
+        int64_t p_base, q_base;
+        if constexpr (ITEMS) {
+            n = 0;
+            while (n + 1 < IT.n && tile >= IT.tile_begin[n + 1]) ++n;
+            tt = tile - IT.tile_begin[n];
+            if (n != n_cur) { set_dims(IT.dims[n][0], IT.dims[n][1], IT.dims[n][2]); n_cur = n; }
+            nt1 = (PL1 + TH - 1) / TH; nt2 = (PL2 + 7) / 8;
+            m2 = IT.m_nt2[n]; m12 = IT.m_nt12[n];
+            p_base = IT.row_off[n] * A.Cp * (int64_t)2; q_base = IT.row_off[n] * A.Cq * (int64_t)2;
+        } else {
+            n = (int)mdivu((uint32_t)tile, A.m_tpn);
+            tt = tile - n * (A.nt[0] * nt1 * nt2);
+            p_base = (int64_t)n * PL0 * p_slab; q_base = (int64_t)n * PL0 * q_slab;
+        }
+        const int td_i = (int)mdivu((uint32_t)tt, m12);
+        tt -= td_i * nt1 * nt2;
+        const int th_i = (int)mdivu((uint32_t)tt, m2);
+        const int tw_i = tt - th_i * nt2;
+        l0d = td_i * TD; l0h = th_i * TH; l0w = tw_i * 8;
+        // descriptors based at the tile origin (dY) / the halo origin (X; may lie before the image: only lanes inside the tensor use it)
+        const int64_t p_org = (int64_t)l0d * p_slab + l0h * p_rowb + l0w * A.Cp * 2 + r0 * 2;
+        const int64_t q_org = (int64_t)(l0d - 1) * q_slab + (l0h - 1) * q_rowb + (l0w - 1) * A.Cq * 2 + k0 * 2;
+        prs = wg_uniform_rsrc(reinterpret_cast<const char*>(A.p) + p_base + p_org, 0x7ffffff0);
+        qrs = wg_uniform_rsrc(reinterpret_cast<const char*>(A.q) + q_base + q_org, 0x7ffffff0);
+        p_okw = l0w + p_pw < PL2;
+        auto rng = [](int lo, int hi) -> uint32_t { return ((1u << hi) - 1u) & ~((1u << lo) - 1u); };   // bits [lo, hi)
+        const uint32_t md = rng(l0d == 0 ? 1 : 0, min(HD, PL0 - l0d + 1));
+        const uint32_t mh = rng(l0h == 0 ? 1 : 0, min(HH, PL1 - l0h + 1));
+        const uint32_t mw = rng(l0w == 0 ? 1 : 0, min(HW, PL2 - l0w + 1));
+        qmask = md | (mh << 6) | (mw << 16);
+    };
+    // piece i of this wave (0..3: dY; 4..: X halo) of the decoded tile -> buffer `buf`
+    auto dma_piece = [&](int i, int buf) {
+        if (i < NPP) {
+            const int pp = tq * NPP + i;
+            const int pd = tq, ph0 = i * 2;
+            const bool ok = p_okw && (l0d + pd < PL0) && (l0h + ph0 + p_hb < PL1);
+            wg_dma16(prs, ok ? p_voff : (int)0x80000000, __builtin_amdgcn_readfirstlane(pd * p_slab + ph0 * p_rowb),
+                     (uint32_t)__builtin_amdgcn_readfirstlane(buf * BUF + pp * 1024));
+        } else {
+            const int j = i - NPP;
+            if (tq + 4 * j < QPIECES) {
+                const bool ok = (qsel[j] & qmask) == qsel[j];
+                wg_dma16(qrs, ok ? qrel[j] : (int)0x80000000, 0, (uint32_t)__builtin_amdgcn_readfirstlane(buf * BUF + PBYTES + (tq + 4 * j) * 1024));
+            }
+        }
+    };
+    const bool do_bias = A.dbias != nullptr && blockIdx.z == 0 && tq == 3;     // the 28th tap slot of both point halves
+    auto tr2 = [&](const char* b0) -> u32x4 {
+        const uint2 a = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0)));
+        const uint2 b = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 4 * RB)));
+        return u32x4{a.x, a.y, b.x, b.y};
+    };
+    // MFMA phase on buffer `buf`; with `stage` the pieces of the decoded (next) tile are issued into the other buffer, one per 8 MFMAs
+    auto compute = [&](int buf, bool stage) {
+        // the pieces of the next tile are issued EARLY in the phase (one per DMA_GAP MFMAs): they must have landed at its end, and a
+        // piece issued with 4 MFMAs to go exposes its whole HBM latency at the barrier (measured: one per 8 MFMAs 0.642 ms, ...)
+        constexpr int KH = 8, U = KH * NTS, QD_ = WG3D_QD, DMA_GAP = WG3D_GAP;
+        // step ks of this half = lattice rows 2 ks, 2 ks + 1 of slices 2 half, 2 half + 1: slice ks >> 2, rows (ks & 3) * 2 + (q >> 1)
+        const char* const pb = smem + buf * BUF + p_lane + half * KH * 2 * PROW;
+        const char* const qb = smem + buf * BUF + q_lane + half * 2 * HH * QROW;
+        u32x4 pf[2], qf[QD_ + 1];
+        auto load_q = [&](int u) -> u32x4 {
+            const int ks = u / NTS, ts = u % NTS;
+            if (ts == NTS - 1 && do_bias) return u32x4{H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2};
+            return tr2(qb + tapoff[ts] + (((ks >> 2) * HH) + (ks & 3) * 2) * QROW);
+        };
+        pf[0] = tr2(pb);
+#pragma unroll
+        for (int u0 = 0; u0 < QD_; ++u0) qf[u0] = load_q(u0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = u / NTS, ts = u % NTS;
+            if (u + QD_ < U) qf[(u + QD_) % (QD_ + 1)] = load_q(u + QD_);
+            if (ts == 0 && ks + 1 < KH) pf[(ks + 1) & 1] = tr2(pb + (ks + 1) * 2 * PROW);
+            if (u < DMA_GAP * NPC && u % DMA_GAP == 0 && stage) dma_piece(u / DMA_GAP, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[ts] = H16<T>::mma32(pf[ks & 1], qf[u % (QD_ + 1)], acc[ts]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int G = gridDim.x, bx = blockIdx.x;
+    // round k covers tiles [k G, (k + 1) G); within a round the workgroups of one XCD take a contiguous run (xcd_compact, written out:
+    // bx < G, so no division)
+    auto tile_of = [&](int b0) {
+        const int cnt = min(G, A.total_tiles - b0);
+        return b0 + ((cnt & 7) ? bx : (bx & 7) * (cnt >> 3) + (bx >> 3));
+    };
+    const bool stager = half == 0;
+    if (bx < A.total_tiles && stager) {
+        decode(tile_of(0));
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) dma_piece(i, 0);
+        if (G + bx < A.total_tiles) decode(tile_of(G));       // the tile staged during the first MFMA phase
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+#ifdef WG3D_TIMING
+    long long t_comp = 0, t_dec = 0, t_bar = 0; int t_n = 0;
+#endif
+    for (int base = 0; base + bx < A.total_tiles; base += G) {
+        const bool has_next = base + G + bx < A.total_tiles;
+#ifdef WG3D_TIMING
+        const long long t0 = __builtin_readcyclecounter();
+#endif
+        if (A.dbg & 2) {
+            if (has_next && stager && !(A.dbg & 1))
+#pragma unroll
+                for (int i = 0; i < NPC; ++i) dma_piece(i, buf ^ 1);
+        } else if (!((A.dbg & 16) && half)) compute(buf, has_next && stager && !(A.dbg & 1));
+#ifdef WG3D_TIMING
+        const long long t1 = __builtin_readcyclecounter();
+#endif
+        // the scalars of the tile after the next one, computed BEFORE the barrier by the waves that staged (their pieces of the next tile
+        // are on their way; their SIMD partners are still in their MFMA phase). ~100 dependent scalar instructions = 780 cycles; placing
+        // them in the middle of the MFMA phase instead was a draw for uniform launches and 50 % slower for the ragged ones.
+        if (stager && base + 2 * G + bx < A.total_tiles) decode(tile_of(base + 2 * G));
+#ifdef WG3D_TIMING
+        const long long t2 = __builtin_readcyclecounter();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                            // every wave is done reading `buf`, the next tile has landed in the other buffer
+        buf ^= 1;
+#ifdef WG3D_TIMING
+        const long long t3 = __builtin_readcyclecounter();
+        t_comp += t1 - t0; t_dec += t2 - t1; t_bar += t3 - t2; ++t_n;
+#endif
+    }
+#ifdef WG3D_TIMING
+    if ((bx == 0 || bx == 100) && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        printf("wg %d wave %d tiles %d: compute %lld decode %lld wait+barrier %lld cycles per tile\n", bx, wv, t_n, t_comp / t_n, t_dec / t_n, t_bar / t_n);
+#endif
+    const int n = lane & 31, mh = (lane >> 5) * 4;
+    if (do_bias && n == 0) {                        // column 0 of the ones-GEMM
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = r0 + (r >> 2) * 8 + mh + (r & 3);
+            if (m < A.R) atomicAdd(A.dbias + m, acc[NTS - 1][r]);
+        }
+    }
+    float* part_out = A.part + ((int64_t)(blockIdx.x * 2 + half) * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
+#pragma unroll
+    for (int ts = 0; ts < NTS; ++ts) {
+        if (tapw[ts] >= 0) {
+            float* pt = part_out + (int64_t)tapw[ts] * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pt[((r >> 2) * 8 + mh + (r & 3)) * 32 + n] = acc[ts][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3x3, stride 2: LDS-DMA form
+// k_wgrad3s (round 4, 16-bit types): the stride-(2, 2, 2) / pad 1 transitions on k_wgrad3d's recipe. The generic k_wgrad ran them at
+// 0.17-0.19 PFLOP/s alone and 1.3 + 0.6 + 0.4 ms inside the step -- skipping them altogether made the step 0.98 ms shorter
+// (profiles/round4_wgrad_strided.txt): one 64-point tile in flight per workgroup behind a 49 KB halo (12 staging pieces per thread,
+// 2 barriers), transpose reads with a 2-voxel stride (2-way bank conflicts), 192 workgroups for 256 CUs.
+//   * tile = 2 x 4 x 8 lattice points of dY (BOTH 32-channel row blocks of the workgroup's pair: the X halo is staged once for them),
+//     halo = 5 x 9 x 17 voxels of one 32-channel block of X; double-buffered by LDS-DMA, one barrier per tile;
+//   * the halo rows are stored DE-INTERLEAVED along W: the 9 even-offset voxels, then the 8 odd ones (the DMA destination is
+//     lane-linear, the SOURCE address per lane is free). Tap c = 1 reads the odd run, c = 0 / 2 the even run at slot 0 / 1: every
+//     fragment is 8 consecutive voxels again, the half wave of a transpose read covers 256 contiguous bytes -- conflict-free;
+//   * 8 waves = (tap class wv & 3: 7 slots) x (row block wv >> 2); v_mfma_32x32x16, 4 steps of 16 points: 28 MFMAs per wave and tile;
+//   * the tile walk is incremental (the workgroup's tile index advances by the grid size: a mixed-radix add with the host's
+//     decomposition of the grid size) -- the ~100 dependent scalar instructions of k_wgrad3d's decode would be a third of a tile here.
+// Waves 0..3 issue all 56 pieces of the next tile in the first 14 MFMA slots.
+struct Wg3sInc { int32_t gw, gh, gd, gn; };      // grid size = gw + nt2 * (gh + nt1 * (gd + nt0 * gn))
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void k_wgrad3s(const WgArgs A, const Wg3sInc INC) {
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    constexpr int RB = 64, NTS = 7, TD = 2, TH = 4, HD = 2 * TD + 1, HH = 2 * TH + 1, HW = 17, NEV = 9;
+    constexpr int PROW = 8 * RB, QROW = HW * RB;
+    constexpr int PBLK = TD * TH * PROW, PBYTES = 2 * PBLK;                        // two row blocks of dY
+    constexpr int QVOX = HD * HH * HW, QPIECES = (QVOX * 4 + 63) / 64, BUF = PBYTES + QPIECES * 1024;
+    constexpr int NPP = 2, NQ = (QPIECES + 3) / 4, NPC = NPP + NQ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int tq = wv & 3, rbw = wv >> 2;
+    const int r0 = blockIdx.y * 64, k0 = blockIdx.z * 32;
+
+    int tapoff[NTS], tapw[NTS];
+#pragma unroll
+    for (int ts = 0; ts < NTS; ++ts) {
+        const int t = tq + ts * 4;
+        const bool valid = t < 27;
+        const int tt = valid ? t : 0;
+        const int a = tt / 9, b = (tt / 3) % 3, c = tt % 3;
+        tapoff[ts] = __builtin_amdgcn_readfirstlane((a * HH + b) * QROW + (c == 1 ? NEV * RB : c == 2 ? RB : 0));
+        tapw[ts] = __builtin_amdgcn_readfirstlane(valid ? tt : -1);
+    }
+    f32x16_t acc[NTS];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // fragment bases: lane group q = (row q >> 1 of the step's two lattice rows, channel block q & 1); lattice rows are 2 halo rows apart
+    const int lane32 = (q & 1) * 32 + (li >> 2) * RB + (li & 3) * 8;
+    const int p_lane = rbw * PBLK + (q >> 1) * PROW + lane32;
+    const int q_lane = PBYTES + (q >> 1) * 2 * QROW + lane32;
+
+    // ---- DMA geometry (waves 0..3). dY piece pp = tq * 2 + i = row block pp >> 2, rows (pp & 3) * 2 + (lane >> 5) of the 8 lattice rows,
+    // column (lane >> 2) & 7. X piece qp = tq + 4 j: granule G = qp * 64 + lane = halo slot G >> 2 (row-major over 5 x 9 x 17 slots,
+    // slot s of a row = W offset 2 s (s < 9) or 2 (s - 9) + 1), part G & 3.
+    const int p_pw = (lane >> 2) & 7, p_hb = lane >> 5, part = lane & 3;
+    const int p_rowb = A.PL[2] * A.Cp * 2, p_slab = A.PL[1] * p_rowb;
+    const int q_rowb = A.QD[2] * A.Cq * 2, q_slab = A.QD[1] * q_rowb;
+    const int p_voff = p_hb * p_rowb + p_pw * A.Cp * 2 + part * 16;
+    uint32_t qsel[NQ];          // bit hd | bit 5 + hh | bit 14 + W offset; bit 31 = no such granule
+    int qrel[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int G = (tq + 4 * j) * 64 + lane;
+        const int vox = G >> 2;
+        const int row = vox / HW, sl = vox - row * HW;
+        const int hd = row / HH, hh = row - hd * HH;
+        const int jw = sl < NEV ? 2 * sl : 2 * (sl - NEV) + 1;
+        const bool valid = vox < QVOX;
+        qsel[j] = valid ? (1u << hd) | (1u << (5 + hh)) | (1u << (14 + jw)) : 0x80000000u;
+        qrel[j] = hd * q_slab + hh * q_rowb + jw * A.Cq * 2 + part * 16;
+    }
+
+    // scalars of the tile being staged
+    __amdgpu_buffer_rsrc_t prs, qrs;
+    int l0d = 0, l0h = 0, l0w = 0;
+    uint32_t qmask = 0;
+    bool p_okw = false;
+    int c_n = 0, c_d = 0, c_h = 0, c_w = 0;               // mixed-radix coordinates of the tile last decoded
+    auto setup = [&]() {
+        l0d = c_d * TD; l0h = c_h * TH; l0w = c_w * 8;
+        const int64_t p_org = (int64_t)c_n * A.PL[0] * p_slab + (int64_t)l0d * p_slab + l0h * p_rowb + l0w * A.Cp * 2 + r0 * 2;
+        const int64_t q_org = (int64_t)c_n * A.QD[0] * q_slab + (int64_t)(2 * l0d - 1) * q_slab + (2 * l0h - 1) * q_rowb + (2 * l0w - 1) * A.Cq * 2 + k0 * 2;
+        prs = wg_uniform_rsrc(reinterpret_cast<const char*>(A.p) + p_org, 0x7ffffff0);
+        qrs = wg_uniform_rsrc(reinterpret_cast<const char*>(A.q) + q_org, 0x7ffffff0);
+        p_okw = l0w + p_pw < A.PL[2];
+        auto rng = [](int lo, int hi) -> uint32_t { return (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u); };   // bits [lo, hi)
+        const uint32_t md = rng(l0d == 0 ? 1 : 0, min(HD, A.QD[0] - 2 * l0d + 1));
+        const uint32_t mh = rng(l0h == 0 ? 1 : 0, min(HH, A.QD[1] - 2 * l0h + 1));
+        const uint32_t mw = rng(l0w == 0 ? 1 : 0, min(HW, A.QD[2] - 2 * l0w + 1));
+        qmask = md | (mh << 5) | (mw << 14);
+    };
+    auto decode = [&](int tile) {                          // full decode (first tile, ragged last round)
+        const int tpn = A.nt[0] * A.nt[1] * A.nt[2];
+        c_n = tile / tpn;
+        int tt = tile - c_n * tpn;
+        c_w = tt % A.nt[2]; tt /= A.nt[2];
+        c_h = tt % A.nt[1];
+        c_d = tt / A.nt[1];
+        setup();
+    };
+    auto advance = [&]() {                                 // tile += grid size
+        c_w += INC.gw; int cy = c_w >= A.nt[2]; c_w -= cy ? A.nt[2] : 0;
+        c_h += INC.gh + cy; cy = c_h >= A.nt[1]; c_h -= cy ? A.nt[1] : 0;
+        c_d += INC.gd + cy; cy = c_d >= A.nt[0]; c_d -= cy ? A.nt[0] : 0;
+        c_n += INC.gn + cy;
+        setup();
+    };
+    auto dma_piece = [&](int i, int buf) {
+        if (i < NPP) {
+            const int pp = tq * NPP + i;
+            const int rb = pp >> 2, pi = pp & 3;
+            const int pd = pi >> 1, ph0 = (pi & 1) * 2;
+            const bool ok = p_okw && (l0d + pd < A.PL[0]) && (l0h + ph0 + p_hb < A.PL[1]);
+            wg_dma16(prs, ok ? p_voff : (int)0x80000000, __builtin_amdgcn_readfirstlane(pd * p_slab + ph0 * p_rowb + rb * 64),
+                     (uint32_t)__builtin_amdgcn_readfirstlane(buf * BUF + pp * 1024));
+        } else {
+            const int j = i - NPP;
+            if (tq + 4 * j < QPIECES) {
+                const bool ok = (qsel[j] & qmask) == qsel[j];
+                wg_dma16(qrs, ok ? qrel[j] : (int)0x80000000, 0, (uint32_t)__builtin_amdgcn_readfirstlane(buf * BUF + PBYTES + (tq + 4 * j) * 1024));
+            }
+        }
+    };
+    auto tr2 = [&](const char* b0) -> u32x4 {
+        const uint2 a = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0)));
+        const uint2 b = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 4 * RB)));
+        return u32x4{a.x, a.y, b.x, b.y};
+    };
+    auto compute = [&](int buf, bool stage) {
+        constexpr int KS2 = TD * TH / 2, U = KS2 * NTS, QD_ = 3;
+        // step ks = lattice rows 2 ks, 2 ks + 1 = slice ks >> 1, rows (ks & 1) * 2 + (q >> 1)
+        const char* const pb = smem + buf * BUF + p_lane;
+        const char* const qb = smem + buf * BUF + q_lane;
+        u32x4 pf[2], qf[QD_ + 1];
+        auto load_q = [&](int u) -> u32x4 {
+            const int ks = u / NTS, ts = u % NTS;
+            return tr2(qb + tapoff[ts] + ((ks >> 1) * 2 * HH + (ks & 1) * 4) * QROW);
+        };
+        pf[0] = tr2(pb);
+#pragma unroll
+        for (int u0 = 0; u0 < QD_; ++u0) qf[u0] = load_q(u0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = u / NTS, ts = u % NTS;
+            if (u + QD_ < U) qf[(u + QD_) % (QD_ + 1)] = load_q(u + QD_);
+            if (ts == 0 && ks + 1 < KS2) pf[(ks + 1) & 1] = tr2(pb + (ks + 1) * 2 * PROW);
+            if (u < NPC && stage) dma_piece(u, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[ts] = H16<T>::mma32(pf[ks & 1], qf[u % (QD_ + 1)], acc[ts]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int G = gridDim.x, bx = blockIdx.x;
+    auto perm = [&](int cnt) { return (cnt & 7) ? bx : (bx & 7) * (cnt >> 3) + (bx >> 3); };   // xcd_compact within a round
+    const bool stager = rbw == 0;
+    const int full = A.total_tiles / G;                       // rounds in which every workgroup has a tile
+    const int pfull = perm(G);
+    // tile of round k: k < full: k G + pfull (advance); the ragged last round: full G + perm(rest)
+    auto to_round = [&](int k) {                               // -> true when this workgroup has a tile in round k (and decodes it)
+        if (k < full) { if (k == 0) decode(pfull); else advance(); return true; }
+        const int rest = A.total_tiles - full * G;
+        if (k == full && bx < rest) { decode(full * G + perm(rest)); return true; }
+        return false;
+    };
+    bool have = false, have_next = false;
+    if (stager) {
+        have = to_round(0);
+        if (have) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) dma_piece(i, 0);
+        }
+        have_next = to_round(1);
+    }
+    have = 0 < full || bx < A.total_tiles - full * G;          // (every wave: does round 0 exist for this workgroup?)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int k = 0; have; ++k) {
+        const bool next_exists = (k + 1 < full) || (k + 1 == full && bx < A.total_tiles - full * G);
+        compute(buf, next_exists && stager);
+        if (stager && next_exists) have_next = to_round(k + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+        have = next_exists;
+    }
+    (void)have_next;
+    const int n = lane & 31, mh = (lane >> 5) * 4;
+    float* part_out = A.part + ((int64_t)blockIdx.x * (gridDim.y * 2 * gridDim.z) + (blockIdx.y * 2 + rbw) * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
+#pragma unroll
+    for (int ts = 0; ts < NTS; ++ts) {
+        if (tapw[ts] >= 0) {
+            float* pt = part_out + (int64_t)tapw[ts] * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pt[((r >> 2) * 8 + mh + (r & 3)) * 32 + n] = acc[ts][r];
         }
     }
 }
@@ -634,19 +1165,56 @@ size_t wgrad_workspace_bytes(const NndetConv* c) {
     return (size_t)slices * rb * kb * ntap * 1024 * sizeof(float);
 }
 
+// the 32x32x16 variant of k_wgrad3 (16-bit types) unless NNDET_WGRAD3_M32=0
+static bool wgrad3_m32() {
+    static const int w = getenv("NNDET_WGRAD3_M32") ? atoi(getenv("NNDET_WGRAD3_M32")) : 1;
+    return w != 0;
+}
+#define WG3_LDS_ATTR(K) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048))
+
+// k_wgrad3d (LDS-DMA form) for the 16-bit launches without a deferred input norm unless NNDET_WGRAD3D=0; its persistent grid:
+// NNDET_WGRAD3D_WGS workgroups of 8 waves over all block pairs (one fits per CU)
+static bool wgrad3d_on() {
+    static const int w = getenv("NNDET_WGRAD3D") ? atoi(getenv("NNDET_WGRAD3D")) : 1;
+    return w != 0;
+}
+static int wgrad3d_slices(int pairs, int total_tiles) {
+    const int total = getenv("NNDET_WGRAD3D_WGS") ? atoi(getenv("NNDET_WGRAD3D_WGS")) : 256;       // (read per call: the tests vary it)
+    int S = (total < 1 || total > 256 ? 256 : total) / pairs;
+    if (S < 1) S = 1;
+    if (S > total_tiles) S = total_tiles;
+    return S;
+}
+static constexpr size_t WG3D_LDS = 2 * (32 * 512 + 38 * 1024);
+template <typename T, bool ITEMS> static int wgrad3d_launch(const WgArgs& b, const WgItems& wi, dim3 g, hipStream_t st) {
+    static bool at = false;
+    if (!at) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3d<T, ITEMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG3D_LDS));
+        at = true;
+    }
+    k_wgrad3d<T, ITEMS><<<g, 512, WG3D_LDS, st>>>(b, wi);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // uniform k_wgrad3 launch for a 16-bit storage type
 template <typename T> static int wgrad3_launch16(const WgArgs& b, dim3 g3, size_t lds3, hipStream_t st) {
     static bool at = false;
     if (!at) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<T, 2, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<T, 2, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<T, 2, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        WG3_LDS_ATTR((k_wgrad3<T, 2, false, 2>));
+        WG3_LDS_ATTR((k_wgrad3<T, 2, false, 1>));
+        WG3_LDS_ATTR((k_wgrad3<T, 2, true, 1>));
+        WG3_LDS_ATTR((k_wgrad3<T, 2, false, 1, false, true>));
+        WG3_LDS_ATTR((k_wgrad3<T, 2, true, 1, false, true>));
         at = true;
     }
     // QDEPTH 1: 248 registers, no spill. With depth 2 the kernel needs > 256 registers at two workgroups per CU and the
     // spill reloads (scratch shares vmcnt) serialise the staging loads of every tile (profiles/round2_wgrad3_spill.txt)
     static const int qd = getenv("NNDET_WGRAD3_QD") ? atoi(getenv("NNDET_WGRAD3_QD")) : 1;
-    if (b.qss) k_wgrad3<T, 2, true, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+    if (wgrad3_m32()) {
+        if (b.qss) k_wgrad3<T, 2, true, 1, false, true><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+        else k_wgrad3<T, 2, false, 1, false, true><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
+    } else if (b.qss) k_wgrad3<T, 2, true, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
     else if (qd == 2) k_wgrad3<T, 2, false, 2><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
     else k_wgrad3<T, 2, false, 1><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
     return 0;
@@ -743,10 +1311,24 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
         if ((ps <= 1.05 * pg || spec_on == 2) && pb < (1LL << 31) && qb < (1LL << 31)) {
             WgArgs b = a;
             b.TD = 4; b.TH = 8;
+            static const int dbg = getenv("NNDET_WGRAD3_DBG") ? atoi(getenv("NNDET_WGRAD3_DBG")) : 0;
+            b.dbg = dbg;
             b.dbias = dbias;                  // P = dY here (not transposed): the kernel also produces the bias gradient
             *bias_done = dbias != nullptr;
             for (int i = 0; i < 3; ++i) { b.H[i] = st3[i] + 2; b.nt[i] = ceil_div(a.PL[i], st3[i]); }
             b.total_tiles = b.N * b.nt[0] * b.nt[1] * b.nt[2];
+            b.m_tpn = magic(b.nt[0] * b.nt[1] * b.nt[2]); b.m_nt2 = magic(b.nt[2]); b.m_nt12 = magic(b.nt[1] * b.nt[2]);
+            if (bf && !b.qss && wgrad3d_on()) {          // LDS-DMA form: two partial slices (point halves) per workgroup
+                const int Sd = wgrad3d_slices(rb * kb, b.total_tiles);
+                if (ws_bytes < (size_t)2 * Sd * rb * kb * 27 * 1024 * sizeof(float)) return NNDET_EWORKSPACE;
+                const int rcd = hf ? wgrad3d_launch<f16_t, false>(b, g_wg_no_items, dim3(Sd, rb, kb), st)
+                                   : wgrad3d_launch<bf16_t, false>(b, g_wg_no_items, dim3(Sd, rb, kb), st);
+                if (rcd) return rcd;
+                const int64_t totald = (int64_t)rb * kb * 27 * 1024;
+                k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totald, 256), ceil_div(2 * Sd, 32)), 256, 0, st>>>(b.part, 2 * Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totald);
+                LAUNCH_CHECK();
+                return 0;
+            }
             const int S3 = wgrad_slices(rb * kb, b.total_tiles);
             const size_t need3 = (size_t)S3 * rb * kb * 27 * 1024 * sizeof(float);
             if (ws_bytes < need3) return NNDET_EWORKSPACE;
@@ -771,6 +1353,44 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             LAUNCH_CHECK();
             return 0;
         }
+    }
+    static const int dbg_skip_s = getenv("NNDET_WGRAD_DBG_SKIP_STRIDED") ? atoi(getenv("NNDET_WGRAD_DBG_SKIP_STRIDED")) : 0;   // timing experiment (wrong results)
+    if (dbg_skip_s && strided && T == 27) return 0;
+    // stride (2, 2, 2) / 3x3x3 / pad 1 in 16 bits, an even number of row blocks, no deferred input norm: k_wgrad3s (NNDET_WGRAD3S=0: off)
+    static const int s3 = getenv("NNDET_WGRAD3S") ? atoi(getenv("NNDET_WGRAD3S")) : 1;
+    if (s3 && bf && !tr && T == 27 && !a.qss && rb % 2 == 0 && c->s[0] == 2 && c->s[1] == 2 && c->s[2] == 2 && c->k[0] == 3 && c->k[1] == 3 &&
+        c->k[2] == 3 && c->p[0] == 1 && c->p[1] == 1 && c->p[2] == 1 &&
+        (int64_t)a.PL[0] * a.PL[1] * a.PL[2] * a.Cp * 2 < (1LL << 31) && (int64_t)a.QD[0] * a.QD[1] * a.QD[2] * a.Cq * 2 < (1LL << 31)) {
+        WgArgs b = a;
+        b.TD = 2; b.TH = 4;
+        const int st3[3] = {2, 4, 8};
+        for (int i = 0; i < 3; ++i) b.nt[i] = ceil_div(a.PL[i], st3[i]);
+        b.total_tiles = b.N * b.nt[0] * b.nt[1] * b.nt[2];
+        const int wgs = getenv("NNDET_WGRAD3S_WGS") ? atoi(getenv("NNDET_WGRAD3S_WGS")) : 256;     // (read per call: the tests vary it)
+        int Ss = (wgs < 2 || wgs > 256 ? 256 : wgs) * 2 / (rb * kb);
+        if (Ss < 1) Ss = 1;
+        if (Ss > b.total_tiles) Ss = b.total_tiles;
+        if (ws_bytes < (size_t)Ss * rb * kb * 27 * 1024 * sizeof(float)) return NNDET_EWORKSPACE;
+        Wg3sInc inc;
+        int g = Ss;
+        inc.gw = g % b.nt[2]; g /= b.nt[2];
+        inc.gh = g % b.nt[1]; g /= b.nt[1];
+        inc.gd = g % b.nt[0]; inc.gn = g / b.nt[0];
+        constexpr size_t lds_s = 2 * (2 * 2 * 4 * 512 + 48 * 1024);
+        static bool at = false;
+        if (!at) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3s<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3s<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            at = true;
+        }
+        dim3 gs(Ss, rb / 2, kb);
+        if (hf) k_wgrad3s<f16_t><<<gs, 512, lds_s, st>>>(b, inc);
+        else k_wgrad3s<bf16_t><<<gs, 512, lds_s, st>>>(b, inc);
+        LAUNCH_CHECK();
+        const int64_t totals = (int64_t)rb * kb * 27 * 1024;
+        k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totals, 256), ceil_div(Ss, 32)), 256, 0, st>>>(b.part, Ss, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totals);
+        LAUNCH_CHECK();
+        return 0;
     }
     if (hf) rc = KS == 8 ? wg_dispatch<f16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<f16_t, 2, 1, 12, true>(a, grid, lds, st, rbk);
     else if (bf) rc = KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st, rbk);
@@ -816,6 +1436,9 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
         for (int a = 0; a < 3; ++a) wi.dims[i][a] = it->dims[i][a];
         wi.row_off[i] = it->row_off[i];
         wi.tile_begin[i] = total;
+        const int n1 = ceil_div(it->dims[i][1], 8), n2 = ceil_div(it->dims[i][2], 8);
+        wi.m_nt2[i] = n2 <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)n2 + 1ull);
+        wi.m_nt12[i] = n1 * n2 <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)(n1 * n2) + 1ull);
         total += ceil_div(it->dims[i][0], 4) * ceil_div(it->dims[i][1], 8) * ceil_div(it->dims[i][2], 8);
     }
     b.total_tiles = total;
@@ -823,6 +1446,17 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
     for (int i = 0; i < 3; ++i) { b.PL[i] = b.QD[i] = it->dims[0][i]; }
     b.nt[0] = ceil_div(b.PL[0], 4); b.nt[1] = ceil_div(b.PL[1], 8); b.nt[2] = ceil_div(b.PL[2], 8);
     const int rb = b.Cp / 32, kb = b.Cq / 32;
+    if (bf && wgrad3d_on()) {
+        const int Sd = wgrad3d_slices(rb * kb, b.total_tiles);
+        if (!ws || ws_bytes < (size_t)2 * Sd * rb * kb * 27 * 1024 * sizeof(float)) return NNDET_EWORKSPACE;
+        b.part = reinterpret_cast<float*>(ws);
+        const int rcd = hf ? wgrad3d_launch<f16_t, true>(b, wi, dim3(Sd, rb, kb), st) : wgrad3d_launch<bf16_t, true>(b, wi, dim3(Sd, rb, kb), st);
+        if (rcd) return rcd;
+        const int64_t totald = (int64_t)rb * kb * 27 * 1024;
+        k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totald, 256), ceil_div(2 * Sd, 32)), 256, 0, st>>>(b.part, 2 * Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totald);
+        LAUNCH_CHECK();
+        return 0;
+    }
     const int S3 = wgrad_slices(rb * kb, b.total_tiles);
     const size_t need3 = (size_t)S3 * rb * kb * 27 * 1024 * sizeof(float);
     if (!ws || ws_bytes < need3) return NNDET_EWORKSPACE;
@@ -836,7 +1470,16 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         at = true;
     }
-    if (hf) k_wgrad3<f16_t, 2, false, 1, true><<<g3, 256, lds3, st>>>(b, wi);
+    static bool atw = false;
+    if (!atw) {
+        WG3_LDS_ATTR((k_wgrad3<bf16_t, 2, false, 1, true, true>));
+        WG3_LDS_ATTR((k_wgrad3<f16_t, 2, false, 1, true, true>));
+        atw = true;
+    }
+    if (bf && wgrad3_m32()) {
+        if (hf) k_wgrad3<f16_t, 2, false, 1, true, true><<<g3, 256, lds3, st>>>(b, wi);
+        else k_wgrad3<bf16_t, 2, false, 1, true, true><<<g3, 256, lds3, st>>>(b, wi);
+    } else if (hf) k_wgrad3<f16_t, 2, false, 1, true><<<g3, 256, lds3, st>>>(b, wi);
     else if (bf) k_wgrad3<bf16_t, 2, false, 1, true><<<g3, 256, lds3, st>>>(b, wi);
     else k_wgrad3<float, 1, false, 2, true><<<g3, 256, lds3, st>>>(b, wi);
     LAUNCH_CHECK();

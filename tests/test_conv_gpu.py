@@ -37,9 +37,10 @@ CONVS = [
     ("stem", 1, 32, 3, 1, 1, False, (9, 10, 12)),
     ("c32_k3_tiles", 32, 32, 3, 1, 1, False, (17, 16, 9)),      # several (8,8,8) tiles of k_ig3 + ragged edges in every axis
     ("c64_k3_tiles", 64, 64, 3, 1, 1, False, (9, 17, 16)),      # several (4,8,8) tiles, 2 K-chunks
+    ("c64to128_s2_tiles", 64, 128, 3, 2, 1, False, (21, 19, 35)),   # k_wgrad3s: 6 x 3 x 3 tiles of (2,4,8) lattice points per image, odd dims, 2 x 2 block pairs
 ]
 SPEC3 = ["c32_k3", "c64_k3", "c128_k3", "head_cls", "head_reg", "c32_k3_tiles", "c64_k3_tiles"]   # 3x3x3 stride 1
-STRIDED = ["c32to64_s2", "c32to32_s2", "c64_s221", "up_222", "up_221"]                             # strided gathers (fwd or dgrad)
+STRIDED = ["c32to64_s2", "c32to32_s2", "c64_s221", "up_222", "up_221", "c64to128_s2_tiles"]                             # strided gathers (fwd or dgrad)
 POINTWISE = ["lateral", "seg_out", "up_222", "up_221", "up_222_c32", "lateral_c64", "lateral_256to128"]   # k_pw's layers (1x1x1, k = s transposed)
 
 
@@ -121,6 +122,33 @@ def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
     if cfg[1] != 1:
         e = relerr(xg.grad.float(), xr.grad)
         assert e <= tol["dx"], f"dgrad rel err {e:.3e}"
+    e = relerr(m.conv.weight.grad, w.grad)
+    assert e <= tol["dw"], f"wgrad rel err {e:.3e}"
+    if b is not None:
+        e = relerr(m.conv.bias.grad, b.grad)
+        assert e <= tol["dw"], f"bias grad rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("wgs", ["2", "6", "256"], ids=["wgs2", "wgs6", "wgs256"])
+@pytest.mark.parametrize("name", ["c64to128_s2_tiles", "c32to64_s2", "c32_k3_tiles", "c64_k3_tiles", "head_reg"])
+def test_lds_dma_weight_gradient_kernels_tile_walk(name, wgs, dtype, monkeypatch):
+    """k_wgrad3d / k_wgrad3s (csrc/conv_wgrad.hip): persistent workgroups that stage the NEXT tile by LDS-DMA while the current one is
+    in the MFMAs. The tile walk (k_wgrad3s: a mixed-radix increment by the grid size, a full decode for the ragged last round;
+    k_wgrad3d: magic-multiplier decode) is exercised with grids of 1-2 workgroups (many rounds per workgroup, carries in every digit),
+    3-6 (ragged last rounds) and the default; the reference is fp32 torch on the same rounded operands."""
+    monkeypatch.setenv("NNDET_WGRAD3S_WGS", wgs)
+    monkeypatch.setenv("NNDET_WGRAD3D_WGS", wgs)
+    m, x, cfg = _mk(name, dtype)
+    tol = TOL[dtype]
+    xr, w, b, _, _, yref = _ref_forward(m, x, cfg, dtype, None, False)
+    gy = torch.randn_like(yref).to(dtype).float()
+    yref.backward(gy)
+    m = m.cuda()
+    xg = x.detach().clone().cuda().to(dtype).requires_grad_(True)
+    y = m(xg)
+    y.backward(gy.cuda().to(dtype))
+    torch.cuda.synchronize()
     e = relerr(m.conv.weight.grad, w.grad)
     assert e <= tol["dw"], f"wgrad rel err {e:.3e}"
     if b is not None:
