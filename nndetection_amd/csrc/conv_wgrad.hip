@@ -857,6 +857,27 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3d(const WgArgs A, const WgItem
     if ((bx == 0 || bx == 100) && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0)
         printf("wg %d wave %d tiles %d: compute %lld decode %lld wait+barrier %lld cycles per tile\n", bx, wv, t_n, t_comp / t_n, t_dec / t_n, t_bar / t_n);
 #endif
+    // the second point half hands its sums to the first through LDS (both buffers are free now; two rounds of 4 + 3 tap slots, 64 KB):
+    // ONE partial slice per workgroup -- half the partial traffic and half the work of k_wgrad_reduce
+    float* const xch = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        if (half) {
+#pragma unroll
+            for (int ts = rd * 4; ts < (rd ? NTS : 4); ++ts)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[((tq * 4 + (ts - rd * 4)) * 16 + r) * 64 + lane] = acc[ts][r];
+        }
+        __syncthreads();
+        if (!half) {
+#pragma unroll
+            for (int ts = rd * 4; ts < (rd ? NTS : 4); ++ts)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ts][r] += xch[((tq * 4 + (ts - rd * 4)) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (half) return;
     const int n = lane & 31, mh = (lane >> 5) * 4;
     if (do_bias && n == 0) {                        // column 0 of the ones-GEMM
 #pragma unroll
@@ -865,7 +886,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3d(const WgArgs A, const WgItem
             if (m < A.R) atomicAdd(A.dbias + m, acc[NTS - 1][r]);
         }
     }
-    float* part_out = A.part + ((int64_t)(blockIdx.x * 2 + half) * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
+    float* part_out = A.part + ((int64_t)blockIdx.x * (gridDim.y * gridDim.z) + blockIdx.y * gridDim.z + blockIdx.z) * ((int64_t)27 * 1024);
 #pragma unroll
     for (int ts = 0; ts < NTS; ++ts) {
         if (tapw[ts] >= 0) {
@@ -1318,14 +1339,14 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             for (int i = 0; i < 3; ++i) { b.H[i] = st3[i] + 2; b.nt[i] = ceil_div(a.PL[i], st3[i]); }
             b.total_tiles = b.N * b.nt[0] * b.nt[1] * b.nt[2];
             b.m_tpn = magic(b.nt[0] * b.nt[1] * b.nt[2]); b.m_nt2 = magic(b.nt[2]); b.m_nt12 = magic(b.nt[1] * b.nt[2]);
-            if (bf && !b.qss && wgrad3d_on()) {          // LDS-DMA form: two partial slices (point halves) per workgroup
+            if (bf && !b.qss && wgrad3d_on()) {          // LDS-DMA form
                 const int Sd = wgrad3d_slices(rb * kb, b.total_tiles);
-                if (ws_bytes < (size_t)2 * Sd * rb * kb * 27 * 1024 * sizeof(float)) return NNDET_EWORKSPACE;
+                if (ws_bytes < (size_t)Sd * rb * kb * 27 * 1024 * sizeof(float)) return NNDET_EWORKSPACE;
                 const int rcd = hf ? wgrad3d_launch<f16_t, false>(b, g_wg_no_items, dim3(Sd, rb, kb), st)
                                    : wgrad3d_launch<bf16_t, false>(b, g_wg_no_items, dim3(Sd, rb, kb), st);
                 if (rcd) return rcd;
                 const int64_t totald = (int64_t)rb * kb * 27 * 1024;
-                k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totald, 256), ceil_div(2 * Sd, 32)), 256, 0, st>>>(b.part, 2 * Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totald);
+                k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totald, 256), ceil_div(Sd, 32)), 256, 0, st>>>(b.part, Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totald);
                 LAUNCH_CHECK();
                 return 0;
             }
@@ -1448,12 +1469,12 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
     const int rb = b.Cp / 32, kb = b.Cq / 32;
     if (bf && wgrad3d_on()) {
         const int Sd = wgrad3d_slices(rb * kb, b.total_tiles);
-        if (!ws || ws_bytes < (size_t)2 * Sd * rb * kb * 27 * 1024 * sizeof(float)) return NNDET_EWORKSPACE;
+        if (!ws || ws_bytes < (size_t)Sd * rb * kb * 27 * 1024 * sizeof(float)) return NNDET_EWORKSPACE;
         b.part = reinterpret_cast<float*>(ws);
         const int rcd = hf ? wgrad3d_launch<f16_t, true>(b, wi, dim3(Sd, rb, kb), st) : wgrad3d_launch<bf16_t, true>(b, wi, dim3(Sd, rb, kb), st);
         if (rcd) return rcd;
         const int64_t totald = (int64_t)rb * kb * 27 * 1024;
-        k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totald, 256), ceil_div(2 * Sd, 32)), 256, 0, st>>>(b.part, 2 * Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totald);
+        k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totald, 256), ceil_div(Sd, 32)), 256, 0, st>>>(b.part, Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totald);
         LAUNCH_CHECK();
         return 0;
     }
