@@ -171,11 +171,23 @@ def up_param_grads(wc: torch.Tensor, w_up: torch.Tensor, bsum: Optional[torch.Te
     return dw_up, dbsum, ec
 
 
+_compose_cache = {}
+
+
 def _compose_up_branch(params, dt):
     """Everything of the absorbed branch that depends on the parameters only (a few dozen small launches): the composed kernels, the
     constant, the border-class bias and the two packed copies of the half-resolution convolution's weights. On the CURRENT stream."""
     import ctypes
     w_lat, w_out, b_out, w_head, b_head, w_up, b_up, b_lat = params
+    if not torch.is_grad_enabled():                 # inference: the parameters do not change between calls
+        from .conv import _pver
+        key = (dt,) + tuple(_pver(t) if t is not None else None for t in params)
+        if _compose_cache.get("key") == key:
+            return _compose_cache["val"]
+        with torch.enable_grad():                   # (only to take the uncached route below)
+            val = _compose_up_branch(params, dt)
+        _compose_cache["key"], _compose_cache["val"] = key, val
+        return val
     dev = w_out.device
     cout, cin, cin1 = w_out.shape[0], w_out.shape[1], w_up.shape[0]
     wh = w_head.detach().reshape(2, cout).float()
@@ -437,6 +449,7 @@ class DiCESegmenterFgBg(nn.Module):
             raise NotImplementedError("only batch_dice=True, do_bg=False (v001.yaml:101-103) is fused")
         self.conv_out = conv(in_channels[0], self.seg_classes, kernel_size=1, padding=0, add_norm=None, add_act=None, bias=True)
         self.conv_intermediate = None
+        self._zero_target = {}                       # (shape, device) -> uint8 zeros for logit_difference
 
     fused_tail = os.environ.get("NNDET_SEG_TAIL", "1") != "0"      # the scalar algebra on the four sums as one kernel (_SegTail)
 
@@ -479,4 +492,41 @@ class DiCESegmenterFgBg(nn.Module):
         return {"seg_ce": self.alpha * ce, "seg_dice": (1 - self.alpha) * (1 - dc)}
 
     def postprocess_for_inference(self, prediction: Dict[str, Tensor], *args, **kwargs) -> Dict[str, Tensor]:
+        if "seg_logits" not in prediction:                        # the decoder left the whole branch to us (BaseRetinaNet.inference_step)
+            z = self.logit_difference(prediction["seg_input"])
+            p1 = torch.sigmoid(z)                                  # softmax over two logits = (sigmoid(l0 - l1), sigmoid(l1 - l0))
+            return {"pred_seg": torch.stack((torch.sigmoid(-z), p1), dim=1)}
         return {"pred_seg": torch.softmax(prediction["seg_logits"].float(), dim=1)}
+
+    @torch.no_grad()
+    def logit_difference(self, seg_input: Tensor) -> Tensor:
+        """z = l1 - l0 per voxel [N, D, H, W] fp32 of the two segmentation logits from the decoder map the decoder stopped at (level 0 before
+        its output convolution / before its lateral / level 1 before the last top-down step: `_nndet_pre_out`, `_nndet_pre_lat`,
+        `_nndet_pre_up`), by the composed convolution of the training step's fused branch (`_SegBranchFn`, csrc/segbranch.hip) -- the
+        32-channel level-0 maps and the logits never exist. Inference only (round 4): the kernel's loss sums are computed against an
+        all-background target and dropped."""
+        pre = getattr(seg_input, "_nndet_pre_out", None)
+        if pre is None:
+            raise L.NndetError("logit_difference: the decoder did not defer its level-0 output convolution")
+        lat = getattr(seg_input, "_nndet_pre_lat", None)
+        up = getattr(seg_input, "_nndet_pre_up", None) if lat else None
+        ref = lat[1] if lat else seg_input                        # a full-resolution map: the target's shape
+        rp, _ = phys(ref)
+        key = (tuple(rp.shape[:4]), rp.device)
+        tgt = self._zero_target.get(key)
+        if tgt is None:
+            self._zero_target.clear()
+            tgt = self._zero_target[key] = torch.zeros(rp.shape[:4], dtype=torch.uint8, device=rp.device)
+
+        class _Ctx:                                               # what _SegBranchFn.forward stores for its backward pass; z is entry 6
+            needs_input_grad = ()
+            def save_for_backward(self, *t):
+                self.saved = t
+        ctx = _Ctx()
+        if up is not None:
+            _SegBranchFn.forward(ctx, seg_input, lat[1], lat[0].conv.weight, pre.conv.weight, pre.conv.bias, self.conv_out.conv.weight,
+                                 self.conv_out.conv.bias, tgt, up.conv.weight, up.conv.bias, lat[0].conv.bias)
+        else:
+            _SegBranchFn.forward(ctx, seg_input, lat[1] if lat else None, lat[0].conv.weight if lat else None, pre.conv.weight, pre.conv.bias,
+                                 self.conv_out.conv.weight, self.conv_out.conv.bias, tgt)
+        return ctx.saved[6]

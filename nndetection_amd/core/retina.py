@@ -143,7 +143,8 @@ class BaseRetinaNet(nn.Module):
         pred_detection = self.head(feature_maps_head)
         anchors = self.anchor_generator(inp, feature_maps_head)
         pred_seg = None
-        fused = self.segmenter is not None and getattr(self, "_fuse_seg_head", False)
+        fused = self.segmenter is not None and (getattr(self, "_fuse_seg_head", False) or
+                                                (getattr(self, "_seg_infer", False) and getattr(features_maps_all[0], "_nndet_pre_out", None) is not None))
         # does the segmenter consume level 0 on its side stream (fused head + loss, train_step) or on THIS stream (inference,
         # evaluation, NNDET_SEG_FUSED=0, wide level 0)? Decided from what it will actually do, not from a flag a previous step may
         # have left behind: only the former may skip the join with the decoder's tail stream.
@@ -166,8 +167,9 @@ class BaseRetinaNet(nn.Module):
         A training step without prediction (`_fuse_seg_head`), 16-bit activations on the GPU, a plain 32 -> 32 3x3x3 output
         convolution whose result only the 2-class segmenter reads."""
         from ..arch import segmenter as S
-        if not (S.SEG_BRANCH and self.segmenter is not None and getattr(self, "_fuse_seg_head", False) and inp.is_cuda
-                and inp.dtype in (torch.bfloat16, torch.float16) and torch.is_grad_enabled() and self._seg_rank1_ok()):
+        training_step = getattr(self, "_fuse_seg_head", False) and torch.is_grad_enabled()
+        if not (S.SEG_BRANCH and self.segmenter is not None and (training_step or getattr(self, "_seg_infer", False)) and inp.is_cuda
+                and inp.dtype in (torch.bfloat16, torch.float16) and self._seg_rank1_ok()):
             return False
         mod = self.decoder.out["P0"][0]
         seg = self.segmenter
@@ -429,7 +431,16 @@ class BaseRetinaNet(nn.Module):
             scores_are_probs=True)
         return b[0], p[0], l[0]
 
+    # inference_step in 16 bits: the segmentation probabilities come from the training step's composed convolution (decoder level 0 --
+    # output convolution, lateral, last top-down step -- and the logits never exist; arch/segmenter.py: logit_difference).
+    # NNDET_SEG_INFER_FUSED=0: the separate layers.
+    seg_infer_fused = os.environ.get("NNDET_SEG_INFER_FUSED", "1") != "0"
+
     @torch.no_grad()
     def inference_step(self, images: Tensor, **kwargs) -> Dict[str, Any]:
-        pred_detection, anchors, pred_seg = self(images)
+        self._seg_infer = bool(self.seg_infer_fused and not self.training)
+        try:
+            pred_detection, anchors, pred_seg = self(images)
+        finally:
+            self._seg_infer = False
         return self.postprocess_for_inference(images=images, pred_detection=pred_detection, pred_seg=pred_seg, anchors=anchors)

@@ -395,6 +395,55 @@ def test_segmentation_branch_fusion_in_train_step(golden_dir, dtype, monkeypatch
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_inference_step_segmentation_from_the_composed_convolution(golden_dir, dtype, monkeypatch):
+    """inference_step in 16 bits takes the segmentation probabilities from the training step's composed convolution (decoder level 0 and
+    the logits never exist; `FgBgSegmenter.logit_difference`). Same detections as with the separate layers; probabilities no further from
+    the fp32 evaluation than those of the separate 16-bit layers (which round the 32-channel map and the logits) allow; fp32 keeps the
+    separate layers; the composed parameter tensors are cached between calls and rebuilt when a parameter changes."""
+    from nndetection_amd.core.retina import BaseRetinaNet
+    from nndetection_amd import _lib as L
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora).eval()
+    x = torch.from_numpy(gn["x"]).cuda()
+    ref32 = net.inference_step(x)["pred_seg"].double()
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(BaseRetinaNet, "seg_infer_fused", fused)
+        calls.clear()
+        out[fused] = net.inference_step(x.to(dtype))
+        hit = any(c.startswith("nndet_segbranch_forward") for c in calls)
+        assert hit == (fused and dtype != torch.float32), (fused, dtype, hit)
+        assert out[fused]["pred_seg"].shape == ref32.shape and out[fused]["pred_seg"].dtype == torch.float32
+        assert net.decoder.defer_out0 is False and net._seg_infer is False
+    for b in range(x.shape[0]):
+        assert torch.equal(out[True]["pred_boxes"][b], out[False]["pred_boxes"][b]) and torch.equal(out[True]["pred_scores"][b], out[False]["pred_scores"][b])
+    e_f = float((out[True]["pred_seg"].double() - ref32).abs().max())
+    e_s = float((out[False]["pred_seg"].double() - ref32).abs().max())
+    assert float((out[True]["pred_seg"].sum(1) - 1).abs().max()) < 1e-6
+    if dtype == torch.float32:
+        assert e_f == 0.0 and e_s == 0.0
+        return
+    assert e_f <= 1.5 * e_s + 1e-4, (e_f, e_s)
+    # cache: a second call builds nothing; a changed parameter (in place, no version bump: the fused optimizers' route) does
+    from nndetection_amd.arch import segmenter as S
+    from nndetection_amd.arch.conv import bump_param_generation
+    monkeypatch.setattr(BaseRetinaNet, "seg_infer_fused", True)
+    key0 = S._compose_cache.get("key")
+    again = net.inference_step(x.to(dtype))
+    assert torch.equal(again["pred_seg"], out[True]["pred_seg"]) and S._compose_cache.get("key") == key0
+    with torch.no_grad():
+        net.segmenter.conv_out.conv.bias.add_(torch.tensor([0.0, 1.0], device="cuda"))
+    bump_param_generation()
+    moved = net.inference_step(x.to(dtype))["pred_seg"]
+    assert S._compose_cache.get("key") != key0 or not net._seg_up_ok(x.to(dtype))
+    assert float((moved[:, 1] - out[True]["pred_seg"][:, 1]).min()) > 0.0          # every foreground probability went up
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_early_consumer_of_the_stage0_output(golden_dir, dtype, monkeypatch):
     """arch/conv.py EARLY_CONSUMER: the first convolution of encoder stage 1 reads the PRE-norm output of stage 0 (norm + ReLU applied
     while staging, `in_affine`) while the normalised tensor is written on an auxiliary stream. Same arithmetic on the same values: the
