@@ -545,15 +545,20 @@ def torch_rocm_baseline(plan_name, batch, timeout_s=240):
 
 def inference_rate(net, x, iters=5):
     """`inference_step` (forward + fused post-processing: top-k on the logits, decode of the survivors, batched NMS) per image."""
-    with torch.no_grad():
-        net.inference_step(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            out = net.inference_step(x)
-        torch.cuda.synchronize()
+    was_training = net.training
+    net.eval()                                   # as nnDetection's validation / predict loops call it (Lightning puts the module in eval mode)
+    try:
+        with torch.no_grad():
+            net.inference_step(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                out = net.inference_step(x)
+            torch.cuda.synchronize()
+    finally:
+        net.train(was_training)
     dt = (time.perf_counter() - t0) / iters
-    return {"ms_per_image": round(dt * 1e3 / x.shape[0], 3), "batch": int(x.shape[0]),
+    return {"ms_per_image": round(dt * 1e3 / x.shape[0], 3), "batch": int(x.shape[0]), "ms_per_batch": round(dt * 1e3, 3),
             "detections": [int(b.shape[0]) for b in out["pred_boxes"]]}
 
 
