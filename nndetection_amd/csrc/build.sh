@@ -36,6 +36,7 @@ build conv_igemm.hip -mllvm -pragma-unroll-threshold=1000000
 build conv_wgrad.hip
 build conv_pw.hip
 build conv_dgs.hip
+build conv_ig3s.hip
 build conv_stem.hip
 build norm.hip
 build segloss.hip

@@ -25,6 +25,8 @@ int pw_covers(const NndetConv* c, int kind);   // 1 if pw_run would take this pr
 // conv_dgs.hip: data gradient of the strided 3x3x3 convolutions, all parity classes from one staged halo; returns 1 = not covered
 int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st);
 int dgs_covers(const NndetConv* c);
+// conv_ig3s.hip: forward of the 32 -> 64 stride-2 3x3x3 transition (LDS-DMA double buffering, weights in registers); returns 1 = not covered
+int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st);
 // conv_wgrad.hip
 int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias, int* bias_done, void* ws, size_t ws_bytes,
               hipStream_t st);   // bias_done = 1: dbias (may be NULL) was accumulated by the weight-gradient kernel itself

@@ -1,0 +1,255 @@
+// Forward pass of the FIRST stride-2 stage transition (3x3x3, stride (2, 2, 2), pad 1, 32 -> 64 padded channels, 16-bit) for gfx950:
+// k_ig3s, the k_ig3r / k_wgrad3s recipe applied to a strided forward convolution (round 4).
+//
+// k_igemm runs this layer at 0.38 ms (135.9 GFLOP, 786 MB algorithmic = 0.14 of the MFMA peak, 0.26 of HBM) on the SERIAL forward
+// chain: its waves wait on memory 51 % of their cycles (register-staged halo, one tile in flight per workgroup; MFMA pipe busy 15 %,
+// profiles/round4_strided_fwd_pmc.txt). Here
+//   * persistent workgroups (one per CU, 4 waves, one per SIMD) walk 2 x 4 x 8-point output tiles; the 5 x 9 x 17-voxel halo of the
+//     NEXT tile goes global -> LDS by LDS-DMA (48 pieces of 1 KB, 12 per wave, issued under the first MFMAs of the current tile) into
+//     the second 48 KB buffer; lanes outside the tensor use an out-of-range offset and the hardware writes the zero padding;
+//   * halo rows are stored de-interleaved along W (9 even offsets, then 8 odd ones), so the 8 W-points of a row read CONSECUTIVE
+//     voxels for every tap (c = 0 / 2: the even run at slot 0 / 1, c = 1: the odd run);
+//   * ALL weights of a wave's 32 output channels live in registers: 27 taps x 2 input-channel halves x 4 VGPRs = 216 per lane, the
+//     A operands of v_mfma_f32_32x32x16; wave = (output-channel half wv & 1, d-plane of the tile wv >> 1): 54 MFMAs per tile on 4
+//     rotating accumulators, B operands = one ds_read_b128 per MFMA (8 input channels of a voxel), prefetched 3 MFMAs ahead;
+//   * the tile walk is a mixed-radix increment by the grid size (k_wgrad3s);
+//   * epilogue after the tile barrier: sum of the 4 accumulators (+ bias), 16-bit pack, 8-byte stores (each lane holds 4 x 4
+//     consecutive channels of one point); the InstanceNorm statistics of the ROUNDED outputs stay in registers over the tiles of an
+//     image and are flushed once per image (32-lane shuffle reduction, fp64 atomics into the replica table).
+// Other channel counts keep k_igemm: 64 -> 128 and 128 -> 256 need 432 / 1728 weight registers per lane in this form.
+#include "common.h"
+#include "conv_common.h"
+
+struct Ig3sArgs {
+    const void* x; const void* w; const float* bias; void* y; double* stats;
+    int32_t N;
+    int32_t I[3], O[3];          // input / output spatial dims
+    int32_t nt[3], total_tiles;  // (2, 4, 8)-point tiles per axis
+    int32_t gw, gh, gd, gn;      // grid size = gw + nt[2] * (gh + nt[1] * (gd + nt[0] * gn))
+};
+
+__device__ __forceinline__ void ig3s_dma16(__amdgpu_buffer_rsrc_t rs, int voff, uint32_t lds_dst) {
+    // M0 is written in the same statement that reads it; hipcc does not count this load: waited for by hand (vmcnt(0) before the barrier)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ig3s_rsrc(const char* p, int num_records) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(((uint64_t)hi << 32) | lo), 0, num_records, 0x00020000);
+}
+
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    constexpr int RB = 64, CY = 64, TD = 2, TH = 4, HD = 2 * TD + 1, HH = 2 * TH + 1, HW = 17, NEV = 9;
+    constexpr int QROW = HW * RB, QVOX = HD * HH * HW, QPIECES = (QVOX * 4 + 63) / 64, BUF = QPIECES * 1024, NQ = QPIECES / 4;
+    static_assert(QPIECES % 4 == 0, "pieces are dealt to 4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int coh = wv & 1, pth = wv >> 1;                 // output-channel half, d-plane of the tile
+    const int n_pt = lane & 31, kg = lane >> 5;            // MFMA column (point) / 8-channel group of this lane
+    const int rr = n_pt >> 3, pw = n_pt & 7;               // the wave's 32 points = 4 rows x 8 W-points of plane pth
+
+    // ---- weights -> registers: packed mode 0 = [tap][64 rows][32 k] (2-byte elements)
+    u32x4 wr[27][2];
+    {
+        const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.w), 0, 27 * 64 * 32 * 2, 0x00020000);
+#pragma unroll
+        for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+                wr[tp][kh] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, ((coh * 32 + n_pt) * 32 + kh * 16 + kg * 8) * 2, tp * (64 * 32 * 2), 0));
+    }
+    float bia[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bia[r] = A.bias ? A.bias[coh * 32 + (r >> 2) * 8 + kg * 4 + (r & 3)] : 0.f;
+
+    // ---- DMA geometry: piece qp = wv + 4 j: granule G = qp * 64 + lane = halo slot G >> 2 (row-major over 5 x 9 x 17 slots, slot s of a
+    // row = W offset 2 s (s < 9) or 2 (s - 9) + 1), 16-byte part G & 3
+    const int q_rowb = A.I[2] * RB, q_slab = A.I[1] * q_rowb;
+    uint32_t qsel[NQ];          // bit hd | bit 5 + hh | bit 14 + W offset; bit 31 = no such granule
+    int qrel[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int G = (wv + 4 * j) * 64 + lane;
+        const int vox = G >> 2;
+        const int row = vox / HW, sl = vox - row * HW;
+        const int hd = row / HH, hh = row - hd * HH;
+        const int jw = sl < NEV ? 2 * sl : 2 * (sl - NEV) + 1;
+        qsel[j] = vox < QVOX ? (1u << hd) | (1u << (5 + hh)) | (1u << (14 + jw)) : 0x80000000u;
+        qrel[j] = hd * q_slab + hh * q_rowb + jw * RB + (G & 3) * 16;
+    }
+    __amdgpu_buffer_rsrc_t qrs;
+    uint32_t qmask = 0;
+    int c_n = 0, c_d = 0, c_h = 0, c_w = 0;               // mixed-radix coordinates of the tile last decoded (= the one being staged)
+    auto setup = [&]() {
+        const int l0d = c_d * TD, l0h = c_h * TH, l0w = c_w * 8;
+        const int64_t q_org = (int64_t)c_n * A.I[0] * q_slab + (int64_t)(2 * l0d - 1) * q_slab + (2 * l0h - 1) * q_rowb + (2 * l0w - 1) * RB;
+        qrs = ig3s_rsrc(reinterpret_cast<const char*>(A.x) + q_org, 0x7ffffff0);
+        auto rng = [](int lo, int hi) -> uint32_t { return (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u); };   // bits [lo, hi)
+        const uint32_t md = rng(l0d == 0 ? 1 : 0, min(HD, A.I[0] - 2 * l0d + 1));
+        const uint32_t mh = rng(l0h == 0 ? 1 : 0, min(HH, A.I[1] - 2 * l0h + 1));
+        const uint32_t mw = rng(l0w == 0 ? 1 : 0, min(HW, A.I[2] - 2 * l0w + 1));
+        qmask = md | (mh << 5) | (mw << 14);
+    };
+    auto decode = [&](int tile) {
+        const int tpn = A.nt[0] * A.nt[1] * A.nt[2];
+        c_n = tile / tpn;
+        int tt = tile - c_n * tpn;
+        c_w = tt % A.nt[2]; tt /= A.nt[2];
+        c_h = tt % A.nt[1];
+        c_d = tt / A.nt[1];
+        setup();
+    };
+    auto advance = [&]() {                                 // tile += grid size
+        c_w += A.gw; int cy = c_w >= A.nt[2]; c_w -= cy ? A.nt[2] : 0;
+        c_h += A.gh + cy; cy = c_h >= A.nt[1]; c_h -= cy ? A.nt[1] : 0;
+        c_d += A.gd + cy; cy = c_d >= A.nt[0]; c_d -= cy ? A.nt[0] : 0;
+        c_n += A.gn + cy;
+        setup();
+    };
+    auto dma_piece = [&](int j, int buf) {
+        const bool ok = (qsel[j] & qmask) == qsel[j];
+        ig3s_dma16(qrs, ok ? qrel[j] : (int)0x80000000, (uint32_t)__builtin_amdgcn_readfirstlane(buf * BUF + (wv + 4 * j) * 1024));
+    };
+
+    // ---- fragment base: point (plane pth, row rr, column pw) at tap (0, 0, 0) = halo row (2 pth, 2 rr), even slot pw; 8 channels kg
+    const int q_lane = ((2 * pth) * HH + 2 * rr) * QROW + pw * RB + kg * 16;
+    f32x16_t acc[4];
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+
+    auto compute = [&](int buf, bool stage) {
+        constexpr int U = 54, QD_ = 3;
+        const char* const qb = smem + buf * BUF + q_lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        u32x4 bf[QD_ + 1];
+        auto load_b = [&](int u) -> u32x4 {
+            const int tp = u >> 1, kh = u & 1;
+            const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
+            return *reinterpret_cast<const u32x4*>(qb + (a * HH + b) * QROW + (c == 1 ? NEV * RB : c == 2 ? RB : 0) + kh * 32);
+        };
+#pragma unroll
+        for (int u0 = 0; u0 < QD_; ++u0) bf[u0] = load_b(u0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u + QD_ < U) bf[(u + QD_) % (QD_ + 1)] = load_b(u + QD_);
+            if (u < NQ && stage) dma_piece(u, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[u & 3] = H16<T>::mma32(wr[u >> 1][u & 1], bf[u % (QD_ + 1)], acc[u & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // statistics of image n: sum over the 32 points (lanes with the same kg), fp64 atomics into this workgroup's replica
+    auto flush_stats = [&](int n) {
+        if constexpr (STATS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = ssum[r], s2 = ssq[r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (n_pt == 0) {
+                    const int co = coh * 32 + (r >> 2) * 8 + kg * 4 + (r & 3);
+                    double* dst = A.stats + (((int64_t)(blockIdx.x % NNDET_STATS_REPLICAS) * A.N + n) * CY + co) * 2;
+                    atomicAdd(dst, (double)s); atomicAdd(dst + 1, (double)s2);
+                }
+                ssum[r] = 0.f; ssq[r] = 0.f;
+            }
+        }
+    };
+    int st_n = -1;                                          // image the register statistics belong to
+    auto epilogue = [&](int n, int td, int th, int tw) {
+        if (STATS && n != st_n) { if (st_n >= 0) flush_stats(st_n); st_n = n; }
+        const int od = td * TD + pth, oh = th * TH + rr, ow = tw * 8 + pw;
+        const bool valid = od < A.O[0] && oh < A.O[1] && ow < A.O[2];
+        T* const yp = reinterpret_cast<T*>(A.y) + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * CY + coh * 32 + kg * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (acc[0][g * 4 + i] + acc[1][g * 4 + i]) + (acc[2][g * 4 + i] + acc[3][g * 4 + i]) + bia[g * 4 + i];
+            uint2 pk;
+            pk.x = H16<T>::pack2(v[0], v[1]); pk.y = H16<T>::pack2(v[2], v[3]);
+            if (valid) {
+                *reinterpret_cast<uint2*>(yp + g * 8) = pk;
+                if constexpr (STATS) {                        // of the ROUNDED values (what the norm kernels will read)
+                    const float r0 = H16<T>::lo(pk.x), r1 = H16<T>::hi(pk.x), r2 = H16<T>::lo(pk.y), r3 = H16<T>::hi(pk.y);
+                    ssum[g * 4 + 0] += r0; ssum[g * 4 + 1] += r1; ssum[g * 4 + 2] += r2; ssum[g * 4 + 3] += r3;
+                    ssq[g * 4 + 0] += r0 * r0; ssq[g * 4 + 1] += r1 * r1; ssq[g * 4 + 2] += r2 * r2; ssq[g * 4 + 3] += r3 * r3;
+                }
+            }
+        }
+    };
+
+    const int G = gridDim.x, bx = blockIdx.x;
+    auto perm = [&](int cnt) { return (cnt & 7) ? bx : (bx & 7) * (cnt >> 3) + (bx >> 3); };   // xcd_compact within a round
+    const int full = A.total_tiles / G, rest = A.total_tiles - full * G;
+    const int pfull = perm(G);
+    auto exists = [&](int k) { return k < full || (k == full && bx < rest); };
+    auto to_round = [&](int k) {                               // decode round k's tile of this workgroup (if it has one)
+        if (k < full) { if (k == 0) decode(pfull); else advance(); }
+        else if (k == full && bx < rest) decode(full * G + perm(rest));
+    };
+    if (!exists(0)) return;
+    to_round(0);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) dma_piece(j, 0);
+    int cur_n = c_n, cur_d = c_d, cur_h = c_h, cur_w = c_w;   // coordinates of the tile in the MFMAs
+    to_round(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int k = 0; exists(k); ++k) {
+        const bool nx = exists(k + 1);
+        compute(buf, nx);
+        const int e_n = cur_n, e_d = cur_d, e_h = cur_h, e_w = cur_w;
+        cur_n = c_n; cur_d = c_d; cur_h = c_h; cur_w = c_w;   // (the scalars of round k + 1, decoded before this phase)
+        if (nx) to_round(k + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                      // every wave is done reading `buf`, the next halo has landed in the other buffer
+        epilogue(e_n, e_d, e_h, e_w);                         // (after the barrier: its stores are not waited for by the next one's vmcnt(0) ... they are, 54 MFMAs later)
+        buf ^= 1;
+    }
+    if (STATS && st_n >= 0) flush_stats(st_n);
+}
+
+// returns 1 = not covered (the caller goes on to k_igemm)
+int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st) {
+    static const int on = getenv("NNDET_IG3S") ? atoi(getenv("NNDET_IG3S")) : 1;
+    if (!on || kind != 0 || res || c->transposed || c->in_affine || !nndet_is16(c->dtype) || c->cin_p != 32 || c->cout_p != 64) return 1;
+    for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 2 || c->p[i] != 1) return 1;
+    const int64_t xb = (int64_t)c->in_d * c->in_h * c->in_w * 64;
+    if (xb >= (1LL << 31) || c->batch <= 0) return 1;
+    Ig3sArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.N = c->batch;
+    a.I[0] = c->in_d; a.I[1] = c->in_h; a.I[2] = c->in_w;
+    a.O[0] = c->out_d; a.O[1] = c->out_h; a.O[2] = c->out_w;
+    a.nt[0] = ceil_div(a.O[0], 2); a.nt[1] = ceil_div(a.O[1], 4); a.nt[2] = ceil_div(a.O[2], 8);
+    a.total_tiles = a.N * a.nt[0] * a.nt[1] * a.nt[2];
+    const int wgs = getenv("NNDET_IG3S_WGS") ? atoi(getenv("NNDET_IG3S_WGS")) : 256;      // (read per call: the tests vary it)
+    int G = wgs < 1 || wgs > 256 ? 256 : wgs;
+    if (G > a.total_tiles) G = a.total_tiles;
+    int g = G;
+    a.gw = g % a.nt[2]; g /= a.nt[2];
+    a.gh = g % a.nt[1]; g /= a.nt[1];
+    a.gd = g % a.nt[0]; a.gn = g / a.nt[0];
+    constexpr size_t lds = 2 * 48 * 1024;
+    static bool at = false;
+    if (!at) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        at = true;
+    }
+    if (c->dtype == NNDET_F16) { if (stats) k_ig3s<f16_t, true><<<G, 256, lds, st>>>(a); else k_ig3s<f16_t, false><<<G, 256, lds, st>>>(a); }
+    else { if (stats) k_ig3s<bf16_t, true><<<G, 256, lds, st>>>(a); else k_ig3s<bf16_t, false><<<G, 256, lds, st>>>(a); }
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -1590,6 +1590,10 @@ int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const 
         const int drc = dgs_run(c, x, w, res, y, st);
         if (drc != 1) return drc;
     }
+    if (kind == 0) {                                                    // forward of the 32 -> 64 stride-2 transition: k_ig3s
+        const int src = ig3s_run(c, kind, x, w, bias, res, y, stats, st);
+        if (src != 1) return src;
+    }
     Plan P;
     int rc = build_plan(c, kind, &P);
     if (rc) return rc;

@@ -38,9 +38,10 @@ CONVS = [
     ("c32_k3_tiles", 32, 32, 3, 1, 1, False, (17, 16, 9)),      # several (8,8,8) tiles of k_ig3 + ragged edges in every axis
     ("c64_k3_tiles", 64, 64, 3, 1, 1, False, (9, 17, 16)),      # several (4,8,8) tiles, 2 K-chunks
     ("c64to128_s2_tiles", 64, 128, 3, 2, 1, False, (21, 19, 35)),   # k_wgrad3s: 6 x 3 x 3 tiles of (2,4,8) lattice points per image, odd dims, 2 x 2 block pairs
+    ("c32to64_s2_tiles", 32, 64, 3, 2, 1, False, (21, 19, 35)),     # k_ig3s (forward) + k_wgrad3s: the same tiling for the 32 -> 64 transition
 ]
 SPEC3 = ["c32_k3", "c64_k3", "c128_k3", "head_cls", "head_reg", "c32_k3_tiles", "c64_k3_tiles"]   # 3x3x3 stride 1
-STRIDED = ["c32to64_s2", "c32to32_s2", "c64_s221", "up_222", "up_221", "c64to128_s2_tiles"]                             # strided gathers (fwd or dgrad)
+STRIDED = ["c32to64_s2", "c32to32_s2", "c64_s221", "up_222", "up_221", "c64to128_s2_tiles", "c32to64_s2_tiles"]                             # strided gathers (fwd or dgrad)
 POINTWISE = ["lateral", "seg_out", "up_222", "up_221", "up_222_c32", "lateral_c64", "lateral_256to128"]   # k_pw's layers (1x1x1, k = s transposed)
 
 
@@ -131,7 +132,7 @@ def test_conv_fwd_bwd(name, spec, dtype, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("wgs", ["2", "6", "256"], ids=["wgs2", "wgs6", "wgs256"])
-@pytest.mark.parametrize("name", ["c64to128_s2_tiles", "c32to64_s2", "c32_k3_tiles", "c64_k3_tiles", "head_reg"])
+@pytest.mark.parametrize("name", ["c64to128_s2_tiles", "c32to64_s2", "c32to64_s2_tiles", "c32_k3_tiles", "c64_k3_tiles", "head_reg"])
 def test_lds_dma_weight_gradient_kernels_tile_walk(name, wgs, dtype, monkeypatch):
     """k_wgrad3d / k_wgrad3s (csrc/conv_wgrad.hip): persistent workgroups that stage the NEXT tile by LDS-DMA while the current one is
     in the MFMAs. The tile walk (k_wgrad3s: a mixed-radix increment by the grid size, a full decode for the ragged last round;
@@ -139,6 +140,7 @@ def test_lds_dma_weight_gradient_kernels_tile_walk(name, wgs, dtype, monkeypatch
     3-6 (ragged last rounds) and the default; the reference is fp32 torch on the same rounded operands."""
     monkeypatch.setenv("NNDET_WGRAD3S_WGS", wgs)
     monkeypatch.setenv("NNDET_WGRAD3D_WGS", wgs)
+    monkeypatch.setenv("NNDET_IG3S_WGS", wgs)             # k_ig3s (forward of the 32 -> 64 transition) walks its tiles the same way
     m, x, cfg = _mk(name, dtype)
     tol = TOL[dtype]
     xr, w, b, _, _, yref = _ref_forward(m, x, cfg, dtype, None, False)
@@ -147,6 +149,8 @@ def test_lds_dma_weight_gradient_kernels_tile_walk(name, wgs, dtype, monkeypatch
     m = m.cuda()
     xg = x.detach().clone().cuda().to(dtype).requires_grad_(True)
     y = m(xg)
+    e = relerr(y.float(), yref)
+    assert e <= tol["fwd"], f"forward rel err {e:.3e}"
     y.backward(gy.cuda().to(dtype))
     torch.cuda.synchronize()
     e = relerr(m.conv.weight.grad, w.grad)
@@ -157,7 +161,7 @@ def test_lds_dma_weight_gradient_kernels_tile_walk(name, wgs, dtype, monkeypatch
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name,norm", [("c32_k3", "instance"), ("c64_k3", "instance"), ("c32to64_s2", "instance"),
+@pytest.mark.parametrize("name,norm", [("c32_k3", "instance"), ("c64_k3", "instance"), ("c32to64_s2", "instance"), ("c32to64_s2_tiles", "instance"),
                                         ("stem", "instance"), ("c128_k3", "group"), ("c64_k3", "group")])
 def test_conv_norm_relu_block(name, norm, dtype):
     m, x, cfg = _mk(name, dtype, norm, True)
