@@ -1,5 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels. Written for CDNA4 only (wave = 64).
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/nndet_amd.h"
@@ -116,6 +118,16 @@ template <> struct H16<float> {   // never used: keeps discarded `if constexpr (
     __device__ static __forceinline__ f32x4 mma(const u32x4&, const u32x4&, const f32x4& c) { return c; }
     __device__ static __forceinline__ f32x16_t mma32(const u32x4&, const u32x4&, const f32x16_t& c) { return c; }
 };
+
+// Timing experiments that leave work out (the results are WRONG): honoured only together with NNDET_TIMING_EXPERIMENTS=1, announced once.
+static inline int nndet_timing_experiment(const char* name) {
+    const char* v = getenv(name);
+    if (!v || !atoi(v)) return 0;
+    const char* gate = getenv("NNDET_TIMING_EXPERIMENTS");
+    if (!gate || atoi(gate) != 1) return 0;
+    fprintf(stderr, "nndet_amd: timing experiment %s=%s is active -- results of this process are WRONG by design\n", name, v);
+    return atoi(v);
+}
 
 // run `F<T>` for the activation type a dtype code names (NNDET_F32 / NNDET_BF16 / NNDET_F16)
 #define NNDET_DISPATCH_DTYPE(dt, CALL)                                      \

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
 
 // returns 1 = not covered (the caller goes on to k_igemm)
 int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st) {
-    static const int on = getenv("NNDET_IG3S") ? atoi(getenv("NNDET_IG3S")) : 1;
+    const int on = getenv("NNDET_IG3S") ? atoi(getenv("NNDET_IG3S")) : 1;       // (read per call: tests compare routes that must share their kernels)
     if (!on || kind != 0 || res || c->transposed || c->in_affine || !nndet_is16(c->dtype) || c->cin_p != 32 || c->cout_p != 64) return 1;
     for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 2 || c->p[i] != 1) return 1;
     const int64_t xb = (int64_t)c->in_d * c->in_h * c->in_w * 64;

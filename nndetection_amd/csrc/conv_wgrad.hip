@@ -1332,7 +1332,7 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
         if ((ps <= 1.05 * pg || spec_on == 2) && pb < (1LL << 31) && qb < (1LL << 31)) {
             WgArgs b = a;
             b.TD = 4; b.TH = 8;
-            static const int dbg = getenv("NNDET_WGRAD3_DBG") ? atoi(getenv("NNDET_WGRAD3_DBG")) : 0;
+            static const int dbg = nndet_timing_experiment("NNDET_WGRAD3_DBG");
             b.dbg = dbg;
             b.dbias = dbias;                  // P = dY here (not transposed): the kernel also produces the bias gradient
             *bias_done = dbias != nullptr;
@@ -1375,7 +1375,7 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             return 0;
         }
     }
-    static const int dbg_skip_s = getenv("NNDET_WGRAD_DBG_SKIP_STRIDED") ? atoi(getenv("NNDET_WGRAD_DBG_SKIP_STRIDED")) : 0;   // timing experiment (wrong results)
+    static const int dbg_skip_s = nndet_timing_experiment("NNDET_WGRAD_DBG_SKIP_STRIDED");
     if (dbg_skip_s && strided && T == 27) return 0;
     // stride (2, 2, 2) / 3x3x3 / pad 1 in 16 bits, an even number of row blocks, no deferred input norm: k_wgrad3s (NNDET_WGRAD3S=0: off)
     static const int s3 = getenv("NNDET_WGRAD3S") ? atoi(getenv("NNDET_WGRAD3S")) : 1;

@@ -525,7 +525,7 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     const int rr = red_rows(spatial * batch);
     dim3 rgrid((unsigned)ceil_div64(spatial, rr), batch);
     const size_t lds = (size_t)c_p * 16;
-    static const int dbg_skip = getenv("NNDET_NORM_DBG_SKIP_REDUCE") ? atoi(getenv("NNDET_NORM_DBG_SKIP_REDUCE")) : 0;   // timing experiment (wrong results)
+    static const int dbg_skip = nndet_timing_experiment("NNDET_NORM_DBG_SKIP_REDUCE");
     if (dbg_skip) {}
     else if (dtype == NNDET_BF16)
         k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
@@ -559,7 +559,7 @@ extern "C" int nndet_norm_backward_items(int32_t dtype, const void* x, const voi
     const int rr = red_rows(total);
     dim3 rgrid((unsigned)ceil_div64(mx, rr), ni.n);
     const size_t lds = (size_t)c_p * 16;
-    static const int dbg_skip = getenv("NNDET_NORM_DBG_SKIP_REDUCE") ? atoi(getenv("NNDET_NORM_DBG_SKIP_REDUCE")) : 0;
+    static const int dbg_skip = nndet_timing_experiment("NNDET_NORM_DBG_SKIP_REDUCE");
     if (dbg_skip) {}
     else if (dtype == NNDET_BF16)
         k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
