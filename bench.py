@@ -463,7 +463,7 @@ def cpu_baseline(plan, device=None, batch=2):
             tgd = {"target_boxes": [b.to(device) for b in tg["target_boxes"]], "target_classes": [c.to(device) for c in tg["target_classes"]],
                    "target_seg": tg["target_seg"].to(device)}
             lg, _ = hip.train_step(x.to(device), tgd, evaluation=False)
-            lc = {k: float(v) for k, v in losses.items()}
+            lc = {k: float(v.detach()) for k, v in losses.items()}
             lgv = {k: float(v) for k, v in lg.items()}
             diff = max(abs(lc[k] - lgv[k]) for k in lc)
             parity = {"what": "losses of the HIP fp32 kernels vs the CPU oracle on the cpu_baseline batch of %d patches (same weights, same sampler permutation)" % batch,
