@@ -19,7 +19,10 @@ __device__ __forceinline__ float f32_unsortable(uint32_t u) {
 // One wave per problem: given the 256-bin histogram `h` of the current digit among the keys matching `prefix`, choose the
 // bin holding the krem-th smallest key, append the digit to the prefix, reduce krem to the rank inside the bin and clear
 // the histogram. Lane = 4 consecutive bins; wave-wide inclusive scan with shuffles.
-__device__ __forceinline__ void radix_pick_wave(u64* prefix, int* krem, unsigned* h, int shift, int lane) {
+// `done` (optional): set to 1 when the chosen bin is taken WHOLE (its count equals the remaining rank): the lower digits cannot change
+// the selection any more, the prefix gets all-ones below `shift` (= the largest key of the bin) and the caller's remaining histogram
+// passes may return at once. Typical for keys whose high 32 bits are (nearly) unique -- scores, hashes -- over 32 bits of index.
+__device__ __forceinline__ void radix_pick_wave(u64* prefix, int* krem, unsigned* h, int shift, int lane, int* done = nullptr) {
     const uint4 c = reinterpret_cast<const uint4*>(h)[lane];
     const unsigned mine = c.x + c.y + c.z + c.w;
     unsigned incl = mine;
@@ -46,7 +49,12 @@ __device__ __forceinline__ void radix_pick_wave(u64* prefix, int* krem, unsigned
             b = k2 + 1;
         }
         if (b > 3) b = 3;
-        *prefix |= ((u64)(lane * 4 + b)) << shift;
+        u64 add = ((u64)(lane * 4 + b)) << shift;
+        if (done && shift > 0 && rem - cum == cc[b]) {
+            add |= (((u64)1) << shift) - 1;
+            *done = 1;
+        }
+        *prefix |= add;
         *krem = (int)(rem - cum);
     }
     reinterpret_cast<uint4*>(h)[lane] = make_uint4(0u, 0u, 0u, 0u);

@@ -86,10 +86,14 @@ __global__ void k_sp_derive(SpArgs A, int32_t* params, int* krem) {
     if (num_neg > pool) num_neg = pool;
     params[2] = num_pos; params[3] = num_neg; params[4] = pool;
     krem[0] = num_pos; krem[1] = pool;
+    krem[2] = 0; krem[3] = 0;                 // "selection decided" flags of the two problems (radix_pick_wave)
 }
 
 // two problems in one pass over the anchors: 0 = positives by selection key, 1 = negatives by (probability desc, index)
-__global__ __launch_bounds__(256) void k_sp_hist(SpArgs A, const u64* __restrict__ prefix, unsigned* __restrict__ hist, int shift) {
+__global__ __launch_bounds__(256) void k_sp_hist(SpArgs A, const u64* __restrict__ prefix, unsigned* __restrict__ hist, int shift,
+                                                 const int* __restrict__ done) {
+    const bool d0 = done[0] != 0, d1 = done[1] != 0;     // a problem whose selection is decided takes no part in the remaining passes
+    if (d0 && d1) return;                                 // (scores / hashes are nearly unique: usually after the 4 passes over them)
     __shared__ unsigned h[2][256];
     h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
     __syncthreads();
@@ -101,9 +105,11 @@ __global__ __launch_bounds__(256) void k_sp_hist(SpArgs A, const u64* __restrict
         if (i < A.N) {
             const float l = A.labels[i];
             if (l >= 1.f) {
-                const u64 key = sp_key_pos(A, (uint32_t)i);
-                if ((shift >= 56) || ((key >> (shift + 8)) == (p0 >> (shift + 8)))) atomicAdd(&h[0][(unsigned)(key >> shift) & 255u], 1u);
-            } else if (l == 0.f) {
+                if (!d0) {
+                    const u64 key = sp_key_pos(A, (uint32_t)i);
+                    if ((shift >= 56) || ((key >> (shift + 8)) == (p0 >> (shift + 8)))) atomicAdd(&h[0][(unsigned)(key >> shift) & 255u], 1u);
+                }
+            } else if (l == 0.f && !d1) {
                 const u64 key = sp_key_neg(A, i);
                 if ((shift >= 56) || ((key >> (shift + 8)) == (p1 >> (shift + 8)))) atomicAdd(&h[1][(unsigned)(key >> shift) & 255u], 1u);
             }
@@ -117,7 +123,8 @@ __global__ __launch_bounds__(256) void k_sp_hist(SpArgs A, const u64* __restrict
 
 __global__ __launch_bounds__(128) void k_sp_pick(u64* __restrict__ prefix, int* __restrict__ krem, unsigned* __restrict__ hist, int shift) {
     const int i = threadIdx.x >> 6;
-    radix_pick_wave(prefix + i, krem + i, hist + i * 256, shift, threadIdx.x & 63);
+    if (krem[2 + i]) return;                              // decided in an earlier pass (its histogram stayed empty)
+    radix_pick_wave(prefix + i, krem + i, hist + i * 256, shift, threadIdx.x & 63, krem + 2 + i);
 }
 
 __global__ __launch_bounds__(256) void k_sp_collect(SpArgs A, const u64* __restrict__ kth, int32_t* __restrict__ params,
@@ -256,7 +263,7 @@ extern "C" int nndet_hnm_sample_f32(const float* labels, const float* scores, in
     while (((int64_t)1 << idx_bits) < N) ++idx_bits;
     for (int shift = 56; shift >= 0; shift -= 8) {
         if (shift < 32 && shift >= idx_bits) continue;
-        k_sp_hist<<<nb, 256, 0, st>>>(A, w.prefix, w.hist, shift);
+        k_sp_hist<<<nb, 256, 0, st>>>(A, w.prefix, w.hist, shift, w.krem + 2);
         LAUNCH_CHECK();
         k_sp_pick<<<1, 128, 0, st>>>(w.prefix, w.krem, w.hist, shift);
         LAUNCH_CHECK();
