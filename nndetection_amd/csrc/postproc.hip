@@ -50,13 +50,15 @@ __device__ __forceinline__ u64 pp_key(float score, uint32_t idx) {
 __global__ void k_pp_init(int B, int K, u64* prefix, int* krem, int* cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    prefix[i] = 0; krem[i] = K; cnt[i] = 0;
+    prefix[i] = 0; krem[i] = K; krem[B + i] = 0; cnt[i] = 0;
 }
 
 // grid (ceil(MC / (256 * PP_ITEMS)), B)
-__global__ __launch_bounds__(256) void k_pp_hist(PpArgs A, const u64* __restrict__ prefix, unsigned* __restrict__ hist, int shift) {
+__global__ __launch_bounds__(256) void k_pp_hist(PpArgs A, const u64* __restrict__ prefix, unsigned* __restrict__ hist, int shift,
+                                                 const int* __restrict__ done) {
     __shared__ unsigned h[256];
     const int b = blockIdx.y;
+    if (done[b]) return;                         // the K-th key of this image is decided (scores are nearly unique: after the 4 score passes)
     h[threadIdx.x] = 0;
     __syncthreads();
     const u64 pre = prefix[b];
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(256) void k_pp_pick(int B, u64* __restrict__ prefix
                                                  unsigned* __restrict__ hist, int shift) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
-    radix_pick_wave(prefix + i, krem + i, hist + (int64_t)i * 256, shift, threadIdx.x & 63);
+    if (krem[B + i]) return;                     // decided in an earlier pass: its histogram stayed empty (radix_select.h)
+    radix_pick_wave(prefix + i, krem + i, hist + (int64_t)i * 256, shift, threadIdx.x & 63, krem + B + i);
 }
 
 // every key <= the K-th smallest goes into the candidate list (exactly K per image: keys are distinct).
@@ -284,7 +287,7 @@ static int pp_layout(int B, int K, char* base, PpWs* w) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t BK = (size_t)B * K;
-    size_t o_p = take((size_t)B * 8), o_k = take((size_t)B * 4), o_c = take((size_t)B * 4), o_h = take((size_t)B * 256 * 4);
+    size_t o_p = take((size_t)B * 8), o_k = take((size_t)B * 8) /* ranks + "decided" flags */, o_c = take((size_t)B * 4), o_h = take((size_t)B * 256 * 4);
     size_t o_so = take((size_t)(B + 1) * 4);
     size_t o_ca = take(BK * 8), o_cs = take(BK * 8), o_cb = take(BK * 24), o_sc = take(BK * 4), o_cl = take(BK * 4), o_ci = take(BK * 4), o_nb = take(BK * 24);
     size_t o_nv = take((size_t)B * 8), o_mx = take((size_t)B * 4), o_kp = take(BK * 8), o_nk = take((size_t)B * 8);
@@ -386,7 +389,7 @@ static int pp_run(const float* scores, int32_t scores_are_probs, const float* de
         while (((int64_t)1 << idx_bits) < A.MC) ++idx_bits;
         for (int shift = 56; shift >= 0; shift -= 8) {
             if (shift < 32 && shift >= idx_bits) continue;   // index digits above the highest set bit are zero for every key
-            k_pp_hist<<<grid, 256, 0, st>>>(A, w.prefix, w.hist, shift);
+            k_pp_hist<<<grid, 256, 0, st>>>(A, w.prefix, w.hist, shift, w.krem + B);
             LAUNCH_CHECK();
             k_pp_pick<<<ceil_div(B, 4), 256, 0, st>>>(B, w.prefix, w.krem, w.hist, shift);
             LAUNCH_CHECK();
