@@ -218,12 +218,189 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
     if (STATS && st_n >= 0) flush_stats(st_n);
 }
 
+// ------------------------------------------------------------------------------------------------ 64 input channels
+// k_ig3s2: the SECOND stride-2 transition (64 -> 128 padded channels: 0.23 ms in k_igemm on the serial forward chain). Two 32-channel
+// chunks of the input: the weights of a wave's 16 output channels for both chunks are 27 x 2 x 4 = 216 registers (A operands of
+// v_mfma_f32_16x16x32), a workgroup = 4 waves = 64 output channels (blockIdx.y picks the block of 64; the input is read once per
+// block). The pipeline unit is (tile, chunk): while the 108 MFMAs of chunk c of a tile run out of one 48 KB buffer, the halo of the next
+// unit -- chunk 1 of the same tile, then chunk 0 of the next tile -- lands in the other one; the accumulators (4 point tiles of 16)
+// live across the two chunks, the epilogue follows the second. Everything else as k_ig3s.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256, 1) void k_ig3s2(const Ig3sArgs A, int cout_p) {
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    constexpr int RB = 64, CX = 64, TD = 2, TH = 4, HD = 2 * TD + 1, HH = 2 * TH + 1, HW = 17, NEV = 9;
+    constexpr int QROW = HW * RB, QVOX = HD * HH * HW, QPIECES = (QVOX * 4 + 63) / 64, BUF = QPIECES * 1024, NQ = QPIECES / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.y * 64 + wv * 16;             // this wave's 16 output channels
+
+    // ---- weights -> registers: packed mode 0 = [tap][cout_p rows][64 k]
+    u32x4 wr[27][2];
+    {
+        const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.w), 0, 27 * cout_p * CX * 2, 0x00020000);
+#pragma unroll
+        for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                wr[tp][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, ((row0 + li) * CX + c * 32 + q * 8) * 2, tp * (cout_p * CX * 2), 0));
+    }
+    float bia[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bia[r] = A.bias ? A.bias[row0 + q * 4 + r] : 0.f;
+
+    const int q_rowb = A.I[2] * CX * 2, q_slab = A.I[1] * q_rowb;
+    uint32_t qsel[NQ];
+    int qrel[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int G = (wv + 4 * j) * 64 + lane;
+        const int vox = G >> 2;
+        const int row = vox / HW, sl = vox - row * HW;
+        const int hd = row / HH, hh = row - hd * HH;
+        const int jw = sl < NEV ? 2 * sl : 2 * (sl - NEV) + 1;
+        qsel[j] = vox < QVOX ? (1u << hd) | (1u << (5 + hh)) | (1u << (14 + jw)) : 0x80000000u;
+        qrel[j] = hd * q_slab + hh * q_rowb + jw * (CX * 2) + (G & 3) * 16;
+    }
+    __amdgpu_buffer_rsrc_t qrs0, qrs1;                      // the two channel chunks of the decoded tile's halo
+    uint32_t qmask = 0;
+    int c_n = 0, c_d = 0, c_h = 0, c_w = 0;
+    auto setup = [&]() {
+        const int l0d = c_d * TD, l0h = c_h * TH, l0w = c_w * 8;
+        const int64_t q_org = (int64_t)c_n * A.I[0] * q_slab + (int64_t)(2 * l0d - 1) * q_slab + (2 * l0h - 1) * q_rowb + (2 * l0w - 1) * (CX * 2);
+        qrs0 = ig3s_rsrc(reinterpret_cast<const char*>(A.x) + q_org, 0x7ffffff0);
+        qrs1 = ig3s_rsrc(reinterpret_cast<const char*>(A.x) + q_org + 64, 0x7ffffff0);
+        auto rng = [](int lo, int hi) -> uint32_t { return (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u); };
+        const uint32_t md = rng(l0d == 0 ? 1 : 0, min(HD, A.I[0] - 2 * l0d + 1));
+        const uint32_t mh = rng(l0h == 0 ? 1 : 0, min(HH, A.I[1] - 2 * l0h + 1));
+        const uint32_t mw = rng(l0w == 0 ? 1 : 0, min(HW, A.I[2] - 2 * l0w + 1));
+        qmask = md | (mh << 5) | (mw << 14);
+    };
+    auto decode = [&](int tile) {
+        const int tpn = A.nt[0] * A.nt[1] * A.nt[2];
+        c_n = tile / tpn;
+        int tt = tile - c_n * tpn;
+        c_w = tt % A.nt[2]; tt /= A.nt[2];
+        c_h = tt % A.nt[1];
+        c_d = tt / A.nt[1];
+        setup();
+    };
+    auto advance = [&]() {
+        c_w += A.gw; int cy = c_w >= A.nt[2]; c_w -= cy ? A.nt[2] : 0;
+        c_h += A.gh + cy; cy = c_h >= A.nt[1]; c_h -= cy ? A.nt[1] : 0;
+        c_d += A.gd + cy; cy = c_d >= A.nt[0]; c_d -= cy ? A.nt[0] : 0;
+        c_n += A.gn + cy;
+        setup();
+    };
+    auto dma_piece = [&](int j, int buf, int chunk) {
+        const bool ok = (qsel[j] & qmask) == qsel[j];
+        ig3s_dma16(chunk ? qrs1 : qrs0, ok ? qrel[j] : (int)0x80000000, (uint32_t)__builtin_amdgcn_readfirstlane(buf * BUF + (wv + 4 * j) * 1024));
+    };
+
+    // point tile j = lattice rows 2 j, 2 j + 1 of the tile's 8 rows (plane j >> 1, rows 2 (j & 1) + (li >> 3)), column li & 7
+    const int q_lane = ((li >> 3) * 2) * QROW + (li & 7) * RB + q * 16;
+    f32x4 acc[4];
+    float ssum[4], ssq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+
+    // MFMAs of chunk `chunk` out of buffer `buf`; `stage`: the pieces of chunk `nchunk` of the decoded tile go into the other buffer
+    auto compute = [&](int buf, int chunk, bool stage, int nchunk) {
+        constexpr int U = 27 * 4, QD_ = 4;
+        const char* const qb = smem + buf * BUF + q_lane;
+        u32x4 bf[QD_ + 1];
+        auto load_b = [&](int u) -> u32x4 {
+            const int tp = u >> 2, j = u & 3;
+            const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
+            return *reinterpret_cast<const u32x4*>(qb + ((2 * (j >> 1) + a) * HH + 4 * (j & 1) + b) * QROW + (c == 1 ? NEV * RB : c == 2 ? RB : 0));
+        };
+#pragma unroll
+        for (int u0 = 0; u0 < QD_; ++u0) bf[u0] = load_b(u0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u + QD_ < U) bf[(u + QD_) % (QD_ + 1)] = load_b(u + QD_);
+            if (u < NQ && stage) dma_piece(u, buf ^ 1, nchunk);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[u & 3] = H16<T>::mma(chunk ? wr[u >> 2][1] : wr[u >> 2][0], bf[u % (QD_ + 1)], acc[u & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto flush_stats = [&](int n) {
+        if constexpr (STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[r], s2 = ssq[r];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (li == 0) {
+                    double* dst = A.stats + (((int64_t)(blockIdx.x % NNDET_STATS_REPLICAS) * A.N + n) * cout_p + row0 + q * 4 + r) * 2;
+                    atomicAdd(dst, (double)s); atomicAdd(dst + 1, (double)s2);
+                }
+                ssum[r] = 0.f; ssq[r] = 0.f;
+            }
+        }
+    };
+    int st_n = -1;
+    auto epilogue = [&](int n, int td, int th, int tw) {
+        if (STATS && n != st_n) { if (st_n >= 0) flush_stats(st_n); st_n = n; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int od = td * TD + (j >> 1), oh = th * TH + 2 * (j & 1) + (li >> 3), ow = tw * 8 + (li & 7);
+            const bool valid = od < A.O[0] && oh < A.O[1] && ow < A.O[2];
+            uint2 pk;
+            pk.x = H16<T>::pack2(acc[j][0] + bia[0], acc[j][1] + bia[1]); pk.y = H16<T>::pack2(acc[j][2] + bia[2], acc[j][3] + bia[3]);
+            if (valid) {
+                T* const yp = reinterpret_cast<T*>(A.y) + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * cout_p + row0 + q * 4;
+                *reinterpret_cast<uint2*>(yp) = pk;
+                if constexpr (STATS) {
+                    const float r0 = H16<T>::lo(pk.x), r1 = H16<T>::hi(pk.x), r2 = H16<T>::lo(pk.y), r3 = H16<T>::hi(pk.y);
+                    ssum[0] += r0; ssum[1] += r1; ssum[2] += r2; ssum[3] += r3;
+                    ssq[0] += r0 * r0; ssq[1] += r1 * r1; ssq[2] += r2 * r2; ssq[3] += r3 * r3;
+                }
+            }
+        }
+    };
+
+    const int G = gridDim.x, bx = blockIdx.x;
+    auto perm = [&](int cnt) { return (cnt & 7) ? bx : (bx & 7) * (cnt >> 3) + (bx >> 3); };
+    const int full = A.total_tiles / G, rest = A.total_tiles - full * G;
+    const int pfull = perm(G);
+    auto exists = [&](int k) { return k < full || (k == full && bx < rest); };
+    auto to_round = [&](int k) {
+        if (k < full) { if (k == 0) decode(pfull); else advance(); }
+        else if (k == full && bx < rest) decode(full * G + perm(rest));
+    };
+    if (!exists(0)) return;
+    to_round(0);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) dma_piece(j, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int k = 0; exists(k); ++k) {
+        const bool nx = exists(k + 1);
+        const int e_n = c_n, e_d = c_d, e_h = c_h, e_w = c_w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        compute(0, 0, true, 1);                               // chunk 0 from buffer 0; chunk 1 of this tile -> buffer 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nx) to_round(k + 1);                              // the next tile's scalars
+        compute(1, 1, nx, 0);                                 // chunk 1 from buffer 1; chunk 0 of the next tile -> buffer 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        epilogue(e_n, e_d, e_h, e_w);
+    }
+    if (STATS && st_n >= 0) flush_stats(st_n);
+}
+
 // returns 1 = not covered (the caller goes on to k_igemm)
 int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st) {
     const int on = getenv("NNDET_IG3S") ? atoi(getenv("NNDET_IG3S")) : 1;       // (read per call: tests compare routes that must share their kernels)
-    if (!on || kind != 0 || res || c->transposed || c->in_affine || !nndet_is16(c->dtype) || c->cin_p != 32 || c->cout_p != 64) return 1;
+    const bool v1 = c->cin_p == 32 && c->cout_p == 64, v2 = c->cin_p == 64 && c->cout_p % 64 == 0 && c->cout_p <= 256 && on != 3;   // (NNDET_IG3S=3: the 32 -> 64 form only)
+    if (!on || kind != 0 || res || c->transposed || c->in_affine || !nndet_is16(c->dtype) || !(v1 || v2)) return 1;
     for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 2 || c->p[i] != 1) return 1;
-    const int64_t xb = (int64_t)c->in_d * c->in_h * c->in_w * 64;
+    const int64_t xb = (int64_t)c->in_d * c->in_h * c->in_w * c->cin_p * 2;
     if (xb >= (1LL << 31) || c->batch <= 0) return 1;
     Ig3sArgs a;
     memset(&a, 0, sizeof(a));
@@ -233,7 +410,9 @@ int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const f
     a.nt[0] = ceil_div(a.O[0], 2); a.nt[1] = ceil_div(a.O[1], 4); a.nt[2] = ceil_div(a.O[2], 8);
     a.total_tiles = a.N * a.nt[0] * a.nt[1] * a.nt[2];
     const int wgs = getenv("NNDET_IG3S_WGS") ? atoi(getenv("NNDET_IG3S_WGS")) : 256;      // (read per call: the tests vary it)
-    int G = wgs < 1 || wgs > 256 ? 256 : wgs;
+    const int ny = v2 ? c->cout_p / 64 : 1;                 // blocks of 64 output channels (k_ig3s2)
+    int G = (wgs < 1 || wgs > 256 ? 256 : wgs) / ny;
+    if (G < 1) G = 1;
     if (G > a.total_tiles) G = a.total_tiles;
     int g = G;
     a.gw = g % a.nt[2]; g /= a.nt[2];
@@ -246,7 +425,18 @@ int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const f
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         at = true;
+    }
+    if (v2) {
+        const dim3 g2(G, ny);
+        if (c->dtype == NNDET_F16) { if (stats) k_ig3s2<f16_t, true><<<g2, 256, lds, st>>>(a, c->cout_p); else k_ig3s2<f16_t, false><<<g2, 256, lds, st>>>(a, c->cout_p); }
+        else { if (stats) k_ig3s2<bf16_t, true><<<g2, 256, lds, st>>>(a, c->cout_p); else k_ig3s2<bf16_t, false><<<g2, 256, lds, st>>>(a, c->cout_p); }
+        LAUNCH_CHECK();
+        return 0;
     }
     if (c->dtype == NNDET_F16) { if (stats) k_ig3s<f16_t, true><<<G, 256, lds, st>>>(a); else k_ig3s<f16_t, false><<<G, 256, lds, st>>>(a); }
     else { if (stats) k_ig3s<bf16_t, true><<<G, 256, lds, st>>>(a); else k_ig3s<bf16_t, false><<<G, 256, lds, st>>>(a); }

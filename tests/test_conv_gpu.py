@@ -161,7 +161,7 @@ def test_lds_dma_weight_gradient_kernels_tile_walk(name, wgs, dtype, monkeypatch
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name,norm", [("c32_k3", "instance"), ("c64_k3", "instance"), ("c32to64_s2", "instance"), ("c32to64_s2_tiles", "instance"),
+@pytest.mark.parametrize("name,norm", [("c32_k3", "instance"), ("c64_k3", "instance"), ("c32to64_s2", "instance"), ("c32to64_s2_tiles", "instance"), ("c64to128_s2_tiles", "instance"),
                                         ("stem", "instance"), ("c128_k3", "group"), ("c64_k3", "group")])
 def test_conv_norm_relu_block(name, norm, dtype):
     m, x, cfg = _mk(name, dtype, norm, True)
