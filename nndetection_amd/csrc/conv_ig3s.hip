@@ -167,22 +167,31 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         if (STATS && n != st_n) { if (st_n >= 0) flush_stats(st_n); st_n = n; }
         const int od = td * TD + pth, oh = th * TH + rr, ow = tw * 8 + pw;
         const bool valid = od < A.O[0] && oh < A.O[1] && ow < A.O[2];
-        T* const yp = reinterpret_cast<T*>(A.y) + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * CY + coh * 32 + kg * 4;
+        T* const yp = reinterpret_cast<T*>(A.y) + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * CY + coh * 32;
+        uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (acc[0][g * 4 + i] + acc[1][g * 4 + i]) + (acc[2][g * 4 + i] + acc[3][g * 4 + i]) + bia[g * 4 + i];
-            uint2 pk;
-            pk.x = H16<T>::pack2(v[0], v[1]); pk.y = H16<T>::pack2(v[2], v[3]);
-            if (valid) {
-                *reinterpret_cast<uint2*>(yp + g * 8) = pk;
-                if constexpr (STATS) {                        // of the ROUNDED values (what the norm kernels will read)
-                    const float r0 = H16<T>::lo(pk.x), r1 = H16<T>::hi(pk.x), r2 = H16<T>::lo(pk.y), r3 = H16<T>::hi(pk.y);
+            pk[g].x = H16<T>::pack2(v[0], v[1]); pk[g].y = H16<T>::pack2(v[2], v[3]);
+            if constexpr (STATS) {                            // of the ROUNDED values (what the norm kernels will read)
+                if (valid) {
+                    const float r0 = H16<T>::lo(pk[g].x), r1 = H16<T>::hi(pk[g].x), r2 = H16<T>::lo(pk[g].y), r3 = H16<T>::hi(pk[g].y);
                     ssum[g * 4 + 0] += r0; ssum[g * 4 + 1] += r1; ssum[g * 4 + 2] += r2; ssum[g * 4 + 3] += r3;
                     ssq[g * 4 + 0] += r0 * r0; ssq[g * 4 + 1] += r1 * r1; ssq[g * 4 + 2] += r2 * r2; ssq[g * 4 + 3] += r3 * r3;
                 }
             }
+        }
+        // lanes l and l + 32 hold the channel quads 8 g + {0..3} / {4..7} of the SAME point: v_permlane32_swap hands the lower lane the
+        // upper one's quads of groups 0 / 1 and the upper lane the lower one's of groups 2 / 3 -> two 16-byte stores per lane instead of
+        // four 8-byte ones (lower lane: channels 0..15, upper lane: 16..31 of the wave's 32). Both lanes belong to one point: same `valid`.
+        typedef unsigned int ig3s_v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const ig3s_v2u sx = __builtin_amdgcn_permlane32_swap(pk[h].x, pk[h + 2].x, false, false);
+            const ig3s_v2u sy = __builtin_amdgcn_permlane32_swap(pk[h].y, pk[h + 2].y, false, false);
+            if (valid) *reinterpret_cast<u32x4*>(yp + kg * 16 + h * 8) = u32x4{sx[0], sy[0], sx[1], sy[1]};
         }
     };
 
@@ -344,21 +353,35 @@ __global__ __launch_bounds__(256, 1) void k_ig3s2(const Ig3sArgs A, int cout_p) 
     int st_n = -1;
     auto epilogue = [&](int n, int td, int th, int tw) {
         if (STATS && n != st_n) { if (st_n >= 0) flush_stats(st_n); st_n = n; }
+        uint2 pk[4];
+        bool valid[4];
+        int64_t vox[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int od = td * TD + (j >> 1), oh = th * TH + 2 * (j & 1) + (li >> 3), ow = tw * 8 + (li & 7);
-            const bool valid = od < A.O[0] && oh < A.O[1] && ow < A.O[2];
-            uint2 pk;
-            pk.x = H16<T>::pack2(acc[j][0] + bia[0], acc[j][1] + bia[1]); pk.y = H16<T>::pack2(acc[j][2] + bia[2], acc[j][3] + bia[3]);
-            if (valid) {
-                T* const yp = reinterpret_cast<T*>(A.y) + ((((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow) * cout_p + row0 + q * 4;
-                *reinterpret_cast<uint2*>(yp) = pk;
-                if constexpr (STATS) {
-                    const float r0 = H16<T>::lo(pk.x), r1 = H16<T>::hi(pk.x), r2 = H16<T>::lo(pk.y), r3 = H16<T>::hi(pk.y);
+            valid[j] = od < A.O[0] && oh < A.O[1] && ow < A.O[2];
+            vox[j] = (((int64_t)n * A.O[0] + od) * A.O[1] + oh) * A.O[2] + ow;
+            pk[j].x = H16<T>::pack2(acc[j][0] + bia[0], acc[j][1] + bia[1]); pk[j].y = H16<T>::pack2(acc[j][2] + bia[2], acc[j][3] + bia[3]);
+            if constexpr (STATS) {
+                if (valid[j]) {
+                    const float r0 = H16<T>::lo(pk[j].x), r1 = H16<T>::hi(pk[j].x), r2 = H16<T>::lo(pk[j].y), r3 = H16<T>::hi(pk[j].y);
                     ssum[0] += r0; ssum[1] += r1; ssum[2] += r2; ssum[3] += r3;
                     ssq[0] += r0 * r0; ssq[1] += r1 * r1; ssq[2] += r2 * r2; ssq[3] += r3 * r3;
                 }
             }
+        }
+        // lane rows q and q ^ 1 hold neighbouring channel quads of the same points: v_permlane16_swap over a PAIR of point tiles gives the
+        // even rows the 8 consecutive channels 4 q .. 4 q + 7 of tile j and the odd rows the channels 4 (q - 1) .. 4 q + 3 of tile j + 1:
+        // one 16-byte store per lane and tile pair instead of two 8-byte ones
+        typedef unsigned int ig3s_v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const ig3s_v2u sx = __builtin_amdgcn_permlane16_swap(pk[j].x, pk[j + 1].x, false, false);
+            const ig3s_v2u sy = __builtin_amdgcn_permlane16_swap(pk[j].y, pk[j + 1].y, false, false);
+            const bool odd = q & 1;
+            const bool ok = odd ? valid[j + 1] : valid[j];
+            T* const yp = reinterpret_cast<T*>(A.y) + (odd ? vox[j + 1] : vox[j]) * cout_p + row0 + (q & 2) * 4;
+            if (ok) *reinterpret_cast<u32x4*>(yp) = u32x4{sx[0], sy[0], sx[1], sy[1]};
         }
     };
 
