@@ -279,12 +279,38 @@ def arena_zeros(shape, dtype, device):
 class _GradPool:
     """One zero-filled fp32 buffer per training step for ALL parameter-gradient accumulators of the convolution nodes (54 fills
     of a few KB .. 11 MB per step otherwise). A fresh torch tensor per step: the gradients handed to autograd are views of it and
-    keep it alive exactly as long as they live, so nothing depends on when the optimizer drops them."""
+    keep it alive exactly as long as they live, so nothing depends on when the optimizer drops them.
+
+    STATIC layout (round 5, installed by nndetection_amd.ddp.GradAllReducer): every parameter owns a fixed region of the
+    reducer's flat bucket memory, `begin()` zero-fills that memory (one fill, as before) and `take_for` hands a node the regions of
+    ITS parameters, so the gradients autograd adopts already sit where the all-reduce reads and writes: no bucket copy, and the
+    region of a parameter without a gradient on this rank (the regressor on a rank without positives, decoder.out.P1) is zero by
+    construction. A region is handed out once per step and only while the parameter has no `.grad` (a second node of the same
+    parameter, or a second backward pass without zero_grad, gets fresh memory and autograd adds it in)."""
 
     def __init__(self):
         self.buf, self.off = None, 0
+        self.static, self.static_flat, self.owner, self.taken, self.armed = None, None, None, set(), False
 
-    def begin(self, numel: int, device):
+    def install_static(self, views: dict, flat: torch.Tensor, owner=None) -> None:
+        """views: {parameter: 1-D fp32 view of `flat` with the parameter's numel} (keyed by the Parameter OBJECTS: a hit is the
+        same live object, never a recycled id); owner: the module whose forward pass calls `begin(..., owner=module)` -- the layout
+        is only armed for that module's steps (another model in the same process keeps the per-step pool)."""
+        import weakref
+        self.static, self.static_flat, self.taken, self.armed = dict(views), flat, set(), False
+        self.owner = weakref.ref(owner) if owner is not None else None
+
+    def remove_static(self, flat=None) -> None:
+        if flat is None or flat is self.static_flat:
+            self.static, self.static_flat, self.owner, self.taken, self.armed = None, None, None, set(), False
+
+    def begin(self, numel: int, device, owner=None):
+        self.armed = False
+        if self.static is not None and self.static_flat.device == device and (self.owner is None or self.owner() is owner):
+            self.static_flat.zero_()                 # (the previous step's all-reduce was waited for by finish() on this stream)
+            self.taken, self.armed = set(), True
+            self.buf, self.off = None, 0             # the few nodes that cannot use their region take fresh zeroed memory
+            return
         self.buf = torch.zeros((int(numel),), dtype=torch.float32, device=device)
         self.off = 0
 
@@ -296,11 +322,41 @@ class _GradPool:
         self.off = start + numel
         return b[start:start + numel]
 
+    def take_for(self, parts, device):
+        """parts: [(parameter or None, numel), ...] of ONE autograd node -> a zeroed fp32 1-D tensor per part: the parameter's
+        static region where one is installed and usable, else consecutive slices of one `take` (the round-2 behaviour)."""
+        out = [None] * len(parts)
+        if self.armed and self.static is not None:
+            for i, (p, n) in enumerate(parts):
+                v = self.static.get(p) if p is not None else None
+                if v is not None and n == v.numel() and v.device == device and p.grad is None and id(p) not in self.taken:
+                    self.taken.add(id(p))
+                    out[i] = v.view(-1)              # a FRESH view: autograd adopts a gradient only if nobody else holds the tensor object
+        rest = [i for i in range(len(parts)) if out[i] is None]
+        if rest:
+            g = self.take(sum(int(parts[i][1]) for i in rest), device)
+            o = 0
+            for i in rest:
+                n = int(parts[i][1])
+                out[i] = g[o:o + n]
+                o += n
+        return out
+
     def end(self):
         self.buf, self.off = None, 0
 
 
 grad_pool = _GradPool()
+
+# Callbacks `fn(list_of_parameters)` told, during the forward pass, that these parameters will NOT receive a gradient in the coming
+# backward pass (arch/heads.py: the regressor on the compact loss route when the batch has no positive anchor). The gradient reducer
+# (nndetection_amd.ddp) registers one: it may then launch their bucket from the hooks of the other parameters instead of from finish().
+no_grad_listeners = []
+
+
+def notify_no_grad(params) -> None:
+    for fn in list(no_grad_listeners):
+        fn(params)
 
 
 _aux_streams = {}

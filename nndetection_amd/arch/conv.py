@@ -279,13 +279,13 @@ def rank1_branch_backward(x_p, a_p, w_out, b_out, w_lat, w_head, b_head, wd, wf,
     nw, nb = w_out.numel(), (cout if b_out is not None else 0)
     nl = w_lat.numel() if w_lat is not None else 0
     nh, nhb = w_head.numel(), (2 if b_head is not None else 0)
-    gbuf = L.grad_pool.take(nw + nb + nl + nh + nhb, dev)
-    o = 0
-    dw = gbuf[o:o + nw].view(w_out.shape); o += nw
-    dbias = gbuf[o:o + nb] if nb else None; o += nb
-    dw_lat = gbuf[o:o + nl].view(w_lat.shape) if nl else None; o += nl
-    dw_head = gbuf[o:o + nh].view(w_head.shape); o += nh
-    db_head = gbuf[o:o + nhb] if nhb else None
+    g_out, g_bo, g_lat, g_head, g_bh = L.grad_pool.take_for(
+        [(w_out, nw), (b_out, nb), (w_lat, nl), (w_head, nh), (b_head, nhb)], dev)
+    dw = g_out.view(w_out.shape)
+    dbias = g_bo if nb else None
+    dw_lat = g_lat.view(w_lat.shape) if nl else None
+    dw_head = g_head.view(w_head.shape)
+    db_head = g_bh if nhb else None
     side = L.wgrad_streams.side(dev, w_out)
     if side is not None:
         L.wgrad_streams.side(dev, w_head)                    # their gradients are produced on that stream as well
@@ -387,13 +387,13 @@ class _ConvFn(torch.autograd.Function):
         dconv, _ = phys(grad_out, dtype=dt, cp=cout_p)
         # dW and dbias of this node are views of the per-step gradient pool (ONE zero fill per step, _lib.grad_pool)
         nw = weight.numel()
-        gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
+        g_w, g_b = L.grad_pool.take_for([(weight, nw), (mod.conv.bias if ctx.has_bias else None, cout if ctx.has_bias else 0)], dev)
         # (NNDET_WGRAD_ALL=0: nodes whose bias gradient comes out of the data-gradient launch keep their weight gradient on this stream)
         keep = (os.environ.get("NNDET_WGRAD_ALL", "1") == "0" and ctx.has_bias and ctx.needs_input_grad[0] and desc.cin_p != 1 and
                 bool(L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc))))
         ctx.wg_side = None if keep else L.wgrad_streams.side(dev, weight)
-        dw = gbuf[:nw].view(weight.shape)
-        dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
+        dw = g_w.view(weight.shape)
+        dbias = g_b if ctx.has_bias else None
         dx = None
         bias_from_dgrad = False
         if _rank1_grads and dconv.data_ptr() not in _rank1_grads and getattr(mod, "_nndet_rank1_consumer", False):
@@ -521,8 +521,7 @@ class _NormFn(torch.autograd.Function):
         y_p, mean_rstd, g32, b32 = ctx.saved_tensors
         dev, dt = y_p.device, y_p.dtype
         g_p, _ = phys(grad_out, dtype=dt, cp=cout_p)
-        gbuf = L.grad_pool.take(2 * cout, dev)
-        dgamma, dbeta = gbuf[:cout], gbuf[cout:]
+        dgamma, dbeta = L.grad_pool.take_for([(mod.norm.weight, cout), (mod.norm.bias, cout)], dev)
         dconv = torch.empty_like(y_p)
         red = L.arena_zeros((L.STATS_REPLICAS * N * cout_p * 2 + N,), torch.float64, dev)     # replica sums + N ticket slots
         L.call("nndet_norm_backward", ctx.code, L.ptr(y_p), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,
@@ -565,8 +564,8 @@ class _StemBlockFn(torch.autograd.Function):
         cout = desc.cout
         g_p, _ = phys(grad_out, dtype=dt, cp=desc.cout_p)
         nw = weight.numel()
-        gbuf = L.grad_pool.take(nw + 2 * cout, dev)
-        dw, dgamma, dbeta = gbuf[:nw].view(weight.shape), gbuf[nw:nw + cout], gbuf[nw + cout:nw + 2 * cout]
+        g_w, dgamma, dbeta = L.grad_pool.take_for([(weight, nw), (mod.norm.weight, cout), (mod.norm.bias, cout)], dev)
+        dw = g_w.view(weight.shape)
         # Parameter gradients only -- but this is the LAST node of a backward pass: nothing is queued behind it on the data-gradient
         # chain, while the weight-gradient stream still has the full-resolution 32 -> 32 weight gradient in front of it. On THIS stream
         # the two run side by side (tools/phase_times.py: the step ended 0.3 ms later with it queued behind that weight gradient).

@@ -162,6 +162,7 @@ class _RegSparseFn(torch.autograd.Function):
                L.ptr(pos.contiguous()), K, L.ptr(t2d), L.ptr(w32), L.ptr(b32), L.ptr(out), L.ptr(raw), L.ptr(rows), L.ptr(c0), L.ptr(lvl),
                L.stream())
         ctx.desc, ctx.meta, ctx.G, ctx.n_scales, ctx.has_bias = desc, meta, G, len(sc), bias is not None
+        ctx.bias_param = bias                        # (the Parameter itself: its gradient region in a static pool is looked up by identity)
         ctx.save_for_backward(t2d, weight, w32, raw, rows, c0, lvl, *sc)
         return out
 
@@ -188,9 +189,9 @@ class _RegSparseFn(torch.autograd.Function):
         else:
             vals = g
         nw, cout = weight.numel(), desc.cout
-        gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
-        dw = gbuf[:nw].view(weight.shape)
-        dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
+        g_w, g_b = L.grad_pool.take_for([(weight, nw), (ctx.bias_param if ctx.has_bias else None, cout if ctx.has_bias else 0)], dev)
+        dw = g_w.view(weight.shape)
+        dbias = g_b if ctx.has_bias else None
         dx32 = torch.empty((meta.rows, desc.cin_p), dtype=torch.float32, device=dev)     # scratch: only the touched rows are used
         dx = torch.zeros_like(t2d)
         L.call("nndet_conv_out_sparse_backward", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(rows), L.ptr(c0), L.ptr(vals),
@@ -535,6 +536,10 @@ class DetectionHeadHNMNative(nn.Module):
         target_boxes_sampled = matched_gt_boxes[sampled_pos_inds]
         if sampled_pos_inds.numel() > 0:
             losses["reg"] = self.regressor.compute_loss(pred_boxes_sampled, target_boxes_sampled) / max(1, sampled_pos_inds.numel())
+        elif torch.is_grad_enabled():
+            # comb.py:397-401: no "reg" key -> the 12 regressor tensors get no gradient on this rank. Tell a gradient reducer now, so
+            # that their bucket is not held back until the end of the backward pass (nndetection_amd.ddp.GradAllReducer.mark_no_grad)
+            L.notify_no_grad(list(self.regressor.parameters()))
         losses["cls"] = self.classifier.compute_loss(box_logits[sampled_inds], labels[sampled_inds])
         return losses, sampled_pos_inds, sampled_neg_inds
 

@@ -155,9 +155,9 @@ class _ItemsConvFn(torch.autograd.Function):
         dev, dt = x2d.device, x2d.dtype
         dconv = grad_out.to(dt).contiguous()
         nw, cout = weight.numel(), desc.cout
-        gbuf = L.grad_pool.take(nw + (cout if ctx.has_bias else 0), dev)
-        dw = gbuf[:nw].view(weight.shape)
-        dbias = gbuf[nw:nw + cout] if ctx.has_bias else None
+        g_w, g_b = L.grad_pool.take_for([(weight, nw), (mod.conv.bias if ctx.has_bias else None, cout if ctx.has_bias else 0)], dev)
+        dw = g_w.view(weight.shape)
+        dbias = g_b if ctx.has_bias else None
         hint = L.grad_hints.pop(dconv)                      # set by _HeadGatherItemsFn.backward: dconv is zero except at <= 170 rows
         if hint is not None:
             # sparse data + weight gradient of this output convolution (csrc/sparse_out.hip); dw / dbias are views of the zeroed pool
@@ -210,8 +210,7 @@ class _ItemsNormFn(torch.autograd.Function):
         y2d, mean_rstd, g32, b32 = ctx.saved_tensors
         dev = y2d.device
         g = grad_out.to(y2d.dtype).contiguous()
-        gbuf = L.grad_pool.take(2 * cout, dev)
-        dgamma, dbeta = gbuf[:cout], gbuf[cout:]
+        dgamma, dbeta = L.grad_pool.take_for([(mod.norm.weight, cout), (mod.norm.bias, cout)], dev)
         dconv = torch.empty_like(y2d)
         red = L.arena_zeros((L.STATS_REPLICAS * meta.n_items * cout_p * 2 + meta.n_items,), torch.float64, dev)
         L.call("nndet_norm_backward_items", ctx.code, L.ptr(y2d), L.ptr(g), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32),

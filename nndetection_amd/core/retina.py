@@ -47,6 +47,8 @@ class MatchedBoxes:
 
 # NNDET_LAZY_TARGETS=0: labels / matched boxes of the batched target assignment as the clamp / gather / compare chain of round 3
 LAZY_TARGETS = os.environ.get("NNDET_LAZY_TARGETS", "1") != "0"
+# NNDET_SEG_FIRST=0: the segmentation branch + loss queued AFTER the detection head (the reference's order, rounds 1-4)
+SEG_FIRST = os.environ.get("NNDET_SEG_FIRST", "1") != "0"
 
 
 class BaseRetinaNet(nn.Module):
@@ -117,7 +119,7 @@ class BaseRetinaNet(nn.Module):
             if grad:                                           # one zero fill for every parameter-gradient accumulator of the step
                 if getattr(self, "_grad_numel", None) is None:
                     self._grad_numel = sum(p.numel() + 64 for p in self.parameters() if p.requires_grad)
-                L.grad_pool.begin(self._grad_numel, inp.device)
+                L.grad_pool.begin(self._grad_numel, inp.device, owner=self)
                 # side channels of the PREVIOUS backward pass (sparse-gradient hints, the factorised segmentation gradient): entries
                 # nobody consumed would pin large tensors across steps
                 L.grad_hints.d.clear()
@@ -140,9 +142,6 @@ class BaseRetinaNet(nn.Module):
             else:
                 self._dec_event = torch.cuda.Event()
                 self._dec_event.record()
-        pred_detection = self.head(feature_maps_head)
-        anchors = self.anchor_generator(inp, feature_maps_head)
-        pred_seg = None
         fused = self.segmenter is not None and (getattr(self, "_fuse_seg_head", False) or
                                                 (getattr(self, "_seg_infer", False) and getattr(features_maps_all[0], "_nndet_pre_out", None) is not None))
         # does the segmenter consume level 0 on its side stream (fused head + loss, train_step) or on THIS stream (inference,
@@ -150,17 +149,45 @@ class BaseRetinaNet(nn.Module):
         # have left behind: only the former may skip the join with the decoder's tail stream.
         seg_on_side = fused and getattr(self, "_seg_side", None) is not None and \
             bool(getattr(self.segmenter, "takes_fused_route", lambda fm: False)(features_maps_all))
+        pred_seg = None
+        # Segmentation branch FIRST (round 5): its autograd nodes are created before the head's, so the backward pass -- the engine
+        # runs ready nodes in decreasing creation order -- issues the whole detection-head backward before the ~45 small launches of
+        # the branch's backward. In the reference's order (loss of the branch computed last = its backward first) the main stream had
+        # nothing queued for ~1.1 ms while the host issued those launches onto the branch's stream (profiles/round4_v3_timeline_one_step.txt
+        # @5967-7135 us). Only on the route train_step forks onto the side stream; NNDET_SEG_FIRST=0 restores the old order.
+        seg_target = getattr(self, "_seg_target", None)
+        if SEG_FIRST and seg_on_side and seg_target is not None and torch.is_grad_enabled():
+            if features_maps_all[0] is not None and self._seg_rank1_ok():
+                features_maps_all[0]._nndet_rank1_ok = True
+            pred_seg = self.segmenter(features_maps_all, fused=True)
+            if isinstance(pred_seg, dict) and "seg_input" in pred_seg:
+                self._seg_losses_early = self._seg_loss_on_side(pred_seg, seg_target)
+        pred_detection = self.head(feature_maps_head)
+        anchors = self.anchor_generator(inp, feature_maps_head)
         if tail_ev is not None and inp.is_cuda:
             if not seg_on_side:                                # level 0 is consumed on this stream: join here,
                 torch.cuda.current_stream(inp.device).wait_event(tail_ev)      # behind the head that was queued in the meantime
             for t in features_maps_all[:1]:
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream(inp.device))
-        if self.segmenter is not None:
+        if self.segmenter is not None and pred_seg is None:
             if fused and features_maps_all[0] is not None and self._seg_rank1_ok():
                 features_maps_all[0]._nndet_rank1_ok = True      # its gradient may travel as d1 (x) (w1 - w0): arch/conv.py
             pred_seg = self.segmenter(features_maps_all, fused=True) if fused else self.segmenter(features_maps_all)
         return pred_detection, anchors, pred_seg
+
+    def _seg_loss_on_side(self, pred_seg, target_seg):
+        """The fused segmentation branch + loss on its side stream (forked behind the decoder, not behind the head)."""
+        seg_s = self._seg_side
+        seg_s.wait_event(self._dec_event)            # the decoder output is ready; the head queued behind it is not waited for
+        for v in pred_seg.values():
+            v.record_stream(seg_s)
+            lat = getattr(v, "_nndet_pre_lat", None)     # the absorbed lateral's input is read on that stream too
+            if lat is not None:
+                lat[1].record_stream(seg_s)
+        target_seg.record_stream(seg_s)
+        with torch.cuda.stream(seg_s):
+            return self.segmenter.compute_loss(pred_seg, target_seg)
 
     def _seg_branch_ok(self, inp: Tensor) -> bool:
         """May this forward pass skip decoder.out.P0 and leave the whole segmentation branch to `_SegBranchFn` (csrc/segbranch.hip)?
@@ -269,12 +296,16 @@ class BaseRetinaNet(nn.Module):
                 self._lazy_fork = torch.cuda.Event()
                 self._lazy_fork.record(main)             # the target tensors are ready here; the forward pass is queued behind it
         self._seg_side = self._aux(images.device, 1) if (overlap and self.segmenter is not None and self._fuse_seg_head) else None
+        self._seg_target = target_seg if self._seg_side is not None else None
+        self._seg_losses_early = None
         try:
             return self._train_step_body(images, lazy, target_boxes, target_classes, target_seg, evaluation, overlap, pre, main, cached)
         finally:                                          # never leave the fork state behind for a later forward() / inference_step()
             self._fuse_seg_head = False
             self.head._defer_reg_out = False
             self._seg_side = None
+            self._seg_target = None
+            self._seg_losses_early = None
 
     def _train_step_body(self, images, lazy, target_boxes, target_classes, target_seg, evaluation, overlap, pre, main, cached):
         pred_detection, anchors, pred_seg = self(images)
@@ -304,18 +335,10 @@ class BaseRetinaNet(nn.Module):
                 self._anchors_by_shape = {}
             self._anchors_by_shape[tuple(images.shape)] = list(anchors)
         losses = {}
-        seg_losses = None
-        if self._seg_side is not None:                   # segmentation loss on its side stream, next to the detection loss
-            seg_s = self._seg_side
-            seg_s.wait_event(self._dec_event)            # the decoder output is ready; the head queued behind it is not waited for
-            for v in pred_seg.values():
-                v.record_stream(seg_s)
-                lat = getattr(v, "_nndet_pre_lat", None)     # the absorbed lateral's input is read on that stream too
-                if lat is not None:
-                    lat[1].record_stream(seg_s)
-            target_seg.record_stream(seg_s)
-            with torch.cuda.stream(seg_s):
-                seg_losses = self.segmenter.compute_loss(pred_seg, target_seg)
+        seg_losses = self._seg_losses_early              # (forward(): the branch was queued before the head, NNDET_SEG_FIRST)
+        self._seg_losses_early = None
+        if seg_losses is None and self._seg_side is not None:      # segmentation loss on its side stream, next to the detection loss
+            seg_losses = self._seg_loss_on_side(pred_seg, target_seg)
         head_losses, pos_idx, neg_idx = self.head.compute_loss(pred_detection, labels, matched_gt_boxes, anchors)
         losses.update(head_losses)
         if seg_losses is not None:

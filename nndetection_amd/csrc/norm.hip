@@ -11,12 +11,14 @@
 
 template <typename T> struct Vec16 {      // the 16-bit storage types (bf16_t, f16_t)
     static constexpr int E = 8;
-    __device__ static __forceinline__ void ld(const T* p, float* v) {
-        const uint4 u = *reinterpret_cast<const uint4*>(p);
+    using raw_t = uint4;                  // one 16-byte piece as loaded; `cvt` widens it (split so that several loads can be in flight)
+    __device__ static __forceinline__ raw_t ldraw(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+    __device__ static __forceinline__ void cvt(const raw_t& u, float* v) {
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = H16<T>::lo(w[i]); v[2 * i + 1] = H16<T>::hi(w[i]); }
     }
+    __device__ static __forceinline__ void ld(const T* p, float* v) { cvt(ldraw(p), v); }
     __device__ static __forceinline__ void st(T* p, const float* v) {
         uint4 u;
         u.x = H16<T>::pack2(v[0], v[1]);
@@ -28,9 +30,10 @@ template <typename T> struct Vec16 {      // the 16-bit storage types (bf16_t, f
 };
 template <> struct Vec16<float> {
     static constexpr int E = 4;
-    __device__ static __forceinline__ void ld(const float* p, float* v) {
-        const float4 f = *reinterpret_cast<const float4*>(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-    }
+    using raw_t = float4;
+    __device__ static __forceinline__ raw_t ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ void cvt(const raw_t& f, float* v) { v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+    __device__ static __forceinline__ void ld(const float* p, float* v) { cvt(ldraw(p), v); }
     __device__ static __forceinline__ void st(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 // Ragged batch (NndetItems): per-item voxel count and first row; n == 0 = uniform batch (image n = rows [n * spatial, (n + 1) * spatial))
@@ -41,7 +44,38 @@ struct NormItems {
 };
 static const NormItems g_norm_uniform = {};
 
+// Per-thread constants of the element-wise / reduction kernels: (mean, rstd) of the thread's E channels from the [N][c_p][2] table
+// (written for all c_p channels, zeros beyond c) and gamma / beta ([c]: clamped index, masked afterwards). ALL loads are issued
+// unconditionally and independently: the `if (ci < c) load` form compiled to one exec-masked load + s_waitcnt vmcnt(0) per element,
+// 32 dependent round trips (~30-60 us) in front of every workgroup's first row (round 5; the 5x5x6 level's reduction took 24-39 us).
+template <int E>
+__device__ __forceinline__ void norm_consts(const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, int n, int c, int c_p, int c0,
+                                            float* mu, float* rs, float* ga, float* be) {
+    const float2* mr = reinterpret_cast<const float2*>(mean_rstd) + ((int64_t)n * c_p + c0);
+    float2 m[E];
+    float g[E], b[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int cj = min(c0 + e, c - 1);
+        m[e] = mr[e];
+        g[e] = gamma[cj];
+        b[e] = beta[cj];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool ok = c0 + e < c;
+        mu[e] = ok ? m[e].x : 0.f;
+        rs[e] = ok ? m[e].y : 0.f;
+        ga[e] = ok ? g[e] : 0.f;
+        be[e] = ok ? b[e] : 0.f;
+    }
+}
+
 #define ROWS_PER_BLOCK 512    // max rows (voxels) handled by one workgroup in the element-wise (apply) kernels
+#ifndef RED_U
+#define RED_U 4               // rows per thread in flight in the reduction kernels (k_norm_bwd_reduce, k_norm_stats, k_colsum)
+#endif
 // rows per workgroup of the element-wise kernels: 512 for the big layers; the pyramid levels P3-P5 (150 ... 4800 rows per image) got
 // 1-10 workgroups per image of 32 dependent load -> store iterations each (24-33 us for 0.6-5 MB): aim at >= ~1024 workgroups
 static inline int apply_rows(int64_t rows_total, int c_p, int esz) {
@@ -82,7 +116,21 @@ __global__ __launch_bounds__(256) void k_norm_stats(const T* __restrict__ x, int
         const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
         const int64_t r1 = min(r0 + RED_ROWS, spatial);
         const T* xb = x + ((int64_t)n * spatial) * c_p + cp * E;
-        for (int64_t r = r0 + rr; r < r1; r += rpi) {
+        // RED_U rows of this thread in flight per iteration (see k_norm_bwd_reduce); same summation order as the plain loop
+        int64_t r = r0 + rr;
+        for (; r + (int64_t)(RED_U - 1) * rpi < r1; r += (int64_t)RED_U * rpi) {
+            typename Vec16<T>::raw_t raw[RED_U];
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) raw[u] = Vec16<T>::ldraw(xb + (r + (int64_t)u * rpi) * c_p);
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) {
+                float v[E];
+                Vec16<T>::cvt(raw[u], v);
+#pragma unroll
+                for (int e = 0; e < E; ++e) { s[e] += v[e]; s2[e] += v[e] * v[e]; }
+            }
+        }
+        for (; r < r1; r += rpi) {
             float v[E];
             Vec16<T>::ld(xb + r * c_p, v);
 #pragma unroll
@@ -247,16 +295,14 @@ __global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, con
     const int64_t r0 = (int64_t)blockIdx.x * RPB;
     if (r0 >= spatial) return;                        // ragged batch: the grid covers the largest item
     float sc[E], sh[E];
+    {
+        float mu[E], rs[E], ga[E], be[E];
+        norm_consts<E>(mean_rstd, gamma, beta, n, c, c_p, cp * E, mu, rs, ga, be);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int ci = cp * E + e;
-        float a = 0.f, b = 0.f;
-        if (ci < c) {
-            const float mean = mean_rstd[((int64_t)n * c_p + ci) * 2], rstd = mean_rstd[((int64_t)n * c_p + ci) * 2 + 1];
-            a = rstd * gamma[ci];
-            b = beta[ci] - mean * a;
+        for (int e = 0; e < E; ++e) {            // (padded channels: rstd = gamma = beta = 0 -> a = b = 0, as before)
+            const float a = rs[e] * ga[e];
+            sc[e] = a; sh[e] = be[e] - mu[e] * a;
         }
-        sc[e] = a; sh[e] = b;
     }
     const int64_t r1 = min(r0 + RPB, spatial);
     const int64_t base = row0 * c_p + cp * E;
@@ -384,23 +430,20 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
     const int cp = threadIdx.x % ppr, rr = threadIdx.x / ppr;
     if (rr < rpi) {
         float mu[E], rs[E], sc[E], sh[E], sa[E], sb[E];
+        {
+            float ga[E], be[E];
+            norm_consts<E>(mean_rstd, gamma, beta, n, c, c_p, cp * E, mu, rs, ga, be);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int ci = cp * E + e;
-            const bool ok = ci < c;
-            mu[e] = ok ? mean_rstd[((int64_t)n * c_p + ci) * 2] : 0.f;
-            rs[e] = ok ? mean_rstd[((int64_t)n * c_p + ci) * 2 + 1] : 0.f;
-            sc[e] = ok ? rs[e] * gamma[ci] : 0.f;
-            sh[e] = ok ? beta[ci] - mu[e] * sc[e] : 0.f;
-            sa[e] = 0.f; sb[e] = 0.f;
+            for (int e = 0; e < E; ++e) {
+                sc[e] = rs[e] * ga[e];
+                sh[e] = be[e] - mu[e] * sc[e];
+                sa[e] = 0.f; sb[e] = 0.f;
+            }
         }
         const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
         const int64_t r1 = min(r0 + RED_ROWS, spatial);
         const int64_t base = row0 * c_p + cp * E;
-        for (int64_t r = r0 + rr; r < r1; r += rpi) {
-            float xv[E], gv[E];
-            Vec16<T>::ld(x + base + r * c_p, xv);
-            Vec16<T>::ld(dy + base + r * c_p, gv);
+        auto row = [&](const float* xv, const float* gv) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const float xh = (xv[e] - mu[e]) * rs[e];
@@ -408,6 +451,32 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
                 if (relu && !(fmaf(xv[e], sc[e], sh[e]) > 0.f)) g = 0.f;   // same expression as the forward pass
                 sa[e] += g; sb[e] += g * xh;
             }
+        };
+        // Round 5: RED_U rows (2 * RED_U 16-byte loads) of this thread in flight per iteration. The plain loop had ONE load pair per
+        // thread outstanding, i.e. one memory round trip per RED_ROWS / rpi iterations: 128 round trips for the 64-channel layers
+        // (0.18-0.29 ms for 315 MB = 1.1-1.7 TB/s inside the step), 0.4-0.9 TB/s for the 128-channel layers and the ragged head
+        // batches (profiles/round4_v3_timeline_one_step.txt). Rows are still added in the order r, r + rpi, ...: same sums.
+        int64_t r = r0 + rr;
+        for (; r + (int64_t)(RED_U - 1) * rpi < r1; r += (int64_t)RED_U * rpi) {
+            typename Vec16<T>::raw_t xr[RED_U], gr[RED_U];
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) {
+                xr[u] = Vec16<T>::ldraw(x + base + (r + (int64_t)u * rpi) * c_p);
+                gr[u] = Vec16<T>::ldraw(dy + base + (r + (int64_t)u * rpi) * c_p);
+            }
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) {
+                float xv[E], gv[E];
+                Vec16<T>::cvt(xr[u], xv);
+                Vec16<T>::cvt(gr[u], gv);
+                row(xv, gv);
+            }
+        }
+        for (; r < r1; r += rpi) {
+            float xv[E], gv[E];
+            Vec16<T>::ld(x + base + r * c_p, xv);
+            Vec16<T>::ld(dy + base + r * c_p, gv);
+            row(xv, gv);
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -485,17 +554,18 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const T* __restrict__ x,
     if (r0 >= spatial) return;                        // ragged batch: the grid covers the largest item
     const float* coef = reinterpret_cast<const float*>(red_ws + ((int64_t)n * c_p) * 2);
     float mu[E], rs[E], ga[E], sc[E], sh[E], k1[E], k2[E];
+    {
+        float be[E];
+        float2 kk[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int ci = cp * E + e;
-        const bool ok = ci < c;
-        mu[e] = ok ? mean_rstd[((int64_t)n * c_p + ci) * 2] : 0.f;
-        rs[e] = ok ? mean_rstd[((int64_t)n * c_p + ci) * 2 + 1] : 0.f;
-        ga[e] = ok ? gamma[ci] : 0.f;
-        sc[e] = ok ? rs[e] * ga[e] : 0.f;
-        sh[e] = ok ? beta[ci] - mu[e] * sc[e] : 0.f;
-        k1[e] = ok ? coef[ci * 2] : 0.f;
-        k2[e] = ok ? coef[ci * 2 + 1] : 0.f;
+        for (int e = 0; e < E; ++e) kk[e] = reinterpret_cast<const float2*>(coef)[cp * E + e];   // [c_p][2], zeros beyond c (k_norm_bwd_reduce)
+        norm_consts<E>(mean_rstd, gamma, beta, n, c, c_p, cp * E, mu, rs, ga, be);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            sc[e] = rs[e] * ga[e];
+            sh[e] = be[e] - mu[e] * sc[e];
+            k1[e] = kk[e].x; k2[e] = kk[e].y;
+        }
     }
     const int64_t r1 = min(r0 + RPB, spatial);
     const int64_t base = row0 * c_p + cp * E;
@@ -594,7 +664,20 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ x, int64_t
         for (int e = 0; e < E; ++e) s[e] = 0.f;
         const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
         const int64_t r1 = min(r0 + RED_ROWS, rows);
-        for (int64_t r = r0 + rr; r < r1; r += rpi) {
+        int64_t r = r0 + rr;
+        for (; r + (int64_t)(RED_U - 1) * rpi < r1; r += (int64_t)RED_U * rpi) {
+            typename Vec16<T>::raw_t raw[RED_U];
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) raw[u] = Vec16<T>::ldraw(x + (r + (int64_t)u * rpi) * c_p + cp * E);
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) {
+                float v[E];
+                Vec16<T>::cvt(raw[u], v);
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[e] += v[e];
+            }
+        }
+        for (; r < r1; r += rpi) {
             float v[E];
             Vec16<T>::ld(x + r * c_p + cp * E, v);
 #pragma unroll

@@ -27,18 +27,30 @@ import torch
 import torch.distributed as dist
 
 
+_ALIGN = 64                             # floats: every parameter's region starts on a 256-byte boundary (as _lib._GradPool.take does)
+
+
+def _padded(n: int) -> int:
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
 class GradBucket:
-    def __init__(self, params: List[torch.nn.Parameter], device, dtype=torch.float32):
+    """`flat`: the bucket's slice of the reducer's ONE flat buffer (so that one fill zeroes all buckets); the parameters' regions are
+    256-byte aligned inside it, the padding stays zero and is reduced along (<= 252 bytes per parameter)."""
+
+    def __init__(self, params: List[torch.nn.Parameter], flat: torch.Tensor):
         self.params = params
-        self.numel = sum(p.numel() for p in params)
-        self.flat = torch.zeros(self.numel, dtype=dtype, device=device)
+        self.flat = flat
+        self.numel = flat.numel()
         self.views, off = [], 0
         for p in params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            off += _padded(p.numel())
+        assert off == self.numel
         self.pending = len(params)
         self.work = None
         self.streams = set()            # raw handles of the streams that accumulated a gradient of this bucket in this backward
+        self.from_hook = False          # launched by a gradient hook (under the backward pass) or by finish()?
 
 
 class GradAllReducer:
@@ -75,16 +87,29 @@ class GradAllReducer:
             raise ValueError("model has no trainable parameters")
         device = params[0].device
         self.buckets: List[GradBucket] = []
-        cur, cur_bytes, limit = [], 0, first_bucket_mb * 2 ** 20
+        groups, cur, cur_bytes, limit = [], [], 0, first_bucket_mb * 2 ** 20
         for p in reversed(params):                       # gradients arrive roughly in reverse registration order
             cur.append(p); cur_bytes += p.numel() * 4
             if cur_bytes >= limit:
-                self.buckets.append(GradBucket(cur, device, bucket_dtype)); cur, cur_bytes, limit = [], 0, bucket_mb * 2 ** 20
+                groups.append(cur); cur, cur_bytes, limit = [], 0, bucket_mb * 2 ** 20
         if cur:
-            self.buckets.append(GradBucket(cur, device, bucket_dtype))
+            groups.append(cur)
+        sizes = [sum(_padded(p.numel()) for p in g) for g in groups]
+        self._flat_all = torch.zeros(sum(sizes), dtype=bucket_dtype, device=device)
+        off = 0
+        for g, n in zip(groups, sizes):
+            self.buckets.append(GradBucket(g, self._flat_all[off:off + n]))
+            off += n
+        # In place (round 5; fp32 buckets, NNDET_DDP_INPLACE=0 disables): the convolution nodes write their parameter gradients
+        # straight into the buckets (_lib.grad_pool static layout), the all-reduce runs on that memory and the optimizer reads it:
+        # no per-step copy of the 75 MB of gradients (2.3 % of a step at world size 1, profiles/round4_scale_sweep_n1_forced_dist.txt).
+        self.inplace = bucket_dtype == torch.float32 and os.environ.get("NNDET_DDP_INPLACE", "1") != "0"
+        self.copied_last = 0            # parameters whose gradient had to be copied into its bucket in the last backward pass
+        self._copied = 0
         if static_unused is None and hasattr(model, "never_used_parameters"):
             static_unused = model.never_used_parameters()
         self._static_unused = {id(p) for p in (static_unused or [])}
+        self._marked = set()            # parameters declared gradient-free for the CURRENT step (mark_no_grad)
         self._where = {}
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
@@ -111,7 +136,39 @@ class GradAllReducer:
         if self.overlap:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.inplace and (self.world > 1 or self.force):
+            from . import _lib as L
+            L.grad_pool.install_static({p: v.reshape(-1) for b in self.buckets for p, v in zip(b.params, b.views)}, self._flat_all,
+                                       owner=model)
+            self._no_grad_cb = self.mark_no_grad
+            L.no_grad_listeners.append(self._no_grad_cb)
         self.broadcast_parameters(model)
+
+    def close(self):
+        """Detach from the model: hooks, the static gradient layout and the no-gradient listener."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        from . import _lib as L
+        L.grad_pool.remove_static(self._flat_all)
+        cb = getattr(self, "_no_grad_cb", None)
+        if cb is not None and cb in L.no_grad_listeners:
+            L.no_grad_listeners.remove(cb)
+
+    def mark_no_grad(self, params):
+        """These parameters will get NO gradient in the coming backward pass (told during the forward pass: the regressor on a rank
+        whose batch has no positive anchor, nndet/arch/heads/comb.py:397-401). They contribute zeros and no longer hold their bucket
+        back: without this, that bucket AND every later one (collectives are issued in order) could only be launched from finish(),
+        i.e. this rank would overlap nothing and the other ranks would wait for it."""
+        if not self.overlap:
+            return
+        for p in params:
+            w = self._where.get(p)
+            if w is None or id(p) in self._static_unused or id(p) in self._marked:
+                continue
+            self._marked.add(id(p))
+            self.buckets[w[0]].pending -= 1
+        # (buckets are launched by the next gradient hook: nothing is issued from inside the forward pass)
 
     def broadcast_parameters(self, model):
         """Rank 0's parameters / buffers to everybody. Written through the tensors themselves under no_grad (NOT `.data`), so
@@ -154,19 +211,29 @@ class GradAllReducer:
                 ev.record()                              # on the communication stream: the bucket's copy starts here
                 self._prof_ev["launch"].append(ev)
             src, dst = [], []
+            zeroed = self._pool_zeroed()                 # this step's buckets were zero-filled by the gradient pool (static layout)
             for p, v in zip(b.params, b.views):
-                if p.grad is None:
-                    v.zero_()                            # unused on this rank: contributes zeros
+                g = p.grad
+                if g is None:
+                    if not zeroed:
+                        v.zero_()                        # unused on this rank: contributes zeros
+                elif g.data_ptr() == v.data_ptr() and g.dtype == v.dtype and g.is_contiguous():
+                    pass                                 # written in place by its autograd node
                 else:
-                    src.append(p.grad); dst.append(v)
+                    src.append(g); dst.append(v)
             if dst:
                 torch._foreach_copy_(dst, src)           # one multi-tensor kernel per bucket instead of one copy per parameter
+            self._copied += len(dst)
             if self.world > 1 or (self.force and dist.is_initialized()):
                 op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
                 b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
             elif self._cuda:
                 b.work = torch.cuda.Event()
                 b.work.record()                          # world 1 (force_overlap): finish() still orders against the copy stream
+
+    def _pool_zeroed(self) -> bool:
+        from . import _lib as L
+        return bool(L.grad_pool.armed and L.grad_pool.static_flat is self._flat_all)
 
     def begin_step(self):
         """profile=True only: call right before backward(); marks t = 0 of the per-bucket launch offsets."""
@@ -191,6 +258,8 @@ class GradAllReducer:
         bi, _ = self._where[p]
         if id(p) in self._static_unused:
             raise RuntimeError("a parameter declared as never used received a gradient")
+        if id(p) in self._marked:
+            raise RuntimeError("a parameter declared gradient-free for this step (mark_no_grad) received a gradient")
         b = self.buckets[bi]
         b.pending -= 1
         if self._cuda:
@@ -204,7 +273,8 @@ class GradAllReducer:
                 b.streams.add(ws.cuda_stream)
         # collectives must be issued in the SAME order on every rank: a bucket is only launched once all
         # earlier buckets are (a bucket holding a parameter that is unused on this rank is launched by finish())
-        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+        while self._next < len(self.buckets) and self.buckets[self._next].pending <= 0:
+            self.buckets[self._next].from_hook = True
             self._launch(self.buckets[self._next])
             self._next += 1
 
@@ -213,8 +283,16 @@ class GradAllReducer:
         if self.world == 1 and not self.force:
             return
         while self._next < len(self.buckets):
+            self.buckets[self._next].from_hook = False
             self._launch(self.buckets[self._next])
             self._next += 1
+        self.launched_from_hooks = [b.from_hook for b in self.buckets]      # (tests / diagnostics: which buckets overlapped the backward pass)
+        self.copied_last, self._copied = self._copied, 0
+        self._marked.clear()
+        if self.inplace:
+            from . import _lib as L
+            if L.grad_pool.static_flat is self._flat_all:
+                L.grad_pool.armed = False                # the buckets now hold REDUCED gradients: regions are handed out again after begin()
         inv = 1.0 / self.world
         prof = self._prof_ev if self.profile else None
         if prof is not None:

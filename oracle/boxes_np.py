@@ -176,6 +176,65 @@ def atss_match(boxes, anchors, num_anchors_per_level: Sequence[int], num_anchors
     return iou, matches
 
 
+def atss_match_blocked(boxes, anchors, num_anchors_per_level: Sequence[int], num_anchors_per_loc: int,
+                       num_candidates: int = 4, rows: int = 100, threads: int = 1) -> np.ndarray:
+    """`atss_match` (center_in_gt=False; nndet/core/boxes/matcher/atss.py:48-122) for sizes whose [G, M] matrices do not fit
+    (2 000 GT x 5 levels x 100 000 anchors = 4 GB per matrix): the GT boxes are walked in blocks of `rows`.
+    Per GT the steps are those of `atss_match` -- the k candidates per level with the smallest (distance, anchor index), IoU of the
+    candidates only (the same element-wise fp32 expression as `box_iou`), threshold = fp32 mean + fp32 unbiased std -- and the arg-max over
+    the GTs (atss.py:109-118: first maximum = lowest GT index) is carried as a running (value, index) pair per anchor. -> matches [M]."""
+    boxes, anchors = _f(boxes).reshape(-1, 6), _f(anchors)
+    G, M = boxes.shape[0], anchors.shape[0]
+    if G == 0:
+        return np.full((M,), BELOW_LOW_THRESHOLD, np.int64)
+    def block(g0):
+        b = boxes[g0:g0 + rows]
+        c1, c2 = box_center(b), box_center(anchors)
+        dx, dy, dz = (c1[:, None, q] - c2[None, :, q] for q in range(3))
+        dist = np.sqrt((dx * dx + dy * dy) + dz * dz)            # == box_center_dist(b, anchors), without the [r, M, 3] temporary
+        del dx, dy, dz
+        cand, start = [], 0
+        for apl in num_anchors_per_level:
+            k = min(num_candidates * num_anchors_per_loc, apl)
+            d = dist[:, start:start + apl]
+            kth = np.partition(d, k - 1, axis=1)[:, k - 1]       # value of the k-th smallest distance per row
+            idx = np.empty((b.shape[0], k), np.int64)
+            for r in range(b.shape[0]):
+                c = np.nonzero(d[r] <= kth[r])[0]                # ascending index; ties of the k-th value included
+                idx[r] = c[np.argsort(d[r][c], kind="stable")[:k]]   # (distance, index) order, lowest index first
+            cand.append(idx + start)
+            start += apl
+        cand = np.concatenate(cand, 1)                           # [r, K]
+        del dist
+        out = []
+        for r in range(b.shape[0]):
+            cov = box_iou(b[r:r + 1], anchors[cand[r]])[0]       # [K]
+            mean = cov.astype(np.float64).mean()
+            std = cov.astype(np.float64).std(ddof=1) if cov.shape[0] > 1 else np.nan
+            thr = F32(mean) + F32(std)
+            pos = cov >= thr
+            out.append((cand[r][pos], cov[pos]))
+        return out
+
+    starts = list(range(0, G, rows))
+    if threads > 1 and len(starts) > 1:                          # numpy releases the GIL in the heavy parts; blocks are independent
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            per_block = list(ex.map(block, starts))
+    else:
+        per_block = [block(g0) for g0 in starts]
+    best = np.full((M,), -INF, F32)
+    matches = np.full((M,), BELOW_LOW_THRESHOLD, np.int64)
+    g = 0
+    for blk in per_block:                                        # the arg-max over the GTs, in GT order
+        for sel, v in blk:
+            upd = v > best[sel]                                  # strict: an equal IoU keeps the lower GT index
+            best[sel[upd]] = v[upd]
+            matches[sel[upd]] = g
+            g += 1
+    return matches
+
+
 def nms2d(boxes, scores, thr):
     """2D NMS: devIoU + nms_kernel + the host scan of nndet/csrc/cuda/nms.cu:22-34,54-96,203-215 (what nndet._C.nms does for [N, 4]
     boxes; the Python wrapper uses torchvision.ops.nms, same rule) -- greedy over descending score (ties: lower index first),

@@ -564,8 +564,14 @@ if __name__ == "__main__":
         # BASELINE.json configs[1] at the BENCHMARKED batch (c002.py:52): the batch-level hard-negative mining (sampler.py:237-270) and
         # batch_dice couple the four patches (round 4; ~40 GB peak: the two models run one after the other)
         golden_net("luna160", lite=True, batch=4, tag="luna160_b4")
+    if "lidc192_b2" in which:
+        # BASELINE.json configs[3] beyond one patch (round 5): two 192x192x128 patches couple through the batch-level hard-negative mining
+        # and batch_dice, and every kernel walks 2 x 1.9 x the tiles of luna160 (~40 GB peak on the CPU)
+        golden_net("lidc192", lite=True, batch=2, tag="lidc192_b2")
     if "lidc192_grad64" in which:
         golden_grad64("lidc192", 1)
+    if "lidc192_b2_grad64" in which:
+        golden_grad64("lidc192", 2, tag="lidc192_b2", lean=True)
     if "luna160_grad64" in which:
         golden_grad64("luna160", 1)
     if "luna160_b4_grad64" in which:

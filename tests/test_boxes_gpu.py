@@ -89,6 +89,30 @@ def test_atss_random_vs_oracle(G, seed):
     biteq(got, ref, f"atss G={G}")
 
 
+def _config5_boxes(rng, n, extent=160.0, smin=2.0, smax=26.0):
+    """centres U(0, 160)^3, sizes U(2, 26) (the survey's probe `rb`)."""
+    c = rng.uniform(0, extent, (n, 3)); s = rng.uniform(smin, smax, (n, 3))
+    return np.stack([c[:, 0] - s[:, 0] / 2, c[:, 1] - s[:, 1] / 2, c[:, 0] + s[:, 0] / 2, c[:, 1] + s[:, 1] / 2,
+                     c[:, 2] - s[:, 2] / 2, c[:, 2] + s[:, 2] / 2], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("G,levels,per_level", [(130, 2, 20000), (2000, 5, 100000)])
+def test_atss_config5_size_vs_blocked_oracle(G, levels, per_level):
+    """BASELINE.json configs[4] / SURVEY 8d config 5 at its STATED size: 2 000 GT boxes against 5 levels x 100 000 anchors, 27 anchors per
+    location, 4 candidates (k = 108 per level) -> 125 GT tiles and 10 000 (GT, level) radix-select problems in nndet_atss3d_match_f32.
+    Bit-exact against the blocked restatement of nndet/core/boxes/matcher/atss.py:48-122 (the dense oracle needs 3 x 4 GB matrices);
+    `tests/test_oracle_golden.py::test_atss_blocked_equals_dense` pins the blocked form to the dense one."""
+    from nndetection_amd.core.boxes import ATSSMatcher
+    rng = np.random.default_rng(0)
+    anchors = np.concatenate([_config5_boxes(rng, per_level) for _ in range(levels)], 0)
+    gt = _config5_boxes(rng, G)
+    npl = [per_level] * levels
+    ref = bx.atss_match_blocked(gt, anchors, npl, 27, 4, rows=50, threads=min(16, os.cpu_count() or 1))
+    _, got = ATSSMatcher(num_candidates=4, center_in_gt=False)(t(gt), t(anchors), npl, 27)
+    biteq(got, ref, f"atss G={G} x {levels} x {per_level}")
+    assert int((ref >= 0).sum()) > 50 * G            # the case is not degenerate: tens of positives per GT
+
+
 def test_atss_batched_matches_per_image():
     """One pass for the whole batch (nndet_atss3d_match_batched_f32) == per-image oracle matches, including images
     without objects at the start / middle / end of the batch and a batch without any object."""

@@ -747,3 +747,41 @@ def test_batched_weight_packing_equals_single(dtype):
     torch.cuda.synchronize()
     for i, (o, r) in enumerate(zip(outs, refs)):
         assert torch.equal(o, r), (specs[i // 2], modes[i], int((o != r).sum()))
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128)])
+def test_strided_forward_kernels_rounding_quality(cin, cout, monkeypatch):
+    """bound the per-layer error of k_ig3s / k_ig3s2 (round 4) and of the k_igemm route they replaced, instead of only the
+    end-to-end trajectory: bf16 outputs against the CORRECTLY ROUNDED float64 convolution of the same bf16 operands (measured with
+    tools/ig3s_accuracy.py: 0.009 % / 0.016 % of the outputs differ from it, no bias). Bounds: <= 0.05 % misrounded, each by one bf16 ulp at
+    most, |mean signed error| <= 2 % of the rms error, epilogue statistics within 1e-5 of float64 sums of the kernel's own outputs."""
+    import ctypes
+    import torch.nn.functional as F
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch.conv import ConvInstanceRelu, _desc, _packed
+    torch.manual_seed(1)
+    sp, B = (33, 31, 35), 2
+    m = ConvInstanceRelu(3, cin, cout, 3, stride=2, padding=1, add_norm=False, add_act=False).cuda()
+    x = (torch.randn(B, *sp, cin, device="cuda") * 1.5).to(torch.bfloat16)
+    d = _desc(x, cin, cout, m.k, m.s, m.p, False)
+    w0 = _packed(m, 0, m.conv.weight, d, torch.bfloat16)
+    wq = m.conv.weight.detach().to(torch.bfloat16).double().cpu()
+    ref = F.conv3d(x.double().cpu().permute(0, 4, 1, 2, 3), wq, None, stride=2, padding=1).permute(0, 2, 3, 4, 1)
+    ref_r = ref.to(torch.bfloat16).double()
+    for ig in ("0", "1"):
+        monkeypatch.setenv("NNDET_IG3S", ig)
+        y = torch.empty((B, d.out_d, d.out_h, d.out_w, cout), dtype=torch.bfloat16, device="cuda")
+        stats = torch.zeros((32, B, cout, 2), dtype=torch.float64, device="cuda")
+        L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, None, L.ptr(y), L.ptr(stats), L.stream())
+        torch.cuda.synchronize()
+        yd = y.double().cpu()
+        mis = (yd != ref_r)
+        frac = float(mis.double().mean())
+        assert frac <= 5e-4, (ig, frac)
+        ulp = 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)           # bf16: 8 significant bits
+        assert bool(((yd - ref_r).abs() <= ulp * 1.0001)[mis].all()), (ig, "an output is off by more than one bf16 ulp")
+        err = yd - ref
+        assert abs(float(err.mean())) <= 0.02 * float(err.pow(2).mean().sqrt()), (ig, float(err.mean()))
+        st = stats.sum(0).cpu()
+        s_ref = torch.stack((yd.sum((1, 2, 3)), (yd * yd).sum((1, 2, 3))), -1)
+        assert float(((st - s_ref).abs() / s_ref.abs().clamp_min(1e-9)).max()) <= 1e-5, ig

@@ -399,3 +399,157 @@ def test_which_steps_may_absorb_the_top_down_step():
         S.SEG_UP = old
     toy = build_model(get_plan("toy64"))                                    # its detection head reads level 1
     assert 1 in tuple(toy.decoder_levels) and not toy._seg_up_ok(torch.zeros(1, 1, 64, 64, 64))
+
+
+# ---- round 5: gradients written IN PLACE into the reducer's buckets (static gradient-pool layout), gradient-free parameters declared
+# ---- during the forward pass (a rank without positive anchors)
+class _PoolLinearFn(torch.autograd.Function):
+    """A linear layer whose backward takes its parameter-gradient memory from _lib.grad_pool exactly like the convolution nodes do
+    (arch/conv.py: take_for): accumulates into zeroed memory and hands autograd views of it."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w, b)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        from nndetection_amd import _lib as L
+        x, w, b = ctx.saved_tensors
+        gw, gb = L.grad_pool.take_for([(w, w.numel()), (b, b.numel())], g.device)
+        dw = gw.view(w.shape)
+        dw += g.t() @ x
+        gb += g.sum(0)
+        return g @ w, dw, gb
+
+
+class _PoolNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a, self.b, self.c, self.reg = nn.Linear(8, 16), nn.Linear(16, 4), nn.Linear(4, 4), nn.Linear(4, 4)
+
+    def forward(self, x, use_reg=True):
+        from nndetection_amd import _lib as L
+        L.grad_pool.begin(sum(p.numel() + 64 for p in self.parameters()), x.device, owner=self)
+        h = x
+        for m in (self.a, self.b, self.c):
+            h = torch.relu(_PoolLinearFn.apply(h, m.weight, m.bias))
+        if use_reg:
+            return h.sum() + _PoolLinearFn.apply(h, self.reg.weight, self.reg.bias).sum()
+        L.notify_no_grad(list(self.reg.parameters()))          # what arch/heads.py does on a batch without positive anchors
+        return h.sum()
+
+
+def _ddp_inplace_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from nndetection_amd.ddp import GradAllReducer
+    from nndetection_amd import _lib as L
+    torch.manual_seed(0)
+    model = _PoolNet()
+    ddp = GradAllReducer(model, first_bucket_mb=1e-4, bucket_mb=2e-4)
+    out = {}
+    for step in range(2):
+        torch.manual_seed(100 + rank + 10 * step)
+        x = torch.randn(5, 8)
+        loss = model(x, use_reg=(rank == 0))                  # rank 1: no gradient for `reg` (declared during the forward pass)
+        loss.backward()
+        n_before = ddp._next                                    # buckets in flight when backward() returns
+        ddp.finish()
+        lo, hi = ddp._flat_all.data_ptr(), ddp._flat_all.data_ptr() + ddp._flat_all.numel() * 4
+        out[step] = dict(launched=list(ddp.launched_from_hooks), n_before=n_before, nb=len(ddp.buckets), copied=ddp.copied_last,
+                         inside=all(lo <= p.grad.data_ptr() < hi for p in model.parameters()),
+                         grads=[p.grad.detach().numpy().copy() for p in model.parameters()])
+        model.zero_grad(set_to_none=True)
+    ddp.close()
+    assert L.grad_pool.static is None and not L.no_grad_listeners
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_in_place_and_gradient_free_rank_gloo_world2():
+    """VERDICT r4 item 8a/8b. (a) The nodes write their parameter gradients into the reducer's bucket memory (static pool layout):
+    no bucket copy (`copied_last == 0`), p.grad lives inside the flat buffer. (b) Rank 1 has no gradient for the `reg` layer (a rank
+    without positive anchors, nndet/arch/heads/comb.py:397-401) and says so during its forward pass: on BOTH ranks every bucket is
+    launched from the gradient hooks, none from finish(). Values: the mean of the two ranks' local gradients, zeros for `reg` on rank 1."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_inplace_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=120) for _ in procs)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for step in range(2):
+        local = []
+        for rank in range(2):                                  # the same two local gradients with stock autograd
+            torch.manual_seed(0)
+            ref = _PoolNet()
+            torch.manual_seed(100 + rank + 10 * step)
+            x = torch.randn(5, 8)
+            h = x
+            for m in (ref.a, ref.b, ref.c):
+                h = torch.relu(m(h))
+            (h.sum() + (ref.reg(h).sum() if rank == 0 else 0.0)).backward()
+            local.append([torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in ref.parameters()])
+        for rank in range(2):
+            r = res[rank][step]
+            assert r["nb"] >= 3 and r["launched"] == [True] * r["nb"] and r["n_before"] == r["nb"], (rank, step, r["launched"], r["n_before"])
+            assert r["copied"] == 0, f"rank {rank} step {step}: {r['copied']} gradients were copied into their bucket"
+            assert r["inside"], "a gradient lives outside the reducer's flat buffer"
+            for got, a, b in zip(r["grads"], *local):
+                assert torch.allclose(torch.from_numpy(got), (a + b) / 2, atol=1e-6), (rank, step)
+
+
+def test_static_pool_hands_a_region_out_once_and_only_without_grad():
+    """The static layout must not alias two contributions: a second node of the same parameter in one backward pass, and a second
+    backward pass while `.grad` is still set (gradient accumulation), get fresh memory; autograd adds them in. Another model in the
+    same process never sees the layout (owner check)."""
+    from nndetection_amd.ddp import GradAllReducer
+    from nndetection_amd import _lib as L
+    torch.manual_seed(0)
+    model = _PoolNet()
+    ddp = GradAllReducer(model, first_bucket_mb=1e-4, bucket_mb=2e-4, force_overlap=True)
+    try:
+        x = torch.randn(5, 8)
+        ref = _PoolNet(); ref.load_state_dict(model.state_dict())
+        h = x
+        for m in (ref.a, ref.b, ref.c):
+            h = torch.relu(m(h))
+        (h.sum() + ref.reg(h).sum() + ref.reg(2 * h).sum()).backward()
+        want = [p.grad.clone() for p in ref.parameters()]
+        # `reg` used twice in one pass
+        L.grad_pool.begin(0, x.device, owner=model)
+        h = x
+        for m in (model.a, model.b, model.c):
+            h = torch.relu(_PoolLinearFn.apply(h, m.weight, m.bias))
+        (h.sum() + _PoolLinearFn.apply(h, model.reg.weight, model.reg.bias).sum()
+         + _PoolLinearFn.apply(2 * h, model.reg.weight, model.reg.bias).sum()).backward()
+        ddp.finish()
+        for p, w in zip(model.parameters(), want):
+            assert torch.allclose(p.grad, w, atol=1e-5)
+        # two forward passes, then their two backward passes, no zero_grad in between: the second pass finds `.grad` set (it lives in the
+        # parameter's region) and must accumulate through fresh memory, not write into the region again
+        model.zero_grad(set_to_none=True)
+        la, lb = model(x), model(3 * x)
+        la.backward(); lb.backward()
+        ddp.finish()
+        ref.zero_grad(set_to_none=True)
+        for xx in (x, 3 * x):
+            h = xx
+            for m in (ref.a, ref.b, ref.c):
+                h = torch.relu(m(h))
+            (h.sum() + ref.reg(h).sum()).backward()
+        for p, g in zip(model.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, g.grad, atol=1e-4)
+        model.zero_grad(set_to_none=True)
+        other = _PoolNet()
+        other(x).backward()                                     # not the owner: per-step pool, gradients outside the buckets
+        lo, hi = ddp._flat_all.data_ptr(), ddp._flat_all.data_ptr() + ddp._flat_all.numel() * 4
+        assert not any(lo <= p.grad.data_ptr() < hi for p in other.parameters())
+    finally:
+        ddp.close()

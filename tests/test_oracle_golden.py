@@ -188,3 +188,22 @@ def test_postproc_oracles_vs_reference_golden(golden_dir):
                                                 1000, 0.1, 0.01, 0.1, 100)
     assert np.array_equal(b, g["ens_out_boxes"]) and np.array_equal(p, g["ens_out_probs"])
     assert np.array_equal(l, g["ens_out_labels"]) and np.array_equal(w, g["ens_out_weights"])
+
+
+def test_atss_blocked_equals_dense():
+    """`atss_match_blocked` (the oracle of the config-5-sized ATSS GPU test) == `atss_match` (pinned to the reference above) for every
+    block size, incl. a GT centre exactly on the anchor lattice (distance ties at the k-th candidate) and single-row blocks."""
+    rng = np.random.default_rng(5)
+    W = [(4, 8, 16), (8, 16, 32), (16, 32, 64)]
+    anchors, npl = bx.anchors_for_image((64, 48, 40), [(16, 12, 10), (8, 6, 5), (4, 3, 3)], W, W, W)
+    for G in (1, 7, 40, 130):
+        c = rng.uniform(0, 48, (G, 3)); s = rng.uniform(4, 24, (G, 3))
+        gt = np.stack([c[:, 0] - s[:, 0] / 2, c[:, 1] - s[:, 1] / 2, c[:, 0] + s[:, 0] / 2, c[:, 1] + s[:, 1] / 2,
+                       c[:, 2] - s[:, 2] / 2, c[:, 2] + s[:, 2] / 2], 1).astype(np.float32)
+        if G > 1:
+            gt[0] = [10, 6, 22, 18, 2, 14]
+        _, ref = bx.atss_match(gt, anchors, npl, 27, 4)
+        for rows, threads in ((1, 1), (16, 4), (100, 1)):
+            got = bx.atss_match_blocked(gt, anchors, npl, 27, 4, rows=rows, threads=threads)
+            assert np.array_equal(ref, got), (G, rows)
+    assert (bx.atss_match_blocked(np.zeros((0, 6), np.float32), anchors, npl, 27, 4) == -1).all()

@@ -60,6 +60,22 @@ def main():
         dt4 = timeit(lambda: m.match_batch(gts, anchors, npl, 27))
         print(f"{'atss match':22s} M = {anchors.shape[0]}, G = {G:2d}: 1 image {dt1 * 1e3:7.3f} ms; batch of 4 in one pass {dt4 * 1e3:7.3f} ms "
               f"({4 * anchors.shape[0] / dt4 / 1e9:.2f} G anchors/s)", flush=True)
+    # SURVEY 8d config 5, ATSS leg: 2 000 GT x 5 levels x 100 000 anchors, 27 anchors per location, 4 candidates (k = 108 per level)
+    rng5 = np.random.default_rng(0)
+    a5_np = np.concatenate([rb(rng5, 100000) for _ in range(5)], 0); g5_np = rb(rng5, 2000)
+    a5, g5 = torch.from_numpy(a5_np).to(dev), torch.from_numpy(g5_np).to(dev)
+    npl5 = [100000] * 5
+    for G in (40, 500, 2000):
+        dt = timeit(lambda: m(g5[:G], a5, npl5, 27), iters=3)
+        print(f"{'atss match (config 5)':22s} M = 5 x 100000, G = {G:4d}: {dt * 1e3:8.3f} ms  {G * a5.shape[0] / dt / 1e9:8.2f} G (GT, anchor) pairs/s  "
+              f"{a5.shape[0] / dt / 1e6:8.2f} M anchors/s", flush=True)
+    if "--no-cpu" not in sys.argv:
+        from oracle import boxes_np as bx
+        th = min(16, os.cpu_count() or 1)
+        t0 = time.perf_counter(); ref5 = bx.atss_match_blocked(g5_np, a5_np, npl5, 27, 4, rows=50, threads=th); dt = time.perf_counter() - t0
+        got5 = m(g5, a5, npl5, 27)[1].cpu().numpy()
+        print(f"cpu oracle atss        M = 5 x 100000, G = 2000: {dt * 1e3:8.1f} ms (numpy, blocked, {th} threads); GPU matches bit-exact: "
+              f"{bool(np.array_equal(ref5, got5))}, positives {int((ref5 >= 0).sum())}", flush=True)
     if "--no-cpu" not in sys.argv:
         from oracle import boxes_np as bx
         t0 = time.perf_counter(); bx.box_iou(g_np[:200], a_np); dt = time.perf_counter() - t0
