@@ -47,8 +47,13 @@ class MatchedBoxes:
 
 # NNDET_LAZY_TARGETS=0: labels / matched boxes of the batched target assignment as the clamp / gather / compare chain of round 3
 LAZY_TARGETS = os.environ.get("NNDET_LAZY_TARGETS", "1") != "0"
-# NNDET_SEG_FIRST=0: the segmentation branch + loss queued AFTER the detection head (the reference's order, rounds 1-4)
-SEG_FIRST = os.environ.get("NNDET_SEG_FIRST", "1") != "0"
+# NNDET_SEG_FIRST=1: the segmentation branch + loss queued BEFORE the detection head, so that the backward pass issues the head's nodes
+# first (the engine runs ready nodes in decreasing creation order). Built in round 5 from the profiler's timeline, where the main stream
+# idles ~1.1 ms while the branch's ~45 small backward launches are issued -- but that gap is the PROFILER's: unprofiled, the host is two to
+# three steps ahead of the GPU (tools/host_lead.py). Measured 13.05 / 13.01 ms with it vs 12.54 / 12.55 without
+# (profiles/round5_ab_seg_first.txt): the branch's HBM-bound forward kernels then run under the head trunks instead of under the sampler's
+# latency-bound passes. OFF by default.
+SEG_FIRST = os.environ.get("NNDET_SEG_FIRST", "0") != "0"
 
 
 class BaseRetinaNet(nn.Module):

@@ -407,12 +407,17 @@ extern "C" int nndet_affine_apply(int32_t dtype, const void* x, const float* sca
 
 // ------------------------------------------------------------------ backward
 // pass 1: per (n, channel): A = sum g, B = sum g * xhat, with g = dy * [relu mask]
-template <typename T>
+template <typename T, bool RELU>
 __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int64_t spatial, int c, int c_p,
-                                                         int N, int relu, double* __restrict__ red_ws, int RED_ROWS, int groups,
+                                                         int N, double* __restrict__ red_ws, int RED_ROWS, int groups,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, const NormItems IT) {
+    // RELU is a compile-time parameter since round 5: with the run-time flag, the branch-free prologue below AND the unrolled row loop,
+    // hipcc (ROCm 7.2) produced a kernel whose dgamma sums were 1-7 % off -- only inside the training step, next to the weight-gradient
+    // kernels of the other stream, never alone (each change alone was fine; tools/r5_race_probe2.py, profiles/round5_norm_reduce_miscompile.txt).
+    // tests/test_model_gpu.py::test_norm_backward_inside_the_step_matches_torch_on_the_same_inputs guards the in-step result.
+    constexpr int relu = RELU ? 1 : 0;
     constexpr int E = Vec16<T>::E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem);
@@ -598,11 +603,11 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     static const int dbg_skip = nndet_timing_experiment("NNDET_NORM_DBG_SKIP_REDUCE");
     if (dbg_skip) {}
     else if (dtype == NNDET_BF16)
-        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
+        (relu ? k_norm_bwd_reduce<bf16_t, true> : k_norm_bwd_reduce<bf16_t, false>)<<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
     else if (dtype == NNDET_F16)
-        k_norm_bwd_reduce<f16_t><<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
+        (relu ? k_norm_bwd_reduce<f16_t, true> : k_norm_bwd_reduce<f16_t, false>)<<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
     else
-        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, relu, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
+        (relu ? k_norm_bwd_reduce<float, true> : k_norm_bwd_reduce<float, false>)<<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
         k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx, rpb, g_norm_uniform);
@@ -632,11 +637,11 @@ extern "C" int nndet_norm_backward_items(int32_t dtype, const void* x, const voi
     static const int dbg_skip = nndet_timing_experiment("NNDET_NORM_DBG_SKIP_REDUCE");
     if (dbg_skip) {}
     else if (dtype == NNDET_BF16)
-        k_norm_bwd_reduce<bf16_t><<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
+        (relu ? k_norm_bwd_reduce<bf16_t, true> : k_norm_bwd_reduce<bf16_t, false>)<<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni);
     else if (dtype == NNDET_F16)
-        k_norm_bwd_reduce<f16_t><<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
+        (relu ? k_norm_bwd_reduce<f16_t, true> : k_norm_bwd_reduce<f16_t, false>)<<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni);
     else
-        k_norm_bwd_reduce<float><<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, relu, red_ws, rr, groups, dgamma, dbeta, ni);
+        (relu ? k_norm_bwd_reduce<float, true> : k_norm_bwd_reduce<float, false>)<<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
         k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (bf16_t*)dx, rpb, ni);
