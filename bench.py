@@ -483,6 +483,15 @@ def torch_rocm_baseline_child(plan_name, batch, warmup=3, steps=10):
     computes them, torch.optim.SGD(nesterov). Runs in a child process (own MIOpen state, bounded by a timeout) and prints one JSON
     object. The ATSS assignment (numpy in the oracle) is computed ONCE on the host before the timed loop and handed in as device
     tensors: the baseline's time contains no target assignment at all (that favours the baseline). Checker / context leg only."""
+    # NNDET_TORCH_BASELINE_MODE=fair (VERDICT r4 item 9): MIOpen's NORMAL find (it benchmarks its solvers per shape; the find-db goes to
+    # /tmp), channels_last_3d tensors and >= 10 warm-up steps -- minutes of set-up, so bench.py's default leg stays "fast" (FAST find,
+    # NCDHW, 3 warm-up steps) and quotes the committed fair measurement next to it (profiles/round5_torch_rocm_baseline_fair.json).
+    fair = os.environ.get("NNDET_TORCH_BASELINE_MODE", "fast") == "fair"
+    if fair:
+        os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", "/tmp/miopen_userdb")
+        os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
+        warmup = max(warmup, 10)
     os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # no exhaustive per-shape kernel search inside a bounded leg
     os.environ.setdefault("MIOPEN_LOG_LEVEL", "1")
     from oracle.retina_torch import OracleRetinaUNet
@@ -495,6 +504,9 @@ def torch_rocm_baseline_child(plan_name, batch, warmup=3, steps=10):
     assigned = tuple(t.to(dev) for t in net.assign(x.shape, tg))
     net.to(dev)
     x = x.to(dev)
+    if fair:
+        net.to(memory_format=torch.channels_last_3d)
+        x = x.contiguous(memory_format=torch.channels_last_3d)
     tgd = {"target_boxes": None, "target_classes": None, "target_seg": tg["target_seg"].to(dev)}
     opt = torch.optim.SGD(net.parameters(), lr=TRAINER_CFG_V001["initial_lr"], momentum=0.9, nesterov=True, weight_decay=3e-5)
     scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14)
@@ -524,7 +536,8 @@ def torch_rocm_baseline_child(plan_name, batch, warmup=3, steps=10):
     print(json.dumps({"value": round(batch * steps / dt, 3), "unit": "patches/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
                       "warmup": warmup, "batch": batch, "first_step_s": round(t_first, 1), "final_loss": round(float(last.detach()), 5),
                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-                      "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "torch": torch.__version__}), flush=True)
+                      "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "memory_format": "channels_last_3d" if fair else "contiguous (NCDHW)",
+                      "mode": "fair" if fair else "fast", "torch": torch.__version__}), flush=True)
 
 
 def torch_rocm_baseline(plan_name, batch, timeout_s=240):
@@ -537,7 +550,17 @@ def torch_rocm_baseline(plan_name, batch, timeout_s=240):
         r = subprocess.run(cmd, cwd=ROOT, timeout=timeout_s, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
-                return dict(base, **json.loads(line))
+                res = dict(base, **json.loads(line))
+                fair_file = os.path.join(ROOT, "profiles", "round5_torch_rocm_baseline_fair.json")
+                if res.get("mode") != "fair" and os.path.isfile(fair_file):        # the committed NORMAL-find / channels-last measurement
+                    try:
+                        with open(fair_file) as f:
+                            fr = json.load(f)
+                        res["fair_reference"] = {k: fr.get(k) for k in ("value", "ms_per_step", "miopen_find_mode", "memory_format", "warmup", "steps")}
+                        res["fair_reference"]["file"] = "profiles/round5_torch_rocm_baseline_fair.json"
+                    except Exception:                         # noqa: BLE001
+                        pass
+                return res
         return dict(base, error="rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
     except Exception as e:                                        # noqa: BLE001
         return dict(base, error="%s: %s" % (type(e).__name__, str(e)[:200]))

@@ -365,6 +365,18 @@ int nndet_norm_apply_items(int32_t dtype, const void* x, const double* stats, co
 int nndet_norm_backward_items(int32_t dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma,
                               const float* beta, const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, int32_t relu,
                               void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream);
+/* Split I/O (round 5): the FIRST layer of the classifier and of the regressor trunk read the same pyramid batch
+ * (nndet/arch/heads/comb.py:85-109 -> classifier.py:160-181, regressor.py:153-173), so they run as ONE convolution 128 -> 2 x 128 and ONE
+ * GroupNorm over the 256 channels (groups of 16 never straddle the two halves). The normalised output is written as two dense tensors --
+ * channels [0, split) to y_lo [rows][split], [split, c_p) to y_hi [rows][c_p - split] -- which the two branches' next layers read; the
+ * backward pass takes the incoming gradient from two such tensors. split: a multiple of 32. */
+int nndet_norm_apply_items_split(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
+                                 const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, float eps, int32_t relu, void* y_lo,
+                                 void* y_hi, int32_t split, float* mean_rstd_out, void* stream);
+int nndet_norm_backward_items_split(int32_t dtype, const void* x, const void* dy_lo, const void* dy_hi, int32_t split,
+                                    const float* mean_rstd, const float* gamma, const float* beta, const NndetItems* items, int32_t c,
+                                    int32_t c_p, int32_t groups, int32_t relu, void* dx, float* dgamma, float* dbeta, double* red_ws,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * InstanceNorm3d / GroupNorm (+ReLU) on NDHWC -- replaces nn.InstanceNorm3d / nndet GroupNorm + nn.ReLU

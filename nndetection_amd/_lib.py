@@ -115,6 +115,8 @@ SIGNATURES = {
     "nndet_conv3d_backward_weight_items": (C.c_int, [_CONVP, _ITEMSP, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_norm_apply_items": (C.c_int, [_I32, _P, _P, _P, _P, _ITEMSP, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     "nndet_norm_backward_items": (C.c_int, [_I32, _P, _P, _P, _P, _P, _ITEMSP, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nndet_norm_apply_items_split": (C.c_int, [_I32, _P, _P, _P, _P, _ITEMSP, _I32, _I32, _I32, _F, _I32, _P, _P, _I32, _P, _P]),
+    "nndet_norm_backward_items_split": (C.c_int, [_I32, _P, _P, _P, _I32, _P, _P, _P, _ITEMSP, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nndet_norm_stats": (C.c_int, [_I32, _P, _I32, _I64, _I32, _P, _P]),
     "nndet_norm_finalize": (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _F, _P, _P, _P]),
     "nndet_affine_apply": (C.c_int, [_I32, _P, _P, _I32, _I64, _I32, _I32, _P, _P]),

@@ -116,6 +116,7 @@ SPARSE_OUT = os.environ.get("NNDET_SPARSE_OUT", "1") != "0"
 # convolution is evaluated at exactly those anchors (csrc/sparse_out.hip: k_ho_forward; backward: k_ho_backward). 197 GFLOP forward
 # + the [4.75 M, 6] fp32 flatten / cat and its zero-filled gradient disappear. NNDET_SPARSE_REG=0: dense deltas as in the reference.
 SPARSE_REG = os.environ.get("NNDET_SPARSE_REG", "1") != "0"
+FUSE_CIN = os.environ.get("NNDET_HEAD_FUSE_CIN", "1") != "0"      # one launch for the first layer of both head trunks (arch/pyramid.py)
 
 
 class DeferredDeltas:
@@ -396,16 +397,24 @@ class DetectionHeadHNMNative(nn.Module):
         side = self._side_streams(x2d.device, 1)[0] if two_streams else None
         if two_streams and torch.is_grad_enabled() and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # intended: one trunk per stream
+        # the FIRST trunk layer of both branches reads x2d: one convolution 128 -> 2 x 128 + one GroupNorm on the main stream (round 5,
+        # arch/pyramid.py: _FusedItemsBlockFn); the branches fork behind it. NNDET_HEAD_FUSE_CIN=0: two launches on two streams.
+        first = {}
+        c_in_r, c_in_c = self.regressor.conv_internal[0], self.classifier.conv_internal[0]
+        if FUSE_CIN and P.fusable_pair(c_in_c, c_in_r, x2d):
+            first["cls"], first["reg"] = P.fused_items_blocks(c_in_c, c_in_r, x2d, meta)
         for name, head, cout, scales in branches:
             on_side = two_streams and name == "reg"
             if on_side:
                 side.wait_stream(main)
                 x2d.record_stream(side)
+                if name in first:
+                    first[name].record_stream(side)
             defer = (name == "reg" and SPARSE_REG and SPARSE_OUT and getattr(self, "_defer_reg_out", False) and torch.is_grad_enabled())
             with torch.cuda.stream(side if on_side else main):
                 t = x2d
-                for blk in head.conv_internal:
-                    t = P.items_block(blk, t, meta)
+                for bi, blk in enumerate(head.conv_internal):
+                    t = first[name] if (bi == 0 and name in first) else P.items_block(blk, t, meta)
                 if defer:                                    # training step: conv_out + Scale only at the sampled positives, later
                     o = DeferredDeltas(t, meta, head, scales, cout, sdim)
                 else:

@@ -18,7 +18,7 @@ from .. import _lib as L
 from ..layout import cpad, phys, logical
 from .conv import _packed, _padded_bias, BaseConvNormAct
 
-__all__ = ["PyramidMeta", "pyramid_meta", "cat_levels", "items_block", "head_gather_items", "supports"]
+__all__ = ["PyramidMeta", "pyramid_meta", "cat_levels", "items_block", "head_gather_items", "supports", "fused_items_blocks", "fusable_pair"]
 
 
 class PyramidMeta:
@@ -217,6 +217,128 @@ class _ItemsNormFn(torch.autograd.Function):
                ctypes.byref(meta.items), cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta),
                L.ptr(red), L.stream())
         return dconv, dgamma, dbeta, None, None, None
+
+
+class _FusedPair:
+    """Stand-in for ONE conv block made of two blocks that read the same input (the first layers of the classifier and the regressor
+    trunk): the channel counts / kernel / norm parameters of the concatenation, and its own packed-weight cache."""
+
+    def __init__(self, a: BaseConvNormAct, b: BaseConvNormAct):
+        self.in_channels, self.out_channels = a.in_channels, a.out_channels + b.out_channels
+        self.split = a.out_channels
+        self.k, self.s, self.p, self.transposed = a.k, a.s, a.p, False
+        cpg = a.out_channels // a.norm_groups
+        self.norm_groups, self.norm_eps, self.relu = self.out_channels // cpg, a.norm_eps, a.relu
+        self._pack_cache = {}
+
+
+def fusable_pair(a, b, x2d: torch.Tensor) -> bool:
+    """Can blocks `a` and `b` (same input) run as one convolution + one GroupNorm? Same 3x3x3 / stride-1 convolution shape without bias,
+    the same kind of norm with whole groups inside each half, output channel counts that are multiples of 32 (the halves are written
+    as two dense tensors, csrc/norm.hip: split I/O)."""
+    ok = (isinstance(a, BaseConvNormAct) and isinstance(b, BaseConvNormAct) and x2d.is_cuda
+          and a.in_channels == b.in_channels and a.out_channels == b.out_channels and a.out_channels % 32 == 0
+          and a.k == b.k == (3, 3, 3) and a.s == b.s == (1, 1, 1) and a.p == b.p == (1, 1, 1) and not a.transposed and not b.transposed
+          and a.conv.bias is None and b.conv.bias is None and a.norm_groups > 0 and a.norm_groups == b.norm_groups
+          and a.out_channels % a.norm_groups == 0 and a.norm_eps == b.norm_eps and a.relu == b.relu
+          and a.conv.weight.dtype == b.conv.weight.dtype == torch.float32)
+    return bool(ok)
+
+
+class _FusedItemsBlockFn(torch.autograd.Function):
+    """conv -> norm -> ReLU of TWO blocks that read the same ragged batch, as one 3x3x3 convolution Cin -> 2 x C and one norm over the 2 C
+    channels (round 5; nndet/arch/heads/comb.py:85-109: the classifier's and the regressor's `conv_internal.c_in` see the same feature
+    maps). Forward: the input is read once (the two launches re-fetched its halo tiles twice, 3.6 x the algorithmic bytes), the
+    normalised halves come out as two dense tensors. Backward: one norm backward over both incoming gradients, ONE data-gradient
+    launch whose accumulator sums both branches (no dX_cls + dX_reg add pass), one weight-gradient launch over the concatenated dY.
+    Per element the convolution / norm arithmetic is that of the separate launches (same tiles, same order): bit-identical outputs."""
+
+    @staticmethod
+    def forward(ctx, x2d, w_a, w_b, g_a, b_a, g_b, b_b, pair, mods, meta):
+        x2d = x2d.contiguous()
+        dev, dt = x2d.device, x2d.dtype
+        desc = _items_desc(x2d, pair, meta)
+        # packed weights of the concatenation, cached until one of the two parameters changes
+        from .conv import _pver
+        ver = (_pver(w_a), _pver(w_b))
+        hit = pair._pack_cache.get(("w", dt))
+        if hit is None or hit[0] != ver:
+            w32 = torch.cat((w_a.detach().float(), w_b.detach().float()), 0).contiguous()
+            bufs = []
+            for mode in (0, 1):
+                n = L.load().nndet_packed_weight_elems(ctypes.byref(desc), mode)
+                buf = torch.empty((n,), dtype=dt, device=dev)
+                L.call("nndet_pack_weight", ctypes.byref(desc), mode, L.ptr(w32), L.ptr(buf), L.stream())
+                bufs.append(buf)
+            hit = pair._pack_cache[("w", dt)] = (ver, bufs)
+        w0, w1 = hit[1]
+        cout, cout_p, split = pair.out_channels, desc.cout_p, pair.split
+        y = torch.empty((meta.rows, cout_p), dtype=dt, device=dev)
+        stats = L.arena_zeros((L.STATS_REPLICAS, meta.n_items, cout_p, 2), torch.float64, dev)
+        L.call("nndet_conv3d_forward_items", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(x2d), L.ptr(w0), None, L.ptr(y), L.ptr(stats),
+               L.stream())
+        g32 = torch.cat((g_a.detach().float(), g_b.detach().float())).contiguous()
+        b32 = torch.cat((b_a.detach().float(), b_b.detach().float())).contiguous()
+        mean_rstd = torch.empty((meta.n_items, cout_p, 2), dtype=torch.float32, device=dev)
+        out_a = torch.empty((meta.rows, split), dtype=dt, device=dev)
+        out_b = torch.empty((meta.rows, cout_p - split), dtype=dt, device=dev)
+        code = L.dtype_code(y)
+        L.call("nndet_norm_apply_items_split", code, L.ptr(y), L.ptr(stats), L.ptr(g32), L.ptr(b32), ctypes.byref(meta.items), cout, cout_p,
+               pair.norm_groups, float(pair.norm_eps), int(pair.relu), L.ptr(out_a), L.ptr(out_b), split, L.ptr(mean_rstd), L.stream())
+        ctx.desc, ctx.pair, ctx.mods, ctx.meta, ctx.code, ctx.w1 = desc, pair, mods, meta, code, w1
+        ctx.save_for_backward(x2d, y, mean_rstd, g32, b32, w_a, w_b)
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        desc, pair, meta = ctx.desc, ctx.pair, ctx.meta
+        mod_a, mod_b = ctx.mods
+        x2d, y, mean_rstd, g32, b32, w_a, w_b = ctx.saved_tensors
+        dev, dt = x2d.device, x2d.dtype
+        cout, cout_p, split = pair.out_channels, desc.cout_p, pair.split
+        ga = ga.to(dt).contiguous() if ga is not None else torch.zeros((meta.rows, split), dtype=dt, device=dev)
+        gb = gb.to(dt).contiguous() if gb is not None else torch.zeros((meta.rows, cout_p - split), dtype=dt, device=dev)
+        nw = w_a.numel()
+        # one contiguous [2 C][Cin][27] weight gradient (the kernel's row stride spans both halves); handed to autograd as its two halves
+        gw, gg, gbt = L.grad_pool.take_for([(None, 2 * nw), (None, cout), (None, cout)], dev)
+        dconv = torch.empty_like(y)
+        red = L.arena_zeros((L.STATS_REPLICAS * meta.n_items * cout_p * 2 + meta.n_items,), torch.float64, dev)
+        L.call("nndet_norm_backward_items_split", ctx.code, L.ptr(y), L.ptr(ga), L.ptr(gb), split, L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32),
+               ctypes.byref(meta.items), cout, cout_p, pair.norm_groups, int(pair.relu), L.ptr(dconv), L.ptr(gg), L.ptr(gbt), L.ptr(red),
+               L.stream())
+        side = L.wgrad_streams.side(dev, w_a)               # weight-gradient stream, forked before the data gradient is queued
+        if side is not None:
+            L.wgrad_streams.side(dev, w_b)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2d)
+            L.call("nndet_conv3d_backward_data_items", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(dconv), L.ptr(ctx.w1), L.ptr(dx),
+                   L.stream())
+        ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
+        if side is not None:
+            x2d.record_stream(side); dconv.record_stream(side)
+        raw = side.cuda_stream if side is not None else L.stream()
+        ws = L.workspace(ws_bytes, dev, raw_stream=raw if side is not None else None)
+        dw = gw.view(2 * w_a.shape[0], *w_a.shape[1:])
+        L.call("nndet_conv3d_backward_weight_items", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(x2d), L.ptr(dconv), L.ptr(dw), None,
+               L.ptr(ws), ws_bytes, raw)
+        ca = mod_a.out_channels
+        return (dx, dw[:ca].to(w_a.dtype), dw[ca:].to(w_b.dtype), gg[:ca], gbt[:ca], gg[ca:], gbt[ca:], None, None, None)
+
+
+_PAIRS: Dict[tuple, _FusedPair] = {}
+
+
+def fused_items_blocks(a: BaseConvNormAct, b: BaseConvNormAct, x2d: torch.Tensor, meta: PyramidMeta):
+    """(a(x), b(x)) for two conv -> norm -> ReLU blocks on the same ragged batch, as one launch per kernel (see _FusedItemsBlockFn)."""
+    key = (id(a), id(b))
+    pair = _PAIRS.get(key)
+    if pair is None or pair.owner() != (a, b):
+        pair = _PAIRS[key] = _FusedPair(a, b)
+        import weakref
+        ra, rb = weakref.ref(a), weakref.ref(b)
+        pair.owner = lambda: (ra(), rb())
+    return _FusedItemsBlockFn.apply(x2d, a.conv.weight, b.conv.weight, a.norm.weight, a.norm.bias, b.norm.weight, b.norm.bias, pair, (a, b), meta)
 
 
 def rounded_w32(mod: BaseConvNormAct, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -126,10 +126,13 @@ class BaseRetinaNet(nn.Module):
                     self._grad_numel = sum(p.numel() + 64 for p in self.parameters() if p.requires_grad)
                 L.grad_pool.begin(self._grad_numel, inp.device, owner=self)
                 # side channels of the PREVIOUS backward pass (sparse-gradient hints, the factorised segmentation gradient): entries
-                # nobody consumed would pin large tensors across steps
-                L.grad_hints.d.clear()
-                from ..arch.conv import _rank1_grads
-                _rank1_grads.clear()
+                # nobody consumed would pin large tensors across steps. Their entries live from one node of a backward
+                # pass to a later node of the SAME pass, so a forward pass that runs INSIDE a backward pass (activation checkpointing
+                # recomputes, a second model driven from a hook) must leave them alone: cleared only at top level.
+                if torch._C._current_graph_task_id() == -1:
+                    L.grad_hints.d.clear()
+                    from ..arch.conv import _rank1_grads
+                    _rank1_grads.clear()
         if hasattr(self.decoder, "defer_out0"):                # decoder.out.P0 + segmentation head + loss as one 32 -> 1 convolution?
             self.decoder.defer_out0 = self._seg_branch_ok(inp)
             self.decoder.absorb_lat0 = self.decoder.defer_out0 and self._seg_lateral_ok()

@@ -171,3 +171,15 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// "Done once per DEVICE" flag for per-kernel attributes (hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function ON A
+// DEVICE: a process that drives a second GPU must set it there too). Thread-safe: two threads may both set the attribute
+// (idempotent), the bit is published afterwards. Usage: static NndetDevOnce f; if (f.need()) { ...hipFuncSetAttribute...; f.done(); }
+#include <atomic>
+struct NndetDevOnce {
+    std::atomic<unsigned long long> bits[4];
+    NndetDevOnce() { for (auto& b : bits) b.store(0ull); }
+    static int dev() { int d = 0; return hipGetDevice(&d) == hipSuccess ? (d & 255) : 0; }
+    bool need() const { const int d = dev(); return !(bits[d >> 6].load(std::memory_order_acquire) & (1ull << (d & 63))); }
+    void done() { const int d = dev(); bits[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release); }
+};

@@ -288,10 +288,10 @@ int dgs_covers(const NndetConv* c) {
 
 template <typename T, int MT, int MAXP, int G>
 static int dgs_launch(const DgsArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
+    static NndetDevOnce attr;
+    if (attr.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgs<T, MT, MAXP, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-        attr = true;
+        attr.done();
     }
     k_dgs<T, MT, MAXP, G><<<grid, 256, lds, st>>>(a);
     LAUNCH_CHECK();

@@ -442,8 +442,8 @@ int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const f
     a.gh = g % a.nt[1]; g /= a.nt[1];
     a.gd = g % a.nt[0]; a.gn = g / a.nt[0];
     constexpr size_t lds = 2 * 48 * 1024;
-    static bool at = false;
-    if (!at) {
+    static NndetDevOnce at;
+    if (at.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -452,7 +452,7 @@ int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const f
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        at = true;
+        at.done();
     }
     if (v2) {
         const dim3 g2(G, ny);

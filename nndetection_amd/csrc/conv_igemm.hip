@@ -1496,9 +1496,9 @@ static int set_lds_attr3_dma() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
     return rc;
 }
-static int g_attr_done = 0;
+static NndetDevOnce g_attr_done;
 static int ensure_attrs() {
-    if (g_attr_done) return 0;
+    if (!g_attr_done.need()) return 0;
     int rc = 0;
     rc |= set_lds_attr3_dma<bf16_t>(); rc |= set_lds_attr3_dma<f16_t>();
     rc |= set_lds_attr<bf16_t, 1, 2, 8, 16, 2>(); rc |= set_lds_attr<bf16_t, 2, 2, 8, 16, 3>(); rc |= set_lds_attr<bf16_t, 2, 2, 4, 24, 3, true>(); rc |= set_lds_attr<bf16_t, 2, 1, 4, 24, 4, true>(); rc |= set_lds_attr<bf16_t, 1, 2, 4, 16, 4>();
@@ -1511,7 +1511,7 @@ static int ensure_attrs() {
     rc |= set_lds_attr<f16_t, 2, 2, 2, 16, 3, true>(); rc |= set_lds_attr<f16_t, 4, 1, 4, 16, 3, true>(); rc |= set_lds_attr<f16_t, 2, 1, 2, 16, 4, true>();
     rc |= set_lds_attr3<f16_t, 1, 2, 8, 2>(); rc |= set_lds_attr3<f16_t, 2, 2, 8, 3>(); rc |= set_lds_attr3<f16_t, 2, 2, 16, 2>();
     if (rc) return rc;
-    g_attr_done = 1;
+    g_attr_done.done();
     return 0;
 }
 

@@ -297,10 +297,10 @@ __global__ __launch_bounds__(256) void k_pw(const PwArgs A) {
 // ------------------------------------------------------------------------------------------------ host side
 template <typename T, int MT, int NKC, int MODE, int U>
 static int pw_launch(const PwArgs& A, int rowblocks, size_t lds, hipStream_t st) {
-    static int attr_done = 0;
-    if (!attr_done) {
+    static NndetDevOnce attr_done;
+    if (attr_done.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw<T, MT, NKC, MODE, U>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_done = 1;
+        attr_done.done();
     }
     // enough waves to cover the HBM latency-bandwidth product: 8 workgroups (32 waves) per CU at most, fewer for small problems
     int64_t wgs = ceil_div64(A.ntiles, 4 * U);

@@ -804,12 +804,12 @@ int stem_wgrad(const NndetConv* c, const void* x, const void* dy, float* dw, hip
     int64_t nchunks = ceil_div64(a.total, 256);
     dim3 grid((unsigned)(nchunks < 1024 ? nchunks : 1024), c->cout_p / 32);
     const size_t lds = (27 * 257 + 1 + 256 * STEM_DYS_STRIDE) * sizeof(float);   // 64.6 KB
-    static bool attr = false;
-    if (!attr) {
+    static NndetDevOnce attr;
+    if (attr.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr = true;
+        attr.done();
     }
     if (c->dtype == NNDET_BF16) k_stem_wgrad<bf16_t><<<grid, 256, lds, st>>>(a);
     else if (c->dtype == NNDET_F16) k_stem_wgrad<f16_t><<<grid, 256, lds, st>>>(a);

@@ -1126,13 +1126,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT, int RBK = 1>
 static int wg_launch(const WgArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
+    static NndetDevOnce attr;
+    if (attr.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, false, RBK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, true, RBK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-        attr = true;
+        attr.done();
     }
     if (a.qss) k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, true, RBK><<<grid, 256, lds, st>>>(a);      // deferred input norm applied while staging X
     else k_wgrad<T, KS, MAXP, MAXQ, PF, NTS, SPLIT, false, RBK><<<grid, 256, lds, st>>>(a);
@@ -1208,10 +1208,10 @@ static int wgrad3d_slices(int pairs, int total_tiles) {
 }
 static constexpr size_t WG3D_LDS = 2 * (32 * 512 + 38 * 1024);
 template <typename T, bool ITEMS> static int wgrad3d_launch(const WgArgs& b, const WgItems& wi, dim3 g, hipStream_t st) {
-    static bool at = false;
-    if (!at) {
+    static NndetDevOnce at;
+    if (at.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3d<T, ITEMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG3D_LDS));
-        at = true;
+        at.done();
     }
     k_wgrad3d<T, ITEMS><<<g, 512, WG3D_LDS, st>>>(b, wi);
     LAUNCH_CHECK();
@@ -1220,14 +1220,14 @@ template <typename T, bool ITEMS> static int wgrad3d_launch(const WgArgs& b, con
 
 // uniform k_wgrad3 launch for a 16-bit storage type
 template <typename T> static int wgrad3_launch16(const WgArgs& b, dim3 g3, size_t lds3, hipStream_t st) {
-    static bool at = false;
-    if (!at) {
+    static NndetDevOnce at;
+    if (at.need()) {
         WG3_LDS_ATTR((k_wgrad3<T, 2, false, 2>));
         WG3_LDS_ATTR((k_wgrad3<T, 2, false, 1>));
         WG3_LDS_ATTR((k_wgrad3<T, 2, true, 1>));
         WG3_LDS_ATTR((k_wgrad3<T, 2, false, 1, false, true>));
         WG3_LDS_ATTR((k_wgrad3<T, 2, true, 1, false, true>));
-        at = true;
+        at.done();
     }
     // QDEPTH 1: 248 registers, no spill. With depth 2 the kernel needs > 256 registers at two workgroups per CU and the
     // spill reloads (scratch shares vmcnt) serialise the staging loads of every tile (profiles/round2_wgrad3_spill.txt)
@@ -1359,11 +1359,11 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
                 const int rc3 = hf ? wgrad3_launch16<f16_t>(b, g3, lds3, st) : wgrad3_launch16<bf16_t>(b, g3, lds3, st);
                 if (rc3) return rc3;
             } else {
-                static bool at = false;
-                if (!at) {
+                static NndetDevOnce at;
+                if (at.need()) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-                    at = true;
+                    at.done();
                 }
                 if (b.qss) k_wgrad3<float, 1, true><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
                 else k_wgrad3<float, 1, false><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
@@ -1398,11 +1398,11 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
         inc.gh = g % b.nt[1]; g /= b.nt[1];
         inc.gd = g % b.nt[0]; inc.gn = g / b.nt[0];
         constexpr size_t lds_s = 2 * (2 * 2 * 4 * 512 + 48 * 1024);
-        static bool at = false;
-        if (!at) {
+        static NndetDevOnce at;
+        if (at.need()) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3s<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3s<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-            at = true;
+            at.done();
         }
         dim3 gs(Ss, rb / 2, kb);
         if (hf) k_wgrad3s<f16_t><<<gs, 512, lds_s, st>>>(b, inc);
@@ -1484,18 +1484,18 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
     b.part = reinterpret_cast<float*>(ws);
     const size_t lds3 = (size_t)32 * (8 * RB + RB / 2) + (size_t)60 * (10 * RB + RB / 2);
     dim3 g3(S3, rb, kb);
-    static bool at = false;
-    if (!at) {
+    static NndetDevOnce at;
+    if (at.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<bf16_t, 2, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<f16_t, 2, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<float, 1, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-        at = true;
+        at.done();
     }
-    static bool atw = false;
-    if (!atw) {
+    static NndetDevOnce atw;
+    if (atw.need()) {
         WG3_LDS_ATTR((k_wgrad3<bf16_t, 2, false, 1, true, true>));
         WG3_LDS_ATTR((k_wgrad3<f16_t, 2, false, 1, true, true>));
-        atw = true;
+        atw.done();
     }
     if (bf && wgrad3_m32()) {
         if (hf) k_wgrad3<f16_t, 2, false, 1, true, true><<<g3, 256, lds3, st>>>(b, wi);

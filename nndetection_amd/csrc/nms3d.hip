@@ -299,11 +299,11 @@ __global__ __launch_bounds__(1024) void k_nms_compact(const u64* __restrict__ ke
 
 static const size_t NMS_SCAN_LDS = (size_t)NMS_SCAN_NBUF * 64 * 64 * 8;
 static int nms_scan_attr() {
-    static int done = 0;
-    if (!done) {
+    static NndetDevOnce done;
+    if (done.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nms_scan_super), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NMS_SCAN_LDS);
         if (e != hipSuccess) return (int)e;
-        done = 1;
+        done.done();
     }
     return 0;
 }

@@ -280,11 +280,15 @@ extern "C" int nndet_norm_finalize(const double* stats, const float* gamma, cons
 }
 
 // ------------------------------------------------------------------ apply: y = relu?((x - mean) * rstd * gamma + beta)
+// Split I/O (round 5, the fused first layer of the two detection-head trunks: one 128 -> 2 x 128 convolution + one GroupNorm over 256
+// channels): the channels [0, split) of the normalised output go to `y` and [split, c_p) to `y1`, each a dense [rows][own channel count]
+// tensor -- what the two branches' next convolutions read -- and the backward kernels read the incoming gradient from two such tensors.
+// y1 / dy1 == NULL: one tensor of c_p channels, as before.
 template <typename T>
 __global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, const float* __restrict__ mean_rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     int64_t spatial, int c, int c_p, int relu, T* __restrict__ y, int RPB,
-                                                    const NormItems IT) {
+                                                    const NormItems IT, T* __restrict__ y1 = nullptr, int split = 0) {
     constexpr int E = Vec16<T>::E;
     const int ppr = c_p / E, rpi = 256 / ppr;
     const int n = blockIdx.y;
@@ -306,8 +310,12 @@ __global__ __launch_bounds__(256) void k_norm_apply(const T* __restrict__ x, con
     }
     const int64_t r1 = min(r0 + RPB, spatial);
     const int64_t base = row0 * c_p + cp * E;
+    const bool hi = y1 != nullptr && cp * E >= split;
+    T* const yo = hi ? y1 : y;
+    const int yp = y1 ? (hi ? c_p - split : split) : c_p;                 // row pitch / first channel of this thread's output tensor
+    const int64_t ybase = row0 * yp + (hi ? cp * E - split : cp * E);
     for (int64_t r = r0 + rr; r < r1; r += rpi)      // AffinePiece: the SAME code the convolutions run when they apply the norm on load
-        *reinterpret_cast<u32x4*>(y + base + r * c_p) = AffinePiece<T>::apply(*reinterpret_cast<const u32x4*>(x + base + r * c_p), sc, sh, relu);
+        *reinterpret_cast<u32x4*>(yo + ybase + r * yp) = AffinePiece<T>::apply(*reinterpret_cast<const u32x4*>(x + base + r * c_p), sc, sh, relu);
 }
 
 extern "C" int nndet_norm_apply(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
@@ -347,11 +355,12 @@ static int norm_items(const NndetItems* it, NormItems* ni, int64_t* total_rows, 
     return 0;
 }
 
-extern "C" int nndet_norm_apply_items(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
-                                      const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, float eps, int32_t relu,
-                                      void* y, float* mean_rstd_out, void* stream) {
+static int norm_apply_items_impl(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
+                                 const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, float eps, int32_t relu,
+                                 void* y, void* y1, int32_t split, float* mean_rstd_out, void* stream) {
     if (!x || !stats || !gamma || !beta || !y || !mean_rstd_out) return NNDET_EINVAL;
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
+    if (y1 && (split <= 0 || split >= c_p || split % 32)) return NNDET_EINVAL;
     NormItems ni;
     int64_t total = 0, mx = 0;
     const int rc = norm_items(items, &ni, &total, &mx);
@@ -362,13 +371,26 @@ extern "C" int nndet_norm_apply_items(int32_t dtype, const void* x, const double
     const int rpb = apply_rows(total, c_p, nndet_esize(dtype));
     dim3 grid((unsigned)ceil_div64(mx, rpb), ni.n);
     if (dtype == NNDET_BF16)
-        k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (bf16_t*)y, rpb, ni);
+        k_norm_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (bf16_t*)y, rpb, ni, (bf16_t*)y1, split);
     else if (dtype == NNDET_F16)
-        k_norm_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (f16_t*)y, rpb, ni);
+        k_norm_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (f16_t*)y, rpb, ni, (f16_t*)y1, split);
     else
-        k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (float*)y, rpb, ni);
+        k_norm_apply<float><<<grid, 256, 0, st>>>((const float*)x, mean_rstd_out, gamma, beta, 0, c, c_p, relu, (float*)y, rpb, ni, (float*)y1, split);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int nndet_norm_apply_items(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
+                                      const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, float eps, int32_t relu,
+                                      void* y, float* mean_rstd_out, void* stream) {
+    return norm_apply_items_impl(dtype, x, stats, gamma, beta, items, c, c_p, groups, eps, relu, y, nullptr, 0, mean_rstd_out, stream);
+}
+
+extern "C" int nndet_norm_apply_items_split(int32_t dtype, const void* x, const double* stats, const float* gamma, const float* beta,
+                                            const NndetItems* items, int32_t c, int32_t c_p, int32_t groups, float eps, int32_t relu,
+                                            void* y_lo, void* y_hi, int32_t split, float* mean_rstd_out, void* stream) {
+    if (!y_hi) return NNDET_EINVAL;
+    return norm_apply_items_impl(dtype, x, stats, gamma, beta, items, c, c_p, groups, eps, relu, y_lo, y_hi, split, mean_rstd_out, stream);
 }
 
 // ------------------------------------------------------------------ y = relu?(x * scale + shift) from a coefficient table
@@ -412,7 +434,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
                                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int64_t spatial, int c, int c_p,
                                                          int N, double* __restrict__ red_ws, int RED_ROWS, int groups,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, const NormItems IT) {
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, const NormItems IT,
+                                                         const T* __restrict__ dy1 = nullptr, int split = 0) {
     // RELU is a compile-time parameter since round 5: with the run-time flag, the branch-free prologue below AND the unrolled row loop,
     // hipcc (ROCm 7.2) produced a kernel whose dgamma sums were 1-7 % off -- only inside the training step, next to the weight-gradient
     // kernels of the other stream, never alone (each change alone was fine; tools/r5_race_probe2.py, profiles/round5_norm_reduce_miscompile.txt).
@@ -448,6 +471,10 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
         const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
         const int64_t r1 = min(r0 + RED_ROWS, spatial);
         const int64_t base = row0 * c_p + cp * E;
+        const bool hi = dy1 != nullptr && cp * E >= split;              // split gradient input (see k_norm_apply)
+        const T* const dyi = hi ? dy1 : dy;
+        const int gp = dy1 ? (hi ? c_p - split : split) : c_p;
+        const int64_t gbase = row0 * gp + (hi ? cp * E - split : cp * E);
         auto row = [&](const float* xv, const float* gv) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -467,7 +494,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
 #pragma unroll
             for (int u = 0; u < RED_U; ++u) {
                 xr[u] = Vec16<T>::ldraw(x + base + (r + (int64_t)u * rpi) * c_p);
-                gr[u] = Vec16<T>::ldraw(dy + base + (r + (int64_t)u * rpi) * c_p);
+                gr[u] = Vec16<T>::ldraw(dyi + gbase + (r + (int64_t)u * rpi) * gp);
             }
 #pragma unroll
             for (int u = 0; u < RED_U; ++u) {
@@ -480,7 +507,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
         for (; r < r1; r += rpi) {
             float xv[E], gv[E];
             Vec16<T>::ld(x + base + r * c_p, xv);
-            Vec16<T>::ld(dy + base + r * c_p, gv);
+            Vec16<T>::ld(dyi + gbase + r * gp, gv);
             row(xv, gv);
         }
 #pragma unroll
@@ -547,7 +574,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const T* __restrict__ x,
                                                         const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const double* __restrict__ red_ws,
                                                         int64_t spatial, int c, int c_p, int relu, T* __restrict__ dx, int RPB,
-                                                        const NormItems IT) {
+                                                        const NormItems IT, const T* __restrict__ dy1 = nullptr, int split = 0) {
     constexpr int E = Vec16<T>::E;
     const int ppr = c_p / E, rpi = 256 / ppr;
     const int n = blockIdx.y;
@@ -574,10 +601,14 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const T* __restrict__ x,
     }
     const int64_t r1 = min(r0 + RPB, spatial);
     const int64_t base = row0 * c_p + cp * E;
+    const bool hi = dy1 != nullptr && cp * E >= split;
+    const T* const dyi = hi ? dy1 : dy;
+    const int gp = dy1 ? (hi ? c_p - split : split) : c_p;
+    const int64_t gbase = row0 * gp + (hi ? cp * E - split : cp * E);
     for (int64_t r = r0 + rr; r < r1; r += rpi) {
         float xv[E], gv[E];
         Vec16<T>::ld(x + base + r * c_p, xv);
-        Vec16<T>::ld(dy + base + r * c_p, gv);
+        Vec16<T>::ld(dyi + gbase + r * gp, gv);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const float xh = (xv[e] - mu[e]) * rs[e];
@@ -603,11 +634,11 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     static const int dbg_skip = nndet_timing_experiment("NNDET_NORM_DBG_SKIP_REDUCE");
     if (dbg_skip) {}
     else if (dtype == NNDET_BF16)
-        (relu ? k_norm_bwd_reduce<bf16_t, true> : k_norm_bwd_reduce<bf16_t, false>)<<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
+        (relu ? k_norm_bwd_reduce<bf16_t, true> : k_norm_bwd_reduce<bf16_t, false>)<<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform, (const bf16_t*)nullptr, 0);
     else if (dtype == NNDET_F16)
-        (relu ? k_norm_bwd_reduce<f16_t, true> : k_norm_bwd_reduce<f16_t, false>)<<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
+        (relu ? k_norm_bwd_reduce<f16_t, true> : k_norm_bwd_reduce<f16_t, false>)<<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform, (const f16_t*)nullptr, 0);
     else
-        (relu ? k_norm_bwd_reduce<float, true> : k_norm_bwd_reduce<float, false>)<<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform);
+        (relu ? k_norm_bwd_reduce<float, true> : k_norm_bwd_reduce<float, false>)<<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, spatial, c, c_p, batch, red_ws, rr, groups, dgamma, dbeta, g_norm_uniform, (const float*)nullptr, 0);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
         k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx, rpb, g_norm_uniform);
@@ -619,11 +650,12 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     return 0;
 }
 
-extern "C" int nndet_norm_backward_items(int32_t dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma,
-                                         const float* beta, const NndetItems* items, int32_t c, int32_t c_p, int32_t groups,
-                                         int32_t relu, void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream) {
+static int norm_backward_items_impl(int32_t dtype, const void* x, const void* dy, const void* dy1, int32_t split, const float* mean_rstd,
+                                    const float* gamma, const float* beta, const NndetItems* items, int32_t c, int32_t c_p, int32_t groups,
+                                    int32_t relu, void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream) {
     if (!x || !dy || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red_ws) return NNDET_EINVAL;
     if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
+    if (dy1 && (split <= 0 || split >= c_p || split % 32)) return NNDET_EINVAL;
     NormItems ni;
     int64_t total = 0, mx = 0;
     const int rc = norm_items(items, &ni, &total, &mx);
@@ -637,20 +669,34 @@ extern "C" int nndet_norm_backward_items(int32_t dtype, const void* x, const voi
     static const int dbg_skip = nndet_timing_experiment("NNDET_NORM_DBG_SKIP_REDUCE");
     if (dbg_skip) {}
     else if (dtype == NNDET_BF16)
-        (relu ? k_norm_bwd_reduce<bf16_t, true> : k_norm_bwd_reduce<bf16_t, false>)<<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni);
+        (relu ? k_norm_bwd_reduce<bf16_t, true> : k_norm_bwd_reduce<bf16_t, false>)<<<rgrid, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni, (const bf16_t*)dy1, split);
     else if (dtype == NNDET_F16)
-        (relu ? k_norm_bwd_reduce<f16_t, true> : k_norm_bwd_reduce<f16_t, false>)<<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni);
+        (relu ? k_norm_bwd_reduce<f16_t, true> : k_norm_bwd_reduce<f16_t, false>)<<<rgrid, 256, lds, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni, (const f16_t*)dy1, split);
     else
-        (relu ? k_norm_bwd_reduce<float, true> : k_norm_bwd_reduce<float, false>)<<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni);
+        (relu ? k_norm_bwd_reduce<float, true> : k_norm_bwd_reduce<float, false>)<<<rgrid, 256, lds, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, 0, c, c_p, ni.n, red_ws, rr, groups, dgamma, dbeta, ni, (const float*)dy1, split);
     LAUNCH_CHECK();
     if (dtype == NNDET_BF16)
-        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (bf16_t*)dx, rpb, ni);
+        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (bf16_t*)dx, rpb, ni, (const bf16_t*)dy1, split);
     else if (dtype == NNDET_F16)
-        k_norm_bwd_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (f16_t*)dx, rpb, ni);
+        k_norm_bwd_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (f16_t*)dx, rpb, ni, (const f16_t*)dy1, split);
     else
-        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (float*)dx, rpb, ni);
+        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, 0, c, c_p, relu, (float*)dx, rpb, ni, (const float*)dy1, split);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int nndet_norm_backward_items(int32_t dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma,
+                                         const float* beta, const NndetItems* items, int32_t c, int32_t c_p, int32_t groups,
+                                         int32_t relu, void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream) {
+    return norm_backward_items_impl(dtype, x, dy, nullptr, 0, mean_rstd, gamma, beta, items, c, c_p, groups, relu, dx, dgamma, dbeta, red_ws, stream);
+}
+
+extern "C" int nndet_norm_backward_items_split(int32_t dtype, const void* x, const void* dy_lo, const void* dy_hi, int32_t split,
+                                               const float* mean_rstd, const float* gamma, const float* beta, const NndetItems* items,
+                                               int32_t c, int32_t c_p, int32_t groups, int32_t relu, void* dx, float* dgamma, float* dbeta,
+                                               double* red_ws, void* stream) {
+    if (!dy_hi) return NNDET_EINVAL;
+    return norm_backward_items_impl(dtype, x, dy_lo, dy_hi, split, mean_rstd, gamma, beta, items, c, c_p, groups, relu, dx, dgamma, dbeta, red_ws, stream);
 }
 
 // ------------------------------------------------------------------ column sums (bias gradient): out[c] += sum_rows x[row][c]

@@ -403,10 +403,10 @@ static int pp_run(const float* scores, int32_t scores_are_probs, const float* de
     if (bitonic && K <= 16384) {
         int N = 2;
         while (N < K) N <<= 1;
-        static bool attr = false;
-        if (!attr) {
+        static NndetDevOnce attr;
+        if (attr.need()) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pp_bitonic), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
-            attr = true;
+            attr.done();
         }
         k_pp_bitonic<<<B, 1024, (size_t)N * 8, st>>>(w.cand, w.cand_sorted, (int)K, N);
         LAUNCH_CHECK();

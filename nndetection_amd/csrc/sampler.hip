@@ -191,7 +191,7 @@ struct SpWs {
 static int sp_layout(int P_cap, int NEG_cap, int POOL_cap, char* base, SpWs* w) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    size_t o_pa = take(32), o_pr = take(16), o_kr = take(8), o_h = take(512 * 4);
+    size_t o_pa = take(32), o_pr = take(16), o_kr = take(16), o_h = take(512 * 4);   // krem: 2 remaining ranks + 2 'decided' flags (k_sp_derive / k_sp_pick / k_sp_hist)
     size_t o_lp = take((size_t)P_cap * 8), o_ps = take((size_t)P_cap * 8);
     size_t o_lq = take((size_t)POOL_cap * 8), o_qs = take((size_t)POOL_cap * 8), o_se = take((size_t)POOL_cap * 8), o_ss = take((size_t)POOL_cap * 8);
     size_t o_nt = take((size_t)NEG_cap * 8), o_ns = take((size_t)NEG_cap * 8);

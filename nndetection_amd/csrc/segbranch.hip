@@ -347,15 +347,15 @@ static int segbranch_launch(int32_t dtype, const void* x, const void* w_packed, 
     if ((int64_t)D * H * W * 64 >= (1LL << 31)) return NNDET_EINVAL;    // 32-bit buffer offsets per image
     const int64_t ntiles = (int64_t)ceil_div(D, SB_TD) * ceil_div(H, SB_TH) * ceil_div(W, SB_TW) * N;
     const unsigned nb = (unsigned)(ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048);      // a multiple of 8: one share per XCD
-    static int attr_done = 0;
-    if (!attr_done) {
+    static NndetDevOnce attr_done;
+    if (attr_done.need()) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<bf16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_fwd<f16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS));
-        attr_done = 1;
+        attr_done.done();
     }
     hipStream_t st = as_stream(stream);
 #define SB_GO(T_, TWO_) k_segbranch_fwd<T_, TWO_><<<nb, 256, SB_LDS, st>>>((const T_*)x, (const uint32_t*)w_packed, (const T_*)x2, \

@@ -326,18 +326,22 @@ def amd_fuse_sgd(opt) -> bool:
     # this edits a CONSTRUCTED optimizer (the reference builds it; we only see the instance): re-validate what torch.optim.SGD's
     # constructor would have checked for fused=True, also for groups added later
     if not getattr(opt, "_nndet_add_group_checked", False):
-        orig_add = opt.add_param_group
-
-        def add_param_group(group, _orig=orig_add):
-            ps = group["params"] if isinstance(group, dict) else group
-            ps = [ps] if isinstance(ps, torch.Tensor) else list(ps)
-            if not all(q.is_cuda and q.dtype == torch.float32 for q in ps):
-                raise ValueError("amd_fuse_sgd switched this optimizer to fused=True: new parameters must be fp32 tensors on the GPU")
-            return _orig(group)
-
-        opt.add_param_group = add_param_group
+        import types
+        opt.add_param_group = types.MethodType(_fused_add_param_group, opt)     # (a module-level function: nothing closes over the instance)
         opt._nndet_add_group_checked = True
     return True
+
+
+def _fused_add_param_group(opt, group):
+    """`add_param_group` of an optimizer that `amd_fuse_sgd` switched to fused=True: torch's own method first (its validation, its error
+    types), then what torch.optim.SGD's constructor would have checked for a fused optimizer; a group that fails is taken out again."""
+    n = len(opt.param_groups)
+    res = type(opt).add_param_group(opt, group)
+    for g in opt.param_groups[n:]:
+        if not all(q.is_cuda and q.dtype == torch.float32 for q in g["params"]):
+            del opt.param_groups[n:]
+            raise ValueError("amd_fuse_sgd switched this optimizer to fused=True: new parameters must be fp32 tensors on the GPU")
+    return res
 
 
 def _autocast_dtype() -> torch.dtype:

@@ -210,3 +210,70 @@ def test_detection_head_items_equals_per_level(dtype, monkeypatch):
         # (GroupNorm statistics order) and nothing averages that out on the small levels
         tol = 0.15 if (dtype != torch.float32 and "scales" in n) else gtol
         assert float((g1[n] - g0[n]).abs().max()) <= tol * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_fused_first_trunk_layer_of_both_branches(dtype):
+    """Round 5: the classifier's and the regressor's first trunk layer read the same ragged batch and run as ONE
+    convolution 128 -> 2 x 128 + ONE GroupNorm over 256 channels with split output (arch/pyramid.py: _FusedItemsBlockFn,
+    nndet_norm_apply_items_split / nndet_norm_backward_items_split). Against the two separate `items_block` launches: conv -> norm -> ReLU
+    outputs BIT-IDENTICAL up to the norm statistics' atomics (1e-6 / 1 ulp), the input gradient = the SUM of the two branches' data
+    gradients from one accumulator (closer to fp32 than the rounded sum of two rounded gradients), weight / norm gradients per branch."""
+    from nndetection_amd.arch import pyramid as P
+    a, b = _block(128, 128, True, 11), _block(128, 128, True, 12)
+    batch = 2
+    fm1 = _fmaps(128, dtype, batch, 5)
+    fm2 = [f.detach().clone().requires_grad_(True) for f in fm1]
+    x1, meta = P.cat_levels(fm1)
+    x2, _ = P.cat_levels(fm2)
+    assert P.fusable_pair(a, b, x1)
+    ya, yb = P.items_block(a, x1, meta), P.items_block(b, x1, meta)
+    fa, fb = P.fused_items_blocks(a, b, x2, meta)
+    tol = 2e-6 if dtype == torch.float32 else 0.0
+    for u, v, n in ((ya, fa, "a"), (yb, fb, "b")):
+        assert u.shape == v.shape
+        d = (u.float() - v.float()).abs()
+        ulp = u.float().abs().clamp_min(1e-3) * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10 if dtype == torch.float16 else 0.0)
+        assert bool((d <= ulp + tol * float(u.float().abs().max())).all()), (n, float(d.max()))
+        assert float((d > 0).float().mean()) < 1e-3, (n, "more than 0.1 % of the outputs differ")
+    g = torch.Generator().manual_seed(3)
+    ga, gb = torch.randn(ya.shape, generator=g).cuda().to(dtype), torch.randn(yb.shape, generator=g).cuda().to(dtype)
+    torch.autograd.backward([ya, yb], [ga, gb])
+    ref = {n: p.grad.clone() for blk, tag in ((a, "a"), (b, "b")) for n, p in ((tag + "." + k, v) for k, v in blk.named_parameters())}
+    ref_dx = [f.grad.clone() for f in fm1]
+    a.zero_grad(set_to_none=True); b.zero_grad(set_to_none=True)
+    torch.autograd.backward([fa, fb], [ga, gb])
+    torch.cuda.synchronize()
+    rel = 2e-5 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    for blk, tag in ((a, "a"), (b, "b")):
+        for k, p in blk.named_parameters():
+            r = ref[tag + "." + k]
+            assert p.grad is not None and float((p.grad - r).abs().max()) <= rel * float(r.abs().max()) + 1e-7, (tag, k)
+    for f, r in zip(fm2, ref_dx):
+        assert float((f.grad.float() - r.float()).abs().max()) <= rel * float(r.float().abs().max()), "input gradient"
+
+
+def test_head_forward_uses_the_fused_first_layer(monkeypatch):
+    """DetectionHeadHNMNative._forward_items takes the fused route by default and NNDET_HEAD_FUSE_CIN=0 restores the two launches; both
+    give the same predictions."""
+    from nndetection_amd.plans import get_plan
+    from nndetection_amd.ptmodule import build_model
+    from nndetection_amd.arch import heads as H
+    from nndetection_amd import _lib as L
+    plan = get_plan("toy64")
+    torch.manual_seed(0)
+    net = build_model(plan).cuda().eval()
+    x = torch.randn(2, 1, *plan["patch_size"], device="cuda").to(torch.bfloat16)
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    outs = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(H, "FUSE_CIN", fuse)
+        calls.clear()
+        with torch.no_grad():
+            pred, _, _ = net(x)
+        assert ("nndet_norm_apply_items_split" in calls) == fuse
+        outs[fuse] = (pred["box_logits"].float().clone(), pred["box_deltas"].float().clone())
+    for u, v in zip(outs[True], outs[False]):
+        assert float((u - v).abs().max()) <= 2e-2 * float(v.abs().max())

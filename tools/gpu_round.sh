@@ -22,6 +22,9 @@ for s in $STAGES; do
     nmspmc) rm -rf gpurun_out/nmspmc; for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES"; do
              tag=$(echo $pass | cut -d' ' -f1); (cd /tmp && timeout 300 rocprofv3 --pmc $pass -d $OLDPWD/gpurun_out/nmspmc/$tag -- python $OLDPWD/tools/nms_microbench.py 10000 3 > $OLDPWD/gpurun_out/nmspmc_$tag.txt 2>&1); done
            python tools/rocpd_pmc.py $(find gpurun_out/nmspmc -name "*_results.db") > gpurun_out/nmspmc_summary.txt 2>&1; grep -A12 "k_nms" gpurun_out/nmspmc_summary.txt | head -70; rm -rf gpurun_out/nmspmc;;
+    gioupmc) rm -rf gpurun_out/gioupmc; for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_TRANS" "FETCH_SIZE WRITE_SIZE"; do
+             tag=$(echo $pass | cut -d' ' -f1); (cd /tmp && timeout 300 rocprofv3 --pmc $pass -d $OLDPWD/gpurun_out/gioupmc/$tag -- python $OLDPWD/tools/giou_microbench.py 3 > $OLDPWD/gpurun_out/gioupmc_$tag.txt 2>&1); done
+           python tools/rocpd_pmc.py $(find gpurun_out/gioupmc -name "*_results.db") > gpurun_out/gioupmc_summary.txt 2>&1; grep -A22 "k_pairwise" gpurun_out/gioupmc_summary.txt | head -60; rm -rf gpurun_out/gioupmc;;
     parity) timeout 1500 python -m pytest tests/test_parity_full_gpu.py tests/test_postprocess_gpu.py tests/test_targets_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_parity.txt 2>&1; tail -40 gpurun_out/t_parity.txt;;
     pyr)   timeout 900 python -m pytest tests/test_pyramid_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/t_pyr.txt 2>&1; tail -40 gpurun_out/t_pyr.txt;;
     ab)    for v in 1 0 1 0; do env "${AB_VAR:-NNDET_HEAD_ITEMS}=$v" timeout 600 python bench.py --steps 60 --warmup 15 --no-extras > gpurun_out/ab_items$v.txt 2>&1; echo "items=$v $(grep -o '"value": [0-9.]*' gpurun_out/ab_items$v.txt | head -1) $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_items$v.txt | head -1)" | tee -a gpurun_out/ab.txt; done;;

@@ -31,6 +31,18 @@ def main():
         for c, v in sorted(agg[k].items()):
             n = max(1, len(disp[(k, c)]))
             print(f"    {c:30s} total {v:22.0f}   dispatches {n:5d}   per dispatch {v / n:18.1f}")
+        per = {c: v / max(1, len(disp[(k, c)])) for c, v in agg[k].items()}
+        # derived (per dispatch; the counters come from separate passes over the same launches). SQ_LEVEL_WAVES reads 0 on this stack, so the
+        # occupancy is taken from the wave-cycle integral: SQ_WAVE_CYCLES (sum over waves of their resident cycles, 4-cycle quanta like
+        # SQ_BUSY_CU_CYCLES) / SQ_BUSY_CU_CYCLES (sum over CUs of their busy cycles) = average waves resident on a busy CU
+        if per.get("SQ_WAVE_CYCLES") and per.get("SQ_BUSY_CU_CYCLES"):
+            print(f"    {'derived: waves per busy CU':30s} {per['SQ_WAVE_CYCLES'] / per['SQ_BUSY_CU_CYCLES']:10.2f}   (SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES; 32 = full)")
+        if per.get("SQ_WAVE_CYCLES") and per.get("SQ_WAIT_INST_ANY") is not None and "SQ_WAIT_INST_ANY" in per:
+            print(f"    {'derived: wave cycles waiting':30s} {per['SQ_WAIT_INST_ANY'] / per['SQ_WAVE_CYCLES']:10.2f}   (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)")
+        if per.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_ANY" in per:
+            print(f"    {'derived: wave cycles issuing':30s} {per['SQ_ACTIVE_INST_ANY'] / per['SQ_WAVE_CYCLES']:10.2f}   (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)")
+        if per.get("SQ_WAVES") and "SQ_INSTS_VALU" in per:
+            print(f"    {'derived: VALU insts per wave':30s} {per['SQ_INSTS_VALU'] / per['SQ_WAVES']:10.1f}")
 
 
 if __name__ == "__main__":
