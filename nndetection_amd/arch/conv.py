@@ -72,6 +72,13 @@ def _pver(t: torch.Tensor):
     return (t._version, t.data_ptr(), PARAM_GENERATION[0])
 
 
+# Caches that do not hang off a conv block (arch/pyramid.py: the packed weights of two FUSED blocks) are additionally keyed on this
+# counter: it advances whenever the per-module caches are dropped wholesale -- the forced re-pack of a training-mode forward pass
+# (prepack_all(force=True): a foreign fused optimizer may have written the parameters without touching their version counters) and a
+# train() <-> eval() switch of the detector (core/retina.py).
+PACK_EPOCH = [0]
+
+
 def _packed(mod, mode: int, weight: torch.Tensor, desc: L.NndetConv, dtype: torch.dtype) -> torch.Tensor:
     """Packed + cast weights, cached per (mode, dtype) until the parameter changes (optimizer step)."""
     key = (mode, dtype)
@@ -122,6 +129,8 @@ def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1), force: bool 
     kernels (torch._fused_sgd_ / _fused_adam_, i.e. torch.optim.*(fused=True)) write the parameters without advancing `_version`
     (nndetection_amd.optim advances it by hand; a foreign optimizer may not)."""
     jobs = []
+    if force:
+        PACK_EPOCH[0] += 1
     for mod in model.modules():
         if not isinstance(mod, BaseConvNormAct):
             continue

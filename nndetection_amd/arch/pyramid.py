@@ -259,8 +259,8 @@ class _FusedItemsBlockFn(torch.autograd.Function):
         dev, dt = x2d.device, x2d.dtype
         desc = _items_desc(x2d, pair, meta)
         # packed weights of the concatenation, cached until one of the two parameters changes
-        from .conv import _pver
-        ver = (_pver(w_a), _pver(w_b))
+        from .conv import _pver, PACK_EPOCH
+        ver = (_pver(w_a), _pver(w_b), PACK_EPOCH[0])
         hit = pair._pack_cache.get(("w", dt))
         if hit is None or hit[0] != ver:
             w32 = torch.cat((w_a.detach().float(), w_b.detach().float()), 0).contiguous()

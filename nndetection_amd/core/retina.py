@@ -95,6 +95,8 @@ class BaseRetinaNet(nn.Module):
             for m in self.modules():
                 if hasattr(m, "_pack_cache"):
                     m._pack_cache.clear()
+            from ..arch.conv import PACK_EPOCH
+            PACK_EPOCH[0] += 1                   # (caches keyed on pairs of blocks, arch/pyramid.py)
         return super().train(mode)
 
     def never_used_parameters(self) -> List[nn.Parameter]:
