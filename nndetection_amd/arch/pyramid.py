@@ -287,6 +287,7 @@ class _FusedItemsBlockFn(torch.autograd.Function):
                pair.norm_groups, float(pair.norm_eps), int(pair.relu), L.ptr(out_a), L.ptr(out_b), split, L.ptr(mean_rstd), L.stream())
         ctx.desc, ctx.pair, ctx.mods, ctx.meta, ctx.code, ctx.w1 = desc, pair, mods, meta, code, w1
         ctx.save_for_backward(x2d, y, mean_rstd, g32, b32, w_a, w_b)
+        ctx.set_materialize_grads(False)        # a branch that is not part of the loss arrives as None (its parameters then get NO gradient)
         return out_a, out_b
 
     @staticmethod
@@ -296,8 +297,13 @@ class _FusedItemsBlockFn(torch.autograd.Function):
         x2d, y, mean_rstd, g32, b32, w_a, w_b = ctx.saved_tensors
         dev, dt = x2d.device, x2d.dtype
         cout, cout_p, split = pair.out_channels, desc.cout_p, pair.split
-        ga = ga.to(dt).contiguous() if ga is not None else torch.zeros((meta.rows, split), dtype=dt, device=dev)
-        gb = gb.to(dt).contiguous() if gb is not None else torch.zeros((meta.rows, cout_p - split), dtype=dt, device=dev)
+        if ga is None and gb is None:
+            return (None,) * 10
+        # One branch without a gradient (the regressor on a batch without positive anchors, nndet/arch/heads/comb.py:397-401): its half
+        # of the incoming gradient is zero and its parameters are handed None, as the separate block would leave them
+        has_a, has_b = ga is not None, gb is not None
+        ga = ga.to(dt).contiguous() if has_a else torch.zeros((meta.rows, split), dtype=dt, device=dev)
+        gb = gb.to(dt).contiguous() if has_b else torch.zeros((meta.rows, cout_p - split), dtype=dt, device=dev)
         nw = w_a.numel()
         # one contiguous [2 C][Cin][27] weight gradient (the kernel's row stride spans both halves); handed to autograd as its two halves
         gw, gg, gbt = L.grad_pool.take_for([(None, 2 * nw), (None, cout), (None, cout)], dev)
@@ -323,7 +329,9 @@ class _FusedItemsBlockFn(torch.autograd.Function):
         L.call("nndet_conv3d_backward_weight_items", ctypes.byref(desc), ctypes.byref(meta.items), L.ptr(x2d), L.ptr(dconv), L.ptr(dw), None,
                L.ptr(ws), ws_bytes, raw)
         ca = mod_a.out_channels
-        return (dx, dw[:ca].to(w_a.dtype), dw[ca:].to(w_b.dtype), gg[:ca], gbt[:ca], gg[ca:], gbt[ca:], None, None, None)
+        return (dx, dw[:ca].to(w_a.dtype) if has_a else None, dw[ca:].to(w_b.dtype) if has_b else None,
+                gg[:ca] if has_a else None, gbt[:ca] if has_a else None, gg[ca:] if has_b else None, gbt[ca:] if has_b else None,
+                None, None, None)
 
 
 _PAIRS: Dict[tuple, _FusedPair] = {}
