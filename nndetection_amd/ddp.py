@@ -110,6 +110,7 @@ class GradAllReducer:
             static_unused = model.never_used_parameters()
         self._static_unused = {id(p) for p in (static_unused or [])}
         self._marked = set()            # parameters declared gradient-free for the CURRENT step (mark_no_grad)
+        self._names = {id(p): n for n, p in model.named_parameters()}
         self._where = {}
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
@@ -259,7 +260,11 @@ class GradAllReducer:
         if id(p) in self._static_unused:
             raise RuntimeError("a parameter declared as never used received a gradient")
         if id(p) in self._marked:
-            raise RuntimeError("a parameter declared gradient-free for this step (mark_no_grad) received a gradient")
+            if p.grad is None:
+                return                                   # (the engine runs the accumulation node of an input whose gradient a Function
+                                                         #  returned as None, with an undefined gradient: nothing arrived)
+            raise RuntimeError("parameter %s was declared gradient-free for this step (mark_no_grad) but received a gradient"
+                               % self._names.get(id(p), "?"))
         b = self.buckets[bi]
         b.pending -= 1
         if self._cuda:
