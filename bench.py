@@ -510,8 +510,9 @@ def torch_rocm_baseline_child(plan_name, batch, warmup=3, steps=10):
     # NNDET_TORCH_BASELINE_MODE=fair: MIOpen's NORMAL find (it benchmarks its solvers per shape; the find-db goes to
     # /tmp), channels_last_3d tensors and >= 10 warm-up steps -- minutes of set-up, so bench.py's default leg stays "fast" (FAST find,
     # NCDHW, 3 warm-up steps) and quotes the committed fair measurement next to it (profiles/round5_torch_rocm_baseline_fair.json).
-    fair = os.environ.get("NNDET_TORCH_BASELINE_MODE", "fast") == "fair"
-    if fair:
+    tb_mode = os.environ.get("NNDET_TORCH_BASELINE_MODE", "fast")       # fast | normal (NORMAL find, NCDHW) | fair (NORMAL find, channels_last_3d)
+    fair = tb_mode == "fair"
+    if tb_mode in ("fair", "normal"):
         os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")
         os.environ.setdefault("MIOPEN_USER_DB_PATH", "/tmp/miopen_userdb")
         os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
@@ -561,7 +562,7 @@ def torch_rocm_baseline_child(plan_name, batch, warmup=3, steps=10):
                       "warmup": warmup, "batch": batch, "first_step_s": round(t_first, 1), "final_loss": round(float(last.detach()), 5),
                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                       "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "memory_format": "channels_last_3d" if fair else "contiguous (NCDHW)",
-                      "mode": "fair" if fair else "fast", "torch": torch.__version__}), flush=True)
+                      "mode": tb_mode, "torch": torch.__version__}), flush=True)
 
 
 def torch_rocm_baseline(plan_name, batch, timeout_s=240):
@@ -575,15 +576,18 @@ def torch_rocm_baseline(plan_name, batch, timeout_s=240):
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 res = dict(base, **json.loads(line))
-                fair_file = os.path.join(ROOT, "profiles", "round5_torch_rocm_baseline_fair.json")
-                if res.get("mode") != "fair" and os.path.isfile(fair_file):        # the committed NORMAL-find / channels-last measurement
-                    try:
-                        with open(fair_file) as f:
-                            fr = json.load(f)
-                        res["fair_reference"] = {k: fr.get(k) for k in ("value", "ms_per_step", "miopen_find_mode", "memory_format", "warmup", "steps")}
-                        res["fair_reference"]["file"] = "profiles/round5_torch_rocm_baseline_fair.json"
-                    except Exception:                         # noqa: BLE001
-                        pass
+                if res.get("mode") == "fast":                  # the committed NORMAL-find measurements (minutes of MIOpen search each)
+                    for key, fn in (("fair_reference", "round5_torch_rocm_baseline_fair.json"), ("normal_find_reference", "round5_torch_rocm_baseline_normal.json")):
+                        fpath = os.path.join(ROOT, "profiles", fn)
+                        if not os.path.isfile(fpath):
+                            continue
+                        try:
+                            with open(fpath) as f:
+                                fr = json.load(f)
+                            res[key] = {k: fr.get(k) for k in ("value", "ms_per_step", "miopen_find_mode", "memory_format", "warmup", "steps", "first_step_s")}
+                            res[key]["file"] = "profiles/" + fn
+                        except Exception:                     # noqa: BLE001
+                            pass
                 return res
         return dict(base, error="rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
     except Exception as e:                                        # noqa: BLE001

@@ -182,6 +182,58 @@ __global__ void k_sp_emit(SpArgs A, const int32_t* __restrict__ params, const u6
     if (i == 0) { counts[0] = num_pos; counts[1] = num_neg; counts[2] = params[0]; counts[3] = params[1]; }
 }
 
+// ---- the whole tail in ONE workgroup (round 5): the three <= POOL_cap-key sorts, the pool-position keys, the index resolution and
+// the emit were 4 rocPRIM radix sorts (3-4 launches each) + 4 small kernels = ~16 launches of 5-14 us in a row on the critical chain
+// between the forward and the backward pass (~0.12 ms). LDS bitonic network (the post-processing's, csrc/postproc.hip: k_pp_bitonic) on
+// keys masked like the radix sorts' bit ranges; every sorted key set is duplicate-free apart from its ~0 padding, so the result is the
+// radix sorts' bit for bit. NNDET_SP_TAIL_FUSED=0 or capacities above 4096: the rocPRIM path.
+__device__ __forceinline__ void sp_bitonic(u64* s, int N, u64 mask, int tid) {
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (N >> 1); t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // pair index t -> element with bit j clear
+                const int l = i | j;
+                const u64 a = s[i], b = s[l];
+                const bool up = (i & k) == 0;
+                if (((a & mask) > (b & mask)) == up) { s[i] = b; s[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sp_tail(SpArgs A, const int32_t* __restrict__ params, const u64* __restrict__ list_pos,
+                                                  const u64* __restrict__ list_pool, int NP2, int NQ2, int NN2,
+                                                  int64_t* __restrict__ pos_idx, int64_t* __restrict__ neg_idx, int64_t* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+    u64* a = reinterpret_cast<u64*>(sp_smem);            // [max(NP2, NQ2)]: positives, then the pool
+    u64* b = a + (NP2 > NQ2 ? NP2 : NQ2);                // [NQ2]: selection keys over the pool positions
+    u64* c = b + NQ2;                                    // [NN2]: the chosen negatives
+    const int tid = threadIdx.x;
+    const int num_pos = params[2], num_neg = params[3], pool = params[4];
+    // positives: everything collected IS the selection -> ascending anchor index (low 32 bits; padding sorts last)
+    for (int i = tid; i < NP2; i += 1024) a[i] = i < A.P_cap ? list_pos[i] : ~0ULL;
+    __syncthreads();
+    sp_bitonic(a, NP2, 0xffffffffULL, tid);
+    for (int i = tid; i < A.P_cap; i += 1024) pos_idx[i] = i < num_pos ? (int64_t)(uint32_t)a[i] : -1;
+    __syncthreads();
+    // pool: ascending key = descending foreground probability, ties by index
+    for (int i = tid; i < NQ2; i += 1024) a[i] = i < A.POOL_cap ? list_pool[i] : ~0ULL;
+    // selection keys over the POSITIONS of the sorted pool (randperm(pool)[:num_neg], sampler.py:205-207)
+    for (int j = tid; j < NQ2; j += 1024)
+        b[j] = (j < A.POOL_cap && j < pool)
+                   ? (((u64)(A.det ? (uint32_t)(pool - 1 - j) : sp_hash(A.seed ^ 0xA5A5A5A55A5A5A5AULL, (uint32_t)j)) << 32) | (u64)(uint32_t)j) : ~0ULL;
+    __syncthreads();
+    sp_bitonic(a, NQ2, ~0ULL, tid);
+    sp_bitonic(b, NQ2, ~0ULL, tid);
+    // chosen pool positions -> anchor indices, ascending (comb.py:268-276: torch.where on the masks)
+    for (int i = tid; i < NN2; i += 1024) c[i] = (i < A.NEG_cap && i < num_neg) ? (u64)(uint32_t)a[(uint32_t)b[i]] : ~0ULL;
+    __syncthreads();
+    sp_bitonic(c, NN2, 0x1ffffffffULL, tid);
+    for (int i = tid; i < A.NEG_cap; i += 1024) neg_idx[i] = i < num_neg ? (int64_t)(uint32_t)c[i] : -1;
+    if (tid == 0) { counts[0] = num_pos; counts[1] = num_neg; counts[2] = params[0]; counts[3] = params[1]; }
+}
+
 struct SpWs {
     int32_t* params; u64* prefix; int* krem; unsigned* hist;
     u64 *list_pos, *pos_sorted, *list_pool, *pool_sorted, *sel, *sel_sorted, *neg_tmp, *neg_sorted;
@@ -272,6 +324,21 @@ extern "C" int nndet_hnm_sample_f32(const float* labels, const float* scores, in
     LAUNCH_CHECK();
     k_sp_collect<<<nb, 256, 0, st>>>(A, w.prefix, w.params, w.list_pos, w.list_pool);
     LAUNCH_CHECK();
+    const char* tf_env = getenv("NNDET_SP_TAIL_FUSED");          // (read per call: the tests run both paths in one process)
+    const int tail_fused = tf_env ? atoi(tf_env) : 1;
+    if (tail_fused && P_cap <= 4096 && POOL_cap <= 4096) {
+        auto p2 = [](int n) { int v = 2; while (v < n) v <<= 1; return v; };
+        const int NP2 = p2(P_cap), NQ2 = p2(POOL_cap), NN2 = p2(NEG_cap);
+        const size_t lds = ((size_t)(NP2 > NQ2 ? NP2 : NQ2) + NQ2 + NN2) * 8;
+        static NndetDevOnce attr;
+        if (attr.need()) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sp_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4096 * 8));
+            attr.done();
+        }
+        k_sp_tail<<<1, 1024, lds, st>>>(A, w.params, w.list_pos, w.list_pool, NP2, NQ2, NN2, pos_idx, neg_idx, counts);
+        LAUNCH_CHECK();
+        return 0;
+    }
     size_t tmp = w.sort_tmp_bytes;
     // positives: everything collected IS the selection -> sort by anchor index only (low 32 bits; padding sorts last)
     HIP_TRY((rocprim::radix_sort_keys<rocprim::default_config, const u64*, u64*>(w.sort_tmp, tmp, w.list_pos, w.pos_sorted, (size_t)P_cap, 0, 32, st, false)));

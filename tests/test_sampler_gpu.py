@@ -73,3 +73,26 @@ def test_sampler_random_mode_properties_and_mask_contract():
     pm, nm = s([t(labels[:150_000]), t(labels[150_000:])], t(probs))
     p2, n2, _ = bx.hnm_counts(int((labels >= 1).sum()), int((labels == 0).sum()), 2)         # two images in this call
     assert pm[0].dtype == torch.uint8 and int(pm[0].sum()) == p2 and int(nm[0].sum()) == n2
+
+
+@pytest.mark.parametrize("N,C,B,n_pos,det", [(200_000, 1, 4, 500, True), (1_186_650 * 4, 1, 4, 12, False), (5000, 1, 1, 0, True),
+                                             (3000, 2, 64, 900, False), (300_000, 1, 8, 3, False)])
+def test_sampler_tail_in_one_workgroup_equals_the_radix_sort_tail(N, C, B, n_pos, det, monkeypatch):
+    """Round 5: the sampler's tail (three sorts of <= pool-capacity keys, the pool-position keys, the index resolution, the emit) as ONE
+    workgroup with an LDS bitonic network (k_sp_tail) against the rocPRIM radix-sort tail of rounds 2-4 (NNDET_SP_TAIL_FUSED=0): the same
+    positives, negatives and counts, in deterministic (reversed permutation) and hashed mode, incl. no positive at all, more positives
+    than the budget, and the benchmark's 4.7 M anchors."""
+    from nndetection_amd.core.boxes import HardNegativeSamplerBatched
+    rng = np.random.default_rng(N + C + n_pos)
+    labels, logits = _case(rng, N, C, n_pos)
+    s = HardNegativeSamplerBatched(32, 0.33, min_neg=1, pool_size=20)
+    s.deterministic = det
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NNDET_SP_TAIL_FUSED", fused)
+        torch.manual_seed(7)
+        pos, neg, counts = s.sample_device(t(labels), t(logits), B)
+        out[fused] = (pos.cpu().numpy(), neg.cpu().numpy(), counts.cpu().numpy())
+    for a, b, what in zip(out["1"], out["0"], ("positives", "negatives", "counts")):
+        assert np.array_equal(a, b), what
+    assert int((out["1"][0] >= 0).sum()) == int(out["1"][2][0]) and int((out["1"][1] >= 0).sum()) == int(out["1"][2][1])
