@@ -325,6 +325,17 @@ int nndet_conv3d_backward_data_bias(const NndetConv* c, const void* dy, const vo
  * not covered (NNDET_EINVAL). */
 int nndet_conv3d_backward_data_acc(const NndetConv* c, const void* dy, const void* w_packed_mode1, void* dx_inout, float* dbias,
                                    void* stream);
+/* The same accumulation, and -- when dx_inout is then the COMPLETE gradient w.r.t. the output of a conv -> norm -> (ReLU) block (this
+ * launch adds the last contribution) -- the two sums per (image, channel) that block's norm backward needs from it, accumulated in the
+ * epilogue from the values being stored: S1 = sum g, S2 = sum g * xhat, g = dx * [ReLU mask], into red_ws's replicas (layout and zeroing
+ * as for nndet_norm_backward). y_norm = the block's pre-norm tensor (shape of dx), mean_rstd / gamma / beta / relu / c_norm = that norm's.
+ * nndet_norm_backward_presummed() then finishes the norm backward without its reduction pass (one read of y_norm here instead of a
+ * read of y_norm and of dx there). nndet_conv3d_dgrad_fuses_norm_reduce() tells whether a problem is covered: the strided 3x3x3 data
+ * gradients in 16-bit types with 32 input channels (the 32 <- 64 transition at full resolution). */
+int32_t nndet_conv3d_dgrad_fuses_norm_reduce(const NndetConv* c);
+int nndet_conv3d_backward_data_acc_normred(const NndetConv* c, const void* dy, const void* w_packed_mode1, void* dx_inout,
+                                           const void* y_norm, const float* mean_rstd, const float* gamma, const float* beta,
+                                           int32_t relu, int32_t c_norm, double* red_ws, void* stream);
 /* dw (fp32, PyTorch layout, ACCUMULATED into: zero it first) ; dbias ([cout] fp32, accumulated) may be NULL.
  * Two-stage reduction through `workspace` (nndet_conv3d_wgrad_workspace_bytes(c) bytes): deterministic, no atomics on dw. */
 size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c);
@@ -406,6 +417,11 @@ int nndet_norm_backward(int32_t dtype, const void* x, const void* dy, const floa
                         const float* gamma, const float* beta, int32_t batch, int64_t spatial, int32_t c,
                         int32_t c_p, int32_t groups, int32_t relu, void* dx, float* dgamma, float* dbeta,
                         double* red_ws, void* stream);
+/* The same with the replica sums of red_ws already accumulated by nndet_conv3d_backward_data_acc_normred (uniform batches only). */
+int nndet_norm_backward_presummed(int32_t dtype, const void* x, const void* dy, const float* mean_rstd,
+                                  const float* gamma, const float* beta, int32_t batch, int64_t spatial, int32_t c,
+                                  int32_t c_p, int32_t groups, int32_t relu, void* dx, float* dgamma, float* dbeta,
+                                  double* red_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmentation loss (2-class) -- replaces DiCESegmenterFgBg.compute_loss: 0.5*CE + 0.5*SoftDice(softmax,

@@ -108,6 +108,8 @@ SIGNATURES = {
     "nndet_conv3d_dgrad_fuses_bias": (_I32, [_CONVP]),
     "nndet_conv3d_backward_data_bias": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data_acc": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
+    "nndet_conv3d_dgrad_fuses_norm_reduce": (_I32, [_CONVP]),
+    "nndet_conv3d_backward_data_acc_normred": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P]),
     "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
     "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_conv3d_forward_items": (C.c_int, [_CONVP, _ITEMSP, _P, _P, _P, _P, _P, _P]),
@@ -122,6 +124,7 @@ SIGNATURES = {
     "nndet_affine_apply": (C.c_int, [_I32, _P, _P, _I32, _I64, _I32, _I32, _P, _P]),
     "nndet_norm_apply": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _F, _I32, _P, _P, _P]),
     "nndet_norm_backward": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nndet_norm_backward_presummed": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nndet_segloss_forward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P, _P]),
     "nndet_segloss_backward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P, _P, _P]),
     "nndet_seghead_forward": (C.c_int, [_I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _P]),

@@ -215,6 +215,17 @@ def deferred(x: torch.Tensor):
 # i.e. 1.09 TFLOP and ~2.4 GB of the 8.9 TFLOP / 27 GB of a 160x160x96 training step disappear (NNDET_SEG_RANK1=0 disables it).
 RANK1 = os.environ.get("NNDET_SEG_RANK1", "1") != "0"
 _rank1_grads = {}
+# Norm-backward sums that arrive with the gradient ("the reduce in the epilogue of the data gradient that produces its
+# input"). An activation with two consumers of ours gets its complete gradient from the SECOND consumer's in-place accumulation
+# (encoder.py set_fuse_grad_accum). When that consumer is the strided 3x3x3 data gradient (k_dgs) and the activation is the output of a
+# materialised conv -> norm -> ReLU block, the kernel also accumulates the two per-channel sums that block's norm backward needs
+# (nndet_conv3d_backward_data_acc_normred) and registers them here under the gradient buffer's address; _NormFn.backward then skips its
+# reduction pass (nndet_norm_backward_presummed). At full resolution: one read of the pre-norm tensor (315 MB at batch 2) inside the
+# data gradient instead of the 0.38 ms k_norm_bwd_reduce launch on the tail of the step. NNDET_NORM_RED_FUSE=0: the separate pass.
+NORM_RED_FUSE = os.environ.get("NNDET_NORM_RED_FUSE", "1") != "0"
+_norm_presums = {}          # gradient buffer address -> (red_ws, mean_rstd of the norm they belong to)
+_last_mean_rstd = [None]    # _NormFn.forward -> BaseConvNormAct.forward (the tag of the block's output)
+norm_red_fused = [0]        # how many norm backward passes took their sums from a data gradient (tests)
 
 
 def rank1_register(fake: torch.Tensor, d1: torch.Tensor, wd: torch.Tensor, sum_d1: torch.Tensor) -> None:
@@ -379,6 +390,7 @@ class _ConvFn(torch.autograd.Function):
             L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats), L.stream())
         ctx.desc, ctx.mod, ctx.has_bias, ctx.has_res = desc_bwd, mod, bias is not None, residual is not None
         ctx.gacc = None if mod.transposed else getattr(x, "_nndet_gacc", None)   # fused accumulation of the input gradient (encoder.py)
+        ctx.norm_src = getattr(x, "_nndet_norm_src", None) if ctx.gacc is not None else None    # (see _norm_presums)
         ctx.x_ss = x_ss                      # (tiny) keeps the table alive for the weight gradient
         ctx.save_for_backward(x_bwd, weight)
         out = logical(y, cout)
@@ -428,8 +440,19 @@ class _ConvFn(torch.autograd.Function):
                 if gacc.get("ev") is not None:               # the first consumer may have run on another stream (decoder tail)
                     torch.cuda.current_stream(dev).wait_event(gacc["ev"])
                     gacc["buf"].record_stream(torch.cuda.current_stream(dev))
-                L.call("nndet_conv3d_backward_data_acc", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(gacc["buf"]),
-                       L.ptr(dbias) if fuses_bias else None, L.stream())
+                ns = ctx.norm_src if NORM_RED_FUSE else None
+                if (ns is not None and not fuses_bias and ns[0].shape == x_p.shape and ns[0].dtype == dt
+                        and L.load().nndet_conv3d_dgrad_fuses_norm_reduce(ctypes.byref(desc))):
+                    ny_p, nmr, nmod = ns
+                    red = L.arena_zeros((L.STATS_REPLICAS * desc.batch * desc.cin_p * 2 + desc.batch,), torch.float64, dev)
+                    L.call("nndet_conv3d_backward_data_acc_normred", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(gacc["buf"]),
+                           L.ptr(ny_p), L.ptr(nmr), L.ptr(nmod.norm.weight.detach()), L.ptr(nmod.norm.bias.detach()), int(nmod.relu),
+                           nmod.out_channels, L.ptr(red), L.stream())
+                    _norm_presums.clear()                      # at most one live entry
+                    _norm_presums[gacc["buf"].data_ptr()] = (red, nmr)
+                else:
+                    L.call("nndet_conv3d_backward_data_acc", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(gacc["buf"]),
+                           L.ptr(dbias) if fuses_bias else None, L.stream())
                 # This node hands autograd NO gradient (the sum lives in the first consumer's buffer), so the engine inserts no
                 # stream synchronisation for it: order the producer's backward stream (= its forward stream) behind the accumulation
                 # ourselves, whichever stream this node runs on.
@@ -519,6 +542,7 @@ class _NormFn(torch.autograd.Function):
                 out = logical(y_p.view(y_p.shape), cout)      # an alias of y's storage (no kernel)
         ctx.mod, ctx.code, ctx.dims = mod, code, (N, spatial, cout, cout_p)
         ctx.save_for_backward(y_p, mean_rstd, g32, b32)
+        _last_mean_rstd[0] = mean_rstd
         if ss is not None:
             ctx.mark_non_differentiable(ss)
         return out, ss
@@ -532,6 +556,12 @@ class _NormFn(torch.autograd.Function):
         g_p, _ = phys(grad_out, dtype=dt, cp=cout_p)
         dgamma, dbeta = L.grad_pool.take_for([(mod.norm.weight, cout), (mod.norm.bias, cout)], dev)
         dconv = torch.empty_like(y_p)
+        pre = _norm_presums.pop(g_p.data_ptr(), None) if _norm_presums else None
+        if pre is not None and pre[1].data_ptr() == mean_rstd.data_ptr():      # the sums came with the gradient (see _norm_presums)
+            norm_red_fused[0] += 1
+            L.call("nndet_norm_backward_presummed", ctx.code, L.ptr(y_p), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,
+                   cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.ptr(pre[0]), L.stream())
+            return logical(dconv, cout), dgamma, dbeta, None, None, None
         red = L.arena_zeros((L.STATS_REPLICAS * N * cout_p * 2 + N,), torch.float64, dev)     # replica sums + N ticket slots
         L.call("nndet_norm_backward", ctx.code, L.ptr(y_p), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,
                cout, cout_p, mod.norm_groups, int(mod.relu), L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.ptr(red), L.stream())
@@ -674,6 +704,9 @@ class BaseConvNormAct(nn.Sequential):
             out._nndet_deferred = (ss, self.relu)
         elif early:
             out._nndet_pre = (y, ss, self.relu, _pre_event[0])
+        if NORM_RED_FUSE and not defer and y.is_cuda and out.requires_grad and self.norm_groups == self.out_channels:
+            out._nndet_norm_src = (phys(y)[0].detach(), _last_mean_rstd[0], self)   # (see _norm_presums)
+        _last_mean_rstd[0] = None
         return out
 
 

@@ -133,8 +133,9 @@ class BaseRetinaNet(nn.Module):
                 # recomputes, a second model driven from a hook) must leave them alone: cleared only at top level.
                 if torch._C._current_graph_task_id() == -1:
                     L.grad_hints.d.clear()
-                    from ..arch.conv import _rank1_grads
+                    from ..arch.conv import _rank1_grads, _norm_presums
                     _rank1_grads.clear()
+                    _norm_presums.clear()
         if hasattr(self.decoder, "defer_out0"):                # decoder.out.P0 + segmentation head + loss as one 32 -> 1 convolution?
             self.decoder.defer_out0 = self._seg_branch_ok(inp)
             self.decoder.absorb_lat0 = self.decoder.defer_out0 and self._seg_lateral_ok()

@@ -23,8 +23,11 @@ int pw_run(const NndetConv* c, int kind, const void* x, const void* w, const flo
            float* dbias = nullptr);
 int pw_covers(const NndetConv* c, int kind);   // 1 if pw_run would take this problem (so a fused dbias is available for kind 1)
 // conv_dgs.hip: data gradient of the strided 3x3x3 convolutions, all parity classes from one staged halo; returns 1 = not covered
-int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st);
+// nr (optional): also accumulate the norm-backward sums of the block that produced this convolution's input (dx = its complete gradient)
+struct DgsNormRed { const void* y; const float* mean_rstd; const float* gamma; const float* beta; double* red_ws; int relu, c; };
+int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st, const DgsNormRed* nr = nullptr);
 int dgs_covers(const NndetConv* c);
+int dgs_fuses_norm_reduce(const NndetConv* c);   // 1 if dgs_run accepts nr for this problem
 // conv_ig3s.hip: forward of the 32 -> 64 stride-2 3x3x3 transition (LDS-DMA double buffering, weights in registers); returns 1 = not covered
 int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st);
 // conv_wgrad.hip

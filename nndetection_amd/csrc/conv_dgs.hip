@@ -63,16 +63,33 @@ struct DgsArgs {
     int32_t ncls;
     DgsClass cls[8];
     DgsTap taps[27];
+    // Norm-backward reduction in the epilogue (round 5, k_dgs<..., NB = true>): dx is the COMPLETE gradient w.r.t. the normalised (+ReLU)
+    // output of a conv -> norm -> ReLU block (this launch adds the last contribution, nndet_conv3d_backward_data_acc), so the sums
+    // k_norm_bwd_reduce would read it back for -- S1 = sum g, S2 = sum g * xhat per (image, channel), g = dx * [ReLU mask] -- are
+    // accumulated here from the values being stored and the block's pre-norm tensor `ny` (one extra read instead of two).
+    const void* ny;             // pre-norm tensor of that block, same shape / layout as dx
+    const float* nmr;           // [N][R][2] mean, rstd (k_norm_finalize)
+    const float* ngamma; const float* nbeta;   // [ncout]
+    double* nred;               // [replicas][N][R][2] (k_norm_bwd_reduce's replica layout, zeroed)
+    int32_t nrelu, ncout;
 };
 
 #define DGS_TD 4
 #define DGS_TH 8
 #define DGS_TW 8
-template <typename T, int MT, int MAXP, int G>
-__global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? 3 : 1) void k_dgs(const DgsArgs A) {
+// NB: also accumulate the norm-backward sums of the block that produced this convolution's input (DgsArgs::ny ...): 16-bit types, 32 rows
+// per workgroup. Costs 32 + 16 + 16 registers (pre-norm values in flight with the residual, mask constants, partial sums): 2 workgroups
+// per CU instead of 3. Measured at full resolution (batch 2, alone): 265 -> 405 us for this kernel against the 220 us reduction pass
+// it replaces (profiles/round5_ab_norm_red_fuse.txt; variants with the constants in LDS, loads behind the MFMA loop or one class at
+// a time were 417-518 us).
+template <typename T, int MT, int MAXP, int G, bool NB = false>
+__global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? (NB ? 2 : 3) : 1) void k_dgs(const DgsArgs A) {
     using M = DgMma<T>;
     constexpr int KC = M::KC, EPL = M::EPL, NT = 4;
+    static_assert(!NB || (sizeof(T) == 2 && MT == 2), "the norm-backward epilogue: 16-bit types, 32 rows per workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float nb_c[NB ? 32 : 1][4];          // per channel of this workgroup's rows: mean, rstd, scale, shift
+    __shared__ double nb_s[NB ? 32 : 1][2];         // S1, S2 of this workgroup
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, q = lane >> 4;
@@ -130,7 +147,32 @@ __global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? 3 : 1) void k_dg
     const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)(row0 + li) * A.K + q * EPL;
     T* dxn = reinterpret_cast<T*>(A.dx) + (int64_t)n * A.I[0] * A.I[1] * A.I[2] * A.R;
     const T* rsn = A.res ? reinterpret_cast<const T*>(A.res) + (int64_t)n * A.I[0] * A.I[1] * A.I[2] * A.R : nullptr;
+    const T* nyn = nullptr;
+    float nsa[MT][4], nsb[MT][4];
+    if constexpr (NB) {
+        nyn = reinterpret_cast<const T*>(A.ny) + (int64_t)n * A.I[0] * A.I[1] * A.I[2] * A.R;
+        if (tid < 32) {
+            const int ch = row0 + tid;
+            const bool ok = ch < A.ncout;
+            const float mu = A.nmr[((int64_t)n * A.R + ch) * 2], rs = A.nmr[((int64_t)n * A.R + ch) * 2 + 1];
+            const float sc = ok ? rs * A.ngamma[ok ? ch : 0] : 0.f;
+            nb_c[tid][0] = ok ? mu : 0.f; nb_c[tid][1] = ok ? rs : 0.f; nb_c[tid][2] = sc;
+            nb_c[tid][3] = ok ? A.nbeta[ok ? ch : 0] - mu * sc : 0.f;           // the forward pass's expressions (k_norm_apply)
+            nb_s[tid][0] = 0.0; nb_s[tid][1] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { nsa[i][rr] = 0.f; nsb[i][rr] = 0.f; }
+    }
     __syncthreads();
+    float csc[NB ? MT : 1][4], csh[NB ? MT : 1][4];          // this lane's 8 channels: the forward pass's scale / shift (ReLU mask)
+    if constexpr (NB) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { csc[i][rr] = nb_c[i * 16 + q * 4 + rr][2]; csh[i][rr] = nb_c[i * 16 + q * 4 + rr][3]; }
+    }
 
     // Classes come in groups of G consecutive ones (G = 2: the two W parities of one (cd, ch)): their outputs interleave voxel by
     // voxel along W, i.e. the two classes fill the two halves of every 128-byte line. Stored one class at a time the half lines sit
@@ -145,7 +187,26 @@ __global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? 3 : 1) void k_dg
         // trip per point tile: 32 <- 64 channels at 160^3 took 0.60 ms with the residual against 0.33 ms without.
         constexpr bool RES16 = sizeof(T) == 2 && MT % 2 == 0;
         u32x4 rpre[RES16 ? G : 1][RES16 ? MT / 2 : 1][RES16 ? NT : 1];
-        if constexpr (RES16) {
+        u32x4 ypre[NB ? G : 1][NB ? MT / 2 : 1][NB ? NT : 1];          // the pre-norm values at the group's outputs, same layout / timing
+        auto load_y = [&]() {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const DgsClass& C = A.cls[cg + g];
+                const bool lv = !(l0d >= C.L[0] || l0h >= C.L[1] || l0w >= C.L[2]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int ld = l0d + wv, lh = l0h + 2 * j + (li >> 3), lw = l0w + (li & 7);
+                    const bool pv = lv && ld < C.L[0] && lh < C.L[1] && lw < C.L[2];
+                    const int od = ld * A.s[0] + C.c[0], oh = lh * A.s[1] + C.c[1], ow = lw * A.s[2] + C.c[2];
+                    const int64_t vo = pv ? (((int64_t)od * A.I[1] + oh) * A.I[2] + ow) * A.R + row0 : 0;     // clamped: loaded, not used
+#pragma unroll
+                    for (int i = 0; i < MT; i += 2)
+                        ypre[NB ? g : 0][NB ? i / 2 : 0][NB ? j : 0] = *reinterpret_cast<const u32x4*>(nyn + vo + i * 16 + (q >> 1) * 8 + (q & 1) * 16);
+                }
+            }
+        };
+        if constexpr (NB) load_y();
+        auto load_res = [&]() {
             if (rsn) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -159,11 +220,12 @@ __global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? 3 : 1) void k_dg
                         const int64_t vo = pv ? (((int64_t)od * A.I[1] + oh) * A.I[2] + ow) * A.R + row0 : 0;     // clamped: loaded, not used
 #pragma unroll
                         for (int i = 0; i < MT; i += 2)
-                            rpre[g][i / 2][j] = *reinterpret_cast<const u32x4*>(rsn + vo + i * 16 + (q >> 1) * 8 + (q & 1) * 16);
+                            rpre[RES16 ? g : 0][RES16 ? i / 2 : 0][RES16 ? j : 0] = *reinterpret_cast<const u32x4*>(rsn + vo + i * 16 + (q >> 1) * 8 + (q & 1) * 16);
                     }
                 }
             }
-        }
+        };
+        if constexpr (RES16) load_res();
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const DgsClass& C = A.cls[cg + g];
@@ -237,6 +299,26 @@ __global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? 3 : 1) void k_dg
                             }
                             pk[h][0] = H16<T>::pack2(v0, v1); pk[h][1] = H16<T>::pack2(v2, v3);
                         }
+                        if constexpr (NB) {        // S1 / S2 from the ROUNDED values (what k_norm_bwd_apply will read back) and the pre-norm tensor
+                            const u32x4 y16 = ypre[g][i / 2][j];
+                            const dgs_v2u y0 = __builtin_amdgcn_permlane16_swap(y16[0], y16[2], false, false);
+                            const dgs_v2u y1 = __builtin_amdgcn_permlane16_swap(y16[1], y16[3], false, false);
+                            const uint32_t yk[2][2] = {{y0[0], y1[0]}, {y0[1], y1[1]}};
+                            if (pv) {
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    const float gv[4] = {H16<T>::lo(pk[h][0]), H16<T>::hi(pk[h][0]), H16<T>::lo(pk[h][1]), H16<T>::hi(pk[h][1])};
+                                    const float yv[4] = {H16<T>::lo(yk[h][0]), H16<T>::hi(yk[h][0]), H16<T>::lo(yk[h][1]), H16<T>::hi(yk[h][1])};
+#pragma unroll
+                                    for (int rr = 0; rr < 4; ++rr) {
+                                        float gm = gv[rr];
+                                        if (A.nrelu && !(fmaf(yv[rr], csc[NB ? i + h : 0][rr], csh[NB ? i + h : 0][rr]) > 0.f)) gm = 0.f;   // the forward pass's expression
+                                        nsa[i + h][rr] += gm;
+                                        nsb[i + h][rr] = fmaf(gm, yv[rr], nsb[i + h][rr]);          // RAW moment sum g*y: centred once per workgroup below
+                                    }
+                                }
+                            }
+                        }
                         const dgs_v2u s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                         const dgs_v2u s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
                         if (pv) *reinterpret_cast<u32x4*>(dxn + vo + i * 16 + (q >> 1) * 8 + (q & 1) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
@@ -256,6 +338,29 @@ __global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? 3 : 1) void k_dg
                     }
                 }
             }
+        }
+    }
+    if constexpr (NB) {
+        // lanes li = 0..15 of a row q hold the same 8 channels: add over the 16 points, then the four waves (d-planes) through LDS,
+        // then ONE fp64 atomic per (channel, sum) and workgroup into k_norm_bwd_reduce's replica layout
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float a = nsa[i][rr], b = nsb[i][rr];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (li == 0) {
+                    atomicAdd(&nb_s[i * 16 + q * 4 + rr][0], (double)a);
+                    atomicAdd(&nb_s[i * 16 + q * 4 + rr][1], (double)b);
+                }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            const int rep = blockIdx.x % NNDET_STATS_REPLICAS;
+            double v = nb_s[tid >> 1][tid & 1];
+            if (tid & 1) v = (double)nb_c[tid >> 1][1] * (v - (double)nb_c[tid >> 1][0] * nb_s[tid >> 1][0]);   // sum g*xhat = rstd * (sum g*y - mean * sum g)
+            if (v != 0.0) atomicAdd(A.nred + (((int64_t)rep * A.N + n) * A.R + row0 + (tid >> 1)) * 2 + (tid & 1), v);
         }
     }
 }
@@ -286,24 +391,37 @@ int dgs_covers(const NndetConv* c) {
     return dyb < (1LL << 31) && dxb < (1LL << 31) ? 1 : 0;
 }
 
-template <typename T, int MT, int MAXP, int G>
+template <typename T, int MT, int MAXP, int G, bool NB = false>
 static int dgs_launch(const DgsArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static NndetDevOnce attr;
     if (attr.need()) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgs<T, MT, MAXP, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgs<T, MT, MAXP, G, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         attr.done();
     }
-    k_dgs<T, MT, MAXP, G><<<grid, 256, lds, st>>>(a);
+    k_dgs<T, MT, MAXP, G, NB><<<grid, 256, lds, st>>>(a);
     LAUNCH_CHECK();
     return 0;
 }
 
+// Can the data gradient of this convolution also accumulate the norm-backward sums of the block that produced its input (DgsNormRed)?
+// k_dgs launches in 16 bits with 32 rows per workgroup and the W-parity class pairs (stride 2 along W).
+int dgs_fuses_norm_reduce(const NndetConv* c) {
+    if (!dgs_covers(c) || !nndet_is16(c->dtype) || c->s[2] != 2) return 0;
+    int hv = 1;
+    const int T[3] = {DGS_TD, DGS_TH, DGS_TW};
+    for (int i = 0; i < 3; ++i) hv *= T[i] + (c->s[i] == 2 ? 1 : 2);
+    const int64_t lds = (int64_t)hv * 64 * (c->cout_p / 32);
+    return !(c->cin_p % 64 == 0 && lds > 70 * 1024) ? 1 : 0;            // (the 64-row variant has no such epilogue)
+}
+
 // returns 1 = not covered (the caller falls back to k_igemm)
-int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st) {
+int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st, const DgsNormRed* nr) {
     if (!dgs_covers(c)) return 1;
+    if (nr && !dgs_fuses_norm_reduce(c)) return NNDET_EINVAL;
     DgsArgs a;
     memset(&a, 0, sizeof(a));
     a.dy = dy; a.w = w; a.res = res; a.dx = dx;
+    if (nr) { a.ny = nr->y; a.nmr = nr->mean_rstd; a.ngamma = nr->gamma; a.nbeta = nr->beta; a.nred = nr->red_ws; a.nrelu = nr->relu; a.ncout = nr->c; }
     a.N = c->batch; a.K = c->cout_p; a.R = c->cin_p;
     const int osp[3] = {c->out_d, c->out_h, c->out_w}, isp[3] = {c->in_d, c->in_h, c->in_w};
     const int T[3] = {DGS_TD, DGS_TH, DGS_TW};
@@ -361,6 +479,10 @@ int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, 
     const bool g2 = c->s[2] == 2;          // classes are enumerated with the W parity fastest: (2k, 2k + 1) differ in cw only
 #define DGS_T(T_, MT_, MP_) (g2 ? dgs_launch<T_, MT_, MP_, 2>(a, grid, lds, st) : dgs_launch<T_, MT_, MP_, 1>(a, grid, lds, st))
 #define DGS_GO(MT_, MP_) (dt == NNDET_BF16 ? DGS_T(bf16_t, MT_, MP_) : dt == NNDET_F16 ? DGS_T(f16_t, MT_, MP_) : DGS_T(float, MT_, MP_))
+    if (nr) {                     // (dgs_fuses_norm_reduce: 16 bits, mt == 2, g2)
+        if (dt == NNDET_BF16) return pieces <= 16 ? dgs_launch<bf16_t, 2, 16, 2, true>(a, grid, lds, st) : dgs_launch<bf16_t, 2, 32, 2, true>(a, grid, lds, st);
+        return pieces <= 16 ? dgs_launch<f16_t, 2, 16, 2, true>(a, grid, lds, st) : dgs_launch<f16_t, 2, 32, 2, true>(a, grid, lds, st);
+    }
     if (pieces <= 16) return mt == 2 ? DGS_GO(2, 16) : DGS_GO(4, 16);
     return mt == 2 ? DGS_GO(2, 32) : DGS_GO(4, 32);
 #undef DGS_GO

@@ -650,6 +650,62 @@ extern "C" int nndet_norm_backward(int32_t dtype, const void* x, const void* dy,
     return 0;
 }
 
+// ---- the sums arrive from somewhere else: the data-gradient kernel that produced `dy` accumulated S1 / S2 per (image, channel) into
+// red_ws's replicas in its epilogue (conv_dgs.hip, k_dgs<..., NB = true>). What is left of pass 1 is the tail of k_norm_bwd_reduce's last
+// workgroup -- replicas -> dgamma / dbeta and the group coefficients over replica 0 -- as its own small launch, then pass 3 unchanged.
+__global__ __launch_bounds__(256) void k_norm_bwd_finalize(double* __restrict__ red_ws, int N, int c, int c_p, int groups, int64_t spatial,
+                                                           const float* __restrict__ gamma, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ch = reinterpret_cast<double*>(smem);    // [c_p][2]
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < c_p * 2; i += 256) {
+        double v = 0.0;
+        for (int r = 0; r < NNDET_STATS_REPLICAS; ++r) v += red_ws[(((int64_t)r * N + n) * c_p) * 2 + i];
+        ch[i] = v;
+    }
+    __syncthreads();
+    const int cpg = c / groups;
+    float* coef = reinterpret_cast<float*>(red_ws + ((int64_t)n * c_p) * 2);
+    for (int i = threadIdx.x; i < c_p; i += 256) {
+        float c1 = 0.f, c2 = 0.f;
+        if (i < c) {
+            atomicAdd(&dbeta[i], (float)ch[i * 2]);
+            atomicAdd(&dgamma[i], (float)ch[i * 2 + 1]);
+            const int g = i / cpg;
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < cpg; ++k) {
+                const double gm = (double)gamma[g * cpg + k];
+                s1 += gm * ch[(g * cpg + k) * 2];
+                s2 += gm * ch[(g * cpg + k) * 2 + 1];
+            }
+            const double m = (double)cpg * (double)spatial;
+            c1 = (float)(s1 / m); c2 = (float)(s2 / m);
+        }
+        coef[i * 2 + 0] = c1;
+        coef[i * 2 + 1] = c2;
+    }
+}
+
+extern "C" int nndet_norm_backward_presummed(int32_t dtype, const void* x, const void* dy, const float* mean_rstd, const float* gamma,
+                                             const float* beta, int32_t batch, int64_t spatial, int32_t c, int32_t c_p, int32_t groups,
+                                             int32_t relu, void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream) {
+    if (!x || !dy || !mean_rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !red_ws) return NNDET_EINVAL;
+    if (c_p % 32 || c_p > 1024 || c <= 0 || c > c_p || groups <= 0 || c % groups) return NNDET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int rpb = apply_rows(spatial * batch, c_p, nndet_esize(dtype));
+    dim3 grid((unsigned)ceil_div64(spatial, rpb), batch);
+    k_norm_bwd_finalize<<<batch, 256, (size_t)c_p * 16, st>>>(red_ws, batch, c, c_p, groups, spatial, gamma, dgamma, dbeta);
+    LAUNCH_CHECK();
+    if (dtype == NNDET_BF16)
+        k_norm_bwd_apply<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (bf16_t*)dx, rpb, g_norm_uniform);
+    else if (dtype == NNDET_F16)
+        k_norm_bwd_apply<f16_t><<<grid, 256, 0, st>>>((const f16_t*)x, (const f16_t*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (f16_t*)dx, rpb, g_norm_uniform);
+    else
+        k_norm_bwd_apply<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, mean_rstd, gamma, beta, red_ws, spatial, c, c_p, relu, (float*)dx, rpb, g_norm_uniform);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 static int norm_backward_items_impl(int32_t dtype, const void* x, const void* dy, const void* dy1, int32_t split, const float* mean_rstd,
                                     const float* gamma, const float* beta, const NndetItems* items, int32_t c, int32_t c_p, int32_t groups,
                                     int32_t relu, void* dx, float* dgamma, float* dbeta, double* red_ws, void* stream) {

@@ -788,3 +788,46 @@ def test_strided_forward_kernels_rounding_quality(cin, cout, monkeypatch):
         st = stats.sum(0).cpu()
         s_ref = torch.stack((yd.sum((1, 2, 3)), (yd * yd).sum((1, 2, 3))), -1)
         assert float(((st - s_ref).abs() / s_ref.abs().clamp_min(1e-9)).max()) <= 1e-5, ig
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("cn,relu,shape", [(32, True, (21, 19, 35)), (24, True, (16, 24, 40)), (32, False, (9, 33, 17))])
+def test_norm_backward_sums_from_the_strided_data_gradient(cn, relu, shape, dtype, monkeypatch):
+    """conv -> InstanceNorm -> ReLU block whose output feeds a 1x1x1 convolution (first consumer in backward) and a stride-2 3x3x3
+    convolution (second consumer: k_dgs adds its data gradient in place). With NORM_RED_FUSE the second consumer also accumulates the
+    block's norm-backward sums (nndet_conv3d_backward_data_acc_normred) and the block's norm backward skips its reduction pass
+    (nndet_norm_backward_presummed). Same rounded gradient values, same expressions: dgamma / dbeta agree to summation order, the
+    gradient behind the norm to the rounding of a few elements."""
+    from nndetection_amd.arch import conv as CV
+    from nndetection_amd.arch.conv import ConvInstanceRelu
+    torch.manual_seed(5)
+    b0 = ConvInstanceRelu(3, 32, cn, 3, padding=1, add_norm=True, add_act=relu).cuda()
+    c1 = ConvInstanceRelu(3, cn, 64, 3, stride=2, padding=1, add_norm=True, add_act=True).cuda()
+    lat = ConvInstanceRelu(3, cn, 32, 1, add_norm=False, add_act=False).cuda()
+    with torch.no_grad():
+        b0.norm.weight.copy_(torch.randn(cn).cuda() * 0.3 + 1.0)
+        b0.norm.bias.copy_(torch.randn(cn).cuda() * 0.3)
+    x0 = torch.randn(2, 32, *shape, device="cuda").to(dtype)
+    g1 = torch.randn(2, 64, *[(s + 1) // 2 for s in shape], device="cuda").to(dtype)
+    g2 = torch.randn(2, 32, *shape, device="cuda").to(dtype)
+    res = {}
+    for mode in (False, True):
+        monkeypatch.setattr(CV, "NORM_RED_FUSE", mode)
+        CV.norm_red_fused[0] = 0
+        for m in (b0, c1, lat):
+            m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        a = b0(x)
+        a._nndet_gacc = {"buf": None, "stream": torch.cuda.current_stream()}
+        y1 = c1(a)
+        y2 = lat(a)
+        torch.autograd.backward([y2, y1], [g2, g1])
+        torch.cuda.synchronize()
+        assert CV.norm_red_fused[0] == (1 if mode else 0)
+        res[mode] = [t.detach().float().clone() for t in (b0.norm.weight.grad, b0.norm.bias.grad, b0.conv.weight.grad, x.grad,
+                                                          c1.conv.weight.grad, lat.conv.weight.grad)]
+    names = ["dgamma", "dbeta", "dw(block)", "dx", "dw(strided)", "dw(lateral)"]
+    tol = [2e-5, 2e-5, 2e-3, 2e-3, 1e-6, 1e-6]
+    for n, t, a_, b_ in zip(names, tol, res[False], res[True]):
+        e = relerr(b_, a_)
+        assert e <= t, f"{n}: fused vs separate reduction rel err {e:.3e}"
