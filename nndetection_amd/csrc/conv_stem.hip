@@ -493,6 +493,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
 // image in LDS (one more 32 x 32 x 32 MFMA per 16 points) -- and a 1-block kernel combines them. This replaces k_norm_bwd_reduce
 // (reads y, dA), k_norm_bwd_apply (reads y, dA, writes dy) and k_stem_wgrad3 (reads dy): 6 passes over a 629 MB tensor become 1, at
 // the very end of the backward pass where nothing else is left to overlap with (round 3 timeline: 1.25 ms -> one 0.3 ms launch).
+// Hand-over point between two phases of ONE wave that exchange data through LDS (lane i writes what lane j reads): the LDS queue of a wave
+// is in order, so no s_barrier is needed -- only the compiler has to keep the accesses on their side (and the data has to have landed).
+__device__ __forceinline__ void stem_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct StemBwdArgs {
     const void* x; const void* dy; const float* w; const float* coef; const float* gamma; const float* beta;
     float* accA; float* accC; float* accB; double* accS;     // [N][Cy][32], [N][Cy][32], [N][32], [N][Cy][2]   (zeroed)
@@ -506,14 +514,23 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
     __shared__ __attribute__((aligned(16))) char dyt[TILE];     // dA tile, rewritten in place with g = dA * mask
     __shared__ __attribute__((aligned(16))) char imt[TILE];     // [point][32 taps] expansion of the image halo
     __shared__ __attribute__((aligned(16))) char xnt[TILE];     // xh = normalised pre-activation, [point][32 channels]
-    __shared__ __attribute__((aligned(16))) uint16_t xh[608];
-    __shared__ float red[2 * 32 * 32 + 32];
-    __shared__ double reds[64];
+    // Exactly 3 tiles = 51 KB of LDS (round 5; 60.8 KB before): at the end of the backward pass this kernel runs beside k_wgrad3d of the
+    // weight-gradient stream, whose persistent workgroups hold 108 KB on EVERY CU -- with 60.8 KB no workgroup of this kernel fitted next
+    // to one of those (160 KB per CU), the two kernels shared the chip CU by CU instead of wave by wave. The small buffers alias tiles
+    // that are dead while they live: the image halo `xh` (tile start -> expansion) sits in xnt (written by the recompute phase, read
+    // until the next tile's first barrier), the final reduction buffers in dyt / imt behind the tile loop.
+    //
+    // NO workgroup barrier inside the tile loop (round 5; 4 per tile before): wave wv owns d-plane wv of every tile -- 64 points = rows
+    // wv * 8 .. wv * 8 + 7 of the three LDS tiles. It stages its own plane of dA and its own 3 x 10 x 10 halo of the image, expands, recomputes
+    // and contracts exactly these points (the contraction steps 2 wv, 2 wv + 1 ARE these 64 points), so every LDS dependency is wave-local
+    // and ordered by the in-order LDS queue of the wave; the four waves drift apart freely and hide each other's load / LDS latencies.
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint16_t* const xh = reinterpret_cast<uint16_t*>(xnt + wv * 8 * PROW);     // [300], inside this wave's own rows of xnt
+    float* const red = reinterpret_cast<float*>(dyt);            // [2 * 32 * 32 + 32]
+    double* const reds = reinterpret_cast<double*>(imt);         // [64]
+    static_assert((2 * 32 * 32 + 32) * 4 <= TILE && 300 * 2 <= 8 * PROW, "aliased buffers fit");
     const int li = lane & 15, q = lane >> 4;
     const int c0 = blockIdx.y * 32, n = blockIdx.z;
-    for (int i = tid; i < 2 * 32 * 32 + 32; i += 256) red[i] = 0.f;
-    if (tid < 64) reds[tid] = 0.0;
     // A fragments of the forward convolution (identical to k_stem_fwd3: the recomputed y is bit-identical to the forward pass's)
     u32x4 af[2];
     float n_sc[2][4], n_sh[2][4], n_rs[2][4], n_mrs[2][4];
@@ -540,24 +557,25 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
             n_sc[i][rr] = a_; n_sh[i][rr] = b_; n_rs[i][rr] = rs; n_mrs[i][rr] = mrs;
         }
     }
-    // dA staging geometry: piece s of a thread = point (pd = s, ph = tid >> 5, pw = (tid >> 2) & 7), 16-byte part tid & 3
-    const int d_ph = tid >> 5, d_pw = (tid >> 2) & 7;
-    const int d_dst0 = d_ph * PROW + d_pw * 64 + (tid & 3) * 16;
-    const int d_rel = (d_ph * A.O[2] + d_pw) * A.Cy * 2 + (tid & 3) * 16;
+    // dA staging geometry: piece k of a lane = point (pd = wv, ph = 2 k + (lane >> 5), pw = (lane >> 2) & 7), 16-byte part lane & 3
+    const int d_ph = lane >> 5, d_pw = (lane >> 2) & 7;
+    const int d_dst0 = (wv * 8 + d_ph) * PROW + d_pw * 64 + (lane & 3) * 16;
     const int d_slab = A.O[1] * A.O[2] * A.Cy * 2;
+    const int d_rel = wv * d_slab + (d_ph * A.O[2] + d_pw) * A.Cy * 2 + (lane & 3) * 16;
+    const int d_step = 2 * A.O[2] * A.Cy * 2;                   // two h-rows further
     const int dy_img = A.O[0] * d_slab, x_img = A.I[0] * A.I[1] * A.I[2] * 2;
     const auto drs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(A.dy)) + (int64_t)n * dy_img + c0 * 2, 0, dy_img - c0 * 2, 0x00020000);
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (int64_t)n * x_img, 0, x_img, 0x00020000);
-    int x_rel[3];
+    int x_rel[5];                                               // this wave's halo: planes wv .. wv + 2 of the tile's 6 x 10 x 10
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int i = tid + s * 256;
-        x_rel[s] = ((i / 100) << 16) | (((i / 10) % 10) << 8) | (i % 10);
+    for (int s = 0; s < 5; ++s) {
+        const int i = lane + s * 64;
+        x_rel[s] = ((wv + i / 100) << 16) | (((i / 10) % 10) << 8) | (i % 10);
     }
-    const int e_pd = tid >> 6, e_ph = (tid >> 3) & 7, e_pw = tid & 7;       // expansion: thread = point tid
-    const int e_base = (e_pd * 10 + e_ph) * 10 + e_pw;
+    const int e_pd = tid >> 6, e_ph = (tid >> 3) & 7, e_pw = tid & 7;       // expansion: thread = point tid (plane e_pd = wv)
+    const int e_base = e_ph * 10 + e_pw;                                    // (relative to this wave's halo planes)
     char* const e_dst = imt + (tid >> 3) * PROW + (tid & 7) * 64;
     const int f_lane = q * PROW + (li >> 2) * 64 + (li & 3) * 8;            // transposed fragment reads (see k_stem_wgrad3)
 
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
     const u32x4 ones = u32x4{H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2};
     const int tiles_per_n = nt0 * nt1 * nt2;
     u32x4 vd[4];
-    uint16_t vx[3];
+    uint16_t vx[5];
     auto issue = [&](int tile, int& l0d, int& l0h, int& l0w) {
         int tt = tile;
         const int tw_i = tt % nt2; tt /= nt2;
@@ -584,15 +602,15 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
         const int td_i = tt / nt1;
         l0d = td_i * 4; l0h = th_i * 8; l0w = tw_i * 8;
         const int d_org = ((l0d * A.O[1] + l0h) * A.O[2] + l0w) * A.Cy * 2;
-        const bool okhw = (l0h + d_ph < A.O[1]) && (l0w + d_pw < A.O[2]);
+        const bool okdw = (l0d + wv < A.O[0]) && (l0w + d_pw < A.O[2]);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             vd[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                drs, (okhw && l0d + s < A.O[0]) ? d_rel + s * d_slab : (int)0x80000000, d_org, 0));
+                drs, (okdw && l0h + 2 * s + d_ph < A.O[1]) ? d_rel + s * d_step : (int)0x80000000, d_org, 0));
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < 5; ++s) {
             const int id = l0d - 1 + (x_rel[s] >> 16), ih = l0h - 1 + ((x_rel[s] >> 8) & 255), iw = l0w - 1 + (x_rel[s] & 255);
-            const bool ok = (tid + s * 256 < 600) && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
+            const bool ok = (lane + s * 64 < 300) && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
             vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, ok ? ((id * A.I[1] + ih) * A.I[2] + iw) * 2 : (int)0x80000000, 0, 0);
         }
     };
@@ -600,13 +618,13 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
     int l0d = 0, l0h = 0, l0w = 0, n0d = 0, n0h = 0, n0w = 0;
     if (tile < tiles_per_n) issue(tile, l0d, l0h, l0w);
     for (; tile < tiles_per_n; tile += gridDim.x) {
-        __syncthreads();                                   // the MFMA phase of the previous tile is done with the LDS tiles
+        // (this wave's MFMA phase of the previous tile has issued its LDS reads: the writes below queue behind them)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(dyt + d_dst0 + s * 8 * PROW) = vd[s];
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(dyt + d_dst0 + s * 2 * PROW) = vd[s];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-            if (tid + s * 256 < 600) xh[tid + s * 256] = vx[s];
-        __syncthreads();
+        for (int s = 0; s < 5; ++s)
+            if (lane + s * 64 < 300) xh[lane + s * 64] = vx[s];
+        stem_wave_lds_sync();
         const int next = tile + gridDim.x;
         if (next < tiles_per_n) issue(next, n0d, n0h, n0w);    // in flight during the rest of this tile
         {   // expansion; a point outside the volume gets a zero row (it must not contribute to B = sum of the shifted image)
@@ -622,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
 #pragma unroll
             for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(e_dst + k * 16) = u32x4{pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]};
         }
-        __syncthreads();
+        stem_wave_lds_sync();
         {   // recompute y, mask the incoming gradient, normalise: g -> dyt (in place), xh -> xnt; S1 / S2 in registers
             u32x4 bf[4];
 #pragma unroll
@@ -658,9 +676,9 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
                 }
             }
         }
-        __syncthreads();
+        stem_wave_lds_sync();
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {                   // wave wv takes the contraction steps 2 wv, 2 wv + 1 (32 points each)
+        for (int kk = 0; kk < 2; ++kk) {                   // wave wv takes the contraction steps 2 wv, 2 wv + 1 (32 points each) = its own plane
             const int ks = wv * 2 + kk;
             u32x4 pf[2], xf[2], qf[2];
 #pragma unroll
@@ -679,9 +697,13 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
                 }
             }
         }
+        stem_wave_lds_sync();                              // (the next tile's stores stay behind this tile's fragment reads)
         l0d = n0d; l0h = n0h; l0w = n0w;
     }
-    // workgroup reduction in LDS, then one atomic per value into the per-image accumulators
+    // workgroup reduction in LDS (the tiles are dead now), then one atomic per value into the per-image accumulators
+    __syncthreads();
+    for (int i = tid; i < 2 * 32 * 32 + 32; i += 256) red[i] = 0.f;
+    if (tid < 64) reds[tid] = 0.0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -894,6 +916,15 @@ extern "C" int nndet_stem_block_backward(const NndetConv* c, const void* x, cons
     for (int i = 0; i < 3; ++i) { b.I[i] = a.I[i]; b.O[i] = a.O[i]; }
     int S, nt[3];
     stem_block_grid(a, c->cout_p, &S, nt);
+    {   // NNDET_STEM_BWD_WGS: total workgroups of the backward kernel (default 512 = 2 per CU; 51 KB of LDS each allow 3)
+        const char* e = getenv("NNDET_STEM_BWD_WGS");
+        if (e && atoi(e) >= 8) {
+            int s_ = atoi(e) / (a.N * (c->cout_p / 32));
+            s_ = s_ < 8 ? 8 : (s_ / 8) * 8;
+            const int64_t tiles = (int64_t)nt[0] * nt[1] * nt[2];
+            S = s_ > tiles ? (int)tiles : s_;
+        }
+    }
     const dim3 grid(S, c->cout_p / 32, a.N);
     if (c->dtype == NNDET_F16) k_stem_bwd3<f16_t><<<grid, 256, 0, st>>>(b, nt[0], nt[1], nt[2]);
     else k_stem_bwd3<bf16_t><<<grid, 256, 0, st>>>(b, nt[0], nt[1], nt[2]);

@@ -1,0 +1,24 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=gpurun_out
+timeout 600 python -m pytest tests/test_conv_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "stem" 2>&1 | tail -4 | cut -c1-300
+P=$PWD/nndetection_amd/csrc/libnndet_amd_prev.so
+: > $O/stem_bwd_variants.txt
+for lib in prev cur; do
+  rm -rf $O/prof
+  L=$PWD/nndetection_amd/csrc/libnndet_amd.so; [ $lib = prev ] && L=$P
+  (cd /tmp && NNDET_AMD_LIB=$L timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/prof -- python $OLDPWD/tools/stem_bwd_microbench.py 6 > $OLDPWD/$O/prof.txt 2>&1)
+  db=$(find $O/prof -name "*_results.db" | head -1)
+  echo "== lib=$lib $(grep 'dgamma' $O/prof.txt | cut -c1-200)" | tee -a $O/stem_bwd_variants.txt
+  [ -n "$db" ] && python tools/rocpd_stats.py "$db" 40 | grep -i "k_stem" | cut -c1-150 | tee -a $O/stem_bwd_variants.txt
+  rm -rf $O/prof
+done
+run() { env "$@" timeout 600 python bench.py --steps 60 --warmup 15 --no-extras 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1; }
+echo "== A/B k_stem_bwd3 without barriers in the tile loop (prev = the build before both stem changes)" | tee $O/ab_stem_nobarrier.txt
+run NNDET_AMD_LIB=$P > /dev/null
+for r in 1 2 3; do
+  echo "prev $(run NNDET_AMD_LIB=$P)" | tee -a $O/ab_stem_nobarrier.txt
+  echo "cur  $(run X=1)" | tee -a $O/ab_stem_nobarrier.txt
+done
