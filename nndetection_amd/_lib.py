@@ -377,6 +377,25 @@ def aux_stream(device):
     return st
 
 
+# Two private torch hooks carry the multi-stream backward pass: the id of the running graph task (to tell one backward pass from the next,
+# and a forward pass that runs INSIDE one) and the engine's end-of-pass callback queue. Both are probed once; without them the
+# weight-gradient stream is switched off (everything stays on the calling stream: slower, same results) instead of failing mid-step
+# after a torch upgrade.
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+_engine = getattr(getattr(torch.autograd, "Variable", None), "_execution_engine", None)
+_queue_callback = getattr(_engine, "queue_callback", None)
+PRIVATE_AUTOGRAD_HOOKS = _graph_task_id is not None and _queue_callback is not None
+if not PRIVATE_AUTOGRAD_HOOKS:
+    import warnings
+    warnings.warn("nndetection_amd: torch._C._current_graph_task_id / the autograd engine's queue_callback are not available in this "
+                  "torch build; weight gradients stay on the main stream (NNDET_WGRAD_STREAM=0 behaviour)")
+
+
+def graph_task_id() -> int:
+    """Id of the backward pass that is running on this thread, -1 outside of one (or when torch does not tell)."""
+    return _graph_task_id() if _graph_task_id is not None else -1
+
+
 class _WgradStreams:
     """Weight-gradient kernels on their own stream. Within a backward pass the data-gradient / norm-backward chain is the critical
     path; a weight gradient is only needed by the optimizer. Launched on a second stream the weight-gradient kernels fill the CUs the
@@ -386,7 +405,7 @@ class _WgradStreams:
     stream when the pass ends, i.e. before the optimizer (or anything else on that stream) reads a gradient. Gradient hooks that read
     gradients DURING the pass (nndetection_amd.ddp) take the stream from `active`. NNDET_WGRAD_STREAM=0 disables it."""
 
-    enabled = os.environ.get("NNDET_WGRAD_STREAM", "1") != "0"
+    enabled = os.environ.get("NNDET_WGRAD_STREAM", "1") != "0" and PRIVATE_AUTOGRAD_HOOKS
 
     def __init__(self):
         self.streams, self.active, self.pending, self.task = {}, {}, [], -1
@@ -395,7 +414,7 @@ class _WgradStreams:
         if not self.enabled or dev.type != "cuda":
             return None
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        task = torch._C._current_graph_task_id()
+        task = graph_task_id()
         if task != self.task:                        # a new backward pass (the previous one may have died before its callback ran)
             for w in self.pending:
                 w._nndet_wg_pending = False
@@ -414,7 +433,7 @@ class _WgradStreams:
             prio = int(os.environ.get("NNDET_WGRAD_PRIO", "1"))
             ws = self.streams[idx] = torch.cuda.Stream(device=dev, priority=prio)
         if not self.active:
-            torch.autograd.Variable._execution_engine.queue_callback(self._done)
+            _queue_callback(self._done)
         self.active[idx] = ws
         weight._nndet_wg_pending = True
         self.pending.append(weight)

@@ -131,7 +131,7 @@ class BaseRetinaNet(nn.Module):
                 # nobody consumed would pin large tensors across steps. Their entries live from one node of a backward
                 # pass to a later node of the SAME pass, so a forward pass that runs INSIDE a backward pass (activation checkpointing
                 # recomputes, a second model driven from a hook) must leave them alone: cleared only at top level.
-                if torch._C._current_graph_task_id() == -1:
+                if L.graph_task_id() == -1:
                     L.grad_hints.d.clear()
                     from ..arch.conv import _rank1_grads, _norm_presums
                     _rank1_grads.clear()

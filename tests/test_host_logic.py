@@ -553,3 +553,29 @@ def test_static_pool_hands_a_region_out_once_and_only_without_grad():
         assert not any(lo <= p.grad.data_ptr() < hi for p in other.parameters())
     finally:
         ddp.close()
+
+
+def test_private_autograd_hooks_are_probed_once_and_degrade_gracefully():
+    """The multi-stream backward pass hangs off two private torch hooks ("one torch upgrade from breaking"): both are probed at
+    import; this torch has them, the graph-task id tells a backward pass from the outside, and without them the weight-gradient stream
+    is simply off (the product then stays on the calling stream -- same results)."""
+    from nndetection_amd import _lib as L
+    assert L.PRIVATE_AUTOGRAD_HOOKS
+    assert L.graph_task_id() == -1
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(L.graph_task_id())
+            return g * 2.0
+
+    x = torch.ones(3, requires_grad=True)
+    Probe.apply(x).sum().backward()
+    assert len(seen) == 1 and seen[0] >= 0 and L.graph_task_id() == -1
+    assert L._WgradStreams.enabled == (os.environ.get("NNDET_WGRAD_STREAM", "1") != "0")
+    assert L.wgrad_streams.side(torch.device("cpu"), torch.nn.Parameter(torch.zeros(1))) is None      # CPU tensors never leave the stream
