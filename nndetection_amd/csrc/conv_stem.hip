@@ -524,6 +524,12 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
     // wv * 8 .. wv * 8 + 7 of the three LDS tiles. It stages its own plane of dA and its own 3 x 10 x 10 halo of the image, expands, recomputes
     // and contracts exactly these points (the contraction steps 2 wv, 2 wv + 1 ARE these 64 points), so every LDS dependency is wave-local
     // and ordered by the in-order LDS queue of the wave; the four waves drift apart freely and hide each other's load / LDS latencies.
+    //
+    // Bank swizzle (round 5): a point's 64 bytes are eight 8-byte slots (4 channels / 4 taps each); slot h of the point in column c of a row
+    // lives at slot h ^ (c >> 1). Unswizzled, the 8-byte accesses of the recompute phase (columns c and c + 4 are 256 B apart = the same
+    // bank) and the 16-byte stores of the expansion were 2- to 4-way conflicts: SQ_LDS_BANK_CONFLICT was 51 % of SQ_LDS_IDX_ACTIVE, the LDS
+    // 66 % busy (profiles/round5_stem_bwd_pmc.txt). Every access below goes through the same map; the expansion stores and the B-fragment
+    // loads of the recompute MFMA are 8-byte accesses now (same LDS cycles as the 16-byte forms).
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint16_t* const xh = reinterpret_cast<uint16_t*>(xnt + wv * 8 * PROW);     // [300], inside this wave's own rows of xnt
     float* const red = reinterpret_cast<float*>(dyt);            // [2 * 32 * 32 + 32]
@@ -559,7 +565,9 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
     }
     // dA staging geometry: piece k of a lane = point (pd = wv, ph = 2 k + (lane >> 5), pw = (lane >> 2) & 7), 16-byte part lane & 3
     const int d_ph = lane >> 5, d_pw = (lane >> 2) & 7;
-    const int d_dst0 = (wv * 8 + d_ph) * PROW + d_pw * 64 + (lane & 3) * 16;
+    const int d_m = d_pw >> 1;                                   // swizzle of this lane's point: the two 8-byte halves of its 16-byte part go to slots (2 k) ^ m, (2 k + 1) ^ m
+    const int d_pt = (wv * 8 + d_ph) * PROW + d_pw * 64;
+    const int d_dst0 = d_pt + (((2 * (lane & 3)) ^ d_m) * 8), d_dst1 = d_pt + (((2 * (lane & 3) + 1) ^ d_m) * 8);
     const int d_slab = A.O[1] * A.O[2] * A.Cy * 2;
     const int d_rel = wv * d_slab + (d_ph * A.O[2] + d_pw) * A.Cy * 2 + (lane & 3) * 16;
     const int d_step = 2 * A.O[2] * A.Cy * 2;                   // two h-rows further
@@ -568,16 +576,38 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
         const_cast<char*>(reinterpret_cast<const char*>(A.dy)) + (int64_t)n * dy_img + c0 * 2, 0, dy_img - c0 * 2, 0x00020000);
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (int64_t)n * x_img, 0, x_img, 0x00020000);
-    int x_rel[5];                                               // this wave's halo: planes wv .. wv + 2 of the tile's 6 x 10 x 10
+    int x_rel[5], x_off[5];                                     // this wave's halo: planes wv .. wv + 2 of the tile's 6 x 10 x 10
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         const int i = lane + s * 64;
-        x_rel[s] = ((wv + i / 100) << 16) | (((i / 10) % 10) << 8) | (i % 10);
+        const int rd = wv + i / 100, rh = (i / 10) % 10, rw = i % 10;
+        x_rel[s] = i < 300 ? ((rd << 16) | (rh << 8) | rw) : 0x7f7f7f7f;       // (no such halo voxel: fails every bounds check below)
+        x_off[s] = ((rd * A.I[1] + rh) * A.I[2] + rw) * 2;                    // byte offset relative to the halo's first voxel
     }
     const int e_pd = tid >> 6, e_ph = (tid >> 3) & 7, e_pw = tid & 7;       // expansion: thread = point tid (plane e_pd = wv)
     const int e_base = e_ph * 10 + e_pw;                                    // (relative to this wave's halo planes)
     char* const e_dst = imt + (tid >> 3) * PROW + (tid & 7) * 64;
-    const int f_lane = q * PROW + (li >> 2) * 64 + (li & 3) * 8;            // transposed fragment reads (see k_stem_wgrad3)
+    const int e_m = (tid & 7) >> 1;
+    // transposed fragment reads (see k_stem_wgrad3): lane = (point column li >> 2 [+ 4 for the second read], slot (li & 3) + 4 i)
+    int f_a[2], f_b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int fc = li >> 2, fh = (li & 3) + 4 * i;
+        f_a[i] = (wv * 8 + q) * PROW + fc * 64 + ((fh ^ (fc >> 1)) * 8);              // (this wave's rows: offsets inside the plane are immediates)
+        f_b[i] = (wv * 8 + q) * PROW + (fc + 4) * 64 + ((fh ^ ((fc + 4) >> 1)) * 8);
+    }
+    auto trfrag = [&](const char* tile_rows, int i) -> u32x4 {      // stem_trfrag through the swizzle
+        const st_s16x4 a_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_lds_s16x4_ptr)(tile_rows + f_a[i]));
+        const st_s16x4 b_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_lds_s16x4_ptr)(tile_rows + f_b[i]));
+        const uint2 ua = __builtin_bit_cast(uint2, a_), ub = __builtin_bit_cast(uint2, b_);
+        return u32x4{ua.x, ua.y, ub.x, ub.y};
+    };
+    // recompute phase: lane = (K chunk / channel quad q, point li = row li >> 3, column li & 7 of the wave's 16-point group)
+    const int r_m = (li >> 1) & 3;
+    const int r_pt = (wv * 8 + (li >> 3)) * PROW + (li & 7) * 64;
+    const int r_bfa = r_pt + (((2 * q) ^ r_m) * 8), r_bfb = r_pt + (((2 * q + 1) ^ r_m) * 8);   // the two tap halves of chunk q (these two reads keep a
+    // 2-way conflict between the lanes q and q ^ 1 of a half wave: reading the halves in a lane-dependent order avoids it for 16 selects per plane -- dearer)
+    const int r_ch[2] = {r_pt + ((q ^ r_m) * 8), r_pt + (((q + 4) ^ r_m) * 8)};                                     // channel quad q of block i
 
     f32x4 accA[2][2], accC[2][2], accB[2];
 #pragma unroll
@@ -592,6 +622,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) { s1[i][rr] = 0.f; s2[i][rr] = 0.f; }
     const u32x4 ones = u32x4{H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2, H16<T>::ONE2};
+    const float relu_floor = A.relu ? 0.f : -__builtin_inff();
     const int tiles_per_n = nt0 * nt1 * nt2;
     u32x4 vd[4];
     uint16_t vx[5];
@@ -602,16 +633,33 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
         const int td_i = tt / nt1;
         l0d = td_i * 4; l0h = th_i * 8; l0w = tw_i * 8;
         const int d_org = ((l0d * A.O[1] + l0h) * A.O[2] + l0w) * A.Cy * 2;
-        const bool okdw = (l0d + wv < A.O[0]) && (l0w + d_pw < A.O[2]);
+        // The kernel is bound by VALU issue (2 waves per SIMD issue 90 % of the cycles, profiles/round5_stem_bwd_pmc.txt): tiles that lie
+        // completely inside the volume / whose halo does (wave-uniform tests) skip the per-lane bounds arithmetic.
+        const bool full = l0d + 4 <= A.O[0] && l0h + 8 <= A.O[1] && l0w + 8 <= A.O[2];
+        if (full) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            vd[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                drs, (okdw && l0h + 2 * s + d_ph < A.O[1]) ? d_rel + s * d_step : (int)0x80000000, d_org, 0));
+            for (int s = 0; s < 4; ++s)
+                vd[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, d_rel + s * d_step, d_org, 0));
+        } else {
+            const bool okdw = (l0d + wv < A.O[0]) && (l0w + d_pw < A.O[2]);
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            const int id = l0d - 1 + (x_rel[s] >> 16), ih = l0h - 1 + ((x_rel[s] >> 8) & 255), iw = l0w - 1 + (x_rel[s] & 255);
-            const bool ok = (lane + s * 64 < 300) && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
-            vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, ok ? ((id * A.I[1] + ih) * A.I[2] + iw) * 2 : (int)0x80000000, 0, 0);
+            for (int s = 0; s < 4; ++s)
+                vd[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    drs, (okdw && l0h + 2 * s + d_ph < A.O[1]) ? d_rel + s * d_step : (int)0x80000000, d_org, 0));
+        }
+        const int x_org = (((l0d - 1) * A.I[1] + (l0h - 1)) * A.I[2] + (l0w - 1)) * 2;       // (scalar; may be negative: added to the lane offset below)
+        const bool inner = l0d >= 1 && l0h >= 1 && l0w >= 1 && l0d + 5 <= A.I[0] && l0h + 9 <= A.I[1] && l0w + 9 <= A.I[2];
+        if (inner) {
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+                vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, (s < 4 || lane < 300 - 256) ? x_org + x_off[s] : (int)0x80000000, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const int id = l0d - 1 + (x_rel[s] >> 16), ih = l0h - 1 + ((x_rel[s] >> 8) & 255), iw = l0w - 1 + (x_rel[s] & 255);
+                const bool ok = (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
+                vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, ok ? x_org + x_off[s] : (int)0x80000000, 0, 0);
+            }
         }
     };
     int tile = xcd_compact(blockIdx.x, gridDim.x, gridDim.x);
@@ -620,7 +668,10 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
     for (; tile < tiles_per_n; tile += gridDim.x) {
         // (this wave's MFMA phase of the previous tile has issued its LDS reads: the writes below queue behind them)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4*>(dyt + d_dst0 + s * 2 * PROW) = vd[s];
+        for (int s = 0; s < 4; ++s) {
+            *reinterpret_cast<uint2*>(dyt + d_dst0 + s * 2 * PROW) = uint2{vd[s][0], vd[s][1]};
+            *reinterpret_cast<uint2*>(dyt + d_dst1 + s * 2 * PROW) = uint2{vd[s][2], vd[s][3]};
+        }
 #pragma unroll
         for (int s = 0; s < 5; ++s)
             if (lane + s * 64 < 300) xh[lane + s * 64] = vx[s];
@@ -628,64 +679,70 @@ __global__ __launch_bounds__(256, 2) void k_stem_bwd3(const StemBwdArgs A, int n
         const int next = tile + gridDim.x;
         if (next < tiles_per_n) issue(next, n0d, n0h, n0w);    // in flight during the rest of this tile
         {   // expansion; a point outside the volume gets a zero row (it must not contribute to B = sum of the shifted image)
-            const bool pv = (l0d + e_pd < A.O[0]) && (l0h + e_ph < A.O[1]) && (l0w + e_pw < A.O[2]);
             uint32_t pk[16];
 #pragma unroll
             for (int t = 0; t < 32; t += 2) {
                 uint32_t lo = 0, hi = 0;
                 if (t < 27) lo = xh[e_base + (t / 9) * 100 + ((t / 3) % 3) * 10 + t % 3];
                 if (t + 1 < 27) hi = xh[e_base + ((t + 1) / 9) * 100 + (((t + 1) / 3) % 3) * 10 + (t + 1) % 3];
-                pk[t >> 1] = pv ? (lo | (hi << 16)) : 0u;
+                pk[t >> 1] = lo | (hi << 16);
+            }
+            if (!(l0d + 4 <= A.O[0] && l0h + 8 <= A.O[1] && l0w + 8 <= A.O[2])) {      // (wave-uniform: a tile that sticks out of the volume)
+                const bool pv = (l0d + e_pd < A.O[0]) && (l0h + e_ph < A.O[1]) && (l0w + e_pw < A.O[2]);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) pk[t] = pv ? pk[t] : 0u;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(e_dst + k * 16) = u32x4{pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]};
+            for (int h = 0; h < 8; ++h) *reinterpret_cast<uint2*>(e_dst + ((h ^ e_m) * 8)) = uint2{pk[2 * h], pk[2 * h + 1]};
         }
         stem_wave_lds_sync();
         {   // recompute y, mask the incoming gradient, normalise: g -> dyt (in place), xh -> xnt; S1 / S2 in registers
             u32x4 bf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int pt = wv * 4 + j;
-                bf[j] = *reinterpret_cast<const u32x4*>(imt + (pt * 2 + (li >> 3)) * PROW + (li & 7) * 64 + q * 16);
+                const uint2 ba = *reinterpret_cast<const uint2*>(imt + j * 2 * PROW + r_bfa);
+                const uint2 bb = *reinterpret_cast<const uint2*>(imt + j * 2 * PROW + r_bfb);
+                bf[j] = u32x4{ba.x, ba.y, bb.x, bb.y};      // taps q * 8 .. q * 8 + 7 in order
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int p = (wv * 4 + j) * 16 + li;
-                const bool valid = (l0d + (p >> 6) < A.O[0]) && (l0h + ((p >> 3) & 7) < A.O[1]) && (l0w + (p & 7) < A.O[2]);
-                const int poff = (p >> 3) * PROW + (p & 7) * 64 + q * 8;
+                // (a point outside the volume needs no special case: its dA was staged as zero -> g = 0, and its row of the expanded image is
+                //  zero -> y = 0, a finite xh that meets a zero row in the correlation C)
+                constexpr int PR2 = 2 * PROW;
+                const int prow = j * PR2;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
                     c = H16<T>::mma(af[i], bf[j], c);
-                    const uint2 dv = *reinterpret_cast<const uint2*>(dyt + poff + i * 32);
+                    const uint2 dv = *reinterpret_cast<const uint2*>(dyt + prow + r_ch[i]);
                     const float d4[4] = {H16<T>::lo(dv.x), H16<T>::hi(dv.x), H16<T>::lo(dv.y), H16<T>::hi(dv.y)};
                     float g4[4], x4[4];
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const float z = fmaf(c[rr], n_sc[i][rr], n_sh[i][rr]);          // the forward pass's expression: same ReLU decisions
-                        const float xn = valid ? fmaf(c[rr], n_rs[i][rr], -n_mrs[i][rr]) : 0.f;
-                        const float g = (!A.relu || z > 0.f) ? d4[rr] : 0.f;             // (dA is zero outside the volume)
+                        const float xn = fmaf(c[rr], n_rs[i][rr], -n_mrs[i][rr]);
+                        const float g = z > relu_floor ? d4[rr] : 0.f;                   // (relu_floor = -inf without ReLU)
                         g4[rr] = g; x4[rr] = xn;
                         s1[i][rr] += g; s2[i][rr] = fmaf(g, xn, s2[i][rr]);
                     }
                     uint2 go, xo;
                     go.x = H16<T>::pack2(g4[0], g4[1]); go.y = H16<T>::pack2(g4[2], g4[3]);
                     xo.x = H16<T>::pack2(x4[0], x4[1]); xo.y = H16<T>::pack2(x4[2], x4[3]);
-                    *reinterpret_cast<uint2*>(dyt + poff + i * 32) = go;
-                    *reinterpret_cast<uint2*>(xnt + poff + i * 32) = xo;
+                    *reinterpret_cast<uint2*>(dyt + prow + r_ch[i]) = go;
+                    *reinterpret_cast<uint2*>(xnt + prow + r_ch[i]) = xo;
                 }
             }
         }
         stem_wave_lds_sync();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                   // wave wv takes the contraction steps 2 wv, 2 wv + 1 (32 points each) = its own plane
-            const int ks = wv * 2 + kk;
+            const int ks = kk;                                 // (relative to the wave's rows, see f_a / f_b)
             u32x4 pf[2], xf[2], qf[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                pf[i] = stem_trfrag(dyt + f_lane + ks * 4 * PROW + i * 32);
-                xf[i] = stem_trfrag(xnt + f_lane + ks * 4 * PROW + i * 32);
-                qf[i] = stem_trfrag(imt + f_lane + ks * 4 * PROW + i * 32);
+                pf[i] = trfrag(dyt + ks * 4 * PROW, i);
+                xf[i] = trfrag(xnt + ks * 4 * PROW, i);
+                qf[i] = trfrag(imt + ks * 4 * PROW, i);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
