@@ -95,6 +95,27 @@ static inline int red_rows(int64_t rows_total) {
     return (int)r;
 }
 
+// End of a reduction workgroup: per-thread partial sums (E channels x 2 sums) -> the workgroup's LDS table [c_p][2] in fp64. The threads of a
+// channel group (same tid % ppr) used to add their partials with LDS atomics one by one: 256 / ppr threads on the same 2 E addresses -- with
+// c_p = 32 that is a 64-way serialised chain of 16 fp64 atomics per thread, and the LDS was busy 29 % of k_norm_bwd_reduce's time with 47 %
+// bank conflicts (profiles/round5_step_pmc_survey.txt). When ppr is a power of two the lanes of a wave that share a channel group are a
+// fixed stride apart: they are added with xor shuffles first (fp32, a 16- ... 2-leaf tree), and only the first ppr lanes of each wave touch the table.
+template <int E>
+__device__ __forceinline__ void norm_block_sums_to_lds(double* red, int ppr, int cp, float* sa, float* sb) {
+    if ((ppr & (ppr - 1)) == 0 && ppr <= 32) {
+        for (int o = ppr; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { sa[e] += __shfl_xor(sa[e], o, 64); sb[e] += __shfl_xor(sb[e], o, 64); }
+        }
+        if ((int)(threadIdx.x & 63) >= ppr) return;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        atomicAdd(&red[(cp * E + e) * 2 + 0], (double)sa[e]);
+        atomicAdd(&red[(cp * E + e) * 2 + 1], (double)sb[e]);
+    }
+}
+
 // ------------------------------------------------------------------ statistics: sum / sumsq per (n, channel)
 // grid (ceil(spatial / ROWS_PER_BLOCK), N)
 template <typename T>
@@ -136,12 +157,8 @@ __global__ __launch_bounds__(256) void k_norm_stats(const T* __restrict__ x, int
 #pragma unroll
             for (int e = 0; e < E; ++e) { s[e] += v[e]; s2[e] += v[e] * v[e]; }
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            atomicAdd(&red[(cp * E + e) * 2 + 0], (double)s[e]);
-            atomicAdd(&red[(cp * E + e) * 2 + 1], (double)s2[e]);
-        }
     }
+    if (rr < rpi || 256 % ppr == 0) norm_block_sums_to_lds<E>(red, ppr, cp, s, s2);      // (256 % ppr == 0: every thread has rows, the shuffles need all lanes)
     __syncthreads();
     const int rep = blockIdx.x % NNDET_STATS_REPLICAS;
     double* dst = stats + ((int64_t)rep * N + n) * c_p * 2;
@@ -510,11 +527,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
             Vec16<T>::ld(dyi + gbase + r * gp, gv);
             row(xv, gv);
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            atomicAdd(&red[(cp * E + e) * 2 + 0], (double)sa[e]);
-            atomicAdd(&red[(cp * E + e) * 2 + 1], (double)sb[e]);
-        }
+        norm_block_sums_to_lds<E>(red, ppr, cp, sa, sb);          // (ppr a power of two: rpi * ppr == 256, every lane is here)
     }
     __syncthreads();
     const int rep = blockIdx.x % NNDET_STATS_REPLICAS;
