@@ -311,6 +311,14 @@ __device__ __forceinline__ float stem_dpp_row_sum(float v) {
     return v;
 }
 
+// Hand-over point between two phases of ONE wave that exchange data through LDS (lane i writes what lane j reads): the LDS queue of a wave
+// is in order, so no s_barrier is needed -- only the compiler has to keep the accesses on their side (and the data has to have landed).
+__device__ __forceinline__ void stem_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // MODE 0: y = conv(x) (+ bias), stored rounded to T, optional statistics of the rounded values (the stand-alone convolution).
 // MODE 1 / 2 = the two passes of the FUSED stem block conv -> InstanceNorm -> ReLU (nndet_stem_block_forward): the convolution is so
 // cheap (27 MACs per output, one input channel) that computing it twice beats writing the pre-norm tensor and reading it back:
@@ -323,9 +331,15 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
                                                       const float* __restrict__ beta = nullptr, int relu = 0) {
     constexpr int PROW = 8 * 64 + 32;
     __shared__ __attribute__((aligned(16))) char imt[32 * PROW];
-    __shared__ __attribute__((aligned(16))) uint16_t xh[608];
+    __shared__ __attribute__((aligned(16))) uint16_t xh_all[4 * 304];
     __shared__ double red[64];
+    // Round 5, the recipe of k_stem_bwd3 (profiles/round5_stem_bwd_pmc.txt: these kernels are bound by VALU issue, and their 16-byte expansion
+    // stores replayed bank conflicts for 47 % of the LDS cycles): NO workgroup barrier in the tile loop -- wave wv owns d-plane wv of every
+    // tile (its own 3 x 10 x 10 halo, its own 64 rows of the expanded tile, the 64 points its MFMAs consume); slot h (8 bytes = 4 taps) of the
+    // point in column c lives at slot h ^ (c >> 1); tiles inside the volume / with their halo inside (wave-uniform tests) skip the per-lane
+    // bounds arithmetic and address their outputs by a scalar tile base + a lane constant.
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint16_t* const xh = xh_all + wv * 304;
     const int li = lane & 15, q = lane >> 4;
     const int c0 = blockIdx.y * 32, n = blockIdx.z;
     if (tid < 64) red[tid] = 0.0;
@@ -364,14 +378,27 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
                 nsc[i][rr] = a_; nsh[i][rr] = b_;
             }
     }
-    int x_rel[3];
+    int x_rel[5], x_off[5];                                     // this wave's halo: planes wv .. wv + 2 of the tile's 6 x 10 x 10
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int i = tid + s * 256;
-        x_rel[s] = ((i / 100) << 16) | (((i / 10) % 10) << 8) | (i % 10);
+    for (int s = 0; s < 5; ++s) {
+        const int i = lane + s * 64;
+        const int rd = wv + i / 100, rh = (i / 10) % 10, rw = i % 10;
+        x_rel[s] = i < 300 ? ((rd << 16) | (rh << 8) | rw) : 0x7f7f7f7f;       // (no such halo voxel: fails every bounds check)
+        x_off[s] = ((rd * A.I[1] + rh) * A.I[2] + rw) * 2;                    // byte offset relative to the halo's first voxel
     }
-    const int e_base = ((tid >> 6) * 10 + ((tid >> 3) & 7)) * 10 + (tid & 7);
+    const int e_base = ((tid >> 3) & 7) * 10 + (tid & 7);                     // (relative to this wave's halo planes)
     char* const e_dst = imt + (tid >> 3) * PROW + (tid & 7) * 64;
+    const int e_m = (tid & 7) >> 1;
+    // MFMA phase: lane = (K chunk / channel quad q, point li = row li >> 3, column li & 7 of the wave's 16-point group j)
+    const int r_m = (li >> 1) & 3;
+    const int r_pt = (wv * 8 + (li >> 3)) * PROW + (li & 7) * 64;
+    const int r_bfa = r_pt + (((2 * q) ^ r_m) * 8), r_bfb = r_pt + (((2 * q + 1) ^ r_m) * 8);
+    int y_rel[4];                                               // output byte offset of point (j, li) relative to the tile's first voxel, channel quad q
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = (wv * 4 + j) * 16 + li;
+        y_rel[j] = ((((p >> 6) * A.O[1] + ((p >> 3) & 7)) * A.O[2] + (p & 7)) * A.Cy + q * 4) * 2;
+    }
     const int x_img = A.I[0] * A.I[1] * A.I[2] * 2;
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A.x)) + (int64_t)n * x_img, 0, x_img, 0x00020000);
     const int y_img = A.O[0] * A.O[1] * A.O[2] * A.Cy * 2;
@@ -382,29 +409,37 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) { ssum[i][rr] = 0.f; ssq[i][rr] = 0.f; }
-    uint16_t vx[3];
+    uint16_t vx[5];
     auto issue = [&](int tile, int& l0d, int& l0h, int& l0w) {
         int tt = tile;
         const int tw_i = tt % nt2; tt /= nt2;
         const int th_i = tt % nt1;
         const int td_i = tt / nt1;
         l0d = td_i * 4; l0h = th_i * 8; l0w = tw_i * 8;
+        const int x_org = (((l0d - 1) * A.I[1] + (l0h - 1)) * A.I[2] + (l0w - 1)) * 2;       // (scalar; may be negative: added to the lane offset)
+        const bool inner = l0d >= 1 && l0h >= 1 && l0w >= 1 && l0d + 5 <= A.I[0] && l0h + 9 <= A.I[1] && l0w + 9 <= A.I[2];
+        if (inner) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int id = l0d - 1 + (x_rel[s] >> 16), ih = l0h - 1 + ((x_rel[s] >> 8) & 255), iw = l0w - 1 + (x_rel[s] & 255);
-            const bool ok = (tid + s * 256 < 600) && (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
-            vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, ok ? ((id * A.I[1] + ih) * A.I[2] + iw) * 2 : (int)0x80000000, 0, 0);
+            for (int s = 0; s < 5; ++s)
+                vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, (s < 4 || lane < 300 - 256) ? x_org + x_off[s] : (int)0x80000000, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const int id = l0d - 1 + (x_rel[s] >> 16), ih = l0h - 1 + ((x_rel[s] >> 8) & 255), iw = l0w - 1 + (x_rel[s] & 255);
+                const bool ok = (unsigned)id < (unsigned)A.I[0] && (unsigned)ih < (unsigned)A.I[1] && (unsigned)iw < (unsigned)A.I[2];
+                vx[s] = __builtin_amdgcn_raw_buffer_load_b16(xrs, ok ? x_org + x_off[s] : (int)0x80000000, 0, 0);
+            }
         }
     };
     int tile = xcd_compact(blockIdx.x, gridDim.x, gridDim.x);     // neighbouring tiles (shared halo rows) on one XCD
     int l0d = 0, l0h = 0, l0w = 0, n0d, n0h, n0w;
     if (tile < tiles_per_n) issue(tile, l0d, l0h, l0w);
     for (; tile < tiles_per_n; tile += gridDim.x) {
-        __syncthreads();                                   // previous tile's MFMA phase is done with imt / xh
+        // (this wave's MFMA phase of the previous tile has issued its LDS reads: the stores below queue behind them)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-            if (tid + s * 256 < 600) xh[tid + s * 256] = vx[s];
-        __syncthreads();
+        for (int s = 0; s < 5; ++s)
+            if (lane + s * 64 < 300) xh[lane + s * 64] = vx[s];
+        stem_wave_lds_sync();
         const int next = tile + gridDim.x;
         if (next < tiles_per_n) issue(next, n0d, n0h, n0w);
         uint32_t pk[16];
@@ -416,20 +451,27 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
             pk[t >> 1] = lo | (hi << 16);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(e_dst + k * 16) = u32x4{pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]};
-        __syncthreads();
+        for (int h = 0; h < 8; ++h) *reinterpret_cast<uint2*>(e_dst + ((h ^ e_m) * 8)) = uint2{pk[2 * h], pk[2 * h + 1]};
+        stem_wave_lds_sync();
         u32x4 bf[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pt = wv * 4 + j;                     // 16 points = rows 2 pt, 2 pt + 1 of the tile
-            bf[j] = *reinterpret_cast<const u32x4*>(imt + (pt * 2 + (li >> 3)) * PROW + (li & 7) * 64 + q * 16);
+        for (int j = 0; j < 4; ++j) {                      // 16 points = rows 2 j, 2 j + 1 of the wave's plane
+            const uint2 ba = *reinterpret_cast<const uint2*>(imt + j * 2 * PROW + r_bfa);
+            const uint2 bb = *reinterpret_cast<const uint2*>(imt + j * 2 * PROW + r_bfb);
+            bf[j] = u32x4{ba.x, ba.y, bb.x, bb.y};
         }
+        stem_wave_lds_sync();                              // (the next tile's stores stay behind these reads)
+        const bool full = l0d + 4 <= A.O[0] && l0h + 8 <= A.O[1] && l0w + 8 <= A.O[2];         // wave-uniform
+        const int y_org = ((l0d * A.O[1] + l0h) * A.O[2] + l0w) * A.Cy * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int p = (wv * 4 + j) * 16 + li;
-            const int ld = l0d + (p >> 6), lh = l0h + ((p >> 3) & 7), lw = l0w + (p & 7);
-            const bool valid = ld < A.O[0] && lh < A.O[1] && lw < A.O[2];
-            const int vo = valid ? (((ld * A.O[1] + lh) * A.O[2] + lw) * A.Cy + q * 4) * 2 : (int)0x80000000;
+            bool valid = true;
+            int vo = y_rel[j];
+            if (!full) {
+                const int p = (wv * 4 + j) * 16 + li;
+                valid = (l0d + (p >> 6) < A.O[0]) && (l0h + ((p >> 3) & 7) < A.O[1]) && (l0w + (p & 7) < A.O[2]);
+                vo = valid ? vo : (int)0x80000000;
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 c = f32x4{bia[i][0], bia[i][1], bia[i][2], bia[i][3]};
@@ -451,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
                 }
                 v2u_t o;
                 o[0] = H16<T>::pack2(c[0], c[1]); o[1] = H16<T>::pack2(c[2], c[3]);
-                __builtin_amdgcn_raw_buffer_store_b64(o, yrs, vo + i * 32, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(o, yrs, vo + i * 32, y_org, 0);
                 if (MODE == 0 && stats && valid) {
                     const float r0 = H16<T>::lo(o[0]), r1 = H16<T>::hi(o[0]);
                     const float r2 = H16<T>::lo(o[1]), r3 = H16<T>::hi(o[1]);
@@ -493,14 +535,6 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd3(const StemArgs A, int nt0,
 // image in LDS (one more 32 x 32 x 32 MFMA per 16 points) -- and a 1-block kernel combines them. This replaces k_norm_bwd_reduce
 // (reads y, dA), k_norm_bwd_apply (reads y, dA, writes dy) and k_stem_wgrad3 (reads dy): 6 passes over a 629 MB tensor become 1, at
 // the very end of the backward pass where nothing else is left to overlap with (round 3 timeline: 1.25 ms -> one 0.3 ms launch).
-// Hand-over point between two phases of ONE wave that exchange data through LDS (lane i writes what lane j reads): the LDS queue of a wave
-// is in order, so no s_barrier is needed -- only the compiler has to keep the accesses on their side (and the data has to have landed).
-__device__ __forceinline__ void stem_wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 struct StemBwdArgs {
     const void* x; const void* dy; const float* w; const float* coef; const float* gamma; const float* beta;
     float* accA; float* accC; float* accB; double* accS;     // [N][Cy][32], [N][Cy][32], [N][32], [N][Cy][2]   (zeroed)
@@ -929,6 +963,17 @@ extern "C" int nndet_stem_block_forward(const NndetConv* c, const void* x, const
     a.x = x; a.w = w_f32; a.bias = nullptr; a.y = nullptr;
     int S, nt[3];
     stem_block_grid(a, c->cout_p, &S, nt);
+    {   // NNDET_STEM_FWD_WGS: total workgroups of the two forward passes. Default 1024 = 4 per CU (20 KB of LDS, ~100 VGPRs): the waves are
+        // independent of each other since round 5, more of them hide more latency (statistics pass alone: 104 us with 512, 84 with 1024, 79 with 2048)
+        const char* e = getenv("NNDET_STEM_FWD_WGS");
+        const int want = (e && atoi(e) >= 8) ? atoi(e) : 1024;
+        {
+            int s_ = want / (a.N * (c->cout_p / 32));
+            s_ = s_ < 8 ? 8 : (s_ / 8) * 8;
+            const int64_t tiles = (int64_t)nt[0] * nt[1] * nt[2];
+            S = s_ > tiles ? (int)tiles : s_;
+        }
+    }
     const dim3 grid(S, c->cout_p / 32, a.N);
     if (c->dtype == NNDET_F16) k_stem_fwd3<f16_t, 1><<<grid, 256, 0, st>>>(a, nt[0], nt[1], nt[2], stats);
     else k_stem_fwd3<bf16_t, 1><<<grid, 256, 0, st>>>(a, nt[0], nt[1], nt[2], stats);
