@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         const int hd = row / HH, hh = row - hd * HH;
         const int jw = sl < NEV ? 2 * sl : 2 * (sl - NEV) + 1;
         qsel[j] = vox < QVOX ? (1u << hd) | (1u << (5 + hh)) | (1u << (14 + jw)) : 0x80000000u;
-        qrel[j] = hd * q_slab + hh * q_rowb + jw * RB + (G & 3) * 16;
+        // Bank swizzle (round 5): the 16-byte part at position G & 3 of a halo voxel holds the voxel's part (G & 3) ^ ((hh >> 1) & 3). A lane of
+        // the MFMA phase reads ONE part of its voxel; with the parts in place, the 16 lanes of a ds_read_b128 group (4 rows x 4 columns, rows
+        // 2 x 1088 B apart, columns 64 B) met on 4 of the 16 part slots: a 4-way conflict on every B-operand read -- SQ_LDS_BANK_CONFLICT was
+        // 72 % of the LDS cycles of this kernel, the LDS 49 % busy (profiles/round5_step_pmc_survey.txt). The source address of a DMA lane is free.
+        qrel[j] = hd * q_slab + hh * q_rowb + jw * RB + (((G & 3) ^ ((hh >> 1) & 3)) * 16);
     }
     __amdgpu_buffer_rsrc_t qrs;
     uint32_t qmask = 0;
@@ -115,7 +119,14 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
     };
 
     // ---- fragment base: point (plane pth, row rr, column pw) at tap (0, 0, 0) = halo row (2 pth, 2 rr), even slot pw; 8 channels kg
-    const int q_lane = ((2 * pth) * HH + 2 * rr) * QROW + pw * RB + kg * 16;
+    const int q_lane = ((2 * pth) * HH + 2 * rr) * QROW + pw * RB;
+    // part kh * 2 + kg of the voxel in halo row 2 rr + b sits at position (kh * 2 + kg) ^ ((2 rr + b) >> 1): rr for b = 0 / 1, rr + 1 for b = 2
+    int q_part[2][2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        q_part[kh][0] = q_lane + (((kh * 2 + kg) ^ (rr & 3)) * 16);
+        q_part[kh][1] = q_lane + (((kh * 2 + kg) ^ ((rr + 1) & 3)) * 16);
+    }
     f32x16_t acc[4];
     float ssum[16], ssq[16];
 #pragma unroll
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
 
     auto compute = [&](int buf, bool stage) {
         constexpr int U = 54, QD_ = 3;
-        const char* const qb = smem + buf * BUF + q_lane;
+        const char* const qb = smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         auto load_b = [&](int u) -> u32x4 {
             const int tp = u >> 1, kh = u & 1;
             const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
-            return *reinterpret_cast<const u32x4*>(qb + (a * HH + b) * QROW + (c == 1 ? NEV * RB : c == 2 ? RB : 0) + kh * 32);
+            return *reinterpret_cast<const u32x4*>(qb + q_part[kh][b == 2] + (a * HH + b) * QROW + (c == 1 ? NEV * RB : c == 2 ? RB : 0));
         };
 #pragma unroll
         for (int u0 = 0; u0 < QD_; ++u0) bf[u0] = load_b(u0);
