@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256, 1) void k_ig3s2(const Ig3sArgs A, int cout_p) 
         const int hd = row / HH, hh = row - hd * HH;
         const int jw = sl < NEV ? 2 * sl : 2 * (sl - NEV) + 1;
         qsel[j] = vox < QVOX ? (1u << hd) | (1u << (5 + hh)) | (1u << (14 + jw)) : 0x80000000u;
-        qrel[j] = hd * q_slab + hh * q_rowb + jw * (CX * 2) + (G & 3) * 16;
+        qrel[j] = hd * q_slab + hh * q_rowb + jw * (CX * 2) + (((G & 3) ^ (((hh >> 1) & 1) * 2)) * 16);    // bank swizzle, see k_ig3s (here: a 2-way conflict
+        //                                                    between the two lattice rows of a 16-point MFMA tile, 2 x 1088 B apart)
     }
     __amdgpu_buffer_rsrc_t qrs0, qrs1;                      // the two channel chunks of the decoded tile's halo
     uint32_t qmask = 0;
@@ -319,7 +320,9 @@ __global__ __launch_bounds__(256, 1) void k_ig3s2(const Ig3sArgs A, int cout_p) 
     };
 
     // point tile j = lattice rows 2 j, 2 j + 1 of the tile's 8 rows (plane j >> 1, rows 2 (j & 1) + (li >> 3)), column li & 7
-    const int q_lane = ((li >> 3) * 2) * QROW + (li & 7) * RB + q * 16;
+    const int q_lane = ((li >> 3) * 2) * QROW + (li & 7) * RB;
+    // part q of the voxel in halo row hh = 2 (li >> 3) + 4 (j & 1) + b sits at position q ^ 2 ((hh >> 1) & 1): the row parity for b = 0 / 1, flipped for b = 2
+    const int q_part[2] = {q_lane + ((q ^ (((li >> 3) & 1) * 2)) * 16), q_lane + ((q ^ ((((li >> 3) + 1) & 1) * 2)) * 16)};
     f32x4 acc[4];
     float ssum[4], ssq[4];
 #pragma unroll
@@ -328,12 +331,12 @@ __global__ __launch_bounds__(256, 1) void k_ig3s2(const Ig3sArgs A, int cout_p) 
     // MFMAs of chunk `chunk` out of buffer `buf`; `stage`: the pieces of chunk `nchunk` of the decoded tile go into the other buffer
     auto compute = [&](int buf, int chunk, bool stage, int nchunk) {
         constexpr int U = 27 * 4, QD_ = 4;
-        const char* const qb = smem + buf * BUF + q_lane;
+        const char* const qb = smem + buf * BUF;
         u32x4 bf[QD_ + 1];
         auto load_b = [&](int u) -> u32x4 {
             const int tp = u >> 2, j = u & 3;
             const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
-            return *reinterpret_cast<const u32x4*>(qb + ((2 * (j >> 1) + a) * HH + 4 * (j & 1) + b) * QROW + (c == 1 ? NEV * RB : c == 2 ? RB : 0));
+            return *reinterpret_cast<const u32x4*>(qb + q_part[b == 2] + ((2 * (j >> 1) + a) * HH + 4 * (j & 1) + b) * QROW + (c == 1 ? NEV * RB : c == 2 ? RB : 0));
         };
 #pragma unroll
         for (int u0 = 0; u0 < QD_; ++u0) bf[u0] = load_b(u0);
