@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round 5 profile set at HEAD (v2): full GPU suite, bench line (driver flags), kernel statistics + one-step timeline, whole-step PMC traffic, phase times.
+# Profile set of HEAD: full GPU suite, bench line (driver flags), kernel statistics + one-step timeline, whole-step PMC traffic, phase times.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 O=gpurun_out
 echo "== full GPU suite"
-timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -6 | cut -c1-300 | tee $O/t_full_v3.txt
+timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -6 | cut -c1-300 | tee $O/t_full.txt
 echo "== smoke"
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 echo "== bench (driver flags)"
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_v3.txt 2>&1; tail -1 $O/bench_v2.txt | cut -c1-300
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.txt 2>&1; tail -1 $O/bench_v2.txt | cut -c1-300
 echo "== phase times"
 timeout 300 python tools/phase_times.py > $O/phase_times.txt 2>&1; tail -4 $O/phase_times.txt
 echo "== prof"
