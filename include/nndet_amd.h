@@ -87,6 +87,14 @@ int nndet_giou3d_diag_fwd_f32(const float* a, const float* b, int64_t n, float e
 int nndet_giou3d_diag_bwd_f32(const float* a, const float* b, const float* grad_out, int64_t n, float eps,
                               float* grad_a, void* stream);
 
+/* Gradient of the full [n, m] GIoU matrix w.r.t. BOTH box sets: generalized_box_iou is an autograd expression in the reference
+ * (nndet/core/boxes/ops.py:106-128,162-185) and GIoULoss back-propagates through it (nndet/losses/regression.py:158-161).
+ * grad_out [n, m] fp32 row-major (the cotangent of nndet_giou3d_pairwise_f32's `out`); grad_a [n, 6] and / or grad_b [m, 6] fp32,
+ * either may be NULL (not wanted). Sub-gradient conventions of torch autograd: max / min split 0.5 / 0.5 on ties, clamp(min=0)
+ * passes the gradient where its argument is >= 0. Deterministic (fixed summation order, float64 partial sums). */
+int nndet_giou3d_pairwise_bwd_f32(const float* a, int64_t n, const float* b, int64_t m, const float* grad_out, float eps,
+                                  float* grad_a, float* grad_b, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Anchor grid -- replaces AnchorGenerator3D.grid_anchors (nndet/core/boxes/anchors.py:337-377).
  *   cell [A,6] fp32 (AnchorGenerator3DS.generate_anchors, anchors.py:526-549)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "nndet_iou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
     "nndet_giou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
     "nndet_iou3d_rowmax_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
+    "nndet_giou3d_pairwise_bwd_f32": (C.c_int, [_P, _I64, _P, _I64, _P, _F, _P, _P, _P]),
     "nndet_giou3d_diag_fwd_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P]),
     "nndet_giou3d_diag_bwd_f32": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
     "nndet_anchors3d_grid_f32": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),

@@ -31,17 +31,30 @@ def box_iou(boxes1: Tensor, boxes2: Tensor, eps: float = 0) -> Tensor:
 
 
 class _GIoUPairwise(torch.autograd.Function):
-    """generalized_box_iou stays differentiable w.r.t. boxes1 (used by losses on [P,P], P <= 42): the
-    matrix comes from the HIP kernel, the gradient is only defined through `giou_diag` (the loss only ever
-    reads the diagonal, nndet/losses/regression.py:158-161)."""
+    """generalized_box_iou is differentiable w.r.t. both box sets, like the reference's autograd expression
+    (nndet/core/boxes/ops.py:106-128,162-185; GIoULoss back-propagates through it, nndet/losses/regression.py:158-161):
+    forward = the pairwise kernel, backward = `nndet_giou3d_pairwise_bwd_f32` (row sums of the analytic gradient)."""
 
     @staticmethod
     def forward(ctx, b1, b2, eps):
-        return _pairwise("nndet_giou3d_pairwise_f32", b1, b2, eps)
+        out = _pairwise("nndet_giou3d_pairwise_f32", b1, b2, eps)
+        if out.numel():
+            ctx.save_for_backward(_f32c(b1), _f32c(b2))
+        ctx.eps = float(eps)
+        ctx.in_dtypes = (b1.dtype, b2.dtype)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        raise L.NndetError("gradient of the full GIoU matrix is not implemented; use giou_diag (what GIoULoss needs)")
+        if not ctx.saved_tensors:                      # empty input: `tensor([])`, nothing to propagate
+            return None, None, None
+        a, b = ctx.saved_tensors
+        g = g.float().contiguous()
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        L.call("nndet_giou3d_pairwise_bwd_f32", L.ptr(a), a.shape[0], L.ptr(b), b.shape[0], L.ptr(g), ctx.eps,
+               L.ptr(ga) if ga is not None else None, L.ptr(gb) if gb is not None else None, L.stream())
+        return (ga.to(ctx.in_dtypes[0]) if ga is not None else None, gb.to(ctx.in_dtypes[1]) if gb is not None else None, None)
 
 
 def generalized_box_iou(boxes1: Tensor, boxes2: Tensor, eps: float = 0) -> Tensor:

@@ -197,6 +197,57 @@ __global__ void k_giou_diag_bwd(const float* __restrict__ a, const float* __rest
     for (int k = 0; k < 6; ++k) ga[i * 6 + k] = gout[k];
 }
 
+// ------------------------------------------------------------------ gradient of the full [n, m] GIoU matrix (ops.py:106-128,162-185)
+// generalized_box_iou is differentiable w.r.t. both box sets in the reference (plain autograd through min / max / clamp); GIoULoss
+// (losses/regression.py:158-161) back-propagates through it. grad_a[i] = sum_j d giou(a_i, b_j) / d a_i * g[i, j]; the expression is
+// symmetric in its arguments (min / max / + commute bit for bit, ties split 0.5 / 0.5), so grad_b[j] = sum_i giou_grad(b_j, a_i) * g[i, j].
+// One workgroup per output row; the 256 threads stride over the other box set, partial sums in float64, combined in a fixed order
+// (deterministic; one rounding per output).
+template <bool TR>
+__global__ __launch_bounds__(256) void k_giou_pairwise_bwd(const float* __restrict__ a, int64_t n, const float* __restrict__ b, int64_t m,
+                                                           const float* __restrict__ go, float eps, float* __restrict__ gout) {
+    // TR = false: row = a_i, partners b_j, cotangent go[i * m + j];  TR = true: row = b_j, partners a_i, cotangent go[i * m + j]
+    __shared__ double red[256 * 6];
+    const int64_t row = blockIdx.x;
+    const float* self = (TR ? b : a) + row * 6;
+    const float* other = TR ? a : b;
+    const int64_t cnt = TR ? n : m;
+    float S[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S[k] = self[k];
+    double acc[6] = {0., 0., 0., 0., 0., 0.};
+    for (int64_t j = threadIdx.x; j < cnt; j += 256) {
+        float O[6], G[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) O[k] = other[j * 6 + k];
+        const float g = TR ? go[j * m + row] : go[row * m + j];
+        giou_grad(S, O, g, eps, G);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += (double)G[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[k * 256 + threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[k * 256 + threadIdx.x] += red[k * 256 + threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) gout[row * 6 + threadIdx.x] = (float)red[threadIdx.x * 256];
+}
+
+extern "C" int nndet_giou3d_pairwise_bwd_f32(const float* a, int64_t n, const float* b, int64_t m, const float* grad_out, float eps,
+                                             float* grad_a, float* grad_b, void* stream) {
+    if (n < 0 || m < 0) return NNDET_EINVAL;
+    if (n == 0 || m == 0) return 0;
+    if (!a || !b || !grad_out || (!grad_a && !grad_b)) return NNDET_EINVAL;
+    if (n > 0x7fffffff || m > 0x7fffffff) return NNDET_EINVAL;
+    if (grad_a) { k_giou_pairwise_bwd<false><<<(unsigned)n, 256, 0, as_stream(stream)>>>(a, n, b, m, grad_out, eps, grad_a); LAUNCH_CHECK(); }
+    if (grad_b) { k_giou_pairwise_bwd<true><<<(unsigned)m, 256, 0, as_stream(stream)>>>(a, n, b, m, grad_out, eps, grad_b); LAUNCH_CHECK(); }
+    return 0;
+}
+
 extern "C" int nndet_giou3d_diag_fwd_f32(const float* a, const float* b, int64_t n, float eps, float* out, void* stream) {
     if (n < 0) return NNDET_EINVAL;
     if (n == 0) return 0;

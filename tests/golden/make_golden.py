@@ -542,15 +542,66 @@ def golden_wbc():
     np.savez_compressed(os.path.join(OUT, "wbc_golden.npz"), **g)
 
 
+def golden_giou_grad():
+    """Gradient of the reference's `generalized_box_iou` (an autograd expression, ops.py:106-128,162-185) w.r.t. BOTH box sets on the
+    [37 x 501] fixture with a random cotangent, and of `GIoULoss` (losses/regression.py:118-162) for N = M in {1, 42, 300}; the torch
+    restatement `oracle/boxes_torch.py` is checked against it here (fp32: same torch ops, so to round-off of the summation order)."""
+    from nndet.core.boxes.ops import generalized_box_iou as ref_giou
+    from nndet.losses.regression import GIoULoss
+    from oracle import boxes_torch as bt
+    rng = np.random.default_rng(7)
+    g = {}
+    b1, b2 = rand_boxes(rng, 37), rand_boxes(rng, 501)
+    b2[5] = b1[3]                                   # an identical pair: every min / max of it is a tie (0.5 / 0.5 sub-gradients)
+    b2[6, :] = b1[4, :]; b2[6, 2] += 1.0            # ties on five of six coordinates
+    cot = rng.standard_normal((37, 501)).astype(np.float32)
+    for eps, tag in ((0.0, ""), (1e-7, "_eps")):
+        t1, t2 = torch.from_numpy(b1).requires_grad_(), torch.from_numpy(b2).requires_grad_()
+        m = ref_giou(t1, t2, eps=eps)
+        m.backward(torch.from_numpy(cot))
+        o1, o2 = torch.from_numpy(b1).requires_grad_(), torch.from_numpy(b2).requires_grad_()
+        mo = bt.generalized_box_iou(o1, o2, eps=eps)
+        mo.backward(torch.from_numpy(cot))
+        eq(mo.detach().numpy(), m.detach().numpy(), f"giou matrix (torch oracle){tag}")
+        for a, b, what in ((o1.grad, t1.grad, "d boxes1"), (o2.grad, t2.grad, "d boxes2")):
+            err = (a - b).abs().max().item() / b.abs().max().item()
+            assert err < 1e-6, (what, err)
+            print(f"  [{err:.1e}] giou pairwise gradient {what}{tag} (torch oracle vs reference autograd)")
+        g[f"pw_ga{tag}"], g[f"pw_gb{tag}"] = t1.grad.numpy(), t2.grad.numpy()
+    g["pw_b1"], g["pw_b2"], g["pw_cot"] = b1, b2, cot
+    for n in (1, 42, 300):
+        tgt = rand_boxes(rng, n)
+        pred = (tgt + rng.uniform(-3, 3, tgt.shape)).astype(np.float32)
+        pred[:, [2, 3, 5]] = np.maximum(pred[:, [2, 3, 5]], pred[:, [0, 1, 4]] + 0.5)
+        if n > 2:
+            pred[1] = tgt[1]                        # a perfect prediction
+        for red in ("sum", "mean"):
+            tp = torch.from_numpy(pred).requires_grad_()
+            loss = GIoULoss(reduction=red, eps=1e-7, loss_weight=2.0)(tp, torch.from_numpy(tgt))
+            loss.backward()
+            op = torch.from_numpy(pred).requires_grad_()
+            lo = bt.giou_loss(op, torch.from_numpy(tgt), eps=1e-7, reduction=red, loss_weight=2.0)
+            lo.backward()
+            assert abs(lo.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item())), (n, red, lo.item(), loss.item())
+            err = (op.grad - tp.grad).abs().max().item() / max(tp.grad.abs().max().item(), 1e-30)
+            assert err < 1e-6, (n, red, err)
+            print(f"  [{err:.1e}] GIoULoss n = {n} reduction = {red}: loss {loss.item():.6f} (torch oracle vs reference)")
+            g[f"loss{n}_{red}"], g[f"loss{n}_{red}_grad"] = np.float32(loss.item()), tp.grad.numpy()
+        g[f"loss{n}_pred"], g[f"loss{n}_tgt"] = pred, tgt
+    np.savez_compressed(os.path.join(OUT, "giou_grad_golden.npz"), **g)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["boxes", "targets", "wbc", "postproc", "tiny", "toy64", "luna160", "luna160_fp64"]
+    which = sys.argv[1:] or ["boxes", "giou_grad", "targets", "wbc", "postproc", "tiny", "toy64", "luna160", "luna160_fp64"]
     if "wbc" in which:
         print("weighted box clustering:"); golden_wbc()
     if "targets" in which:
         print("target preparation:"); golden_targets()
     if "boxes" in which:
         print("box ops:"); golden_boxes()
+    if "giou_grad" in which:
+        print("GIoU gradients:"); golden_giou_grad()
     print("network:")
     if "tiny" in which:
         golden_net("tiny")

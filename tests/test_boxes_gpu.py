@@ -44,6 +44,83 @@ def test_iou_shapes_vs_oracle(n, m):
     biteq(generalized_box_iou(t(a), t(b), eps=1e-7), bx.generalized_box_iou(a, b, 1e-7), "giou")
 
 
+# ---- gradient of the full GIoU matrix (generalized_box_iou "must stay differentiable"; ops.py:106-128,162-185)
+@pytest.fixture(scope="module")
+def gg(golden_dir):
+    return np.load(os.path.join(golden_dir, "giou_grad_golden.npz"))
+
+
+def _close64(got, want64, what, rel=2e-6):
+    """fp32 result of the HIP kernel (float64 partial sums, one rounding) against the float64 evaluation of the oracle expression"""
+    got = got.detach().double().cpu().numpy()
+    want = want64.detach().cpu().numpy()
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want).max() / scale
+    assert err <= rel, (what, err)
+
+
+@pytest.mark.parametrize("eps,tag", [(0.0, ""), (1e-7, "_eps")])
+def test_giou_pairwise_backward_fixture_random_cotangent(gg, eps, tag):
+    """[37 x 501] with a random cotangent, ties included (an identical pair, a pair tied on five coordinates): against the reference's
+    own autograd (fp32, fixture) and against autograd of the oracle expression in float64."""
+    from nndetection_amd.core.boxes import generalized_box_iou
+    from oracle import boxes_torch as bt
+    b1, b2 = t(gg["pw_b1"]).requires_grad_(), t(gg["pw_b2"]).requires_grad_()
+    m = generalized_box_iou(b1, b2, eps=eps)
+    biteq(m.detach(), bx.generalized_box_iou(gg["pw_b1"], gg["pw_b2"], eps), "giou forward under autograd")
+    m.backward(t(gg["pw_cot"]))
+    o1 = torch.from_numpy(gg["pw_b1"]).double().requires_grad_()
+    o2 = torch.from_numpy(gg["pw_b2"]).double().requires_grad_()
+    bt.generalized_box_iou(o1, o2, eps=eps).backward(torch.from_numpy(gg["pw_cot"]).double())
+    _close64(b1.grad, o1.grad, "d boxes1 vs float64")
+    _close64(b2.grad, o2.grad, "d boxes2 vs float64")
+    for got, ref in ((b1.grad, gg[f"pw_ga{tag}"]), (b2.grad, gg[f"pw_gb{tag}"])):      # the reference's fp32 autograd: its own summation noise
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    # only one side requires a gradient
+    b1n = t(gg["pw_b1"]).requires_grad_()
+    generalized_box_iou(b1n, t(gg["pw_b2"]), eps=eps).backward(t(gg["pw_cot"]))
+    assert torch.equal(b1n.grad, b1.grad)
+    b2n = t(gg["pw_b2"]).requires_grad_()
+    generalized_box_iou(t(gg["pw_b1"]), b2n, eps=eps).backward(t(gg["pw_cot"]))
+    assert torch.equal(b2n.grad, b2.grad)
+
+
+@pytest.mark.parametrize("n", [1, 42, 300])
+@pytest.mark.parametrize("red", ["sum", "mean"])
+def test_reference_giou_loss_formula_trains_through_the_pairwise_op(gg, n, red):
+    """The reference's GIoULoss (losses/regression.py:158-161): generalized_box_iou -> torch.diag -> reduction -> weight * -1, on OUR op;
+    loss and d loss / d pred against the reference fixture and the float64 oracle; equals the O(P) `giou_diag` route bit for bit."""
+    from nndetection_amd.core.boxes import generalized_box_iou, giou_diag
+    from oracle import boxes_torch as bt
+    pred, tgt = t(gg[f"loss{n}_pred"]).requires_grad_(), t(gg[f"loss{n}_tgt"])
+    d = torch.diag(generalized_box_iou(pred, tgt, eps=1e-7), diagonal=0)
+    loss = 2.0 * -1 * (d.sum() if red == "sum" else d.mean())
+    loss.backward()
+    ref = float(gg[f"loss{n}_{red}"])
+    assert abs(loss.item() - ref) <= 2e-6 * max(1.0, abs(ref))
+    o = torch.from_numpy(gg[f"loss{n}_pred"]).double().requires_grad_()
+    bt.giou_loss(o, torch.from_numpy(gg[f"loss{n}_tgt"]).double(), eps=1e-7, reduction=red, loss_weight=2.0).backward()
+    _close64(pred.grad, o.grad, "d loss / d pred vs float64")
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), gg[f"loss{n}_{red}_grad"], rtol=0, atol=2e-5 * np.abs(gg[f"loss{n}_{red}_grad"]).max())
+    p2 = t(gg[f"loss{n}_pred"]).requires_grad_()
+    d2 = giou_diag(p2, tgt, eps=1e-7)
+    (2.0 * -1 * (d2.sum() if red == "sum" else d2.mean())).backward()
+    assert torch.equal(d2.detach(), d.detach())
+    np.testing.assert_allclose(p2.grad.cpu().numpy(), pred.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_giou_pairwise_backward_empty_and_c_abi_argument_checks():
+    from nndetection_amd.core.boxes import generalized_box_iou
+    from nndetection_amd import _lib as L
+    e = generalized_box_iou(torch.zeros(0, 6, device="cuda", requires_grad=True), torch.rand(4, 6, device="cuda"))
+    assert e.numel() == 0
+    a = torch.rand(3, 6, device="cuda"); g = torch.rand(3, 3, device="cuda")
+    lib = L.load()
+    assert lib.nndet_giou3d_pairwise_bwd_f32(L.ptr(a), 3, L.ptr(a), 3, L.ptr(g), 0.0, None, None, L.stream()) == -1   # no output wanted
+    assert lib.nndet_giou3d_pairwise_bwd_f32(L.ptr(a), -1, L.ptr(a), 3, L.ptr(g), 0.0, L.ptr(a), None, L.stream()) == -1
+    assert lib.nndet_giou3d_pairwise_bwd_f32(L.ptr(a), 0, L.ptr(a), 3, L.ptr(g), 0.0, L.ptr(a), None, L.stream()) == 0
+
+
 def test_iou_empty():
     from nndetection_amd.core.boxes import box_iou
     e = box_iou(torch.zeros(0, 6, device="cuda"), torch.rand(4, 6, device="cuda"))

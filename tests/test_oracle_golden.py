@@ -207,3 +207,25 @@ def test_atss_blocked_equals_dense():
             got = bx.atss_match_blocked(gt, anchors, npl, 27, 4, rows=rows, threads=threads)
             assert np.array_equal(ref, got), (G, rows)
     assert (bx.atss_match_blocked(np.zeros((0, 6), np.float32), anchors, npl, 27, 4) == -1).all()
+
+
+# ---- differentiable GIoU (round 6): the torch restatement oracle/boxes_torch.py against the reference's autograd
+def test_giou_gradients_torch_oracle_vs_reference_fixture(golden_dir):
+    from oracle import boxes_torch as bt
+    g = np.load(os.path.join(golden_dir, "giou_grad_golden.npz"))
+    cot = torch.from_numpy(g["pw_cot"])
+    for eps, tag in ((0.0, ""), (1e-7, "_eps")):
+        b1, b2 = torch.from_numpy(g["pw_b1"]).requires_grad_(), torch.from_numpy(g["pw_b2"]).requires_grad_()
+        bt.generalized_box_iou(b1, b2, eps=eps).backward(cot)
+        np.testing.assert_allclose(b1.grad.numpy(), g[f"pw_ga{tag}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(b2.grad.numpy(), g[f"pw_gb{tag}"], rtol=1e-5, atol=1e-6)
+    for n in (1, 42, 300):
+        for red in ("sum", "mean"):
+            p = torch.from_numpy(g[f"loss{n}_pred"]).requires_grad_()
+            loss = bt.giou_loss(p, torch.from_numpy(g[f"loss{n}_tgt"]), eps=1e-7, reduction=red, loss_weight=2.0)
+            loss.backward()
+            assert abs(loss.item() - float(g[f"loss{n}_{red}"])) <= 1e-6 * max(1.0, abs(float(g[f"loss{n}_{red}"])))
+            np.testing.assert_allclose(p.grad.numpy(), g[f"loss{n}_{red}_grad"], rtol=1e-5, atol=1e-7)
+        # the matrix values of the torch oracle are the numpy oracle's, bit for bit
+        m = bt.generalized_box_iou(torch.from_numpy(g[f"loss{n}_pred"]), torch.from_numpy(g[f"loss{n}_tgt"]), eps=1e-7).numpy()
+        biteq(m, bx.generalized_box_iou(g[f"loss{n}_pred"], g[f"loss{n}_tgt"], 1e-7))
