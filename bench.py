@@ -132,22 +132,104 @@ class Route:
         return loss
 
     def timed(self, warmup, steps, world=1):
+        sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)      # (--cpu-dry-run: nothing to wait for)
         for _ in range(warmup):
             last = self.step()
-        torch.cuda.synchronize()
+        sync()
         if self.ddp is not None and self.ddp.profile:
             self.ddp.profile_reset()                    # the exposed-communication figures cover the timed steps only
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             last = self.step()
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         return time.perf_counter() - t0, last
+
+
+class _DryLinearFn(torch.autograd.Function):
+    """Dry run only: a linear layer whose backward takes its parameter-gradient memory from `_lib.grad_pool.take_for` exactly as the
+    convolution nodes do (arch/conv.py), so that the in-place reducer path is the one the launcher rehearsal exercises."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w, b)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        from nndetection_amd import _lib as L
+        x, w, b = ctx.saved_tensors
+        gw, gb = L.grad_pool.take_for([(w, w.numel()), (b, b.numel())], g.device)
+        dw = gw.view(w.shape)
+        dw += g.t() @ x
+        gb += g.sum(0)
+        return g @ w, dw, gb
+
+
+class _DryNet(torch.nn.Module):
+    """Stand-in with the three kinds of parameters the reducer has to cope with: a trunk every rank uses, a "regressor"
+    that a rank without positive anchors does not use, a `decoder.out.P1`-like layer nobody uses. NOT the product and NOT a
+    measurement: `--cpu-dry-run` rehearses the launcher / rendezvous / seeding / reducer / optimizer wiring on CPU tensors over gloo."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = torch.nn.ModuleList([torch.nn.Linear(64, 256), torch.nn.Linear(256, 256), torch.nn.Linear(256, 64)])
+        self.regressor = torch.nn.Linear(64, 64)
+        self.out_p1 = torch.nn.Linear(64, 64)
+
+    def never_used_parameters(self):
+        return list(self.out_p1.parameters())
+
+    def forward(self, x, positives: bool):
+        from nndetection_amd import _lib as L
+        L.grad_pool.begin(sum(p.numel() + 64 for p in self.parameters()), x.device, owner=self)
+        h = x
+        for m in self.trunk:
+            h = torch.relu(_DryLinearFn.apply(h, m.weight, m.bias))
+        if positives:
+            return (h * h).mean() + _DryLinearFn.apply(h, self.regressor.weight, self.regressor.bias).pow(2).mean()
+        L.notify_no_grad(list(self.regressor.parameters()))          # what arch/heads.py does on a batch without positive anchors
+        return (h * h).mean()
+
+
+class DryRoute:
+    """`Route` for `--cpu-dry-run`: same construction order (seed 0 model -> optimizer -> reducer -> per-rank seed), same step
+    (forward, begin_step, backward, finish, optimizer step, scheduler step, zero_grad), same `timed` bracket -- on the stand-in."""
+
+    def __init__(self, rank, world, ddp_factory):
+        from nndetection_amd.ptmodule import configure_optimizer
+        torch.manual_seed(rank)                           # DIFFERENT initial parameters per rank: the reducer must broadcast rank 0's
+        self.net = _DryNet()
+        self.opt, self.sched = configure_optimizer(self.net)
+        g = torch.Generator().manual_seed(1000 + rank)
+        self.data = [torch.randn(16, 64, generator=g) for _ in range(NBATCH)]
+        self.positive_free = world > 1 and rank == world - 1
+        self.ddp = ddp_factory(self.net) if ddp_factory is not None else None
+        self.scaler, self.it = None, 0
+        torch.manual_seed(1234 + rank)
+
+    def step(self):
+        self.it += 1
+        loss = self.net(self.data[self.it % NBATCH], positives=not self.positive_free)
+        if self.ddp is not None:
+            self.ddp.begin_step()
+        loss.backward()
+        if self.ddp is not None:
+            self.ddp.finish()
+        self.opt.step()
+        self.sched.step()
+        self.opt.zero_grad(set_to_none=True)
+        return loss
+
+    timed = None                                          # bound below: Route.timed works on both (its synchronisations are no-ops on the CPU)
+
+
+DryRoute.timed = Route.timed
 
 
 def side_route(plan, batch, dtype_name, device, via_plugin, warmup=8, steps=24):
@@ -613,6 +695,50 @@ def inference_rate(net, x, iters=5):
             "detections": [int(b.shape[0]) for b in out["pred_boxes"]]}
 
 
+def dry_run(args, world, rank, force_dist):
+    """`--cpu-dry-run` (multi-GPU without hardware). Everything `main()` does around the step for N ranks -- environment
+    (RANK / WORLD_SIZE / MASTER_*), process group, reducer with the NNDET_DDP_* knobs and its cross-rank layout check, the step loop,
+    barrier + max-over-ranks timing, one JSON line from rank 0 -- with the gloo backend and a CPU stand-in network. Adds what a
+    rehearsal can prove: every rank ends with bit-identical parameters although they started different and one rank had no positives."""
+    import hashlib
+    from nndetection_amd.ddp import GradAllReducer
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ddp_factory = None
+    if world > 1 or force_dist:
+        ddp_factory = lambda net: GradAllReducer(net, force_overlap=force_dist, overlap=os.environ.get("NNDET_DDP_OVERLAP", "1") != "0", profile=False)
+    route = DryRoute(rank, world, ddp_factory)
+    dt, last = route.timed(args.warmup, args.steps, world)
+    digest = hashlib.sha256(b"".join(p.detach().numpy().tobytes() for p in route.net.parameters())).digest()
+    mine = torch.tensor(list(digest), dtype=torch.uint8)
+    digests, tt, hooks = [mine], torch.tensor([dt], dtype=torch.float64), None
+    if world > 1:
+        digests = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(digests, mine)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        flag = torch.tensor([int(all(route.ddp.launched_from_hooks))], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        hooks = bool(flag.item())
+    if rank == 0:
+        red = route.ddp
+        print(json.dumps({
+            "metric": "patches/sec (fwd+bwd) RetinaUNet", "value": None, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(float(tt.item()) / max(1, args.steps) * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "none", "dry_run": True,
+            "config": {"workload": "CPU DRY RUN of the N-rank launch on a stand-in network over gloo: NOT a measurement of the hot path", "parallelism": "dp%d" % world},
+            "params_identical_on_all_ranks": len({bytes(d.tolist()) for d in digests}) == 1, "positive_free_rank": world - 1 if world > 1 else None,
+            "all_buckets_launched_from_hooks_on_all_ranks": hooks, "final_loss": round(float(last.detach()), 6),
+            "ddp": None if red is None else {"buckets": len(red.buckets), "bucket_numel": [b.numel for b in red.buckets], "layout_digest": red.layout_digest[:16],
+                                             "first_bucket_mb": red.first_bucket_mb, "bucket_mb": red.bucket_mb, "in_place": bool(red.inplace),
+                                             "copied_last": red.copied_last, "exposed_allreduce_ms": None, "backward_to_ready_ms": None}}), flush=True)
+    if world > 1 or force_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -628,6 +754,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / NMS / CPU legs (only the timed steps)")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm leg (torch_rocm_baseline)")
     ap.add_argument("--torch-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="NOT a measurement: rehearse the N-rank launch (rendezvous, per-rank seeds, reducer layout check, in-place bucket path, "
+                         "a positive-free rank, optimizer) on CPU tensors over gloo with a stand-in network; prints a JSON line with value null")
     args = ap.parse_args()
     if args.torch_baseline_child:
         from nndetection_amd.plans import get_plan as _gp
@@ -639,6 +768,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("NNDET_BENCH_FORCE_DIST") == "1"     # exercise the RCCL / bucket path at world size 1 (testing)
+    if args.cpu_dry_run:
+        return dry_run(args, world, rank, force_dist)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -310,9 +310,28 @@ class _GradPool:
         if flat is None or flat is self.static_flat:
             self.static, self.static_flat, self.owner, self.taken, self.armed = None, None, None, set(), False
 
+    def _static_in_use(self) -> bool:
+        """Does a parameter's `.grad` still live in the static memory? After a backward pass (and after the reducer's finish()) the
+        gradients ARE that memory: a zero fill would wipe them -- gradient accumulation over micro-batches without zero_grad, a
+        grad-enabled forward pass between finish() and optimizer.step()."""
+        flat = self.static_flat
+        lo = flat.data_ptr()
+        hi = lo + flat.numel() * flat.element_size()
+        for p in self.static:
+            g = p.grad
+            if g is not None and lo <= g.data_ptr() < hi:
+                return True
+        return False
+
     def begin(self, numel: int, device, owner=None):
         self.armed = False
-        if self.static is not None and self.static_flat.device == device and (self.owner is None or self.owner() is owner):
+        # the static layout is armed (and its memory zero-filled) only by a TOP-LEVEL forward pass of the owner whose parameters hold
+        # no gradient in that memory: a forward pass inside a backward pass (checkpoint recompute) or on top of accumulated / reduced
+        # gradients keeps the per-step pool, and autograd adds its gradients to the existing ones
+        if self.static is not None and self.static_flat.device == device and (self.owner is None or self.owner() is owner) \
+                and graph_task_id() == -1 and not self._static_in_use():
+            for fn in list(step_begin_listeners):
+                fn()
             self.static_flat.zero_()                 # (the previous step's all-reduce was waited for by finish() on this stream)
             self.taken, self.armed = set(), True
             self.buf, self.off = None, 0             # the few nodes that cannot use their region take fresh zeroed memory
@@ -358,6 +377,9 @@ grad_pool = _GradPool()
 # backward pass (arch/heads.py: the regressor on the compact loss route when the batch has no positive anchor). The gradient reducer
 # (nndetection_amd.ddp) registers one: it may then launch their bucket from the hooks of the other parameters instead of from finish().
 no_grad_listeners = []
+# Callbacks `fn()` run when a top-level training forward pass arms the static gradient layout, i.e. when a new step begins: the reducer
+# drops the per-step declarations of a forward pass that was never followed by backward + finish() (skipped step, exception, NaN guard).
+step_begin_listeners = []
 
 
 def notify_no_grad(params) -> None:

@@ -143,6 +143,9 @@ class GradAllReducer:
                                        owner=model)
             self._no_grad_cb = self.mark_no_grad
             L.no_grad_listeners.append(self._no_grad_cb)
+            self._begin_cb = self.reset_step_marks
+            L.step_begin_listeners.append(self._begin_cb)
+        self.check_layout_across_ranks()
         self.broadcast_parameters(model)
 
     def close(self):
@@ -155,6 +158,53 @@ class GradAllReducer:
         cb = getattr(self, "_no_grad_cb", None)
         if cb is not None and cb in L.no_grad_listeners:
             L.no_grad_listeners.remove(cb)
+        cb = getattr(self, "_begin_cb", None)
+        if cb is not None and cb in L.step_begin_listeners:
+            L.step_begin_listeners.remove(cb)
+
+    def layout_signature(self) -> str:
+        """What every rank must agree on before the first collective: bucket boundaries (sizes in elements), the parameters of each
+        bucket by NAME, shape and order, the never-used set, the bucket dtype and whether the collective averages."""
+        import hashlib
+        h = hashlib.sha256()
+        h.update(("dtype=%s avg=%d world=%d\n" % (self.bucket_dtype, int(self._avg_in_collective), self.world)).encode())
+        for bi, b in enumerate(self.buckets):
+            h.update(("bucket %d numel=%d expected=%d\n" % (bi, b.numel, b.expected)).encode())
+            for p in b.params:
+                h.update(("  %s %s unused=%d\n" % (self._names.get(id(p), "?"), tuple(p.shape), int(id(p) in self._static_unused))).encode())
+        return h.hexdigest()
+
+    def check_layout_across_ranks(self) -> None:
+        """All ranks must have built the SAME bucket layout and never-used set: a mismatch (a different NNDET_DDP_* environment on one
+        rank, a model built from another plan, a parameter frozen on one rank only) makes the ranks issue collectives of different
+        sizes -- on RCCL that is a hang of the whole 8-GPU job, not an error. One all-gather of a 32-byte digest at construction."""
+        self.layout_digest = self.layout_signature()
+        if self.world <= 1 or not dist.is_initialized():
+            return
+        mine = torch.tensor(list(bytes.fromhex(self.layout_digest)), dtype=torch.uint8)
+        backend = dist.get_backend(self.pg)
+        if backend == "nccl":
+            mine = mine.to(self.buckets[0].flat.device)
+        got = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(got, mine, group=self.pg)
+        digests = [bytes(t.cpu().tolist()).hex() for t in got]
+        bad = [r for r, d in enumerate(digests) if d != digests[0]]
+        if bad:
+            rank = dist.get_rank(self.pg)
+            raise RuntimeError(
+                "GradAllReducer: the gradient bucket layout differs between ranks (rank 0: %s..., ranks %s differ; this is rank %d with "
+                "%d buckets of %s elements, %d never-used parameters, first/bucket MB %s/%s). Every rank must build the same model "
+                "and use the same NNDET_DDP_FIRST_MB / NNDET_DDP_BUCKET_MB / NNDET_DDP_BF16 / NNDET_DDP_AVG settings."
+                % (digests[0][:12], bad, rank, len(self.buckets), [b.numel for b in self.buckets], len(self._static_unused),
+                   self.first_bucket_mb, self.bucket_mb))
+
+    def reset_step_marks(self) -> None:
+        """A new top-level training forward pass begins (called by _lib.grad_pool.begin): declarations of a forward pass that was never
+        followed by backward + finish() (skipped step, exception, NaN guard) must not leak into this step."""
+        if self._marked and self._next == 0:
+            for b in self.buckets:
+                b.pending = b.expected
+            self._marked.clear()
 
     def mark_no_grad(self, params):
         """These parameters will get NO gradient in the coming backward pass (told during the forward pass: the regressor on a rank

@@ -555,6 +555,101 @@ def test_static_pool_hands_a_region_out_once_and_only_without_grad():
         ddp.close()
 
 
+def test_static_pool_never_wipes_gradients_that_live_in_it():
+    """after a backward pass -- and after finish() -- the parameters' gradients ARE the reducer's flat memory. A
+    grad-enabled forward pass must not zero-fill it while they live there: (a) a forward / backward micro-batch loop without zero_grad
+    (gradient accumulation), (b) a forward pass between finish() and optimizer.step(), (c) a forward pass INSIDE a backward pass
+    (checkpoint recompute). In all three the layout stays un-armed, the per-step pool serves the nodes and autograd adds in place."""
+    from nndetection_amd.ddp import GradAllReducer
+    from nndetection_amd import _lib as L
+    torch.manual_seed(0)
+    model = _PoolNet()
+    ref = _PoolNet(); ref.load_state_dict(model.state_dict())
+    ddp = GradAllReducer(model, first_bucket_mb=1e-4, bucket_mb=2e-4, force_overlap=True)
+
+    def ref_step(xx):
+        h = xx
+        for m in (ref.a, ref.b, ref.c):
+            h = torch.relu(m(h))
+        (h.sum() + ref.reg(h).sum()).backward()
+
+    try:
+        x1, x2, x3 = torch.randn(5, 8), torch.randn(5, 8), torch.randn(5, 8)
+        # (a) two micro-batches, finish() after each backward, NO zero_grad in between
+        model(x1).backward(); ddp.finish()
+        assert not L.grad_pool.armed
+        g1 = [p.grad.clone() for p in model.parameters()]
+        model(x2).backward(); ddp.finish()
+        ref_step(x1); ref_step(x2)
+        for p, g in zip(model.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, g.grad, atol=1e-4), "accumulated gradient differs from stock autograd"
+        # (b) a grad-enabled forward pass between finish() and optimizer.step(): the reduced gradients survive
+        before = [p.grad.clone() for p in model.parameters()]
+        loss_unused = model(x3)                                  # begin() runs here
+        assert not L.grad_pool.armed, "the static layout was armed on top of live gradients"
+        for p, b in zip(model.parameters(), before):
+            assert torch.equal(p.grad, b), "a forward pass wiped the gradients the optimizer is about to read"
+        del loss_unused
+        model.zero_grad(set_to_none=True); ref.zero_grad(set_to_none=True)
+        assert g1[0].abs().sum() > 0
+        # (c) a forward pass of the owner INSIDE a backward pass leaves the armed layout (and what was written into it) alone
+        inner = {}
+
+        class Recompute(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t * 1.0
+
+            @staticmethod
+            def backward(ctx, g):
+                with torch.enable_grad():
+                    inner["armed_before"], inner["taken_before"] = L.grad_pool.armed, set(L.grad_pool.taken)
+                    model(x2)                                   # checkpoint-style recompute: calls grad_pool.begin inside the pass
+                    inner["armed_after"], inner["taken_after"] = L.grad_pool.armed, set(L.grad_pool.taken)
+                return g
+
+        h = x1
+        L.grad_pool.begin(0, x1.device, owner=model)
+        assert L.grad_pool.armed
+        for m in (model.a, model.b, model.c):
+            h = torch.relu(_PoolLinearFn.apply(h, m.weight, m.bias))
+        (Recompute.apply(h).sum() + _PoolLinearFn.apply(h, model.reg.weight, model.reg.bias).sum()).backward()
+        ddp.finish()
+        assert inner["armed_before"] and inner["taken_before"], "the reg node ran before the recompute node and took its regions"
+        assert not inner["armed_after"], "a forward pass inside a backward pass must not re-arm (and zero) the static layout"
+        ref_step(x1)
+        for p, g in zip(model.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, g.grad, atol=1e-4)
+    finally:
+        ddp.close()
+
+
+def test_no_grad_declaration_of_an_abandoned_step_does_not_leak_into_the_next():
+    """a no-positives forward pass declares the regressor gradient-free; if that step is abandoned (skipped, exception, NaN
+    guard: no backward, no finish) the next step WITH positives must neither raise from the gradient hook nor launch a bucket early."""
+    from nndetection_amd.ddp import GradAllReducer
+    torch.manual_seed(0)
+    model = _PoolNet()
+    ddp = GradAllReducer(model, first_bucket_mb=1e-4, bucket_mb=2e-4, force_overlap=True)
+    try:
+        x = torch.randn(5, 8)
+        model(x, use_reg=False)                                  # declares `reg` gradient-free ... and is abandoned
+        assert ddp._marked
+        model(x, use_reg=True).backward()                        # a new top-level forward pass: the declarations are dropped
+        ddp.finish()
+        assert ddp.launched_from_hooks == [True] * len(ddp.buckets)
+        assert all(b.pending == b.expected for b in ddp.buckets) and not ddp._marked
+        ref = _PoolNet(); ref.load_state_dict(model.state_dict())
+        h = x
+        for m in (ref.a, ref.b, ref.c):
+            h = torch.relu(m(h))
+        (h.sum() + ref.reg(h).sum()).backward()
+        for p, g in zip(model.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, g.grad, atol=1e-5)
+    finally:
+        ddp.close()
+
+
 def test_private_autograd_hooks_are_probed_once_and_degrade_gracefully():
     """The multi-stream backward pass hangs off two private torch hooks ("one torch upgrade from breaking"): both are probed at
     import; this torch has them, the graph-task id tells a backward pass from the outside, and without them the weight-gradient stream
