@@ -8,8 +8,12 @@ A "step" = one full training step of RetinaUNetV001 on one batch of synthetic 16
 assignment, hard-negative sampling, losses, backward, gradient all-reduce (N > 1), SGD(nesterov) step, LR step.
 Inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0:
   metric/value = patches/s (whole job),
-  roofline = the kernel with the most FLOPs per launch (k_ig3r) vs the MFMA roofline, HIP-event timed here, HBM traffic from PMC
-             passes run by this process when rocprofv3 is installed (else the committed profiles/*.json, marked as such),
+  roofline = the kernel family with the most TIME per step and the one that ends the step: the 3x3x3 weight gradient k_wgrad3d, its largest
+             launch (32 -> 32 at full resolution) vs the MFMA roofline, HIP-event timed INSIDE the training step on the weight-gradient
+             stream (and alone), HBM traffic from PMC passes run by this process when rocprofv3 is installed,
+  roofline_ig3r / chip_probe = the kernel with the most FLOPs per launch (k_ig3r forward, the `roofline` of rounds 1-5), alone: a chip probe,
+  timed_blocks = three back-to-back timed blocks (value = the first), box_microbench = BASELINE.json configs[4] at its sizes,
+  config3_lidc192 = configs[3] (192x192x128, fp16, batch 4): ms per step + peak HBM,
   roofline_dominant = the kernel with the most TIME per step (the ragged head trunk launch), step_roofline = algorithmic FLOPs and
              bytes of the whole step / ms_per_step,
   routes = the same step through the registered plugin's `training_step` (batch dicts, device-side targets), in fp32 and in fp16
@@ -390,7 +394,7 @@ def head_trunk_roofline(plan, batch, dtype, device, iters=30):
             "note": "in isolation; inside the step the classifier / regressor trunks and the weight-gradient stream share the CUs"}
 
 
-def measure_traffic_pmc(timeout_s=150):
+def measure_traffic_pmc(timeout_s=150, kernel="k_ig3r", order="fwd"):
     """HBM bytes per launch of the roofline kernel from the PMC counters, measured NOW: two rocprofv3 passes (FETCH_SIZE and
     WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md "Counter slots") over tools/conv_microbench.py e0_32x32_full (the same
     launch as `conv_roofline`), FETCH_SIZE doubled as the guide prescribes for gfx950 (wide coalesced reads are tallied at half
@@ -405,7 +409,7 @@ def measure_traffic_pmc(timeout_s=150):
         return None
     vals = {}
     tmp = tempfile.mkdtemp(prefix="nndet_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", MICRO_ORDER="fwd", MICRO_ITERS="6")
+    env = dict(os.environ, TMPDIR="/tmp", MICRO_ORDER=order, MICRO_ITERS="6")
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
@@ -418,7 +422,7 @@ def measure_traffic_pmc(timeout_s=150):
                 kcol = "kernel_name" if "kernel_name" in cols else "name"
                 vcol = "value" if "value" in cols else "counter_value"
                 for k, c, v in db.execute(f"select {kcol}, counter_name, {vcol} from counters_collection"):
-                    if c == ctr and "k_ig3r" in k:
+                    if c == ctr and kernel in k:
                         tot += float(v); n += 1
             if n == 0:
                 return None
@@ -491,6 +495,141 @@ def conv_roofline(plan, batch, dtype, device, iters=50):
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops_per_launch": int(flops), "algorithmic_bytes_per_launch": int(alg_bytes),
             "ms_per_launch": round(float(ms), 4), "algorithmic_GBs": round(gbs, 1), "hbm_frac_of_8TBs": round(gbs / 8000.0, 4),
             "measured_mfma_ceiling_TFs": 1900.0}
+
+
+def wgrad_roofline(route, plan, batch, dtype, device, in_step=8, alone=12):
+    """The kernel that dominates the profile and ends the step: the 3x3x3 / stride 1 weight gradient, k_wgrad3d -- its largest
+    launch, 32 -> 32 channels at full resolution (encoder.stages.0.convs.0.1). HIP events bracket exactly that kernel on the stream it
+    is launched on (the weight-gradient stream; the library records the caller's events around the one launch whose tile count
+    matches, include/nndet_amd.h: nndet_probe_wgrad3d): `in_step` extra training steps after the timed region give its duration INSIDE
+    the step (next to the data-gradient chain it shares the chip with), `alone` back-to-back launches its duration alone.
+    achieved = algorithmic FLOPs per launch / the in-step duration."""
+    import ctypes
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch.conv import ConvInstanceRelu, _desc, _packed
+    from nndetection_amd.layout import cpad
+    P = tuple(plan["patch_size"])
+    c = plan["arch"]["start_channels"]
+    tiles = batch * ((P[0] + 3) // 4) * ((P[1] + 7) // 8) * ((P[2] + 7) // 8)
+    lib = L.load()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()                          # (torch creates the hipEvent at the first record; the library re-records them)
+    torch.cuda.synchronize()
+    h0, h1 = e0.cuda_event, e1.cuda_event
+
+    def probed(fn):
+        lib.nndet_probe_wgrad3d(tiles, h0, h1)
+        fn()
+        torch.cuda.synchronize()
+        lib.nndet_probe_wgrad3d(0, None, None)
+        return e0.elapsed_time(e1)
+
+    ms_step = None
+    if route is not None and os.environ.get("NNDET_WGRAD3D", "1") != "0":
+        probed(route.step)
+        v = sorted(probed(route.step) for _ in range(in_step))
+        ms_step = {"mean": sum(v) / len(v), "median": v[len(v) // 2], "min": v[0], "max": v[-1], "n": len(v)}
+    m = ConvInstanceRelu(3, c, c, 3, stride=1, padding=1, add_norm=False, add_act=False).to(device)
+    x = torch.randn(batch, *P, cpad(c), device=device).to(dtype)
+    d = _desc(x, c, c, m.k, m.s, m.p, False)
+    dy = torch.randn(batch, d.out_d, d.out_h, d.out_w, d.cout_p, device=device).to(dtype)
+    dw = torch.zeros_like(m.conv.weight)
+    wsb = lib.nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = L.workspace(wsb, x.device)
+    st = L.stream()
+    call = lambda: L.call("nndet_conv3d_backward_weight", ctypes.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), None, L.ptr(ws), wsb, st)
+    for _ in range(20):
+        call()
+    va = sorted(probed(call) for _ in range(alone))
+    ms_alone = sum(va) / len(va)
+    del x, dy
+    nvox = batch * P[0] * P[1] * P[2]
+    esz = torch.tensor([], dtype=dtype).element_size()
+    flops = 2.0 * nvox * 27 * c * c
+    alg_bytes = 2 * nvox * cpad(c) * esz + 27 * c * c * 4
+    ms = ms_step["mean"] if ms_step is not None else ms_alone
+    tfs = flops / (ms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    if MEASURE_PMC[0] and batch == 4 and P == (160, 160, 96) and dtype == torch.bfloat16:
+        pm = measure_traffic_pmc(kernel="k_wgrad3d", order="wgrad")
+        if pm is not None and "hbm_bytes" in pm:
+            traffic, traffic_src = pm["hbm_bytes"], pm
+        else:
+            traffic_src = pm
+    dn = str(dtype).replace("torch.", "").replace("bfloat16", "bf16").replace("float16", "f16")
+    out = {"bound": "mfma", "kernel": "k_wgrad3d<%s> weight gradient of conv3d 3x3x3 32->32 @%dx%dx%d, batch %d (encoder.stages.0.convs.0.1)" % (dn, *P, batch),
+           "achieved": round(tfs, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tfs / 2500.0, 4), "traffic": traffic, "traffic_source": traffic_src,
+           "algorithmic_flops_per_launch": int(flops), "algorithmic_bytes_per_launch": int(alg_bytes),
+           "ms_per_launch": round(float(ms), 4), "timed": "inside the training step (HIP events on the weight-gradient stream around this one kernel, %d steps after the timed region)"
+           % (ms_step["n"] if ms_step else 0) if ms_step is not None else "alone (back-to-back launches)",
+           "in_step_ms": {k: (round(v, 4) if k != "n" else v) for k, v in ms_step.items()} if ms_step is not None else None,
+           "alone_ms": round(float(ms_alone), 4), "alone_TFLOPs": round(flops / (ms_alone * 1e-3) / 1e12, 1),
+           "alone_frac": round(flops / (ms_alone * 1e-3) / 1e12 / 2500.0, 4),
+           "flop_per_byte": round(flops / alg_bytes, 1), "measured_mfma_ceiling_TFs": 1900.0,
+           "note": "k_wgrad3d is the family with the most kernel time per step (11 uniform + 3 ragged launches); this is its largest launch. Inside the step it "
+                   "shares the chip with the data-gradient chain of the main stream, so its in-step duration is longer than alone."}
+    if traffic is not None:
+        out["traffic_over_algorithmic"] = round(traffic / alg_bytes, 3)
+    return out
+
+
+def box_microbench_config5(device):
+    """BASELINE.json configs[4] at its stated sizes: pairwise IoU / GIoU [2000 x 100000], ATSS with 2 000 GT x 5 levels
+    x 100 000 anchors (27 anchors per location, 4 candidates), NMS on 1 000 / 10 000 / 100 000 boxes with distinct scores. Parity at these
+    sizes is the tests' job (tests/test_boxes_gpu.py, tests/test_atss_gpu.py: bit-exact); here they are only timed."""
+    from nndetection_amd.core.boxes import box_iou, generalized_box_iou, nms, ATSSMatcher
+
+    def rb(rng, n):
+        c = rng.uniform(0, 160.0, (n, 3)); s_ = rng.uniform(2.0, 26.0, (n, 3))
+        return np.stack([c[:, 0] - s_[:, 0] / 2, c[:, 1] - s_[:, 1] / 2, c[:, 0] + s_[:, 0] / 2, c[:, 1] + s_[:, 1] / 2,
+                         c[:, 2] - s_[:, 2] / 2, c[:, 2] + s_[:, 2] / 2], 1).astype(np.float32)
+
+    def timeit(fn, iters=5):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    rng = np.random.default_rng(0)
+    a, g = torch.from_numpy(rb(rng, 100000)).to(device), torch.from_numpy(rb(rng, 2000)).to(device)
+    out = {"sizes": "SURVEY 8d config 5: anchors [100000, 6] per level x 5 levels, GT [2000, 6]"}
+    pairs = 2000 * 100000
+    for key, fn in (("box_iou", box_iou), ("generalized_box_iou", generalized_box_iou)):
+        dt = timeit(lambda: fn(g, a))
+        out[key] = {"ms": round(dt * 1e3, 4), "Gpairs_per_s": round(pairs / dt / 1e9, 1), "algorithmic_GBs": round((4 * pairs + 24 * 102000) / dt / 1e9, 1),
+                    "hbm_frac_of_8TBs": round((4 * pairs + 24 * 102000) / dt / 8e12, 4)}
+    out["nms"] = {}
+    for n in (1000, 10000, 100000):
+        b = torch.from_numpy(rb(rng, n)).to(device)
+        sc = torch.from_numpy(((rng.permutation(n) + 1) / (n + 1)).astype(np.float32)).to(device)
+        dt = timeit(lambda: nms(b, sc, 0.6), iters=5 if n < 100000 else 2)
+        out["nms"][str(n)] = {"ms": round(dt * 1e3, 4), "Mboxes_per_s": round(n / dt / 1e6, 2)}
+    rng5 = np.random.default_rng(0)
+    a5 = torch.from_numpy(np.concatenate([rb(rng5, 100000) for _ in range(5)], 0)).to(device)
+    g5 = torch.from_numpy(rb(rng5, 2000)).to(device)
+    m = ATSSMatcher(num_candidates=4, center_in_gt=False)
+    dt = timeit(lambda: m(g5, a5, [100000] * 5, 27), iters=3)
+    out["atss"] = {"ms": round(dt * 1e3, 3), "G_gt_anchor_pairs_per_s": round(2000 * 500000 / dt / 1e9, 1), "gt": 2000, "anchors": 500000, "levels": 5}
+    return out
+
+
+def config3_lidc192(device, warmup=4, steps=8):
+    """BASELINE.json configs[3] on ONE GPU's share: Task012_LIDC-like plan, 192x192x128 patches, fp16 convolutions (+ GradScaler, the
+    reference's precision=16), batch 4 per GPU: ms per step and peak HBM (SURVEY 8d config 4 asks for the peak per GPU)."""
+    from nndetection_amd.plans import get_plan
+    plan = get_plan("lidc192")
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(device)
+    r = Route(plan, 4, "f16", device, 0, False)
+    dt, last = r.timed(warmup, steps)
+    out = {"plan": "lidc192", "patch": list(plan["patch_size"]), "batch_per_gpu": 4, "dtype": "f16 + GradScaler", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "patches_per_s": round(4 * steps / dt, 2),
+           "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2), "final_loss": round(float(last.detach().float().item()), 5)}
+    del r
+    torch.cuda.empty_cache()
+    return out
 
 
 MEASURE_PMC = [True]
@@ -802,6 +941,17 @@ def main():
         dt = float(tt.item())
     loss_val = float(last.detach().float().item())
     peak_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    # two more timed blocks of the same K steps (no warm-up in between): `value` stays the FIRST block (the driver-flag run); the
+    # median of the three goes into `timed_blocks` so that one slow block (or a slow chip's first seconds) is visible as such
+    blocks_ms = [dt / args.steps * 1e3]
+    if not args.no_extras:
+        for _ in range(2):
+            dtb, _l = route.timed(0, args.steps, world)
+            if world > 1:
+                tb = torch.tensor([dtb], device=device, dtype=torch.float64)
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                dtb = float(tb.item())
+            blocks_ms.append(dtb / args.steps * 1e3)
     ddp_prof = None
     if route.ddp is not None and route.ddp.profile:
         route.ddp.profile_collect()                      # (events of the timed steps; read outside the timed region)
@@ -825,6 +975,11 @@ def main():
                        "loss_scaling": "torch.amp.GradScaler (sync-free: fused SGD takes scale / found_inf on the device)" if route.scaler is not None else None},
             "final_loss": round(loss_val, 5), "peak_hbm_gib": round(peak_gb, 2),
         }
+        if len(blocks_ms) > 1:
+            med = sorted(blocks_ms)[len(blocks_ms) // 2]
+            out["timed_blocks"] = {"ms_per_step": [round(b, 3) for b in blocks_ms], "median_ms_per_step": round(med, 3),
+                                   "median_patches_per_s": round(batch * world / (med * 1e-3), 2),
+                                   "note": "three back-to-back blocks of --steps steps; `value` is the first (the driver-flag run)"}
         if route.scaler is not None:
             out["grad_scale"] = float(route.scaler.get_scale())
         if ddp_prof is not None:
@@ -879,9 +1034,22 @@ def main():
         if not args.no_extras:
             x_inf = route.batch["data"].to(dtype) if args.via_plugin else route.x
             out["inference"] = inference_rate(net, x_inf)
+            # the dominant kernel (k_wgrad3d), timed INSIDE extra training steps of the same route and alone -- before the route goes away
+            try:
+                out["roofline"] = wgrad_roofline(route if (world == 1 and dtype != torch.float32) else None, plan, batch, dtype, device)
+            except Exception as e:                                           # noqa: BLE001 -- never lose the headline to a side leg
+                out["roofline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             del route, x_inf, net
             torch.cuda.empty_cache()
-            out["roofline"] = conv_roofline(plan, batch, dtype, device)      # rank 0's GPU; the other ranks are done
+            # the kernel with the most FLOPs per launch, alone: the `roofline` block of rounds 1-5, kept as a chip probe (it did not
+            # change since round 2: its alone-time compares the chips of two runs)
+            pmc_keep = MEASURE_PMC[0]
+            MEASURE_PMC[0] = False                                           # (its traffic: the committed PMC summary; the live passes go to k_wgrad3d)
+            out["roofline_ig3r"] = conv_roofline(plan, batch, dtype, device)      # rank 0's GPU; the other ranks are done
+            MEASURE_PMC[0] = pmc_keep
+            out["chip_probe"] = {"k_ig3r_forward_alone_ms": out["roofline_ig3r"]["ms_per_launch"], "k_ig3r_TFLOPs": out["roofline_ig3r"]["achieved"],
+                                 "k_wgrad3d_alone_ms": out["roofline"].get("alone_ms"),
+                                 "note": "alone-times of two MFMA-bound kernels on this chip: compare across runs before comparing `value` (the pool's chips differ by +-4 %)"}
             out["roofline_dominant"] = head_trunk_roofline(plan, batch, dtype, device)
             if STEP_PMC[0] is not None:
                 # L2-miss traffic of the ragged head-trunk launches INSIDE the training step (4 forward + 4 data-gradient launches), from the
@@ -903,6 +1071,15 @@ def main():
                     if isinstance(sr_src, dict):
                         sr_src.pop(k_, None)                  # (the per-kernel list is only used here; the line stays readable)
             out["nms"] = nms_rate(device)
+            try:
+                out["box_microbench"] = box_microbench_config5(device)       # BASELINE.json configs[4] at its stated sizes
+            except Exception as e:                                           # noqa: BLE001
+                out["box_microbench"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            if world == 1 and args.plan == "luna160" and not args.no_routes:
+                try:
+                    out["config3_lidc192"] = config3_lidc192(device)         # BASELINE.json configs[3] (one GPU's share)
+                except Exception as e:                                       # noqa: BLE001
+                    out["config3_lidc192"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             if world == 1 and not args.no_routes:
                 # the other routes on short runs in this process: what the drop-in (plugin) delivers next to the direct route, the
                 # exact-fp32 kernels (north_star's 1e-4 parity path), fp16 + GradScaler (the reference's own precision=16)

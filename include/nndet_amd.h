@@ -41,6 +41,18 @@ const char* nndet_version(void);
 /* Number of bytes of LDS / registers are compile-time; this reports the arch the library was built for. */
 const char* nndet_arch(void);
 
+/* Stream plumbing for the data-parallel / multi-stream wiring (replaces nothing in the reference, which leaves streams to
+ * Lightning, scripts/train.py:265-289): a HIP stream restricted to the compute units whose bits are set in cu_mask (`words` 32-bit
+ * words, bit i of word w = CU 32 w + i; hipExtStreamCreateWithCUMask). The caller owns the stream and destroys it with
+ * nndet_stream_destroy. */
+int nndet_stream_create_cumask(const uint32_t* cu_mask, int32_t words, void** stream_out);
+int nndet_stream_destroy(void* stream);
+/* Measurement hook (bench.py `roofline`): the NEXT launch of the 3x3x3 / stride 1 weight-gradient kernel (k_wgrad3d, uniform form) whose
+ * problem has exactly `total_tiles` tiles of 4 x 8 x 8 output points records ev_start right before and ev_stop right after that ONE
+ * kernel on the stream it is launched on (the caller's hipEvent_t handles, created with timing enabled). One shot: disarmed by the
+ * launch that matched, or by total_tiles = 0. Returns 0. No effect on results. */
+int nndet_probe_wgrad3d(int64_t total_tiles, void* ev_start, void* ev_stop);
+
 /* ------------------------------------------------------------------------------------------------
  * 3D NMS -- replaces nndet._C.nms (nms_cuda, nndet/csrc/cuda/nms.cu:148-221; kernel :99-145;
  * IoU :36-51) including its score sort and, unlike the reference, the greedy scan stays on the GPU

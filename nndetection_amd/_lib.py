@@ -64,6 +64,9 @@ SIGNATURES = {
     "nndet_iou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
     "nndet_giou3d_pairwise_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
     "nndet_iou3d_rowmax_f32": (C.c_int, [_P, _I64, _P, _I64, _F, _P, _P]),
+    "nndet_stream_create_cumask": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_void_p)]),
+    "nndet_stream_destroy": (C.c_int, [_P]),
+    "nndet_probe_wgrad3d": (C.c_int, [_I64, _P, _P]),
     "nndet_giou3d_pairwise_bwd_f32": (C.c_int, [_P, _I64, _P, _I64, _P, _F, _P, _P, _P]),
     "nndet_giou3d_diag_fwd_f32": (C.c_int, [_P, _P, _I64, _F, _P, _P]),
     "nndet_giou3d_diag_bwd_f32": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
@@ -419,6 +422,34 @@ def graph_task_id() -> int:
     return _graph_task_id() if _graph_task_id is not None else -1
 
 
+_cumask_streams = []                                 # (keeps the raw handles alive for the life of the process)
+
+
+def cumask_stream(dev, spec: str):
+    """A stream restricted to a CU partition (hipExtStreamCreateWithCUMask through the C ABI), as a torch.cuda.ExternalStream.
+    spec: "N" = the first N CUs of the mask order, "N/S" = N CUs taken with stride S... written out: CU i is enabled iff
+    (i % S) < N % S ... kept simple: "N" -> bits [0, N); "xHEX" -> the literal 256-bit mask, least significant word first."""
+    words = (C.c_uint32 * 8)()
+    if spec.startswith("x"):
+        v = int(spec[1:], 16)
+        for w in range(8):
+            words[w] = (v >> (32 * w)) & 0xffffffff
+    elif ":" in spec:                                # "N:S" = N of every S consecutive CUs (an interleaved partition)
+        n, st = (int(t) for t in spec.split(":"))
+        for i in range(256):
+            if i % st < n:
+                words[i // 32] |= 1 << (i % 32)
+    else:
+        n = max(1, min(256, int(spec)))
+        for i in range(n):
+            words[i // 32] |= 1 << (i % 32)
+    out = C.c_void_p()
+    with torch.cuda.device(dev):
+        check(load().nndet_stream_create_cumask(C.cast(words, C.c_void_p), 8, C.byref(out)), "nndet_stream_create_cumask")
+    _cumask_streams.append(out.value)
+    return torch.cuda.ExternalStream(out.value, device=dev)
+
+
 class _WgradStreams:
     """Weight-gradient kernels on their own stream. Within a backward pass the data-gradient / norm-backward chain is the critical
     path; a weight gradient is only needed by the optimizer. Launched on a second stream the weight-gradient kernels fill the CUs the
@@ -454,7 +485,11 @@ class _WgradStreams:
             # lowest queue priority the device offers: the critical chain on the other streams gets the CUs first, the weight
             # gradients take what is left (NNDET_WGRAD_PRIO overrides: -1 high, 0 normal, 1 low on ROCm)
             prio = int(os.environ.get("NNDET_WGRAD_PRIO", "1"))
-            ws = self.streams[idx] = torch.cuda.Stream(device=dev, priority=prio)
+            mask = os.environ.get("NNDET_WGRAD_CUMASK", "")
+            if mask:
+                ws = self.streams[idx] = cumask_stream(dev, mask)
+            else:
+                ws = self.streams[idx] = torch.cuda.Stream(device=dev, priority=prio)
         if not self.active:
             _queue_callback(self._done)
         self.active[idx] = ws

@@ -5,6 +5,21 @@
 extern "C" const char* nndet_version(void) { return "nndetection_amd 0.3.0 (round 3: f32 | bf16 | f16)"; }
 extern "C" const char* nndet_arch(void) { return "gfx950"; }
 
+// A HIP stream restricted to a set of compute units (hipExtStreamCreateWithCUMask): torch cannot create one, the host side wraps the
+// handle in torch.cuda.ExternalStream. Used for the A/B of the weight-gradient stream on a CU partition (NNDET_WGRAD_CUMASK).
+extern "C" int nndet_stream_create_cumask(const uint32_t* cu_mask, int32_t words, void** stream_out) {
+    if (!cu_mask || words <= 0 || words > 32 || !stream_out) return NNDET_EINVAL;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, cu_mask));
+    *stream_out = st;
+    return 0;
+}
+extern "C" int nndet_stream_destroy(void* stream) {
+    if (!stream) return NNDET_EINVAL;
+    HIP_TRY(hipStreamDestroy(as_stream(stream)));
+    return 0;
+}
+
 static int check_conv(const NndetConv* c) {
     if (!c) return NNDET_EINVAL;
     if (c->dtype != NNDET_F32 && c->dtype != NNDET_BF16 && c->dtype != NNDET_F16) return NNDET_EINVAL;
