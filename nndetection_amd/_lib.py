@@ -511,10 +511,14 @@ wgrad_streams = _WgradStreams()
 
 class _GradHints:
     """Side channel between autograd nodes: a node that KNOWS more about the gradient it returns than the dense tensor says (it is
-    sparse: arch/heads.py) registers that knowledge under the tensor's address; the node that receives exactly this tensor (same
-    address -- views and no-op casts keep it, anything that copies or accumulates does not) may use it instead of reading the
-    tensor. The dense tensor stays a VALID gradient, so a consumer that finds no hint computes the same result the slow way. An entry
-    keeps its tensor alive (its address cannot be reused while the hint exists) and is dropped when consumed or after 16 newer ones."""
+    sparse: arch/heads.py) registers that knowledge under the tensor's address; the node that receives exactly this memory (same
+    address and size -- views and no-op casts keep it, anything that copies or sums does not) may use it instead of reading the
+    tensor. The dense tensor stays a VALID gradient, so a consumer that finds no hint computes the same result the slow way.
+    Why an address key cannot alias: an entry HOLDS its tensor, so the caching allocator cannot hand that address to
+    anybody else while the entry exists, and an entry that is gone matches nothing. What the address does not tell is an in-place
+    modification -- the engine adds a second contribution in place when it holds the only reference to a gradient: every entry
+    therefore carries the tensor's version counter at registration (shared by all views of the storage) and is void when it moved.
+    Entries are dropped when consumed, after 16 newer ones, and at the next top-level training forward pass."""
 
     def __init__(self):
         self.d = {}
@@ -522,16 +526,21 @@ class _GradHints:
     def put(self, t: torch.Tensor, payload: dict) -> None:
         if len(self.d) >= 16:
             self.d.pop(next(iter(self.d)))
-        self.d[t.data_ptr()] = (t, payload)
+        self.d[t.data_ptr()] = (t, payload, t._version)
 
     def pop(self, t: torch.Tensor):
         e = self.d.pop(t.data_ptr(), None)
         if e is None:
             return None
-        keep, payload = e
+        keep, payload, ver = e
         if keep.numel() * keep.element_size() != t.numel() * t.element_size() or keep.dtype != t.dtype:
             return None                                  # same address, other tensor (a sub-view): not ours
+        if t._version != ver or keep._version != ver:
+            return None                                  # written in place since (accumulated by the engine, a hook): the hint is stale
         return payload
+
+    def clear(self) -> None:
+        self.d.clear()
 
 
 grad_hints = _GradHints()

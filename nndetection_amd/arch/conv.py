@@ -231,12 +231,17 @@ norm_red_fused = [0]        # how many norm backward passes took their sums from
 def rank1_register(fake: torch.Tensor, d1: torch.Tensor, wd: torch.Tensor, sum_d1: torch.Tensor) -> None:
     """fake: the unwritten [N, D, H, W, C_p] gradient tensor; d1 [N, D, H, W, 1]; wd [C] fp32; sum_d1: 0-dim fp32 (= sum of d1)."""
     _rank1_grads.clear()                                   # at most one live entry (one segmentation branch per backward pass)
-    _rank1_grads[fake.data_ptr()] = (d1, wd, sum_d1, fake)
+    # the entry HOLDS `fake` (its address cannot be handed to another tensor while the entry lives) and its version counter: an
+    # in-place write by anybody else (the engine accumulating a second contribution, a hook) voids it -- loudly, see below
+    _rank1_grads[fake.data_ptr()] = (d1, wd, sum_d1, fake, fake._version)
 
 
 def _rank1_backward(ctx, dconv, weight, x_p, desc, dw, dbias, side, raw):
     """Backward of a 3x3x3 / stride 1 / pad 1 convolution whose output gradient is d1 (x) wd (see above). Returns dx (physical)."""
-    d1, wd, sum_d1, _ = _rank1_grads.pop(dconv.data_ptr())
+    d1, wd, sum_d1, fake, ver = _rank1_grads.pop(dconv.data_ptr())
+    if dconv._version != ver or fake._version != ver or dconv.numel() != fake.numel():
+        raise L.NndetError("the factorised gradient of the fused segmentation head was modified in place before it reached decoder.out.P0 "
+                           "(gradient accumulation / a hook on an unwritten tensor); set NNDET_SEG_RANK1=0 for the dense gradient")
     dev, dt = x_p.device, x_p.dtype
     cout, cin = desc.cout, desc.cin
     w_r = weight.detach().to(dt).float()                                     # what the forward kernels multiplied with
@@ -442,6 +447,8 @@ class _ConvFn(torch.autograd.Function):
                     gacc["buf"].record_stream(torch.cuda.current_stream(dev))
                 ns = ctx.norm_src if NORM_RED_FUSE else None
                 if (ns is not None and not fuses_bias and ns[0].shape == x_p.shape and ns[0].dtype == dt
+                        and ns[2].norm.weight.dtype == torch.float32 and ns[2].norm.bias.dtype == torch.float32     # (read as raw fp32)
+                        and ns[2].norm.weight.is_contiguous() and ns[2].norm.bias.is_contiguous()
                         and L.load().nndet_conv3d_dgrad_fuses_norm_reduce(ctypes.byref(desc))):
                     ny_p, nmr, nmod = ns
                     red = L.arena_zeros((L.STATS_REPLICAS * desc.batch * desc.cin_p * 2 + desc.batch,), torch.float64, dev)
@@ -449,7 +456,9 @@ class _ConvFn(torch.autograd.Function):
                            L.ptr(ny_p), L.ptr(nmr), L.ptr(nmod.norm.weight.detach()), L.ptr(nmod.norm.bias.detach()), int(nmod.relu),
                            nmod.out_channels, L.ptr(red), L.stream())
                     _norm_presums.clear()                      # at most one live entry
-                    _norm_presums[gacc["buf"].data_ptr()] = (red, nmr)
+                    # the entry holds the buffer (no address reuse while it lives) and its version counter: a further contribution
+                    # that autograd adds IN PLACE into this storage (a third consumer, a hook) advances it and voids the sums
+                    _norm_presums[gacc["buf"].data_ptr()] = (red, nmr, gacc["buf"], gacc["buf"]._version)
                 else:
                     L.call("nndet_conv3d_backward_data_acc", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(gacc["buf"]),
                            L.ptr(dbias) if fuses_bias else None, L.stream())
@@ -557,6 +566,8 @@ class _NormFn(torch.autograd.Function):
         dgamma, dbeta = L.grad_pool.take_for([(mod.norm.weight, cout), (mod.norm.bias, cout)], dev)
         dconv = torch.empty_like(y_p)
         pre = _norm_presums.pop(g_p.data_ptr(), None) if _norm_presums else None
+        if pre is not None and (pre[2]._version != pre[3] or g_p._version != pre[3]):
+            pre = None                                     # modified in place since the sums were taken: reduce again from the tensor
         if pre is not None and pre[1].data_ptr() == mean_rstd.data_ptr():      # the sums came with the gradient (see _norm_presums)
             norm_red_fused[0] += 1
             L.call("nndet_norm_backward_presummed", ctx.code, L.ptr(y_p), L.ptr(g_p), L.ptr(mean_rstd), L.ptr(g32), L.ptr(b32), N, spatial,

@@ -132,7 +132,7 @@ class BaseRetinaNet(nn.Module):
                 # pass to a later node of the SAME pass, so a forward pass that runs INSIDE a backward pass (activation checkpointing
                 # recomputes, a second model driven from a hook) must leave them alone: cleared only at top level.
                 if L.graph_task_id() == -1:
-                    L.grad_hints.d.clear()
+                    L.grad_hints.clear()
                     from ..arch.conv import _rank1_grads, _norm_presums
                     _rank1_grads.clear()
                     _norm_presums.clear()

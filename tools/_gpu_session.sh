@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
-NNDET_AMD_LIB=$PWD/nndetection_amd/csrc/libnndet_amd_timing.so MICRO_ITERS=2 MICRO_ORDER=wgrad timeout 300 python tools/conv_microbench.py e0_32x32_full e1_64x64 2>&1 | grep -v amdgpu.ids | tail -60 | tee gpurun_out/wg3e_timing.txt
+for i in 1 2 3; do timeout 900 python -m pytest tests/test_parity_full_gpu.py -m gpu -q --tb=short -p no:cacheprovider -x -k "luna160_bf16_end_to_end" > gpurun_out/t_bf16_$i.txt 2>&1; tail -3 gpurun_out/t_bf16_$i.txt; grep -i "cos\|norm" gpurun_out/parity_bf16.txt | tail -6; done
+timeout 1200 python -m pytest tests/test_model_gpu.py tests/test_pyramid_gpu.py tests/test_plugin_gpu.py -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/t_model.txt 2>&1; tail -5 gpurun_out/t_model.txt
