@@ -15,6 +15,7 @@
 // Optional residual (dx += ...: the fused gradient accumulation of nndet_conv3d_backward_data_acc), read at the element it writes.
 #include "common.h"
 #include "conv_common.h"
+#include <type_traits>
 
 template <typename T> struct DgMma {     // the 16-bit storage types (bf16_t, f16_t)
     static constexpr int KC = 32, EPL = 8;
@@ -365,6 +366,374 @@ __global__ __launch_bounds__(256, (MT == 2 && sizeof(T) == 2) ? (NB ? 2 : 3) : 1
     }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent form (round 6)
+// k_dgsp: the 32 <- 64 channel stride-(2, 2, 2) transition in 16 bits (encoder stage 0 <- 1, the full-resolution data gradient that also
+// completes the gradient of the first block's output and carries its norm-backward sums). k_dgs moves 2.0 GB for it at 2.7 TB/s
+// (0.75 ms alone at batch 4, 0.81 ms in the step; profiles/round5_dgs_pmc.txt): one workgroup per tile, and inside it six memory round
+// trips in a row -- two for the register-staged halo, then per class pair "request residual + pre-norm values, run a 1 us MFMA loop whose
+// first weight load (vmcnt is in-order) waits for them, epilogue" -- with 11.5 k instructions per wave and tile, a third of them address
+// arithmetic (59 % of the wave cycles in s_waitcnt, 32 % issuing). Here
+//   * ONE persistent workgroup per CU (4 waves, up to 512 registers each) walks the lattice tiles;
+//   * all 27 x 2 x 2 weight fragments live in LDS for the life of the workgroup (108 KB, lane-linear: conflict-free ds_read_b128), so the
+//     MFMA loops issue no vector-memory instruction at all;
+//   * the dY halo of the NEXT tile goes global -> LDS by LDS-DMA (source pre-swizzled, out-of-tensor granules = out-of-range offsets ->
+//     the hardware writes the zero padding) right after the last MFMA loop of the current tile, under its last epilogue;
+//   * residual and pre-norm values of class pair g + 1 are requested BEFORE the MFMA loop of pair g into the second of two register sets
+//     (16 x 16-byte buffer loads per lane) and are consumed one MFMA loop + one epilogue later; every address is
+//     descriptor (image) + scalar (tile, class) + a lane constant: no per-access address arithmetic, validity by out-of-range offsets;
+//   * stride (2, 2, 2) is compile time: the 8 parity classes with their 1-8 taps are fully unrolled with immediate LDS offsets, in the
+//     tap / chunk order of k_dgs (dx is bit-identical to k_dgs).
+// LDS: 108 KB weights + 51 KB halo (5 x 9 x 9 voxels x 128 B, single buffer: the MFMA loops are 40 % of a tile, the DMA lands under the
+// epilogue that follows). NNDET_DGSP=0 restores k_dgs.
+struct DgspArgs {
+    const void* dy; const void* w; const void* res; void* dx;
+    int32_t N, O[3], I[3], nt[3];
+    int32_t total_tiles;
+    const void* ny; const float* nmr; const float* ngamma; const float* nbeta; double* nred;
+    int32_t nrelu, ncout;
+};
+
+__device__ __forceinline__ void dgsp_dma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rs), "s"(soff), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dgsp_rsrc(const char* p, int num_records) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(((uint64_t)hi << 32) | lo), 0, num_records, 0x00020000);
+}
+typedef __attribute__((address_space(3))) char* dgsp_lds_ptr;
+
+template <typename T, bool RES, bool NB>
+__global__ __launch_bounds__(256, 1) void k_dgsp(const DgspArgs A) {
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    constexpr int HD = 5, HH = 9, HW = 9, HV = HD * HH * HW, CHB = HV * 64, NGR = 2 * HV * 4, NPIECE = (NGR + 63) / 64;
+    constexpr int WBYTES = 108 * 1024, NPW = (NPIECE + 3) / 4;
+    constexpr int NLOAD = (RES ? 8 : 0) + (NB ? 8 : 0);               // vector-memory loads of one prefetch set per wave
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int G = gridDim.x, bx = blockIdx.x;
+    const uint32_t sb = (uint32_t)(uintptr_t)(dgsp_lds_ptr)smem;
+
+    // ---- weights -> LDS, once: fragment f = (tap * 2 + chunk) * 2 + row tile, 64 lanes x 16 bytes, lane-linear
+    {
+        const T* wl = reinterpret_cast<const T*>(A.w) + (int64_t)li * 64 + q * 8;
+        for (int f = wv; f < 108; f += 4) {
+            const int i = f & 1, kc = (f >> 1) & 1, tap = f >> 2;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wl + ((int64_t)tap * 32 + i * 16) * 64 + kc * 32);
+            *reinterpret_cast<u32x4*>(smem + f * 1024 + lane * 16) = v;
+        }
+    }
+    // ---- lane constants
+    const uint32_t wa0 = sb + lane * 16, wa1 = wa0 + 65536;             // weight fragments: base + f * 1024 (f >= 64 from the second base)
+    uint32_t hb[4][2];                                                  // dY fragments: halo base of point tile j for the two swizzle phases
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ph = 2 * j + (li >> 3), pw = li & 7;
+        const int brow = wv * HH + ph;
+        const int b0 = ((brow * HW + pw) * 64 + q * 16) ^ ((brow & 1) << 5);
+        hb[j][0] = sb + WBYTES + b0; hb[j][1] = sb + WBYTES + (b0 ^ 32);
+    }
+    asm volatile("" : "+v"(hb[0][0]), "+v"(hb[0][1]), "+v"(hb[1][0]), "+v"(hb[1][1]));
+    asm volatile("" : "+v"(hb[2][0]), "+v"(hb[2][1]), "+v"(hb[3][0]), "+v"(hb[3][1]));
+    // output side: byte offset of this lane's 16 bytes of lattice point (wv, 2 j + (li >> 3), li & 7) relative to the tile's class-0 origin
+    const int I1 = A.I[1], I2 = A.I[2];
+    int lo_out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        lo_out[j] = ((2 * wv * I1 + 2 * (2 * j + (li >> 3))) * I2 + 2 * (li & 7)) * 64 + ((q >> 1) * 8 + (q & 1) * 16) * 2;
+    // halo DMA: piece p = wv + 4 k, granule g = p * 64 + lane -> chunk, voxel, stored part; source = logical part (swizzle undone)
+    int hrel[NPW];
+    uint32_t hsel[NPW];          // bit hd | bit 5 + hh | bit 14 + hw; bit 31 = no such granule
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int g = (wv + 4 * k) * 64 + lane;
+        const int kc = g / (HV * 4), gi = g - kc * (HV * 4);
+        const int hv = gi >> 2, slot = gi & 3;
+        const int row = hv / HW, hw = hv - row * HW;
+        const int hd = row / HH, hh = row - hd * HH;
+        const int lp = slot ^ ((row & 1) << 1);
+        hsel[k] = g < NGR ? (1u << hd) | (1u << (5 + hh)) | (1u << (14 + hw)) : 0x80000000u;
+        hrel[k] = ((hd * A.O[1] + hh) * A.O[2] + hw) * 128 + kc * 64 + lp * 16;
+    }
+    const int img_out = A.I[0] * I1 * I2 * 64, img_dy = A.O[0] * A.O[1] * A.O[2] * 128;      // bytes per image (< 2^31: host)
+    // class lattices (stride 2): L[axis][parity]
+    const int L0[2] = {(A.I[0] + 1) >> 1, A.I[0] >> 1}, L1[2] = {(I1 + 1) >> 1, I1 >> 1}, L2[2] = {(I2 + 1) >> 1, I2 >> 1};
+
+    // ---- tile walk (flat index over (n, td, th, tw); XCD-compact start as in k_wgrad3e)
+    const int pstart = (G & 7) ? bx : (bx & 7) * (G >> 3) + (bx >> 3);
+    const int ntile = pstart < A.total_tiles ? (A.total_tiles - pstart + G - 1) / G : 0;
+    const int tpi = A.nt[0] * A.nt[1] * A.nt[2];
+    struct Tile { int n, l0d, l0h, l0w, obase; };
+    auto locate = [&](int flat) -> Tile {
+        Tile t;
+        t.n = flat / tpi;
+        int tt = flat - t.n * tpi;
+        const int tw = tt % A.nt[2]; tt /= A.nt[2];
+        const int th = tt % A.nt[1], td = tt / A.nt[1];
+        t.l0d = td * DGS_TD; t.l0h = th * DGS_TH; t.l0w = tw * DGS_TW;
+        t.obase = ((2 * t.l0d * I1 + 2 * t.l0h) * I2 + 2 * t.l0w) * 64;
+        return t;
+    };
+    auto issue_halo = [&](const Tile& t) {
+        const auto drs = dgsp_rsrc(reinterpret_cast<const char*>(A.dy) + (int64_t)t.n * img_dy, img_dy);
+        const int soff = ((t.l0d * A.O[1] + t.l0h) * A.O[2] + t.l0w) * 128;
+        auto rng = [](int hi) -> uint32_t { return hi >= 32 ? 0xffffffffu : (hi <= 0 ? 0u : (1u << hi) - 1u); };
+        const uint32_t mask = rng(min(HD, A.O[0] - t.l0d)) | (rng(min(HH, A.O[1] - t.l0h)) << 5) | (rng(min(HW, A.O[2] - t.l0w)) << 14);
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            if ((k + 1) * 4 <= NPIECE || wv + 4 * k < NPIECE) {
+                const bool ok = (hsel[k] & mask) == hsel[k];
+                dgsp_dma16(drs, ok ? hrel[k] : (int)0x80000000, soff, (uint32_t)__builtin_amdgcn_readfirstlane(sb + WBYTES + (wv + 4 * k) * 1024));
+            }
+        }
+    };
+
+    // ---- norm-backward sums (NB): constants of the lane's 8 channels for image n, partial sums across this workgroup's tiles of image n
+    float csc[2][4], csh[2][4], nsa[2][4], nsb[2][4];
+    int n_cur = -1;
+    auto flush = [&]() {
+        if constexpr (NB) {
+            if (n_cur < 0) return;
+            const int rep = (bx * 4 + wv) % NNDET_STATS_REPLICAS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    float a = nsa[i][rr], b = nsb[i][rr];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                    const int ch = i * 16 + q * 4 + rr;
+                    if (li == 0 && ch < A.ncout) {
+                        const double mu = (double)A.nmr[((int64_t)n_cur * 32 + ch) * 2], rs = (double)A.nmr[((int64_t)n_cur * 32 + ch) * 2 + 1];
+                        double* dst = A.nred + (((int64_t)rep * A.N + n_cur) * 32 + ch) * 2;
+                        if (a != 0.f) atomicAdd(dst, (double)a);
+                        const double v2 = rs * ((double)b - mu * (double)a);      // sum g * xhat = rstd * (sum g * y - mean * sum g)
+                        if (v2 != 0.0) atomicAdd(dst + 1, v2);
+                    }
+                    nsa[i][rr] = 0.f; nsb[i][rr] = 0.f;
+                }
+        }
+    };
+    auto enter_image = [&](int n) {
+        if constexpr (NB) {
+            if (n == n_cur) return;
+            flush();
+            n_cur = n;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int ch = i * 16 + q * 4 + rr;
+                    const bool ok = ch < A.ncout;
+                    const float mu = A.nmr[((int64_t)n * 32 + ch) * 2], rs = A.nmr[((int64_t)n * 32 + ch) * 2 + 1];
+                    const float sc = ok ? rs * A.ngamma[ok ? ch : 0] : 0.f;
+                    csc[i][rr] = sc; csh[i][rr] = ok ? A.nbeta[ok ? ch : 0] - mu * sc : 0.f;       // the forward pass's expressions (k_norm_apply)
+                    nsa[i][rr] = 0.f; nsb[i][rr] = 0.f;
+                }
+        }
+    };
+
+    // ---- prefetch sets: residual / pre-norm values of one class pair (cd, ch), both W parities, 4 point tiles
+    struct PSet { u32x4 r[2][4], y[2][4]; int vo[2][4]; };
+    auto request = [&](PSet& P, const Tile& t, int cd, int ch) {
+        const auto rrs = dgsp_rsrc(reinterpret_cast<const char*>(RES ? A.res : A.dx) + (int64_t)t.n * img_out, img_out);
+        const auto yrs = dgsp_rsrc(reinterpret_cast<const char*>(NB ? A.ny : A.dx) + (int64_t)t.n * img_out, img_out);
+        const bool dv = t.l0d + wv < L0[cd];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int soff = t.obase + ((cd * I1 + ch) * I2 + g) * 64;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool pv = dv && (t.l0h + 2 * j + (li >> 3) < L1[ch]) && (t.l0w + (li & 7) < L2[g]);
+                P.vo[g][j] = pv ? lo_out[j] : (int)0x80000000;             // out of range: loads return 0, the store is dropped
+                if constexpr (RES) P.r[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, P.vo[g][j], soff, 0));
+                if constexpr (NB) P.y[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, P.vo[g][j], soff, 0));
+            }
+        }
+    };
+
+    // ---- one class pair: MFMA loops of both W parities (taps in k_dgs's order: d, h, w entries; parity 1 = {(t 0, delta 1), (t 2, delta 0)})
+    f32x4 acc[2][2][4];
+    typedef __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
+    auto lds128 = [](uint32_t a) -> u32x4 { return *(lds_u32x4_ptr)(uintptr_t)a; };
+    auto mfma_pair = [&](auto cd_, auto ch_) {
+        constexpr int cd = decltype(cd_)::value, ch = decltype(ch_)::value;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            constexpr int nd = cd ? 2 : 1, nh = ch ? 2 : 1;
+            const int nw = g ? 2 : 1;
+#pragma unroll
+            for (int x = 0; x < nd; ++x)
+#pragma unroll
+                for (int y = 0; y < nh; ++y)
+#pragma unroll
+                    for (int z = 0; z < 2; ++z) {
+                        if (z >= nw) continue;
+                        const int td = cd ? (x ? 2 : 0) : 1, dd = cd ? (x ? 0 : 1) : 0;
+                        const int th = ch ? (y ? 2 : 0) : 1, dh = ch ? (y ? 0 : 1) : 0;
+                        const int tw = g ? (z ? 2 : 0) : 1, dw = g ? (z ? 0 : 1) : 0;
+                        const int wt = (td * 3 + th) * 3 + tw;
+                        const int trow = dd * HH + dh;
+                        const int toff = (trow * HW + dw) * 64, ph = trow & 1;
+#pragma unroll
+                        for (int kc = 0; kc < 2; ++kc) {
+                            u32x4 af[2], bf[4];
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const int f = (wt * 2 + kc) * 2 + i;
+                                af[i] = f < 64 ? lds128(wa0 + f * 1024) : lds128(wa1 + (f - 64) * 1024);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) bf[j] = lds128(hb[j][ph] + kc * CHB + toff);
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[g][i][j] = H16<T>::mma(af[i], bf[j], acc[g][i][j]);
+                        }
+                    }
+        }
+    };
+    // ---- epilogue of a class pair: (+ residual) -> pack -> (norm-backward sums from the ROUNDED values) -> one 16-byte store per lane and point
+    auto epilogue = [&](PSet& P, const Tile& t, int cd, int ch) {
+        const auto ors = dgsp_rsrc(reinterpret_cast<char*>(A.dx) + (int64_t)t.n * img_out, img_out);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int soff = t.obase + ((cd * I1 + ch) * I2 + g) * 64;
+                uint32_t pk[2][2], rk[2][2] = {{0u, 0u}, {0u, 0u}};
+                if constexpr (RES) {                 // store layout -> MFMA layout (v_permlane16_swap is an involution)
+                    const u32x4 r16 = P.r[g][j];
+                    const v2u t0 = __builtin_amdgcn_permlane16_swap(r16[0], r16[2], false, false);
+                    const v2u t1 = __builtin_amdgcn_permlane16_swap(r16[1], r16[3], false, false);
+                    rk[0][0] = t0[0]; rk[1][0] = t0[1]; rk[0][1] = t1[0]; rk[1][1] = t1[1];
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float v0 = acc[g][h][j][0], v1 = acc[g][h][j][1], v2 = acc[g][h][j][2], v3 = acc[g][h][j][3];
+                    if constexpr (RES) {
+                        v0 += H16<T>::lo(rk[h][0]); v1 += H16<T>::hi(rk[h][0]);
+                        v2 += H16<T>::lo(rk[h][1]); v3 += H16<T>::hi(rk[h][1]);
+                    }
+                    pk[h][0] = H16<T>::pack2(v0, v1); pk[h][1] = H16<T>::pack2(v2, v3);
+                }
+                if constexpr (NB) {
+                    const u32x4 y16 = P.y[g][j];
+                    const v2u y0 = __builtin_amdgcn_permlane16_swap(y16[0], y16[2], false, false);
+                    const v2u y1 = __builtin_amdgcn_permlane16_swap(y16[1], y16[3], false, false);
+                    const uint32_t yk[2][2] = {{y0[0], y1[0]}, {y0[1], y1[1]}};
+                    if (P.vo[g][j] >= 0) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float gv[4] = {H16<T>::lo(pk[h][0]), H16<T>::hi(pk[h][0]), H16<T>::lo(pk[h][1]), H16<T>::hi(pk[h][1])};
+                            const float yv[4] = {H16<T>::lo(yk[h][0]), H16<T>::hi(yk[h][0]), H16<T>::lo(yk[h][1]), H16<T>::hi(yk[h][1])};
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                float gm = gv[rr];
+                                if (A.nrelu && !(fmaf(yv[rr], csc[h][rr], csh[h][rr]) > 0.f)) gm = 0.f;     // the forward pass's expression
+                                nsa[h][rr] += gm;
+                                nsb[h][rr] = fmaf(gm, yv[rr], nsb[h][rr]);                               // raw moment, centred at the flush
+                            }
+                        }
+                    }
+                }
+                const v2u s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                const v2u s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+                // (no SGPR offset on the store: hipcc guards the "VALU overwrites the data registers of a 16-byte store" hazard only for
+                //  stores without one -- conv_igemm.hip: k_ig3r, tools/scan_store_hazard.py; an out-of-range lane offset stays out of range)
+                __builtin_amdgcn_raw_buffer_store_b128(v4u_t{s0[0], s1[0], s0[1], s1[1]}, ors, P.vo[g][j] + soff, 0, 0);
+            }
+    };
+
+    if (ntile == 0) return;
+    Tile cur = locate(pstart), nxt = cur;
+    PSet SA, SB;
+    issue_halo(cur);
+    enter_image(cur.n);
+    request(SA, cur, 0, 0);                                 // (always: it also forms the store offsets)
+    for (int k = 0; k < ntile; ++k) {
+        const bool has_next = k + 1 < ntile;
+        if (has_next) nxt = locate(pstart + (k + 1) * G);
+        // group 0 = (cd 0, ch 0)
+        request(SB, cur, 0, 1);
+        if constexpr (NLOAD == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the halo pieces are older than this set
+        else if constexpr (NLOAD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // halo (and, first time, the weights) visible to every wave
+        mfma_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        epilogue(SA, cur, 0, 0);
+        // group 1 = (0, 1)
+        request(SA, cur, 1, 0);
+        mfma_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        epilogue(SB, cur, 0, 1);
+        // group 2 = (1, 0)
+        request(SB, cur, 1, 1);
+        mfma_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        epilogue(SA, cur, 1, 0);
+        // group 3 = (1, 1); the next tile's first set is requested before its MFMA loop, the next halo right after it
+        if (has_next) request(SA, nxt, 0, 0);
+        mfma_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        __syncthreads();                                    // every wave is done reading this tile's halo
+        if (has_next) issue_halo(nxt);
+        epilogue(SB, cur, 1, 1);
+        if (has_next) { enter_image(nxt.n); cur = nxt; }
+    }
+    flush();
+}
+
+// launch rule: 16 bits, 32 <- 64 channels (padded), stride (2, 2, 2), 32-bit byte offsets per image
+static int dgsp_on() { const char* e = getenv("NNDET_DGSP"); return e ? atoi(e) : 1; }     // (read per call: the tests compare the forms)
+static bool dgsp_covers(const NndetConv* c) {
+    if (!dgsp_on() || !nndet_is16(c->dtype) || c->cin_p != 32 || c->cout_p != 64) return false;
+    for (int i = 0; i < 3; ++i) if (c->s[i] != 2 || c->k[i] != 3 || c->p[i] != 1) return false;
+    return (int64_t)c->in_d * c->in_h * c->in_w * 64 < (1LL << 31) && (int64_t)c->out_d * c->out_h * c->out_w * 128 < (1LL << 31);
+}
+template <typename T, bool RES, bool NB> static int dgsp_launch(const DgspArgs& a, int grid, hipStream_t st) {
+    constexpr int LDS = 108 * 1024 + 51 * 1024;
+    static NndetDevOnce attr;
+    if (attr.need()) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgsp<T, RES, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr.done();
+    }
+    k_dgsp<T, RES, NB><<<grid, 256, LDS, st>>>(a);
+    LAUNCH_CHECK();
+    return 0;
+}
+static int dgsp_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st, const DgsNormRed* nr) {
+    if (res && res != dx) return 1;                        // (the residual is read through the output's descriptor layout: in place only)
+    DgspArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = dy; a.w = w; a.res = res; a.dx = dx; a.N = c->batch;
+    const int osp[3] = {c->out_d, c->out_h, c->out_w}, isp[3] = {c->in_d, c->in_h, c->in_w};
+    const int T3[3] = {DGS_TD, DGS_TH, DGS_TW};
+    for (int i = 0; i < 3; ++i) {
+        if (osp[i] != (isp[i] + 2 - 3) / 2 + 1) return NNDET_EINVAL;
+        a.O[i] = osp[i]; a.I[i] = isp[i];
+        a.nt[i] = ceil_div((isp[i] + 1) / 2, T3[i]);
+    }
+    a.total_tiles = a.N * a.nt[0] * a.nt[1] * a.nt[2];
+    if (nr) { a.ny = nr->y; a.nmr = nr->mean_rstd; a.ngamma = nr->gamma; a.nbeta = nr->beta; a.nred = nr->red_ws; a.nrelu = nr->relu; a.ncout = nr->c; }
+    const char* ge = getenv("NNDET_DGSP_WGS");
+    int grid = ge ? atoi(ge) : 256;
+    if (grid < 1 || grid > 1024) grid = 256;
+    if (grid > a.total_tiles) grid = a.total_tiles;
+    const bool hf = c->dtype == NNDET_F16;
+#define DGSP_GO(R_, N_) (hf ? dgsp_launch<f16_t, R_, N_>(a, grid, st) : dgsp_launch<bf16_t, R_, N_>(a, grid, st))
+    if (res) return nr ? DGSP_GO(true, true) : DGSP_GO(true, false);
+    return nr ? NNDET_EINVAL : DGSP_GO(false, false);
+#undef DGSP_GO
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static uint32_t dgs_magic(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)d + 1ull); }
 
@@ -418,6 +787,10 @@ int dgs_fuses_norm_reduce(const NndetConv* c) {
 int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, void* dx, hipStream_t st, const DgsNormRed* nr) {
     if (!dgs_covers(c)) return 1;
     if (nr && !dgs_fuses_norm_reduce(c)) return NNDET_EINVAL;
+    if (dgsp_covers(c)) {                                   // the persistent form (round 6) for the full-resolution transition
+        const int prc = dgsp_run(c, dy, w, res, dx, st, nr);
+        if (prc != 1) return prc;
+    }
     DgsArgs a;
     memset(&a, 0, sizeof(a));
     a.dy = dy; a.w = w; a.res = res; a.dx = dx;

@@ -835,3 +835,55 @@ def test_norm_backward_sums_from_the_strided_data_gradient(cn, relu, shape, dtyp
     for n, t, a_, b_ in zip(names, tol, res[False], res[True]):
         e = relerr(b_, a_)
         assert e <= t, f"{n}: fused vs separate reduction rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("batch,shape", [(2, (21, 19, 35)), (1, (40, 32, 24)), (3, (9, 33, 17)), (2, (64, 48, 32))], ids=["odd", "even", "odd3", "tiles"])
+def test_persistent_strided_data_gradient_is_bit_identical_to_k_dgs(batch, shape, dtype, monkeypatch):
+    """k_dgsp (csrc/conv_dgs.hip, round 6: persistent workgroups, weights in LDS, LDS-DMA halo, two register sets of prefetched residual /
+    pre-norm values) against k_dgs (NNDET_DGSP=0) through the three C entry points of the 32 <- 64 stride-2 data gradient -- plain,
+    accumulating, accumulating + norm-backward sums: same taps, chunks and accumulation order per output element, so dx must be
+    BIT-IDENTICAL (ragged volumes, several images per workgroup walk, grids of 3 workgroups = many tiles and image changes per
+    workgroup); the sums agree to fp32 summation order and with a float64 evaluation of the stored gradient."""
+    import ctypes
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch.conv import ConvInstanceRelu, _desc, _packed
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    m = ConvInstanceRelu(3, 32, 64, 3, stride=2, padding=1, add_norm=False, add_act=False).to(dev)
+    x = torch.randn(batch, *shape, 32, device=dev).to(dtype)
+    d = _desc(x, 32, 64, m.k, m.s, m.p, False)
+    w1 = _packed(m, 1, m.conv.weight, d, dtype)
+    dy = torch.randn(batch, d.out_d, d.out_h, d.out_w, 64, device=dev).to(dtype)
+    res0 = torch.randn(batch, *shape, 32, device=dev).to(dtype)
+    ny = (torch.randn(batch, *shape, 32, device=dev) * 1.5 + 0.3).to(dtype)
+    mr = torch.stack((ny.float().mean((1, 2, 3)), 1.0 / (ny.float().var((1, 2, 3), unbiased=False) + 1e-5).sqrt()), -1).contiguous()
+    gam, bet = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.3
+    st = L.stream()
+    out = {}
+    for form, wgs in (("0", "256"), ("1", "256"), ("1", "3")):
+        monkeypatch.setenv("NNDET_DGSP", form)
+        monkeypatch.setenv("NNDET_DGSP_WGS", wgs)
+        dx_plain = torch.full_like(x, float("nan"))
+        L.call("nndet_conv3d_backward_data", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx_plain), st)
+        dx_acc = res0.clone()
+        L.call("nndet_conv3d_backward_data_acc", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx_acc), None, st)
+        dx_nb = res0.clone()
+        red = torch.zeros(L.STATS_REPLICAS * batch * 32 * 2 + batch, dtype=torch.float64, device=dev)
+        L.call("nndet_conv3d_backward_data_acc_normred", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx_nb), L.ptr(ny), L.ptr(mr), L.ptr(gam), L.ptr(bet), 1, 32,
+               L.ptr(red), st)
+        torch.cuda.synchronize()
+        out[(form, wgs)] = (dx_plain, dx_acc, dx_nb, red[:L.STATS_REPLICAS * batch * 32 * 2].view(L.STATS_REPLICAS, batch, 32, 2).sum(0))
+    ref = out[("0", "256")]
+    assert not torch.isnan(ref[0].float()).any()
+    for key in (("1", "256"), ("1", "3")):
+        got = out[key]
+        for i, what in enumerate(("plain", "accumulating", "accumulating + norm sums")):
+            assert torch.equal(got[i], ref[i]), f"{key}: dx of the {what} form differs from k_dgs"
+        assert float(((got[3] - ref[3]).abs() / ref[3].abs().clamp_min(1e-3)).max()) <= 1e-4, key
+    # the sums against float64 from the stored gradient (the definition: S1 = sum g [mask], S2 = sum g [mask] xhat)
+    xh = (ny.double() - mr[:, :, 0].double().view(batch, 1, 1, 1, 32)) * mr[:, :, 1].double().view(batch, 1, 1, 1, 32)
+    sc = (mr[:, :, 1] * gam).view(batch, 1, 1, 1, 32); sh = (bet - mr[:, :, 0] * (mr[:, :, 1] * gam)).view(batch, 1, 1, 1, 32)
+    gm = out[("1", "3")][2].double() * (torch.addcmul(sh, ny.float(), sc) > 0)
+    s64 = torch.stack((gm.sum((1, 2, 3)), (gm * xh).sum((1, 2, 3))), -1)
+    assert float(((out[("1", "3")][3] - s64).abs() / s64.abs().amax((0, 1), keepdim=True)).max()) <= 1e-6
