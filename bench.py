@@ -422,7 +422,7 @@ def measure_traffic_pmc(timeout_s=150, kernel="k_ig3r", order="fwd"):
                 kcol = "kernel_name" if "kernel_name" in cols else "name"
                 vcol = "value" if "value" in cols else "counter_value"
                 for k, c, v in db.execute(f"select {kcol}, counter_name, {vcol} from counters_collection"):
-                    if c == ctr and kernel in k:
+                    if c == ctr and kernel in k and "k_wgrad3s" not in k:
                         tot += float(v); n += 1
             if n == 0:
                 return None
@@ -551,13 +551,13 @@ def wgrad_roofline(route, plan, batch, dtype, device, in_step=8, alone=12):
     tfs = flops / (ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     if MEASURE_PMC[0] and batch == 4 and P == (160, 160, 96) and dtype == torch.bfloat16:
-        pm = measure_traffic_pmc(kernel="k_wgrad3d", order="wgrad")
+        pm = measure_traffic_pmc(kernel="k_wgrad3", order="wgrad")      # (k_wgrad3e, or k_wgrad3d under NNDET_WGRAD3D=1)
         if pm is not None and "hbm_bytes" in pm:
             traffic, traffic_src = pm["hbm_bytes"], pm
         else:
             traffic_src = pm
     dn = str(dtype).replace("torch.", "").replace("bfloat16", "bf16").replace("float16", "f16")
-    out = {"bound": "mfma", "kernel": "k_wgrad3d<%s> weight gradient of conv3d 3x3x3 32->32 @%dx%dx%d, batch %d (encoder.stages.0.convs.0.1)" % (dn, *P, batch),
+    out = {"bound": "mfma", "kernel": "k_wgrad3e<%s> (round 6 form of k_wgrad3d) weight gradient of conv3d 3x3x3 32->32 @%dx%dx%d, batch %d (encoder.stages.0.convs.0.1)" % (dn, *P, batch),
            "achieved": round(tfs, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tfs / 2500.0, 4), "traffic": traffic, "traffic_source": traffic_src,
            "algorithmic_flops_per_launch": int(flops), "algorithmic_bytes_per_launch": int(alg_bytes),
            "ms_per_launch": round(float(ms), 4), "timed": "inside the training step (HIP events on the weight-gradient stream around this one kernel, %d steps after the timed region)"

@@ -880,7 +880,8 @@ def test_persistent_strided_data_gradient_is_bit_identical_to_k_dgs(batch, shape
         got = out[key]
         for i, what in enumerate(("plain", "accumulating", "accumulating + norm sums")):
             assert torch.equal(got[i], ref[i]), f"{key}: dx of the {what} form differs from k_dgs"
-        assert float(((got[3] - ref[3]).abs() / ref[3].abs().clamp_min(1e-3)).max()) <= 1e-4, key
+        # (S2 = rstd * (sum g y - mean * sum g) cancels: compared against the largest sum of its kind, as the float64 check below)
+        assert float(((got[3] - ref[3]).abs() / ref[3].abs().amax((0, 1), keepdim=True)).max()) <= 2e-5, key
     # the sums against float64 from the stored gradient (the definition: S1 = sum g [mask], S2 = sum g [mask] xhat)
     xh = (ny.double() - mr[:, :, 0].double().view(batch, 1, 1, 1, 32)) * mr[:, :, 1].double().view(batch, 1, 1, 1, 32)
     sc = (mr[:, :, 1] * gam).view(batch, 1, 1, 1, 32); sh = (bet - mr[:, :, 0] * (mr[:, :, 1] * gam)).view(batch, 1, 1, 1, 32)

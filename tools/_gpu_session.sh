@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
-for v in 0 1 0 1; do NNDET_DGSP=$v timeout 300 python tools/phase_times.py 40 2>&1 | grep -v amdgpu.ids | tail -3 | sed "s/^/dgsp=$v /"; done | tee gpurun_out/phase_dgsp.txt
+timeout 600 python -m pytest tests/test_conv_gpu.py -m gpu -q --tb=long -p no:cacheprovider -k "persistent_strided" 2>&1 | grep -v "^$" | tail -40
