@@ -241,7 +241,14 @@ def fusable_pair(a, b, x2d: torch.Tensor) -> bool:
           and a.k == b.k == (3, 3, 3) and a.s == b.s == (1, 1, 1) and a.p == b.p == (1, 1, 1) and not a.transposed and not b.transposed
           and a.conv.bias is None and b.conv.bias is None and a.norm_groups > 0 and a.norm_groups == b.norm_groups
           and a.out_channels % a.norm_groups == 0 and a.norm_eps == b.norm_eps and a.relu == b.relu
-          and a.conv.weight.dtype == b.conv.weight.dtype == torch.float32)
+          and a.conv.weight.dtype == b.conv.weight.dtype == torch.float32
+          #  affine norms on both sides, and the same trainability: a frozen half would still get its weight-gradient work and
+          # a gradient it must not receive
+          and getattr(a.norm, "weight", None) is not None and getattr(a.norm, "bias", None) is not None
+          and getattr(b.norm, "weight", None) is not None and getattr(b.norm, "bias", None) is not None
+          and a.conv.weight.requires_grad == b.conv.weight.requires_grad
+          and a.norm.weight.requires_grad == b.norm.weight.requires_grad == a.norm.bias.requires_grad == b.norm.bias.requires_grad
+          and (a.conv.weight.requires_grad or not torch.is_grad_enabled()))
     return bool(ok)
 
 
@@ -344,7 +351,8 @@ def fused_items_blocks(a: BaseConvNormAct, b: BaseConvNormAct, x2d: torch.Tensor
     if pair is None or pair.owner() != (a, b):
         pair = _PAIRS[key] = _FusedPair(a, b)
         import weakref
-        ra, rb = weakref.ref(a), weakref.ref(b)
+        drop = lambda _r, k=key: _PAIRS.pop(k, None)          #  the entry dies with either block: ids are recycled
+        ra, rb = weakref.ref(a, drop), weakref.ref(b, drop)
         pair.owner = lambda: (ra(), rb())
     return _FusedItemsBlockFn.apply(x2d, a.conv.weight, b.conv.weight, a.norm.weight, a.norm.bias, b.norm.weight, b.norm.bias, pair, (a, b), meta)
 
