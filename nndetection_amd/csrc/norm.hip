@@ -551,8 +551,27 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const T* __restrict__ x
     for (int i = threadIdx.x; i < c_p * 2; i += 256) {
         double v = 0.0;
         const int nrep = nblk < (unsigned)NNDET_STATS_REPLICAS ? (int)nblk : NNDET_STATS_REPLICAS;     // replica = workgroup index % 32: only these were written
-        for (int r = 0; r < nrep; ++r)
-            v += __hip_atomic_load(&red_ws[(((int64_t)r * N + n) * c_p) * 2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Round 6: eight replica loads in flight per thread. The plain loop `v += load(r)` was a chain of up to 32 DEPENDENT L2 round trips at
+        // the very end of every launch -- the last workgroup of an image, alone on the chip: 18 us for 3 replicas, 45 us for 10, 50+ us for 32
+        // (profiles/round6_timeline_one_step.txt: the reductions of the 10^3 / 5^3-voxel layers took 4 x their apply passes). Same order of
+        // additions: bit-identical sums.
+        const double* src = red_ws + ((int64_t)n * c_p) * 2 + i;
+        const int64_t rstride = (int64_t)N * c_p * 2;
+        int r = 0;
+        for (; r + 8 <= nrep; r += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = __hip_atomic_load(src + (int64_t)(r + u) * rstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = r + u < nrep ? __hip_atomic_load(src + (int64_t)(r + u) * rstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (r + u < nrep) v += t[u];
+        }
         ch[i] = v;
     }
     __syncthreads();
