@@ -1415,29 +1415,44 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3s(const WgArgs A, const Wg3sIn
 
 static const WgItems g_wg_no_items = {};
 
-// dW[r][k][tap] += sum_s part[s][pair][tap][r%32][k%32]; one thread per (pair, tap, r, k); consecutive threads = consecutive k.
-// With !SPLIT (1-3 taps) every wave holds a partial of every tap: those are summed here too (nsub = 4 sub-slices).
+// dW[r][k][tap] += sum_s part[s][pair][tap][r%32][k%32].
+// Round 6: one workgroup per (pair, row r) and block of 32 slices. The first form had one thread per element in the PARTIAL layout
+// ([tap][r][k], k fastest) and wrote dW[r][k][tap] from there: consecutive threads 27 floats apart, every 128-byte line of dW touched by
+// 27 different threads (read-modify-write) -- 34 us for the 22 MB of a 320 x 320 layer, 0.65 ms of kernel time per step on the stream that
+// ends the step. Here the (tap, k) tile of one output row is summed with coalesced reads (32 k = 128 bytes per tap and slice),
+// transposed through LDS and written as ONE contiguous run of 32 x ntap floats of dW (PyTorch layout: [r][k][tap]). Same order of
+// additions over the slices: same values.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int S, int pairs, int kb, int ntap,
-                                                      int R, int K, int64_t sr, int64_t sk, float* __restrict__ dw, int64_t total) {
-    // grid (ceil(total / 256), ceil(S / 32)): a thread sums 32 slices of one element (coalesced across threads), then
-    // one atomic per thread: total * S / 32 atomics (< 1 M) instead of the 42 M of the atomics-only scheme.
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int k = (int)(e & 31), r = (int)((e >> 5) & 31);
-    const int64_t pt = e >> 10;               // pair * ntap + tap
-    const int t = (int)(pt % ntap), pair = (int)(pt / ntap);
+                                                      int R, int K, int64_t sr, int64_t sk, float* __restrict__ dw) {
+    __shared__ float tile[27 * 32 + 32];
+    const int pair = blockIdx.x >> 5, r = blockIdx.x & 31;
     const int rbi = pair / kb, kbi = pair % kb;
-    const int rg = rbi * 32 + r, kg = kbi * 32 + k;
-    if (rg >= R || kg >= K) return;
+    const int rg = rbi * 32 + r;
+    if (rg >= R) return;                                  // uniform
+    const int ne = ntap * 32;
     const int64_t stride = (int64_t)pairs * ntap * 1024;
     const int s0 = blockIdx.y * 32, s1 = min(S, s0 + 32);
-    float acc = 0.f;
-    const float* src = part + e + (int64_t)s0 * stride;
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        const int t = e >> 5, k = e & 31;
+        const float* src = part + ((int64_t)pair * ntap + t) * 1024 + r * 32 + k + (int64_t)s0 * stride;
+        float acc = 0.f;
 #pragma unroll 8
-    for (int s2 = s0; s2 < s1; ++s2, src += stride) acc += *src;
-    float* dst = &dw[rg * sr + kg * sk + t];
-    if (gridDim.y == 1) *dst += acc;          // single writer per element (S <= 32): no atomic needed, deterministic
-    else atomicAdd(dst, acc);
+        for (int s2 = s0; s2 < s1; ++s2, src += stride) acc += *src;
+        tile[k * ntap + t] = acc;                         // (27 is odd: consecutive k land on different banks)
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < ne; w += 256) {
+        const int k = w / ntap, t = w - k * ntap;
+        const int kg = kbi * 32 + k;
+        if (kg >= K) continue;
+        float* dst = &dw[rg * sr + kg * sk + t];          // sk == ntap: w runs through 32 x ntap CONSECUTIVE floats
+        if (gridDim.y == 1) *dst += tile[w];              // single writer per element (S <= 32): no atomic needed, deterministic
+        else atomicAdd(dst, tile[w]);
+    }
+}
+static inline void wgrad_reduce_launch(const float* part, int S, int pairs, int kb, int ntap, int R, int K, int64_t sr, int64_t sk, float* dw,
+                                       hipStream_t st) {
+    k_wgrad_reduce<<<dim3((unsigned)pairs * 32, (unsigned)ceil_div(S, 32)), 256, 0, st>>>(part, S, pairs, kb, ntap, R, K, sr, sk, dw);
 }
 
 template <typename T, int KS, int MAXP, int MAXQ, bool PF, int NTS, bool SPLIT, int RBK = 1>
@@ -1689,7 +1704,7 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
                                    : wgrad3d_launch<bf16_t, false>(b, g_wg_no_items, dim3(Sd, rb, kb), st);
                 if (rcd) return rcd;
                 const int64_t totald = (int64_t)rb * kb * 27 * 1024;
-                k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totald, 256), ceil_div(Sd, 32)), 256, 0, st>>>(b.part, Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totald);
+                wgrad_reduce_launch(b.part, Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
                 LAUNCH_CHECK();
                 return 0;
             }
@@ -1713,7 +1728,7 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
             }
             LAUNCH_CHECK();
             const int64_t total3 = (int64_t)rb * kb * 27 * 1024;
-            k_wgrad_reduce<<<dim3((unsigned)ceil_div64(total3, 256), ceil_div(S3, 32)), 256, 0, st>>>(b.part, S3, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, total3);
+            wgrad_reduce_launch(b.part, S3, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
             LAUNCH_CHECK();
             return 0;
         }
@@ -1752,7 +1767,7 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
         else k_wgrad3s<bf16_t><<<gs, 512, lds_s, st>>>(b, inc);
         LAUNCH_CHECK();
         const int64_t totals = (int64_t)rb * kb * 27 * 1024;
-        k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totals, 256), ceil_div(Ss, 32)), 256, 0, st>>>(b.part, Ss, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totals);
+        wgrad_reduce_launch(b.part, Ss, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
         LAUNCH_CHECK();
         return 0;
     }
@@ -1761,7 +1776,7 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
     else rc = KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
     if (rc) return rc;
     const int64_t total = (int64_t)rb * kb * a.ntap * 1024;
-    k_wgrad_reduce<<<dim3((unsigned)ceil_div64(total, 256), ceil_div(slices, 32)), 256, 0, st>>>(a.part, slices, rb * kb, kb, a.ntap, a.R, a.K, a.sr, a.sk, dw, total);
+    wgrad_reduce_launch(a.part, slices, rb * kb, kb, a.ntap, a.R, a.K, a.sr, a.sk, dw, st);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1817,7 +1832,7 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
         const int rcd = hf ? wgrad3d_launch<f16_t, true>(b, wi, dim3(Sd, rb, kb), st) : wgrad3d_launch<bf16_t, true>(b, wi, dim3(Sd, rb, kb), st);
         if (rcd) return rcd;
         const int64_t totald = (int64_t)rb * kb * 27 * 1024;
-        k_wgrad_reduce<<<dim3((unsigned)ceil_div64(totald, 256), ceil_div(Sd, 32)), 256, 0, st>>>(b.part, Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, totald);
+        wgrad_reduce_launch(b.part, Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
         LAUNCH_CHECK();
         return 0;
     }
@@ -1848,7 +1863,7 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
     else k_wgrad3<float, 1, false, 2, true><<<g3, 256, lds3, st>>>(b, wi);
     LAUNCH_CHECK();
     const int64_t total3 = (int64_t)rb * kb * 27 * 1024;
-    k_wgrad_reduce<<<dim3((unsigned)ceil_div64(total3, 256), ceil_div(S3, 32)), 256, 0, st>>>(b.part, S3, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, total3);
+    wgrad_reduce_launch(b.part, S3, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
     LAUNCH_CHECK();
     return 0;
 }

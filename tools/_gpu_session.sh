@@ -1,7 +1,5 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out; O=gpurun_out
-echo "== full GPU suite"; timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -6 | cut -c1-300 | tee $O/t_full.txt
-echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-echo "== bench (driver flags)"; timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.txt 2>$O/bench_err.txt; tail -c 300 $O/bench_driver_flags.txt
-echo "== phase times"; timeout 300 python tools/phase_times.py > $O/phase_times.txt 2>&1; tail -3 $O/phase_times.txt
-echo "== prof"; tools/gpu_round.sh prof > $O/prof_stdout.txt 2>&1; head -8 $O/kernel_stats.txt | cut -c1-150; head -3 $O/timeline.txt
-echo "== step traffic"; tools/gpu_round.sh steptraffic > $O/steptraffic_stdout.txt 2>&1; tail -20 $O/steptraffic_stdout.txt | head -16 | cut -c1-120
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_conv_gpu.py tests/test_pyramid_gpu.py -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -3
+MICRO_ITERS=20 MICRO_ORDER=wgrad,wgrad timeout 300 python tools/conv_microbench.py e0_32x32_full e1_64x64 p2_128x128 e3_256x256 e4_320x320 e1_32to64_s2 lat_p1_1x1 2>&1 | grep -v amdgpu.ids
+NNDET_AMD_LIB=$PWD/nndetection_amd/csrc/libnndet_amd_prev.so MICRO_ITERS=20 MICRO_ORDER=wgrad,wgrad timeout 300 python tools/conv_microbench.py e0_32x32_full e1_64x64 p2_128x128 e3_256x256 e4_320x320 e1_32to64_s2 lat_p1_1x1 2>&1 | grep -v amdgpu.ids | sed "s/^/prev /"
+rm -f gpurun_out/ablib.txt; bash tools/gpu_round.sh ablib 2>&1 | tail -4
