@@ -85,10 +85,6 @@ __global__ __launch_bounds__(128) void k_ho_backward(const int32_t* __restrict__
     const int qd = pd + t / 9 - 1, qh = ph + (t / 3) % 3 - 1, qw = pw + t % 3 - 1;
     const bool inside = (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W;
     const int c0 = c0s[k];
-    if constexpr (MODE == 1) {
-        if (t == 13 && dbias && (int)threadIdx.x < G && c0 + (int)threadIdx.x < cout)          // (the centre tap is always inside)
-            atomicAdd(dbias + c0 + threadIdx.x, vals[(int64_t)k * G + threadIdx.x]);
-    }
     if (!inside) return;                                                     // zero padding (uniform)
     const int64_t qrow = It.row_off[it] + ((int64_t)qd * H + qh) * W + qw;
     if constexpr (MODE == 0) {
@@ -100,19 +96,78 @@ __global__ __launch_bounds__(128) void k_ho_backward(const int32_t* __restrict__
 #pragma unroll
         for (int g = 0; g < 8; ++g) v[g] = (g < G && c0 + g < cout) ? vals[(int64_t)k * G + g] : 0.f;
         for (int ci = threadIdx.x; ci < cin; ci += blockDim.x) {
-            const float xv = Elem<T>::ld(x[qrow * cin_p + ci]);
             float acc = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 if (g < G && c0 + g < cout) {
                     const int64_t wi = ((int64_t)(c0 + g) * cin + ci) * 27 + t;
                     acc = fmaf(v[g], w[wi], acc);                            // y[p][c] = sum W[c][ci][t] x[p + t - 1][ci]
-                    atomicAdd(dw + wi, v[g] * xv);
                 }
             }
             atomicAdd(dx32 + qrow * cin_p + ci, acc);
         }
     }
+}
+
+// Weight and bias gradient of the output convolution from the K entries, GATHERED (round 6): one workgroup per (output channel c, tap t),
+// thread = input channel: dW[c][ci][t] += sum over the entries k that cover c (c0_k <= c < c0_k + G) of v_k[c - c0_k] * x[row_k + t - 1][ci],
+// in entry order, ONE writer per element. The first form scattered from k_ho_backward<1> with 6-8 fp32 atomics per thread into dW (870 k
+// atomics for the regressor's 42 entries): 47-50 us per output convolution on the chain at the start of the backward pass whatever the
+// number of entries, and a summation order that changed from run to run. Here every workgroup looks at the K (row, c0) pairs once
+// (flags in LDS), then touches only its ~K G / cout matching entries.
+template <typename T>
+__global__ __launch_bounds__(128) void k_ho_wgrad(const int32_t* __restrict__ rows, const int32_t* __restrict__ c0s, const float* __restrict__ vals,
+                                                  int K, int G, const HoItems It, const T* __restrict__ x, int cin, int cin_p, int cout,
+                                                  float* __restrict__ dw, float* __restrict__ dbias) {
+    __shared__ int64_t qrow_s[256];        // row of the tap's voxel of entry k0 + i (-1: not covering c / unused slot / outside the volume)
+    __shared__ float val_s[256];
+    const int c = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};   // ci = tid + 128 i (cin <= 512)
+    float bsum = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 256) {
+        __syncthreads();
+        for (int i = tid; i < 256; i += 128) {
+            const int k = k0 + i;
+            int64_t q = -1;
+            float v = 0.f;
+            if (k < K) {
+                const int row = rows[k], g = c - c0s[k];
+                if (row >= 0 && g >= 0 && g < G) {
+                    v = vals[(int64_t)k * G + g];
+                    int it = 0;
+                    while (it + 1 < It.n && row >= It.row_off[it + 1]) ++it;
+                    const int D = It.dims[it][0], H = It.dims[it][1], W = It.dims[it][2];
+                    const int pos = row - (int)It.row_off[it];
+                    const int pd = pos / (H * W), ph = (pos / W) % H, pw = pos % W;
+                    const int qd = pd + t / 9 - 1, qh = ph + (t / 3) % 3 - 1, qw = pw + t % 3 - 1;
+                    if ((unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W)
+                        q = It.row_off[it] + ((int64_t)qd * H + qh) * W + qw;
+                    else q = -2;                                   // covers c, tap outside the volume (zero padding): bias only
+                }
+            }
+            qrow_s[i] = q; val_s[i] = v;
+        }
+        __syncthreads();
+        const int n = min(256, K - k0);
+        for (int i = 0; i < n; ++i) {
+            const int64_t q = qrow_s[i];
+            if (q == -1) continue;                                 // uniform
+            const float v = val_s[i];
+            bsum += v;
+            if (q < 0) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ci = tid + 128 * u;
+                if (ci < cin) acc[u] = fmaf(v, Elem<T>::ld(x[q * cin_p + ci]), acc[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ci = tid + 128 * u;
+        if (ci < cin && acc[u] != 0.f) dw[((int64_t)c * cin + ci) * 27 + t] += acc[u];
+    }
+    if (t == 13 && tid == 0 && dbias && bsum != 0.f) dbias[c] += bsum;      // (the centre tap is always inside: every covering entry counts once)
 }
 
 // Forward of an output convolution at K sampled anchors only (training: the regression loss reads the box deltas of the <= 42 sampled
@@ -315,7 +370,7 @@ extern "C" int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetIte
     if (!c || !items || items->n_items < 1 || items->n_items > NNDET_MAX_ITEMS || K < 0 || G <= 0 || G > 8) return NNDET_EINVAL;
     if (c->transposed || c->cin_p % 32 || c->cout_p % 32) return NNDET_EINVAL;
     for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 1 || c->p[i] != 1) return NNDET_EINVAL;
-    if (!x || !w_f32 || !dx32_scratch || !dx_zeroed || !dw) return NNDET_EINVAL;
+    if (!x || !w_f32 || !dx32_scratch || !dx_zeroed || !dw || c->cin > 512) return NNDET_EINVAL;
     if (K == 0) return 0;
     if (!rows || !c0 || !vals) return NNDET_EINVAL;
     hipStream_t st = as_stream(stream);
@@ -324,7 +379,8 @@ extern "C" int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetIte
     const dim3 grid(K, 27);
 #define HO_BWD(T_, MODE_) k_ho_backward<T_, MODE_><<<grid, 128, 0, st>>>(rows, c0, vals, G, It, (const T_*)x, c->cin, c->cin_p, w_f32, c->cout, \
                                                                          dx32_scratch, (T_*)dx_zeroed, dw, dbias)
-#define HO_ALL(T_) do { HO_BWD(T_, 0); HO_BWD(T_, 1); HO_BWD(T_, 2); } while (0)
+#define HO_ALL(T_) do { HO_BWD(T_, 0); HO_BWD(T_, 1); HO_BWD(T_, 2); \
+                        k_ho_wgrad<T_><<<dim3(c->cout, 27), 128, 0, st>>>(rows, c0, vals, K, G, It, (const T_*)x, c->cin, c->cin_p, c->cout, dw, dbias); } while (0)
     if (c->dtype == NNDET_BF16) HO_ALL(bf16_t);
     else if (c->dtype == NNDET_F16) HO_ALL(f16_t);
     else if (c->dtype == NNDET_F32) HO_ALL(float);
