@@ -115,14 +115,26 @@ __global__ __launch_bounds__(128) void k_ho_backward(const int32_t* __restrict__
 // atomics for the regressor's 42 entries): 47-50 us per output convolution on the chain at the start of the backward pass whatever the
 // number of entries, and a summation order that changed from run to run. Here every workgroup looks at the K (row, c0) pairs once
 // (flags in LDS), then touches only its ~K G / cout matching entries.
-template <typename T>
+template <typename T, int NU>
 __global__ __launch_bounds__(128) void k_ho_wgrad(const int32_t* __restrict__ rows, const int32_t* __restrict__ c0s, const float* __restrict__ vals,
                                                   int K, int G, const HoItems It, const T* __restrict__ x, int cin, int cin_p, int cout,
                                                   float* __restrict__ dw, float* __restrict__ dbias) {
-    __shared__ int64_t qrow_s[256];        // row of the tap's voxel of entry k0 + i (-1: not covering c / unused slot / outside the volume)
-    __shared__ float val_s[256];
+    constexpr int EB = 16 / NU;            // entries per batch: 16 row loads in flight per thread
+    __shared__ int64_t it_off[NNDET_MAX_ITEMS];    // the item table in LDS: the slots decode their entries in PARALLEL with per-lane item indices
+    __shared__ int it_dim[NNDET_MAX_ITEMS][3];     // (a per-lane index into the by-value kernel argument would send the table to scratch; decoding the
+                                                   //  covering entries one after the other cost 4 integer divisions each: 72 us when one anchor class
+                                                   //  holds most of the sampled anchors)
+    __shared__ int64_t q_s[256];           // slot i of the chunk: row of the tap's voxel of entry k0 + i, -2 = zero padding, -1 = does not cover c
+    __shared__ float v_s[256];
+    __shared__ int64_t cq_s[256];          // the covering entries compacted in entry order
+    __shared__ float cv_s[256];
+    __shared__ int cn_s;
     const int c = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};   // ci = tid + 128 i (cin <= 512)
+    if (tid < It.n) { it_off[tid] = It.row_off[tid]; it_dim[tid][0] = It.dims[tid][0]; it_dim[tid][1] = It.dims[tid][1]; it_dim[tid][2] = It.dims[tid][2]; }
+    const int nit = It.n;
+    float acc[NU];                         // ci = tid + 128 u (cin <= 128 NU)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = 0.f;
     float bsum = 0.f;
     for (int k0 = 0; k0 < K; k0 += 256) {
         __syncthreads();
@@ -135,35 +147,57 @@ __global__ __launch_bounds__(128) void k_ho_wgrad(const int32_t* __restrict__ ro
                 if (row >= 0 && g >= 0 && g < G) {
                     v = vals[(int64_t)k * G + g];
                     int it = 0;
-                    while (it + 1 < It.n && row >= It.row_off[it + 1]) ++it;
-                    const int D = It.dims[it][0], H = It.dims[it][1], W = It.dims[it][2];
-                    const int pos = row - (int)It.row_off[it];
+                    while (it + 1 < nit && row >= it_off[it + 1]) ++it;
+                    const int D = it_dim[it][0], H = it_dim[it][1], W = it_dim[it][2];
+                    const int pos = row - (int)it_off[it];
                     const int pd = pos / (H * W), ph = (pos / W) % H, pw = pos % W;
                     const int qd = pd + t / 9 - 1, qh = ph + (t / 3) % 3 - 1, qw = pw + t % 3 - 1;
-                    if ((unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W)
-                        q = It.row_off[it] + ((int64_t)qd * H + qh) * W + qw;
-                    else q = -2;                                   // covers c, tap outside the volume (zero padding): bias only
+                    q = ((unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W)
+                            ? it_off[it] + ((int64_t)qd * H + qh) * W + qw : -2;
                 }
             }
-            qrow_s[i] = q; val_s[i] = v;
+            q_s[i] = q; v_s[i] = v;
         }
         __syncthreads();
-        const int n = min(256, K - k0);
-        for (int i = 0; i < n; ++i) {
-            const int64_t q = qrow_s[i];
-            if (q == -1) continue;                                 // uniform
-            const float v = val_s[i];
-            bsum += v;
-            if (q < 0) continue;
+        if (tid < 64) {                    // wave 0: ballot + prefix count per group of 64 slots -> entry order kept
+            int base = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ci = tid + 128 * u;
-                if (ci < cin) acc[u] = fmaf(v, Elem<T>::ld(x[q * cin_p + ci]), acc[u]);
+            for (int grp = 0; grp < 4; ++grp) {
+                const int64_t q = q_s[grp * 64 + tid];
+                const float v = v_s[grp * 64 + tid];
+                const unsigned long long m = __ballot(q != -1);
+                if (q != -1) { const int at = base + __popcll(m & ((1ULL << tid) - 1ULL)); cq_s[at] = q; cv_s[at] = v; }
+                base += __popcll(m);
+            }
+            if (tid == 0) cn_s = base;
+        }
+        __syncthreads();
+        const int n = cn_s;
+        for (int i = 0; i < n; i += EB) {
+            float v4[EB], x4[EB][NU];
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const int64_t q = i + e < n ? cq_s[i + e] : -2;
+                v4[e] = i + e < n ? cv_s[i + e] : 0.f;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    // UNCONDITIONAL load of a clamped address (a conditional load makes hipcc branch and wait per load: one round trip each);
+                    // entries that do not count carry v = 0 or are zeroed here
+                    const int ci = min(tid + 128 * u, cin - 1);
+                    const float xv = Elem<T>::ld(x[(q >= 0 ? q : 0) * cin_p + ci]);
+                    x4[e][u] = (q >= 0 && tid + 128 * u < cin) ? xv : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                bsum += v4[e];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) acc[u] = fmaf(v4[e], x4[e][u], acc[u]);
             }
         }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int ci = tid + 128 * u;
         if (ci < cin && acc[u] != 0.f) dw[((int64_t)c * cin + ci) * 27 + t] += acc[u];
     }
@@ -380,7 +414,9 @@ extern "C" int nndet_conv_out_sparse_backward(const NndetConv* c, const NndetIte
 #define HO_BWD(T_, MODE_) k_ho_backward<T_, MODE_><<<grid, 128, 0, st>>>(rows, c0, vals, G, It, (const T_*)x, c->cin, c->cin_p, w_f32, c->cout, \
                                                                          dx32_scratch, (T_*)dx_zeroed, dw, dbias)
 #define HO_ALL(T_) do { HO_BWD(T_, 0); HO_BWD(T_, 1); HO_BWD(T_, 2); \
-                        k_ho_wgrad<T_><<<dim3(c->cout, 27), 128, 0, st>>>(rows, c0, vals, K, G, It, (const T_*)x, c->cin, c->cin_p, c->cout, dw, dbias); } while (0)
+                        if (c->cin <= 128) k_ho_wgrad<T_, 1><<<dim3(c->cout, 27), 128, 0, st>>>(rows, c0, vals, K, G, It, (const T_*)x, c->cin, c->cin_p, c->cout, dw, dbias); \
+                        else if (c->cin <= 256) k_ho_wgrad<T_, 2><<<dim3(c->cout, 27), 128, 0, st>>>(rows, c0, vals, K, G, It, (const T_*)x, c->cin, c->cin_p, c->cout, dw, dbias); \
+                        else k_ho_wgrad<T_, 4><<<dim3(c->cout, 27), 128, 0, st>>>(rows, c0, vals, K, G, It, (const T_*)x, c->cin, c->cin_p, c->cout, dw, dbias); } while (0)
     if (c->dtype == NNDET_BF16) HO_ALL(bf16_t);
     else if (c->dtype == NNDET_F16) HO_ALL(f16_t);
     else if (c->dtype == NNDET_F32) HO_ALL(float);
