@@ -427,8 +427,8 @@ _cumask_streams = []                                 # (keeps the raw handles al
 
 def cumask_stream(dev, spec: str):
     """A stream restricted to a CU partition (hipExtStreamCreateWithCUMask through the C ABI), as a torch.cuda.ExternalStream.
-    spec: "N" = the first N CUs of the mask order, "N/S" = N CUs taken with stride S... written out: CU i is enabled iff
-    (i % S) < N % S ... kept simple: "N" -> bits [0, N); "xHEX" -> the literal 256-bit mask, least significant word first."""
+    spec: "N" = CUs [0, N) of the mask order; "N:S" = N of every S consecutive CUs (an interleaved partition); "xHEX" = the literal
+    256-bit mask. Measured in round 6: a CU-masked queue runs the training step 3 x slower whatever the mask (profiles/round6_ab_cumask.txt)."""
     words = (C.c_uint32 * 8)()
     if spec.startswith("x"):
         v = int(spec[1:], 16)

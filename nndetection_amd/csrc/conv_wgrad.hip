@@ -1703,7 +1703,6 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
                 const int rcd = hf ? wgrad3d_launch<f16_t, false>(b, g_wg_no_items, dim3(Sd, rb, kb), st)
                                    : wgrad3d_launch<bf16_t, false>(b, g_wg_no_items, dim3(Sd, rb, kb), st);
                 if (rcd) return rcd;
-                const int64_t totald = (int64_t)rb * kb * 27 * 1024;
                 wgrad_reduce_launch(b.part, Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
                 LAUNCH_CHECK();
                 return 0;
@@ -1727,7 +1726,6 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
                 else k_wgrad3<float, 1, false><<<g3, 256, lds3, st>>>(b, g_wg_no_items);
             }
             LAUNCH_CHECK();
-            const int64_t total3 = (int64_t)rb * kb * 27 * 1024;
             wgrad_reduce_launch(b.part, S3, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
             LAUNCH_CHECK();
             return 0;
@@ -1766,7 +1764,6 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
         if (hf) k_wgrad3s<f16_t><<<gs, 512, lds_s, st>>>(b, inc);
         else k_wgrad3s<bf16_t><<<gs, 512, lds_s, st>>>(b, inc);
         LAUNCH_CHECK();
-        const int64_t totals = (int64_t)rb * kb * 27 * 1024;
         wgrad_reduce_launch(b.part, Ss, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
         LAUNCH_CHECK();
         return 0;
@@ -1775,7 +1772,6 @@ int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, floa
     else if (bf) rc = KS == 8 ? wg_dispatch<bf16_t, 8, 4, 10, true>(a, grid, lds, st) : wg_dispatch<bf16_t, 2, 1, 12, true>(a, grid, lds, st, rbk);
     else rc = KS == 8 ? wg_dispatch<float, 8, 8, 20, false>(a, grid, lds, st) : wg_dispatch<float, 2, 2, 24, false>(a, grid, lds, st);
     if (rc) return rc;
-    const int64_t total = (int64_t)rb * kb * a.ntap * 1024;
     wgrad_reduce_launch(a.part, slices, rb * kb, kb, a.ntap, a.R, a.K, a.sr, a.sk, dw, st);
     LAUNCH_CHECK();
     return 0;
@@ -1831,7 +1827,6 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
         b.part = reinterpret_cast<float*>(ws);
         const int rcd = hf ? wgrad3d_launch<f16_t, true>(b, wi, dim3(Sd, rb, kb), st) : wgrad3d_launch<bf16_t, true>(b, wi, dim3(Sd, rb, kb), st);
         if (rcd) return rcd;
-        const int64_t totald = (int64_t)rb * kb * 27 * 1024;
         wgrad_reduce_launch(b.part, Sd, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
         LAUNCH_CHECK();
         return 0;
@@ -1862,7 +1857,6 @@ int wgrad_items_run(const NndetConv* c, const NndetItems* it, const void* x, con
     else if (bf) k_wgrad3<bf16_t, 2, false, 1, true><<<g3, 256, lds3, st>>>(b, wi);
     else k_wgrad3<float, 1, false, 2, true><<<g3, 256, lds3, st>>>(b, wi);
     LAUNCH_CHECK();
-    const int64_t total3 = (int64_t)rb * kb * 27 * 1024;
     wgrad_reduce_launch(b.part, S3, rb * kb, kb, 27, b.R, b.K, b.sr, b.sk, dw, st);
     LAUNCH_CHECK();
     return 0;
