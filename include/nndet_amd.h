@@ -318,6 +318,17 @@ int nndet_conv3d_forward(const NndetConv* c, const void* x, const void* w_packed
                          const void* residual /* NULL or [N,od,oh,ow,cout_p]: y = conv + bias + residual (UFPN top-down add,
                                                 nndet/arch/decoder/base.py:410) */,
                          void* y, double* stats, void* stream);
+/* The forward convolution of a block whose INPUT arrives pre-norm (c->in_affine set: the coefficient table of nndet_norm_finalize,
+ * nndet/arch/conv.py:195,271 conv -> norm -> ReLU -> next conv), for a producer whose normalised output is ALSO needed in HBM (the
+ * decoder's lateral, the segmentation branch and the backward pass read it): ONE call that
+ *   writes  x_norm = relu?(x_pre * scale + shift)   (what nndet_norm_apply / nndet_affine_apply write, bit for bit) and
+ *   returns y = conv(x_norm) (+ bias, + statistics) exactly as nndet_conv3d_forward(x_norm) would.
+ * For the 32 -> 64 stride-2 3x3x3 transition on 16-bit types (nndet_conv3d_forward_norm_input_fused(c) != 0) this is ONE launch
+ * (k_ig3s<.., PRE>: the halo is transformed in LDS and the tile's core voxels are stored on the way), i.e. the separate 1.26 GB
+ * normalisation pass of the largest activation disappears; every other problem runs nndet_affine_apply + nndet_conv3d_forward. */
+int32_t nndet_conv3d_forward_norm_input_fused(const NndetConv* c);
+int nndet_conv3d_forward_norm_input(const NndetConv* c, const void* x_pre, void* x_norm, const void* w_packed_mode0, const float* bias,
+                                    void* y, double* stats, void* stream);
 /* dx[N,id,ih,iw,cin_p] = conv^T(dy[N,od,oh,ow,cout_p]) */
 int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w_packed_mode1,
                                void* dx, void* stream);

@@ -108,6 +108,8 @@ SIGNATURES = {
     "nndet_conv3d_backward_data": (C.c_int, [_CONVP, _P, _P, _P, _P]),
     "nndet_conv3d_splitk_workspace_bytes": (_SZ, [_CONVP, _I32]),
     "nndet_conv3d_forward_ws": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "nndet_conv3d_forward_norm_input_fused": (C.c_int32, [_CONVP]),
+    "nndet_conv3d_forward_norm_input": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_conv3d_backward_data_ws": (C.c_int, [_CONVP, _P, _P, _P, _P, _SZ, _P]),
     "nndet_conv3d_dgrad_fuses_bias": (_I32, [_CONVP]),
     "nndet_conv3d_backward_data_bias": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),

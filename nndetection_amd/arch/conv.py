@@ -198,6 +198,28 @@ DEFER_NORM = os.environ.get("NNDET_DEFER_NORM", "0") != "0"
 EARLY_CONSUMER = os.environ.get("NNDET_EARLY_CONSUMER", "0") != "0"
 _pre_event = [None]
 
+# Round 6: the consumer WRITES the normalised tensor (NNDET_NORM_INPUT_FUSE=0 disables it). Same producer / consumer pair, but no second
+# pass at all: the producer only computes the coefficient table (nndet_norm_finalize) and hands on an UNWRITTEN output buffer tagged
+# `_nndet_pre = (pre-norm tensor, table, relu, None, state)`; the stride-2 convolution reads the pre-norm tensor, transforms the halo
+# in LDS and stores each tile's core voxels of the normalised tensor on the way (nndet_conv3d_forward_norm_input -> k_ig3s<.., PRE>,
+# csrc/conv_ig3s.hip). 1.26 GB read + written once less on the serial chain of the forward pass; bit-identical values. Anybody else
+# who meets the tag first (`ensure_materialized`: the encoder after the stage, a hook, a consumer the fused launch does not cover)
+# writes the buffer with the plain nndet_affine_apply pass.
+NORM_INPUT_FUSE = os.environ.get("NNDET_NORM_INPUT_FUSE", "1") != "0"
+
+
+def ensure_materialized(x: torch.Tensor) -> None:
+    """Write the normalised tensor behind an unconsumed `_nndet_pre` fill tag (see NORM_INPUT_FUSE) on the current stream."""
+    pre = getattr(x, "_nndet_pre", None)
+    if pre is None or len(pre) < 5 or pre[4]["done"]:
+        return
+    y_p, _ = phys(pre[0])
+    x_p, _ = phys(x)
+    N, cp = y_p.shape[0], y_p.shape[4]
+    spatial = y_p.shape[1] * y_p.shape[2] * y_p.shape[3]
+    L.call("nndet_affine_apply", L.dtype_code(y_p), L.ptr(y_p), L.ptr(pre[1]), N, spatial, cp, int(pre[2]), L.ptr(x_p), L.stream())
+    pre[4]["done"] = True
+
 
 def deferred(x: torch.Tensor):
     """(scale_shift [N, C_p, 2] fp32, relu) if `x` is a DEFERRED activation -- the pre-norm output of a conv block whose
@@ -358,12 +380,14 @@ class _ConvFn(torch.autograd.Function):
                 raise L.NndetError("deferred input normalisation: unsupported consumer or coefficient table shape")
             desc.in_affine, desc.in_relu = x_ss.data_ptr(), int(x_relu)
         x_bwd, desc_bwd = x_p, desc
+        x_fill = None
         if pre is not None:                      # early consumer: THIS launch reads the pre-norm tensor + table; backward sees the plain input
             pre_p, _ = phys(pre[0])
             if x_ss is not None or tuple(pre_p.shape) != tuple(x_p.shape) or pre_p.dtype != x_p.dtype or tuple(pre[1].shape) != (desc.batch, desc.cin_p, 2):
                 raise L.NndetError("early consumer: the pre-norm tensor does not match the input")
             desc = _desc(x_p, mod.in_channels, mod.out_channels, mod.k, mod.s, mod.p, mod.transposed)
             desc.in_affine, desc.in_relu = pre[1].data_ptr(), int(pre[2])
+            x_fill = x_p if len(pre) > 4 else None   # NORM_INPUT_FUSE: this launch also WRITES the normalised input
             x_p = pre_p
         dev, dt = x_p.device, x_p.dtype
         N, cout, cout_p = desc.batch, desc.cout, desc.cout_p
@@ -387,7 +411,13 @@ class _ConvFn(torch.autograd.Function):
             if tuple(r_p.shape) != tuple(y.shape):
                 raise L.NndetError(f"residual shape {tuple(residual.shape)} does not match the conv output")
         sk = 0 if stem else _splitk_bytes(mod, desc, 0)
-        if sk:                                   # small problem: the channel chunks are spread over several workgroups per tile
+        if x_fill is not None:
+            if residual is not None or stem:
+                raise L.NndetError("norm-input fusion: unsupported consumer")
+            L.call("nndet_conv3d_forward_norm_input", ctypes.byref(desc), L.ptr(x_p), L.ptr(x_fill), L.ptr(w_arg), L.ptr(b_p), L.ptr(y), L.ptr(stats),
+                   L.stream())
+            pre[4]["done"] = True
+        elif sk:                                   # small problem: the channel chunks are spread over several workgroups per tile
             ws = L.workspace(sk, dev)
             L.call("nndet_conv3d_forward_ws", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats),
                    L.ptr(ws), sk, L.stream())
@@ -524,7 +554,7 @@ class _NormFn(torch.autograd.Function):
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         mean_rstd = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
         code = L.dtype_code(y_p)
-        if materialize and materialize != 2:
+        if materialize and materialize not in (2, 3):
             out_p = torch.empty_like(y_p)
             L.call("nndet_norm_apply", code, L.ptr(y_p), L.ptr(stats), L.ptr(g32), L.ptr(b32), N, spatial, cout, cout_p,
                    mod.norm_groups, float(mod.norm_eps), int(mod.relu), L.ptr(out_p), L.ptr(mean_rstd), L.stream())
@@ -534,7 +564,9 @@ class _NormFn(torch.autograd.Function):
             ss = torch.empty((N, cout_p, 2), dtype=torch.float32, device=dev)
             L.call("nndet_norm_finalize", L.ptr(stats), L.ptr(g32), L.ptr(b32), N, spatial, cout, cout_p, mod.norm_groups,
                    float(mod.norm_eps), L.ptr(mean_rstd), L.ptr(ss), L.stream())
-            if materialize == 2:                              # early consumer: materialise on the auxiliary stream (see EARLY_CONSUMER)
+            if materialize == 3:                              # the first consumer writes it (see NORM_INPUT_FUSE)
+                out = logical(torch.empty_like(y_p), cout)
+            elif materialize == 2:                            # early consumer: materialise on the auxiliary stream (see EARLY_CONSUMER)
                 out_p = torch.empty_like(y_p)
                 cur, aux = torch.cuda.current_stream(dev), L.aux_stream(dev)
                 ev = torch.cuda.Event()
@@ -677,6 +709,15 @@ class BaseConvNormAct(nn.Sequential):
         if initializer is not None:
             self.apply(initializer)
 
+    def _norm_input_fused(self, x: torch.Tensor, pre) -> bool:
+        """Does ONE launch cover this convolution reading `pre` and writing the normalised tensor (nndet_conv3d_forward_norm_input_fused)?"""
+        x_p, _ = phys(x)
+        desc = _desc(x_p, self.in_channels, self.out_channels, self.k, self.s, self.p, self.transposed)
+        if tuple(pre[1].shape) != (desc.batch, desc.cin_p, 2):
+            return False
+        desc.in_affine, desc.in_relu = pre[1].data_ptr(), int(pre[2])
+        return bool(L.load().nndet_conv3d_forward_norm_input_fused(ctypes.byref(desc)))
+
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """residual (optional, only without norm): returns conv(x) + residual from ONE kernel (epilogue add).
         `x` may be a deferred activation (see `deferred`); with `self.defer_output` (set by OUR containers for outputs that only
@@ -699,20 +740,29 @@ class BaseConvNormAct(nn.Sequential):
         if pre is not None:
             use = (self.early_input and x.is_cuda and not self.transposed and self.in_channels != 1 and pre[0].dtype == x.dtype
                    and pre[0].shape == x.shape)
-            if not use:                          # not the consumer this was meant for: only order behind the materialising pass
+            if len(pre) > 4:                     # NORM_INPUT_FUSE: only the launch that writes the tensor while it stages may take it unwritten
+                use = use and residual is None and not pre[4]["done"] and self._norm_input_fused(x, pre)
+                if not use:
+                    ensure_materialized(x)
+                    pre = None
+            elif not use:                        # not the consumer this was meant for: only order behind the materialising pass
                 torch.cuda.current_stream(x.device).wait_event(pre[3])
                 pre = None
         y, stats = _ConvFn.apply(x, x_ss, x_relu, self.conv.weight, self.conv.bias, self, residual, has_norm, pre)
-        if pre is not None:
+        if pre is not None and pre[3] is not None:
             torch.cuda.current_stream(x.device).wait_event(pre[3])    # from here on the normalised tensor is complete for this stream
         if not has_norm:
             return y
         defer = bool(self.defer_output) and DEFER_NORM and y.is_cuda
         early = (not defer) and bool(self.early_output) and EARLY_CONSUMER and y.is_cuda
-        out, ss = _NormFn.apply(y, self.norm.weight, self.norm.bias, stats, self, 2 if early else (not defer))
+        fill = ((not defer) and (not early) and bool(self.early_output) and NORM_INPUT_FUSE and y.is_cuda
+                and y.dtype in (torch.bfloat16, torch.float16))
+        out, ss = _NormFn.apply(y, self.norm.weight, self.norm.bias, stats, self, 3 if fill else (2 if early else (not defer)))
         if defer:
             mark_padded(out)
             out._nndet_deferred = (ss, self.relu)
+        elif fill:
+            out._nndet_pre = (y, ss, self.relu, None, {"done": False})
         elif early:
             out._nndet_pre = (y, ss, self.relu, _pre_event[0])
         if NORM_RED_FUSE and not defer and y.is_cuda and out.requires_grad and self.norm_groups == self.out_channels:

@@ -11,7 +11,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
-from .conv import conv_kwargs_helper
+from .conv import conv_kwargs_helper, ensure_materialized
 
 
 class UFPNModular(nn.Module):
@@ -88,6 +88,7 @@ class UFPNModular(nn.Module):
         up (and the stream joined) by the next forward(); the deepest level is not worth a fork (the decoder needs it first)."""
         if not (self.early_laterals and fm.is_cuda and level < self.num_level - 1):
             return
+        ensure_materialized(fm)        # (arch/conv.py NORM_INPUT_FUSE: this reader comes before the convolution that would have written it)
         dev = fm.device
         main = torch.cuda.current_stream(dev)
         need0 = not (self.skip_unused_out and self.used_levels is not None and 0 not in self.used_levels)

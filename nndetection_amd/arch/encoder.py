@@ -4,6 +4,8 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
+from .conv import ensure_materialized
+
 
 class Encoder(nn.Module):
     def __init__(self, conv: Callable, conv_kernels, strides, block_cls, in_channels: int, start_channels: int,
@@ -43,7 +45,9 @@ class Encoder(nn.Module):
             pre = getattr(x, "_nndet_pre", None)
             x_in, x = x, module(x)
             if pre is not None:                  # (set_early_consumer: whatever the stage did with the tag, order this stream behind the
-                if x_in.is_cuda:                 #  materialising pass before the tensor is handed to anybody else)
+                if len(pre) > 4:                 #  materialising pass -- or run it: NORM_INPUT_FUSE -- before the tensor is handed to anybody else)
+                    ensure_materialized(x_in)
+                elif x_in.is_cuda:
                     torch.cuda.current_stream(x_in.device).wait_event(pre[3])
                 del x_in._nndet_pre
             if sid in self.out_stages:

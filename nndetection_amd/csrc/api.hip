@@ -49,6 +49,29 @@ extern "C" int nndet_conv3d_forward(const NndetConv* c, const void* x, const voi
     return igemm_run(c, 0, x, w, bias, residual, y, stats, st);
 }
 
+extern "C" int32_t nndet_conv3d_forward_norm_input_fused(const NndetConv* c) {
+    if (!c || check_conv(c) || !c->in_affine) return 0;
+    return ig3s_covers_pre(c);
+}
+
+extern "C" int nndet_conv3d_forward_norm_input(const NndetConv* c, const void* x_pre, void* x_norm, const void* w, const float* bias,
+                                               void* y, double* stats, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!x_pre || !x_norm || !w || !y || !c->in_affine || c->transposed || c->cin_p == 1 || x_pre == x_norm) return NNDET_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (ig3s_covers_pre(c)) {
+        rc = ig3s_run(c, 0, x_pre, w, bias, nullptr, y, stats, st, x_norm);
+        if (rc != 1) return rc;
+    }
+    const int64_t spatial = (int64_t)c->in_d * c->in_h * c->in_w;
+    rc = nndet_affine_apply(c->dtype, x_pre, c->in_affine, c->batch, spatial, c->cin_p, c->in_relu, x_norm, stream);
+    if (rc) return rc;
+    NndetConv plain = *c;
+    plain.in_affine = nullptr; plain.in_relu = 0;
+    return igemm_run(&plain, 0, x_norm, w, bias, nullptr, y, stats, st);
+}
+
 extern "C" int nndet_conv3d_backward_data(const NndetConv* c, const void* dy, const void* w, void* dx, void* stream) {
     int rc = check_conv(c);
     if (rc) return rc;

@@ -29,7 +29,9 @@ int dgs_run(const NndetConv* c, const void* dy, const void* w, const void* res, 
 int dgs_covers(const NndetConv* c);
 int dgs_fuses_norm_reduce(const NndetConv* c);   // 1 if dgs_run accepts nr for this problem
 // conv_ig3s.hip: forward of the 32 -> 64 stride-2 3x3x3 transition (LDS-DMA double buffering, weights in registers); returns 1 = not covered
-int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st);
+int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st,
+             void* xn = nullptr);   // xn: see nndet_conv3d_forward_norm_input
+int ig3s_covers_pre(const NndetConv* c);   // 1 if ig3s_run(.., xn != NULL) takes this problem (in_affine set)
 // conv_wgrad.hip
 int wgrad_run(const NndetConv* c, const void* x, const void* dy, float* dw, float* dbias, int* bias_done, void* ws, size_t ws_bytes,
               hipStream_t st);   // bias_done = 1: dbias (may be NULL) was accumulated by the weight-gradient kernel itself

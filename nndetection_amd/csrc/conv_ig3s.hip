@@ -20,12 +20,39 @@
 #include "common.h"
 #include "conv_common.h"
 
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+
+// D (VGPRs) = A (ACCUMULATION registers) x B (VGPRs) + C for the kernels whose weights live in registers: with 216 weight registers per
+// lane hipcc keeps them in AGPRs and copies every A operand back with 4 v_accvgpr_read before its MFMA -- 216 VALU instructions per
+// tile and wave, ALL the VALU work of k_ig3s and the reason its waves spent half their cycles issuing (profiles/round6_ig3s_pre_pmc.txt).
+// gfx90a+ MFMAs read srcA from an AGPR directly; only inline assembly can say so. Hazards hipcc no longer sees (it does not look into the
+// assembly) are covered by construction: an accumulator is reused by every 4th MFMA (no back-to-back dependency), the first MFMA of a
+// tile takes C = 0 (no VALU-written accumulator), wait states in front of it (the epilogue's reads of the previous tile) and behind
+// the last one (VALU reads of the results) are explicit; the B operands are ordinary register inputs (hipcc waits for their LDS loads).
+template <typename T> struct MfmaA;
+template <> struct MfmaA<bf16_t> {
+    __device__ static __forceinline__ void first32(f32x16_t& d, const u32x4& a, const u32x4& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "v"(b)); }
+    __device__ static __forceinline__ void acc32(f32x16_t& d, const u32x4& a, const u32x4& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b)); }
+};
+template <> struct MfmaA<f16_t> {
+    __device__ static __forceinline__ void first32(f32x16_t& d, const u32x4& a, const u32x4& b) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "v"(b)); }
+    __device__ static __forceinline__ void acc32(f32x16_t& d, const u32x4& a, const u32x4& b) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b)); }
+};
+#ifndef IG3S_ASM_MFMA
+#define IG3S_ASM_MFMA 1
+#endif
+
 struct Ig3sArgs {
     const void* x; const void* w; const float* bias; void* y; double* stats;
     int32_t N;
     int32_t I[3], O[3];          // input / output spatial dims
     int32_t nt[3], total_tiles;  // (2, 4, 8)-point tiles per axis
     int32_t gw, gh, gd, gn;      // grid size = gw + nt[2] * (gh + nt[1] * (gd + nt[0] * gn))
+    // k_ig3s<.., PRE = true>: x is the PRE-norm output of the previous convolution; the kernel reads relu?(x * scale + shift) and
+    // writes that normalised tensor to xn on the way (each voxel by the ONE tile whose 4 x 8 x 16 input core holds it)
+    const float* ss;             // [N][32][2] (scale, shift) fp32 (nndet_norm_finalize)
+    void* xn;
+    int32_t ss_relu;
 };
 
 __device__ __forceinline__ void ig3s_dma16(__amdgpu_buffer_rsrc_t rs, int voff, uint32_t lds_dst) {
@@ -38,7 +65,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ig3s_rsrc(const char* p, int n
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(((uint64_t)hi << 32) | lo), 0, num_records, 0x00020000);
 }
 
-template <typename T, bool STATS>
+template <typename T, bool STATS, bool PRE>
 __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
     constexpr int RB = 64, CY = 64, TD = 2, TH = 4, HD = 2 * TD + 1, HH = 2 * TH + 1, HW = 17, NEV = 9;
@@ -64,12 +91,17 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
     float bia[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bia[r] = A.bias ? A.bias[coh * 32 + (r >> 2) * 8 + kg * 4 + (r & 3)] : 0.f;
+    if constexpr (PRE) {       // (consumed here, see t_coef: the epilogue must not wait for them by hipcc's count)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bia[r]));
+    }
 
     // ---- DMA geometry: piece qp = wv + 4 j: granule G = qp * 64 + lane = halo slot G >> 2 (row-major over 5 x 9 x 17 slots, slot s of a
     // row = W offset 2 s (s < 9) or 2 (s - 9) + 1), 16-byte part G & 3
     const int q_rowb = A.I[2] * RB, q_slab = A.I[1] * q_rowb;
     uint32_t qsel[NQ];          // bit hd | bit 5 + hh | bit 14 + W offset; bit 31 = no such granule
     int qrel[NQ];
+    uint32_t qcls = 0, qown = 0;   // PRE: 2 bits per piece = swizzle class of the granule's halo row; 1 bit per piece = the voxel is in the tile's core
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int G = (wv + 4 * j) * 64 + lane;
@@ -83,7 +115,12 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         // 2 x 1088 B apart, columns 64 B) met on 4 of the 16 part slots: a 4-way conflict on every B-operand read -- SQ_LDS_BANK_CONFLICT was
         // 72 % of the LDS cycles of this kernel, the LDS 49 % busy (profiles/round5_step_pmc_survey.txt). The source address of a DMA lane is free.
         qrel[j] = hd * q_slab + hh * q_rowb + jw * RB + (((G & 3) ^ ((hh >> 1) & 3)) * 16);
+        if constexpr (PRE) {
+            qcls |= (uint32_t)((hh >> 1) & 3) << (2 * j);
+            qown |= (uint32_t)(vox < QVOX && hd >= 1 && hd <= 2 * TD && hh >= 1 && hh <= 2 * TH && jw >= 1 && jw <= 16) << j;
+        }
     }
+    int64_t c_org = 0;                                     // byte offset of the decoded tile's halo origin in x (and in xn)
     __amdgpu_buffer_rsrc_t qrs;
     uint32_t qmask = 0;
     int c_n = 0, c_d = 0, c_h = 0, c_w = 0;               // mixed-radix coordinates of the tile last decoded (= the one being staged)
@@ -91,6 +128,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         const int l0d = c_d * TD, l0h = c_h * TH, l0w = c_w * 8;
         const int64_t q_org = (int64_t)c_n * A.I[0] * q_slab + (int64_t)(2 * l0d - 1) * q_slab + (2 * l0h - 1) * q_rowb + (2 * l0w - 1) * RB;
         qrs = ig3s_rsrc(reinterpret_cast<const char*>(A.x) + q_org, 0x7ffffff0);
+        c_org = q_org;
         auto rng = [](int lo, int hi) -> uint32_t { return (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u); };   // bits [lo, hi)
         const uint32_t md = rng(l0d == 0 ? 1 : 0, min(HD, A.I[0] - 2 * l0d + 1));
         const uint32_t mh = rng(l0h == 0 ? 1 : 0, min(HH, A.I[1] - 2 * l0h + 1));
@@ -118,6 +156,56 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         ig3s_dma16(qrs, ok ? qrel[j] : (int)0x80000000, (uint32_t)__builtin_amdgcn_readfirstlane(buf * BUF + (wv + 4 * j) * 1024));
     };
 
+    // ---- PRE: the transform of a landed halo, relu?(x * scale + shift) in place + the core voxels out to xn. A lane works on channel
+    // part lane & 3 of its voxels (ONE set of 8 + 8 coefficients in registers); with the bank swizzle that part sits at position
+    // (lane & 3) ^ class(row) of the voxel: written by another lane of the SAME wave's piece, so the wave's own vmcnt wait orders it.
+    __amdgpu_buffer_rsrc_t trs = qrs;                      // xn at the origin of the tile being transformed
+    uint32_t tmask = 0;
+    int t_n = -1, ss_n = -1;
+    f32x2_t scp[4], shp[4];                                // (pairs: the operands of v_pk_fma_f32)
+    const uint32_t floor2 = A.ss_relu ? 0u : 0x80008000u;  // v_pk_max_i16 against (0, 0) = ReLU on the packed pair (AffinePiece); against INT16_MIN = identity
+    u32x4 tv = {0, 0, 0, 0}, tr = {0, 0, 0, 0};
+    auto take_t = [&]() {                                  // the decoded tile becomes the one to transform
+        if constexpr (PRE) {
+            tmask = qmask; t_n = c_n;
+            trs = ig3s_rsrc(reinterpret_cast<const char*>(A.xn) + c_org, 0x7ffffff0);
+        }
+    };
+    auto t_coef = [&]() {
+        if constexpr (PRE) {
+            if (t_n != ss_n) {
+                float sc[8], sh[8];
+                load_affine<8>(A.ss, t_n, 32, (lane & 3) * 8, sc, sh); ss_n = t_n;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { scp[i] = f32x2_t{sc[2 * i], sc[2 * i + 1]}; shp[i] = f32x2_t{sh[2 * i], sh[2 * i + 1]}; }
+                // consumed HERE: otherwise hipcc waits for these loads where the transform first uses them -- by ITS count of what is
+                // outstanding, a vmcnt(0) in every tile that drains the halo requests it knows nothing about
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(scp[i]), "+v"(shp[i]));
+            }
+        }
+    };
+    auto t_addr = [&](int j, int buf) -> int { return buf * BUF + (wv + 4 * j) * 1024 + ((lane * 16) ^ (int)(((qcls >> (2 * j)) & 3u) << 4)); };
+    auto t_read = [&](int j, int buf) { tv = *reinterpret_cast<const u32x4*>(smem + t_addr(j, buf)); };
+    auto t_half = [&](int h) {                             // AffinePiece<T>::apply on dwords 2 h, 2 h + 1 (the same operations in the same order)
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 2 * h; i < 2 * h + 2; ++i) {
+            const f32x2_t x = {H16<T>::lo(tv[i]), H16<T>::hi(tv[i])};
+            const f32x2_t r = __builtin_elementwise_fma(x, scp[i], shp[i]);
+            const uint32_t pk = H16<T>::pack2(r[0], r[1]);
+            tr[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), __builtin_bit_cast(s16x2, floor2)));
+        }
+    };
+    auto t_write = [&](int j, int buf) {
+        const bool ok = (qsel[j] & tmask) == qsel[j];      // (the zero padding stays zero)
+        const u32x4 o = {ok ? tr[0] : 0u, ok ? tr[1] : 0u, ok ? tr[2] : 0u, ok ? tr[3] : 0u};
+        *reinterpret_cast<u32x4*>(smem + t_addr(j, buf)) = o;
+        const bool own = ok && ((qown >> j) & 1u);
+        // (no SGPR offset on a 16-byte store: tests/test_isa_hazards.py; lanes that do not own their voxel use an out-of-range offset, dropped by the hardware)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, o), trs, own ? (qrel[j] ^ (int)(((qcls >> (2 * j)) & 3u) << 4)) : (int)0x80000000, 0, 0);
+    };
+
     // ---- fragment base: point (plane pth, row rr, column pw) at tap (0, 0, 0) = halo row (2 pth, 2 rr), even slot pw; 8 channels kg
     const int q_lane = ((2 * pth) * HH + 2 * rr) * QROW + pw * RB;
     // part kh * 2 + kg of the voxel in halo row 2 rr + b sits at position (kh * 2 + kg) ^ ((2 rr + b) >> 1): rr for b = 0 / 1, rr + 1 for b = 2
@@ -132,13 +220,17 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
 
-    auto compute = [&](int buf, bool stage) {
+    // PRE: while tile k runs out of `buf`, the halo of tile k + 2 is requested into `sbuf` (MFMA slots 0 .. 11) and the one of tile k + 1, landed
+    // in `tbuf`, is transformed (4 slots per piece from slot T0 on: read | dwords 0, 1 | dwords 2, 3 | write + store)
+    auto compute = [&](int buf, auto stage, int sbuf, auto trans, int tbuf) {
         constexpr int U = 54, QD_ = 3;
         const char* const qb = smem + buf * BUF;
+#if !IG3S_ASM_MFMA
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#endif
         u32x4 bf[QD_ + 1];
         auto load_b = [&](int u) -> u32x4 {
             const int tp = u >> 1, kh = u & 1;
@@ -150,9 +242,35 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u + QD_ < U) bf[(u + QD_) % (QD_ + 1)] = load_b(u + QD_);
-            if (u < NQ && stage) dma_piece(u, buf ^ 1);
+            if constexpr (PRE) {
+                constexpr int T0 = 4;
+                if (u < NQ && stage) dma_piece(u, sbuf);
+                if (trans && u >= T0 && u < T0 + 4 * NQ) {
+                    const int pj = (u - T0) >> 2, ps = (u - T0) & 3;
+                    if (u == T0) {
+                        // the halo in `tbuf` was requested one tile ago. Issued after it, by this wave, ALWAYS (masked lanes use out-of-range
+                        // offsets, the instructions are not predicated): NQ xn stores + 2 output stores of the previous tile (+ the T0
+                        // requests of this one); a statistics flush in between only makes the wait longer than needed
+                        if (stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ + 2 + T0) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ + 2) : "memory");
+                    }
+                    if (ps == 0) t_read(pj, tbuf);
+                    else if (ps == 1) t_half(0);
+                    else if (ps == 2) t_half(1);
+                    else t_write(pj, tbuf);
+                }
+            } else {
+                if (u < NQ && stage) dma_piece(u, buf ^ 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
+#if IG3S_ASM_MFMA
+            if (u == 0) asm volatile("s_nop 4");              // (the epilogue of the previous tile read these registers)
+            if (u < 4) MfmaA<T>::first32(acc[u & 3], wr[u >> 1][u & 1], bf[u % (QD_ + 1)]);
+            else MfmaA<T>::acc32(acc[u & 3], wr[u >> 1][u & 1], bf[u % (QD_ + 1)]);
+            if (u == U - 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");   // 20 wait states before anything reads the results
+#else
             acc[u & 3] = H16<T>::mma32(wr[u >> 1][u & 1], bf[u % (QD_ + 1)], acc[u & 3]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -174,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         }
     };
     int st_n = -1;                                          // image the register statistics belong to
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(A.y, 0, PRE ? (int)((int64_t)A.N * A.O[0] * A.O[1] * A.O[2] * CY * 2) : 0, 0x00020000);
     auto epilogue = [&](int n, int td, int th, int tw) {
         if (STATS && n != st_n) { if (st_n >= 0) flush_stats(st_n); st_n = n; }
         const int od = td * TD + pth, oh = th * TH + rr, ow = tw * 8 + pw;
@@ -202,7 +321,12 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         for (int h = 0; h < 2; ++h) {
             const ig3s_v2u sx = __builtin_amdgcn_permlane32_swap(pk[h].x, pk[h + 2].x, false, false);
             const ig3s_v2u sy = __builtin_amdgcn_permlane32_swap(pk[h].y, pk[h + 2].y, false, false);
-            if (valid) *reinterpret_cast<u32x4*>(yp + kg * 16 + h * 8) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+            if constexpr (PRE) {   // (always issued: the vmcnt arithmetic of the transform counts on two stores per tile)
+                const int64_t off = (reinterpret_cast<const char*>(yp + kg * 16 + h * 8) - reinterpret_cast<const char*>(A.y));
+                __builtin_amdgcn_raw_buffer_store_b128(v4u_t{sx[0], sy[0], sx[1], sy[1]}, yrs, valid ? (int)off : (int)0x80000000, 0, 0);
+            } else {
+                if (valid) *reinterpret_cast<u32x4*>(yp + kg * 16 + h * 8) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+            }
         }
     };
 
@@ -216,6 +340,58 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
         else if (k == full && bx < rest) decode(full * G + perm(rest));
     };
     if (!exists(0)) return;
+    if constexpr (PRE) {
+        // three halo buffers: tile k in the MFMAs | tile k + 1 landed, being transformed | tile k + 2 in flight. No vmcnt(0) in the steady
+        // state: a wave waits for ITS pieces of the halo it is about to transform (in-order counter, see compute), the barrier per tile
+        // orders the LDS traffic (transform -> MFMA reads of the next tile, MFMA reads -> the next request into that buffer).
+        auto lds_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        to_round(0);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) dma_piece(j, 0);
+        take_t();
+        int e_n = c_n, e_d = c_d, e_h = c_h, e_w = c_w;       // tile k (epilogue)
+        int n_n = 0, n_d = 0, n_h = 0, n_w = 0;               // tile k + 1
+        t_coef();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) { t_read(j, 0); t_half(0); t_half(1); t_write(j, 0); }
+        if (exists(1)) {
+            to_round(1);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) dma_piece(j, 1);
+            take_t();
+            n_n = c_n; n_d = c_d; n_h = c_h; n_w = c_w;
+            if (exists(2)) to_round(2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        int buf = 0;
+        for (int k = 0; exists(k); ++k) {
+            const bool nx = exists(k + 1), nx2 = exists(k + 2);
+            const int b1 = buf == 2 ? 0 : buf + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            if (nx) t_coef();
+            // (compile-time flags: the steady state is one branch-free body)
+            if (nx2) compute(buf, std::true_type{}, b2, std::true_type{}, b1);
+            else if (nx) compute(buf, std::false_type{}, b2, std::true_type{}, b1);
+            else compute(buf, std::false_type{}, b2, std::false_type{}, b1);
+            const int p_n = e_n, p_d = e_d, p_h = e_h, p_w = e_w;
+            e_n = n_n; e_d = n_d; e_h = n_h; e_w = n_w;
+            if (nx2) {
+                take_t();
+                n_n = c_n; n_d = c_d; n_h = c_h; n_w = c_w;
+                if (exists(k + 3)) to_round(k + 3);
+            }
+            lds_barrier();
+            epilogue(p_n, p_d, p_h, p_w);
+            buf = b1;
+        }
+        if (STATS && st_n >= 0) flush_stats(st_n);
+        return;
+    }
     to_round(0);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) dma_piece(j, 0);
@@ -226,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void k_ig3s(const Ig3sArgs A) {
     int buf = 0;
     for (int k = 0; exists(k); ++k) {
         const bool nx = exists(k + 1);
-        compute(buf, nx);
+        compute(buf, nx, 0, false, 0);
         const int e_n = cur_n, e_d = cur_d, e_h = cur_h, e_w = cur_w;
         cur_n = c_n; cur_d = c_d; cur_h = c_h; cur_w = c_w;   // (the scalars of round k + 1, decoded before this phase)
         if (nx) to_round(k + 2);
@@ -432,10 +608,22 @@ __global__ __launch_bounds__(256, 1) void k_ig3s2(const Ig3sArgs A, int cout_p) 
 }
 
 // returns 1 = not covered (the caller goes on to k_igemm)
-int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st) {
-    const int on = getenv("NNDET_IG3S") ? atoi(getenv("NNDET_IG3S")) : 1;       // (read per call: tests compare routes that must share their kernels)
+static int ig3s_on() { return getenv("NNDET_IG3S") ? atoi(getenv("NNDET_IG3S")) : 1; }   // (read per call: tests compare routes that must share their kernels)
+int ig3s_covers_pre(const NndetConv* c) {
+    if (!ig3s_on() || !c->in_affine || c->transposed || !nndet_is16(c->dtype) || c->cin_p != 32 || c->cout_p != 64 || c->batch <= 0) return 0;
+    for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 2 || c->p[i] != 1) return 0;
+    if ((int64_t)c->in_d * c->in_h * c->in_w * c->cin_p * 2 >= (1LL << 31)) return 0;
+    return (int64_t)c->batch * c->out_d * c->out_h * c->out_w * 64 * 2 < (1LL << 31);
+}
+
+// xn != NULL (with c->in_affine): x is the pre-norm tensor, the normalised one is written to xn by the same launch (k_ig3s<.., PRE>)
+int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y, double* stats, hipStream_t st,
+             void* xn) {
+    const int on = ig3s_on();
     const bool v1 = c->cin_p == 32 && c->cout_p == 64, v2 = c->cin_p == 64 && c->cout_p % 64 == 0 && c->cout_p <= 256 && on != 3;   // (NNDET_IG3S=3: the 32 -> 64 form only)
-    if (!on || kind != 0 || res || c->transposed || c->in_affine || !nndet_is16(c->dtype) || !(v1 || v2)) return 1;
+    const bool pre = c->in_affine && xn;
+    if (!on || kind != 0 || res || c->transposed || (c->in_affine && !pre) || !nndet_is16(c->dtype) || !(v1 || v2)) return 1;
+    if (pre && !ig3s_covers_pre(c)) return 1;
     for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 2 || c->p[i] != 1) return 1;
     const int64_t xb = (int64_t)c->in_d * c->in_h * c->in_w * c->cin_p * 2;
     if (xb >= (1LL << 31) || c->batch <= 0) return 1;
@@ -455,13 +643,17 @@ int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const f
     a.gw = g % a.nt[2]; g /= a.nt[2];
     a.gh = g % a.nt[1]; g /= a.nt[1];
     a.gd = g % a.nt[0]; a.gn = g / a.nt[0];
-    constexpr size_t lds = 2 * 48 * 1024;
+    constexpr size_t lds = 2 * 48 * 1024, lds3 = 3 * 48 * 1024;
     static NndetDevOnce at;
     if (at.need()) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<bf16_t, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s<f16_t, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<bf16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3s2<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -475,8 +667,15 @@ int ig3s_run(const NndetConv* c, int kind, const void* x, const void* w, const f
         LAUNCH_CHECK();
         return 0;
     }
-    if (c->dtype == NNDET_F16) { if (stats) k_ig3s<f16_t, true><<<G, 256, lds, st>>>(a); else k_ig3s<f16_t, false><<<G, 256, lds, st>>>(a); }
-    else { if (stats) k_ig3s<bf16_t, true><<<G, 256, lds, st>>>(a); else k_ig3s<bf16_t, false><<<G, 256, lds, st>>>(a); }
+    if (pre) {
+        a.ss = c->in_affine; a.xn = xn; a.ss_relu = c->in_relu;
+        if (c->dtype == NNDET_F16) { if (stats) k_ig3s<f16_t, true, true><<<G, 256, lds3, st>>>(a); else k_ig3s<f16_t, false, true><<<G, 256, lds3, st>>>(a); }
+        else { if (stats) k_ig3s<bf16_t, true, true><<<G, 256, lds3, st>>>(a); else k_ig3s<bf16_t, false, true><<<G, 256, lds3, st>>>(a); }
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (c->dtype == NNDET_F16) { if (stats) k_ig3s<f16_t, true, false><<<G, 256, lds, st>>>(a); else k_ig3s<f16_t, false, false><<<G, 256, lds, st>>>(a); }
+    else { if (stats) k_ig3s<bf16_t, true, false><<<G, 256, lds, st>>>(a); else k_ig3s<bf16_t, false, false><<<G, 256, lds, st>>>(a); }
     LAUNCH_CHECK();
     return 0;
 }

@@ -888,3 +888,68 @@ def test_persistent_strided_data_gradient_is_bit_identical_to_k_dgs(batch, shape
     gm = out[("1", "3")][2].double() * (torch.addcmul(sh, ny.float(), sc) > 0)
     s64 = torch.stack((gm.sum((1, 2, 3)), (gm * xh).sum((1, 2, 3))), -1)
     assert float(((out[("1", "3")][3] - s64).abs() / s64.abs().amax((0, 1), keepdim=True)).max()) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("relu", [1, 0], ids=["relu", "linear"])
+@pytest.mark.parametrize("batch,shape", [(1, (8, 8, 16)), (3, (13, 19, 37)), (2, (4, 9, 50)), (2, (22, 32, 48))],
+                         ids=["one_tile", "ragged", "thin", "tiles"])
+def test_stride2_forward_that_writes_its_normalised_input(batch, shape, relu, dtype, monkeypatch):
+    """nndet_conv3d_forward_norm_input (k_ig3s<.., PRE>, round 6): the 32 -> 64 stride-2 transition reads the PRE-norm tensor + the
+    coefficient table, transforms the halo in LDS and stores the normalised tensor on the way. Against the two launches it replaces
+    (nndet_affine_apply, then nndet_conv3d_forward = the plain k_ig3s on the materialised tensor): the normalised tensor and the
+    convolution output must be BIT-IDENTICAL (same fmaf / pack / ReLU, same taps and accumulators), every voxel of the normalised
+    tensor written exactly by its one owner (NaN canary), the statistics equal to fp64 atomics' order; grids of 1 / 3 / 7 workgroups
+    walk many tiles, rounds with and without a successor, and image changes (coefficient reload) per workgroup."""
+    import ctypes
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch.conv import ConvInstanceRelu, _desc, _packed
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    m = ConvInstanceRelu(3, 32, 64, 3, stride=2, padding=1, add_norm=False, add_act=False, bias=True).to(dev)
+    y0 = (torch.randn(batch, *shape, 32, device=dev) * 1.7 + 0.2).to(dtype)              # the pre-norm tensor
+    ss = torch.stack((torch.rand(batch, 32, device=dev) + 0.5, torch.randn(batch, 32, device=dev) * 0.4), -1).contiguous()
+    d = _desc(y0, 32, 64, m.k, m.s, m.p, False)
+    w0 = _packed(m, 0, m.conv.weight, d, dtype)
+    bias = m.conv.bias.detach().float().contiguous()
+    bias_p = torch.zeros(64, device=dev); bias_p[:64] = bias
+    st = L.stream()
+    code = L.dtype_code(y0)
+    spatial = shape[0] * shape[1] * shape[2]
+    # the two launches
+    a_ref = torch.empty_like(y0)
+    L.call("nndet_affine_apply", code, L.ptr(y0), L.ptr(ss), batch, spatial, 32, relu, L.ptr(a_ref), st)
+    out_ref = torch.full((batch, d.out_d, d.out_h, d.out_w, 64), float("nan"), device=dev, dtype=dtype)
+    st_ref = torch.zeros(L.STATS_REPLICAS, batch, 64, 2, dtype=torch.float64, device=dev)
+    L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(a_ref), L.ptr(w0), L.ptr(bias_p), None, L.ptr(out_ref), L.ptr(st_ref), st)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out_ref.float()).any()
+    dp = _desc(y0, 32, 64, m.k, m.s, m.p, False)
+    dp.in_affine, dp.in_relu = ss.data_ptr(), relu
+    assert L.load().nndet_conv3d_forward_norm_input_fused(ctypes.byref(dp)) == 1
+    for wgs in ("256", "1", "3", "7"):
+        monkeypatch.setenv("NNDET_IG3S_WGS", wgs)
+        for with_stats in (True, False):
+            a = torch.full_like(y0, float("nan"))
+            out = torch.full_like(out_ref, float("nan"))
+            stt = torch.zeros_like(st_ref) if with_stats else None
+            L.call("nndet_conv3d_forward_norm_input", ctypes.byref(dp), L.ptr(y0), L.ptr(a), L.ptr(w0), L.ptr(bias_p), L.ptr(out), L.ptr(stt), st)
+            torch.cuda.synchronize()
+            assert torch.equal(a.view(torch.int16), a_ref.view(torch.int16)), f"wgs {wgs}: the normalised tensor differs"
+            assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)), f"wgs {wgs}: the convolution output differs"
+            if with_stats:
+                s, r = stt.sum(0), st_ref.sum(0)
+                assert float(((s - r).abs() / (r.abs() + 1.0)).max()) <= 2e-6     # (fp32 partial sums per workgroup and image: the walk differs with the grid)
+    # a problem the fused launch does not cover runs the two launches behind the same entry point
+    m2 = ConvInstanceRelu(3, 32, 32, 3, stride=1, padding=1, add_norm=False, add_act=False).to(dev)
+    d2 = _desc(y0, 32, 32, m2.k, m2.s, m2.p, False)
+    w2 = _packed(m2, 0, m2.conv.weight, d2, dtype)
+    o_ref = torch.empty(batch, *shape, 32, device=dev, dtype=dtype)
+    L.call("nndet_conv3d_forward", ctypes.byref(d2), L.ptr(a_ref), L.ptr(w2), None, None, L.ptr(o_ref), None, st)
+    d2p = _desc(y0, 32, 32, m2.k, m2.s, m2.p, False)
+    d2p.in_affine, d2p.in_relu = ss.data_ptr(), relu
+    assert L.load().nndet_conv3d_forward_norm_input_fused(ctypes.byref(d2p)) == 0
+    a2, o2 = torch.full_like(y0, float("nan")), torch.full_like(o_ref, float("nan"))
+    L.call("nndet_conv3d_forward_norm_input", ctypes.byref(d2p), L.ptr(y0), L.ptr(a2), L.ptr(w2), None, L.ptr(o2), None, st)
+    torch.cuda.synchronize()
+    assert torch.equal(a2.view(torch.int16), a_ref.view(torch.int16)) and torch.equal(o2.view(torch.int16), o_ref.view(torch.int16))

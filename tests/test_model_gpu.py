@@ -461,6 +461,7 @@ def test_early_consumer_of_the_stage0_output(golden_dir, dtype, monkeypatch):
     from nndetection_amd.arch import conv as C
     from nndetection_amd import _lib as L
     monkeypatch.setenv("NNDET_IG3S", "0")             # like with like: a consumer that applies the norm on load cannot stage by LDS-DMA (k_ig3s)
+    monkeypatch.setattr(C, "NORM_INPUT_FUSE", False)  # (round 6: the route that replaced this one, tested below)
     gn, plan, tg = _load(golden_dir)
     ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
     net = _hip_model(plan, ora)
@@ -496,6 +497,59 @@ def test_early_consumer_of_the_stage0_output(golden_dir, dtype, monkeypatch):
         for n, g0 in ref[2].items():
             d = float((gr[n] - g0).abs().max())
             assert d <= tol * (float(g0.abs().max()) + 1e-12) + 1e-7, (n, d, float(g0.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_stage1_convolution_writes_the_normalised_stage0_output(golden_dir, dtype, monkeypatch):
+    """arch/conv.py NORM_INPUT_FUSE (round 6): stage 0's last block only computes its coefficient table; the first (stride-2) convolution
+    of stage 1 reads the pre-norm tensor and writes the normalised one on the way (nndet_conv3d_forward_norm_input, k_ig3s<.., PRE>),
+    no nndet_norm_apply pass for that block. The stage-0 output and every deeper feature map are the same tensors bit for bit, losses and
+    gradients agree to the noise of the statistics' atomics, the tag does not leak, and with the fused kernel switched off
+    (NNDET_IG3S=0) the consumer falls back to the plain materialising pass with the same values."""
+    from nndetection_amd.arch import conv as C
+    from nndetection_amd import _lib as L
+    gn, plan, tg = _load(golden_dir)
+    ora = fill_state(OracleRetinaUNet(plan["arch"], plan["anchors"], MODEL_CFG_V001))
+    net = _hip_model(plan, ora)
+    x = torch.from_numpy(gn["x"]).cuda().to(dtype)
+    monkeypatch.setattr(torch, "randperm", det_randperm)
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    res = {}
+    for mode in ("fused", "off", "fused", "fallback"):
+        monkeypatch.setattr(C, "NORM_INPUT_FUSE", mode != "off")
+        monkeypatch.setenv("NNDET_IG3S", "0" if mode == "fallback" else "1")
+        net.zero_grad(set_to_none=True)
+        calls.clear()
+        with torch.no_grad():
+            feats = net.encoder(x)
+        torch.cuda.synchronize()
+        assert ("nndet_conv3d_forward_norm_input" in calls) == (mode == "fused")
+        assert ("nndet_affine_apply" in calls) == (mode == "fallback")
+        assert all(not hasattr(f, "_nndet_pre") for f in feats)
+        fs = [f.detach().float().cpu().clone() for f in feats]
+        losses, _ = net.train_step(x, _cuda_targets(tg), evaluation=False)
+        (sum(losses.values()) * (256.0 if dtype == torch.float16 else 1.0)).backward()
+        torch.cuda.synchronize()
+        res.setdefault(mode, []).append((fs, {k: float(v.detach()) for k, v in losses.items()},
+                                         {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    ltol = 2e-3 if dtype == torch.bfloat16 else 3e-4
+    ref = res["off"][0]
+    for mode in ("fused", "fallback"):
+        for fs, ls, gr in res[mode]:
+            assert torch.equal(fs[0], ref[0][0]), mode                 # the normalised stage-0 output itself
+            for f, r in zip(fs[1:], ref[0][1:]):                       # (deeper stages: the same kernels on the same values, up to the atomics)
+                assert float((f - r).abs().max()) <= (tol if mode == "fused" else 4 * tol) * float(r.abs().max())
+            for k, v in ref[1].items():
+                assert abs(ls[k] - v) <= ltol * max(1.0, abs(v)), (mode, k, ls[k], v)
+            assert set(gr) == set(ref[2])
+            if mode == "fallback":            # (NNDET_IG3S=0: k_igemm rounds the stride-2 output its own way, the gradients are another sample)
+                continue
+            for n, g0 in ref[2].items():
+                dd = float((gr[n] - g0).abs().max())
+                assert dd <= tol * (float(g0.abs().max()) + 1e-12) + 1e-7, (mode, n, dd, float(g0.abs().max()))
 
 
 def test_head_levels_are_written_into_the_ragged_batch_buffer(golden_dir, monkeypatch):

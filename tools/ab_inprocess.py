@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""A/B of a host-side switch INSIDE one process: blocks of training steps alternate between the two settings (same allocations, same
+clock / thermal state, drift cancels), HIP-event timed per block. Process-level A/B runs of bench.py differ by up to +-1 % between
+identical runs on this pool; this tool resolves ~0.1 %.
+  tools/ab_inprocess.py module.attr [blocks=12] [steps_per_block=20]        e.g. nndetection_amd.arch.conv.NORM_INPUT_FUSE
+  tools/ab_inprocess.py env:NAME ...                                        (an environment variable the library reads per call: 1 / 0)"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from nndetection_amd.plans import get_plan
+
+what = sys.argv[1]
+blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+spb = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+if what.startswith("env:"):
+    def setv(on): os.environ[what[4:]] = "1" if on else "0"
+else:
+    mod, attr = what.rsplit(".", 1)
+    M = importlib.import_module(mod)
+    def setv(on): setattr(M, attr, bool(on))
+dev = torch.device("cuda:0")
+r = bench.Route(get_plan("luna160"), 4, "bf16", dev, 0, False)
+for on in (True, False):
+    setv(on)
+    for _ in range(8):
+        r.step()
+torch.cuda.synchronize()
+t = {True: [], False: []}
+cpu = {True: [], False: []}
+for b in range(2 * blocks):
+    on = (b % 2 == 0) ^ ((b // 2) % 2 == 1)          # ABBA order
+    setv(on)
+    for _ in range(3):
+        r.step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    c0 = time.perf_counter()
+    for _ in range(spb):
+        r.step()
+    cpu[on].append((time.perf_counter() - c0) / spb * 1e3)        # host time to ENQUEUE a step (no synchronisation inside)
+    e1.record(); torch.cuda.synchronize()
+    t[on].append(e0.elapsed_time(e1) / spb)
+for on in (True, False):
+    a = np.array(t[on])
+    print(f"{what}={int(on)}: mean {a.mean():.4f} ms  median {np.median(a):.4f}  min {a.min():.4f}  max {a.max():.4f}  ({len(a)} blocks of {spb} steps); host enqueue {np.mean(cpu[on]):.3f} ms / step")
+d = np.array(t[True]) - np.array(t[False])
+print(f"on - off: mean {d.mean():+.4f} ms  median {np.median(d):+.4f}  (paired by position; standard error {d.std(ddof=1) / np.sqrt(len(d)):.4f})")

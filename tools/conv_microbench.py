@@ -84,7 +84,19 @@ def main():
         r = torch.randn_like(y)
         fr = lambda: L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, L.ptr(r), L.ptr(y), None, st)     # + fused residual (decoder top-down add)
         ga = lambda: L.call("nndet_conv3d_backward_data_acc", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx), None, st)            # dx += (fused gradient accumulation)
-        fns = {"fwd": f, "dgrad": g, "wgrad": h, "fwd_res": fr, "dgrad_acc": ga}
+        # forward that reads a pre-norm tensor + coefficient table and writes the normalised input on the way (round 6, k_ig3s<.., PRE>),
+        # next to the two launches it replaces (fwd_two); both with the statistics epilogue as in the step
+        ss = torch.stack((torch.rand(B, d.cin_p, device="cuda") + 0.5, torch.randn(B, d.cin_p, device="cuda") * 0.3), -1).contiguous()
+        xn = torch.empty_like(x)
+        stats = torch.zeros(L.STATS_REPLICAS, B, d.cout_p, 2, dtype=torch.float64, device="cuda")
+        dpre = _desc(x, cin, cout, m.k, m.s, m.p, tr)
+        dpre.in_affine, dpre.in_relu = ss.data_ptr(), 1
+        fp = lambda: L.call("nndet_conv3d_forward_norm_input", ctypes.byref(dpre), L.ptr(x), L.ptr(xn), L.ptr(w0), None, L.ptr(y), L.ptr(stats), st)
+        def f2():
+            L.call("nndet_affine_apply", L.dtype_code(x), L.ptr(x), L.ptr(ss), B, sp[0] * sp[1] * sp[2], d.cin_p, 1, L.ptr(xn), st)
+            L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(xn), L.ptr(w0), None, None, L.ptr(y), L.ptr(stats), st)
+        fs = lambda: L.call("nndet_conv3d_forward", ctypes.byref(d), L.ptr(x), L.ptr(w0), None, None, L.ptr(y), L.ptr(stats), st)     # + statistics epilogue
+        fns = {"fwd": f, "dgrad": g, "wgrad": h, "fwd_res": fr, "dgrad_acc": ga, "fwd_pre": fp, "fwd_two": f2, "fwd_stats": fs}
         for nm in order:
             ms = timeit(fns[nm], iters)
             res.append(f"{nm} {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF/s {byts / ms / 1e6:7.0f} GB/s")
