@@ -367,6 +367,17 @@ int32_t nndet_conv3d_dgrad_fuses_norm_reduce(const NndetConv* c);
 int nndet_conv3d_backward_data_acc_normred(const NndetConv* c, const void* dy, const void* w_packed_mode1, void* dx_inout,
                                            const void* y_norm, const float* mean_rstd, const float* gamma, const float* beta,
                                            int32_t relu, int32_t c_norm, double* red_ws, void* stream);
+/* The same sums from a data gradient that WRITES dx (one consumer: conv -> norm -> ReLU -> conv inside an encoder stage,
+ * nndet/arch/blocks/basic.py:45-151): dx = conv^T(dy) and, in the epilogue, S1 / S2 of the block that produced this convolution's
+ * input, from the values being stored and that block's pre-norm tensor -- the k_norm_bwd_reduce launch (a read of dx and of y_norm that
+ * runs 2-3x slower than alone next to the weight-gradient stream) leaves the serial chain of the backward pass.
+ * nndet_conv3d_dgrad_normred_supported(): 3x3x3 / stride 1 / padding 1 in 16-bit types on the k_ig3 configurations with 32 or 64 rows
+ * per workgroup (every stride-1 layer of the encoder from 64 channels on; not the 32 -> 32 full-resolution layers, whose input is the
+ * fused stem block). */
+int32_t nndet_conv3d_dgrad_normred_supported(const NndetConv* c);
+int nndet_conv3d_backward_data_normred(const NndetConv* c, const void* dy, const void* w_packed_mode1, void* dx, const void* y_norm,
+                                       const float* mean_rstd, const float* gamma, const float* beta, int32_t relu, int32_t c_norm,
+                                       double* red_ws, void* stream);
 /* dw (fp32, PyTorch layout, ACCUMULATED into: zero it first) ; dbias ([cout] fp32, accumulated) may be NULL.
  * Two-stage reduction through `workspace` (nndet_conv3d_wgrad_workspace_bytes(c) bytes): deterministic, no atomics on dw. */
 size_t nndet_conv3d_wgrad_workspace_bytes(const NndetConv* c);

@@ -116,6 +116,8 @@ SIGNATURES = {
     "nndet_conv3d_backward_data_acc": (C.c_int, [_CONVP, _P, _P, _P, _P, _P]),
     "nndet_conv3d_dgrad_fuses_norm_reduce": (_I32, [_CONVP]),
     "nndet_conv3d_backward_data_acc_normred": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P]),
+    "nndet_conv3d_backward_data_normred": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P]),
+    "nndet_conv3d_dgrad_normred_supported": (C.c_int32, [_CONVP]),
     "nndet_conv3d_wgrad_workspace_bytes": (_SZ, [_CONVP]),
     "nndet_conv3d_backward_weight": (C.c_int, [_CONVP, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_conv3d_forward_items": (C.c_int, [_CONVP, _ITEMSP, _P, _P, _P, _P, _P, _P]),

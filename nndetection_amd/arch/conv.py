@@ -245,6 +245,10 @@ _rank1_grads = {}
 # reduction pass (nndet_norm_backward_presummed). At full resolution: one read of the pre-norm tensor (315 MB at batch 2) inside the
 # data gradient instead of the 0.38 ms k_norm_bwd_reduce launch on the tail of the step. NNDET_NORM_RED_FUSE=0: the separate pass.
 NORM_RED_FUSE = os.environ.get("NNDET_NORM_RED_FUSE", "1") != "0"
+# Round 6: the same for the plain chains conv -> norm -> ReLU -> conv inside an encoder stage (ONE consumer, the stride-1 3x3x3 data
+# gradient in k_ig3 writes dx and takes the sums: nndet_conv3d_backward_data_normred). The k_norm_bwd_reduce launches it replaces sit
+# on the serial chain of the backward pass and run 2-3 x slower than alone next to the weight-gradient stream. NNDET_NORM_RED_CHAIN=0: off.
+NORM_RED_CHAIN = os.environ.get("NNDET_NORM_RED_CHAIN", "1") != "0"
 _norm_presums = {}          # gradient buffer address -> (red_ws, mean_rstd of the norm they belong to)
 _last_mean_rstd = [None]    # _NormFn.forward -> BaseConvNormAct.forward (the tag of the block's output)
 norm_red_fused = [0]        # how many norm backward passes took their sums from a data gradient (tests)
@@ -425,7 +429,7 @@ class _ConvFn(torch.autograd.Function):
             L.call("nndet_conv3d_forward", ctypes.byref(desc), L.ptr(x_p), L.ptr(w_arg), L.ptr(b_p), L.ptr(r_p), L.ptr(y), L.ptr(stats), L.stream())
         ctx.desc, ctx.mod, ctx.has_bias, ctx.has_res = desc_bwd, mod, bias is not None, residual is not None
         ctx.gacc = None if mod.transposed else getattr(x, "_nndet_gacc", None)   # fused accumulation of the input gradient (encoder.py)
-        ctx.norm_src = getattr(x, "_nndet_norm_src", None) if ctx.gacc is not None else None    # (see _norm_presums)
+        ctx.norm_src = getattr(x, "_nndet_norm_src", None)    # (see _norm_presums; with or without a fused gradient accumulation)
         ctx.x_ss = x_ss                      # (tiny) keeps the table alive for the weight gradient
         ctx.save_for_backward(x_bwd, weight)
         out = logical(y, cout)
@@ -505,8 +509,23 @@ class _ConvFn(torch.autograd.Function):
                 dx_p = None
             else:
                 dx_p = torch.empty_like(x_p)
+            ns = ctx.norm_src if (NORM_RED_FUSE and NORM_RED_CHAIN and gacc is None and dx_p is not None) else None
             if dx_p is None:
                 pass
+            elif (ns is not None and ns[0].shape == x_p.shape and ns[0].dtype == dt and not _splitk_bytes(mod, desc, 1)
+                    and ns[2].norm.weight.dtype == torch.float32 and ns[2].norm.bias.dtype == torch.float32     # (read as raw fp32)
+                    and ns[2].norm.weight.is_contiguous() and ns[2].norm.bias.is_contiguous()
+                    and L.load().nndet_conv3d_dgrad_normred_supported(ctypes.byref(desc))):
+                # x is the output of a materialised conv -> norm -> ReLU block and (as far as this node can know) read by this
+                # convolution only: the data gradient also takes that block's norm-backward sums (k_ig3<.., NB>). If autograd adds another
+                # contribution after all, the sum is another tensor or an in-place write (version counter): the entry is not used.
+                ny_p, nmr, nmod = ns
+                red = L.arena_zeros((L.STATS_REPLICAS * desc.batch * desc.cin_p * 2 + desc.batch,), torch.float64, dev)
+                L.call("nndet_conv3d_backward_data_normred", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p),
+                       L.ptr(ny_p), L.ptr(nmr), L.ptr(nmod.norm.weight.detach()), L.ptr(nmod.norm.bias.detach()), int(nmod.relu),
+                       nmod.out_channels, L.ptr(red), L.stream())
+                _norm_presums.clear()                      # at most one live entry
+                _norm_presums[dx_p.data_ptr()] = (red, nmr, dx_p, dx_p._version)
             elif dbias is not None and L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)):
                 # pointwise kernels read every dy element once: the bias gradient comes out of the same pass
                 L.call("nndet_conv3d_backward_data_bias", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.ptr(dbias), L.stream())

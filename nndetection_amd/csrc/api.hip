@@ -128,6 +128,22 @@ extern "C" int nndet_conv3d_dgrad_fuses_norm_reduce(const NndetConv* c) {
     return dgs_fuses_norm_reduce(c);
 }
 
+extern "C" int32_t nndet_conv3d_dgrad_normred_supported(const NndetConv* c) {
+    if (check_conv(c) || c->cin_p == 1 || c->transposed) return 0;
+    return ig3_fuses_norm_reduce(c);
+}
+
+extern "C" int nndet_conv3d_backward_data_normred(const NndetConv* c, const void* dy, const void* w, void* dx, const void* y_norm,
+                                                  const float* mean_rstd, const float* gamma, const float* beta, int32_t relu,
+                                                  int32_t c_norm, double* red_ws, void* stream) {
+    int rc = check_conv(c);
+    if (rc) return rc;
+    if (!dy || !w || !dx || !y_norm || !mean_rstd || !gamma || !beta || !red_ws || c->cin_p == 1 || c->transposed) return NNDET_EINVAL;
+    if (c_norm <= 0 || c_norm > c->cin_p || !ig3_fuses_norm_reduce(c)) return NNDET_EINVAL;
+    const DgsNormRed nr = {y_norm, mean_rstd, gamma, beta, red_ws, relu ? 1 : 0, c_norm};
+    return igemm_run(c, 1, dy, w, nullptr, nullptr, dx, nullptr, as_stream(stream), nullptr, nullptr, 0, &nr);
+}
+
 extern "C" int nndet_conv3d_backward_data_acc_normred(const NndetConv* c, const void* dy, const void* w, void* dx, const void* y_norm,
                                                       const float* mean_rstd, const float* gamma, const float* beta, int32_t relu,
                                                       int32_t c_norm, double* red_ws, void* stream) {

@@ -10,7 +10,9 @@
 
 // conv_igemm.hip
 int igemm_run(const NndetConv* c, int kind /*0 fwd, 1 bwd-data*/, const void* x, const void* w, const float* bias,
-              const void* res, void* y, double* stats, hipStream_t st, float* dbias = nullptr, void* ws = nullptr, size_t ws_bytes = 0);
+              const void* res, void* y, double* stats, hipStream_t st, float* dbias = nullptr, void* ws = nullptr, size_t ws_bytes = 0,
+              const struct DgsNormRed* nr = nullptr);   // nr (kind 1 only): also the norm-backward sums of the block that produced this conv's input
+int ig3_fuses_norm_reduce(const NndetConv* c);          // 1 if igemm_run accepts nr for this problem (stride-1 3x3x3 data gradients in k_ig3, 16 bits)
 size_t igemm_splitk_bytes(const NndetConv* c, int kind);   // > 0: igemm_run splits K when given that much workspace
 // ragged batches (NndetItems): 3x3x3 / stride 1 / pad 1 only
 int items_check(const NndetConv* c, const NndetItems* it);

@@ -121,6 +121,12 @@ struct IgArgs {
     // rounding and the norm statistics happen in k_ig_splitk_reduce. ksplit <= 1 / part == NULL: off.
     int32_t ksplit, pad_;
     float* part;
+    // Norm-backward sums in the epilogue (round 6, k_ig3<..., NB = true>, data gradient only): y is the COMPLETE gradient w.r.t. the
+    // normalised (+ReLU) output of the conv -> norm -> ReLU block that produced this convolution's input, so the sums that block's
+    // k_norm_bwd_reduce would read it back for -- S1 = sum g, S2 = sum g * xhat per (image, channel), g = y * [ReLU mask] -- are
+    // accumulated here from the values being stored and the block's pre-norm tensor `ny` (DgsArgs of conv_dgs.hip: same fields, same sums)
+    const void* ny; const float* nmr; const float* ngamma; const float* nbeta; double* nred;
+    int32_t nrelu, ncout;
 };
 
 // Ragged batch (NndetItems): per-item dims and first voxel row; only k_ig3<..., ITEMS = true> reads it (blockIdx.z = item,
@@ -581,9 +587,13 @@ __device__ __forceinline__ void ig3_lds_dma16(__amdgpu_buffer_rsrc_t rs, int vof
 // DMA (128-row configuration, ONE workgroup per CU): the halo of channel chunk kc + 1 goes global -> LDS by LDS-DMA into the second
 // 64 KB buffer WHILE the taps of chunk kc are multiplied -- one 1 KB piece per tap, issued from inside the tap loop (vmcnt is in-order:
 // pieces issued in one go in front of a tap's weight loads would be waited for together with them), weight fragments 4 taps ahead.
-template <typename T, int WR, int MT, int NT, int MINW, bool AFF = false, bool ITEMS = false, bool DMA = false>
+template <typename T, int WR, int MT, int NT, int MINW, bool AFF = false, bool ITEMS = false, bool DMA = false, bool NB = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : MINW)) void k_ig3(const IgArgs A, const IgItems IT) {
     using M = Mma<T>;
+    static_assert(!NB || (sizeof(T) == 2 && MT == 2 && !ITEMS), "the norm-backward epilogue: 16-bit types, two row tiles per wave, uniform batches");
+    constexpr int NBR = WR * MT * 16;                  // rows (= channels of the gradient) of this workgroup
+    __shared__ float nb_c[NB ? NBR : 1][4];          // per channel: mean, rstd, scale, shift of the norm whose backward sums are taken
+    __shared__ double nb_s[NB ? NBR : 1][2];         // S1, raw sum g * y of this workgroup
     constexpr int KC = M::KC, EPL = M::EPL;
     constexpr int TD = NT / WR, TH = 8, TW = 8;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV4 = HD * HH * HW * 4;
@@ -799,11 +809,47 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : MINW)) void k_ig3(const 
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bia[i][r] = A.bias ? A.bias[rl + i * 16 + r] : 0.f;
+    float csc[NB ? MT : 1][4], csh[NB ? MT : 1][4], nsa[NB ? MT : 1][4], nsb[NB ? MT : 1][4];
+    const auto nyrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(NB ? A.ny : A.y)) + out_base, 0, NB ? out_bytes : 0, 0x00020000);
+    if constexpr (NB) {
+        if (tid < NBR) {
+            const int ch = row0 + tid;
+            const bool ok = ch < A.ncout;
+            const float mu = A.nmr[((int64_t)n * A.Cy + ch) * 2], rs = A.nmr[((int64_t)n * A.Cy + ch) * 2 + 1];
+            const float sc = ok ? rs * A.ngamma[ok ? ch : 0] : 0.f;
+            nb_c[tid][0] = ok ? mu : 0.f; nb_c[tid][1] = ok ? rs : 0.f; nb_c[tid][2] = sc;
+            nb_c[tid][3] = ok ? A.nbeta[ok ? ch : 0] - mu * sc : 0.f;           // the forward pass's expressions (k_norm_apply)
+            nb_s[tid][0] = 0.0; nb_s[tid][1] = 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                csc[i][r] = nb_c[(wr * MT + i) * 16 + q * 4 + r][2]; csh[i][r] = nb_c[(wr * MT + i) * 16 + q * 4 + r][3];
+                nsa[i][r] = 0.f; nsb[i][r] = 0.f;
+            }
+    }
+    constexpr int YB = 4;                              // pre-norm pieces requested together (the stores in between would order them one by one)
+    u32x4 ypre[NB ? YB : 1];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int ld = ld0 + (j >> 2), lh = lh0 + 2 * (j & 3);
         const bool valid = (ld < O0) && (lh < O1) && (lw < O2);
         const int so = (j >> 2) * oslab + 2 * (j & 3) * orow;
+        if constexpr (NB) {
+            if (j % YB == 0) {
+#pragma unroll
+                for (int jj = 0; jj < YB && j + jj < NT; ++jj) {
+                    const int ld_ = ld0 + ((j + jj) >> 2), lh_ = lh0 + 2 * ((j + jj) & 3);
+                    const bool v_ = (ld_ < O0) && (lh_ < O1) && (lw < O2);
+                    const int vb16_ = vb + (((q >> 1) * 8 + (q & 1) * 16) - q * 4) * (int)sizeof(T);
+                    ypre[jj] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(nyrs, v_ ? vb16_ : (int)0x80000000,
+                                                                                              ((j + jj) >> 2) * oslab + 2 * ((j + jj) & 3) * orow, 0));
+                }
+            }
+        }
         if constexpr (sizeof(T) == 2 && MT == 2) {
             // bf16, two row tiles per wave: ONE 16-byte store per lane instead of two 8-byte ones (the epilogue is store-issue bound).
             // v_permlane16_swap exchanges the packed row-tile-0 values of the odd lane rows with the row-tile-1 values of the even
@@ -826,6 +872,26 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : MINW)) void k_ig3(const 
                     ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
                 }
             }
+            if constexpr (NB) {        // S1 / S2 from the ROUNDED values (what k_norm_bwd_apply will read back) and the pre-norm tensor (k_dgs<.., NB>)
+                const u32x4 y16 = ypre[j % YB];            // in the layout of the 16-byte stores: the same swap (an involution) gives the MFMA layout
+                const v2u_t y0 = __builtin_amdgcn_permlane16_swap(y16[0], y16[2], false, false);
+                const v2u_t y1 = __builtin_amdgcn_permlane16_swap(y16[1], y16[3], false, false);
+                const uint32_t yk[2][2] = {{y0[0], y1[0]}, {y0[1], y1[1]}};
+                if (valid) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float gv[4] = {H16<T>::lo(pk[h][0]), H16<T>::hi(pk[h][0]), H16<T>::lo(pk[h][1]), H16<T>::hi(pk[h][1])};
+                        const float yv[4] = {H16<T>::lo(yk[h][0]), H16<T>::hi(yk[h][0]), H16<T>::lo(yk[h][1]), H16<T>::hi(yk[h][1])};
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            float gm = gv[rr];
+                            if (A.nrelu && !(fmaf(yv[rr], csc[NB ? h : 0][rr], csh[NB ? h : 0][rr]) > 0.f)) gm = 0.f;   // the forward pass's expression
+                            nsa[NB ? h : 0][rr] += gm;
+                            nsb[NB ? h : 0][rr] = fmaf(gm, yv[rr], nsb[NB ? h : 0][rr]);      // RAW moment sum g * y: centred once per workgroup below
+                        }
+                    }
+                }
+            }
             const v2u_t s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
             const v2u_t s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
             const v4u_t st16 = {s0[0], s1[0], s0[1], s1[1]};
@@ -846,6 +912,29 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : MINW)) void k_ig3(const 
                     ssq[i][0] += v0 * v0; ssq[i][1] += v1 * v1; ssq[i][2] += v2 * v2; ssq[i][3] += v3 * v3;
                 }
             }
+        }
+    }
+    if constexpr (NB) {
+        // lanes li = 0..15 of a row q hold the same 8 channels: add over the 16 points, then the waves of a row block through LDS, then
+        // ONE fp64 atomic per (channel, sum) and workgroup into k_norm_bwd_reduce's replica layout
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float a = nsa[i][rr], b = nsb[i][rr];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (li == 0) {
+                    atomicAdd(&nb_s[(wr * MT + i) * 16 + q * 4 + rr][0], (double)a);
+                    atomicAdd(&nb_s[(wr * MT + i) * 16 + q * 4 + rr][1], (double)b);
+                }
+            }
+        __syncthreads();
+        if (tid < NBR * 2) {
+            const int rep = (blockIdx.x + blockIdx.z * 7) % NNDET_STATS_REPLICAS;
+            double v = nb_s[tid >> 1][tid & 1];
+            if (tid & 1) v = (double)nb_c[tid >> 1][1] * (v - (double)nb_c[tid >> 1][0] * nb_s[tid >> 1][0]);   // sum g*xhat = rstd * (sum g*y - mean * sum g)
+            if (v != 0.0) atomicAdd(A.nred + (((int64_t)rep * A.N + n) * A.Cy + row0 + (tid >> 1)) * 2 + (tid & 1), v);
         }
     }
     if (A.stats) {
@@ -1470,6 +1559,23 @@ static int launch_cfg(const Plan& P, hipStream_t st) {
     return 0;
 }
 
+// data gradient + norm-backward sums (IgArgs::ny ...): the k_ig3 configurations with two row tiles per wave, 16-bit types
+template <typename T>
+static int launch_cfg_nb(const Plan& P, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        switch (P.cfg) {
+            case 5: k_ig3<T, 1, 2, 8, 2, false, false, false, true><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
+            case 6: k_ig3<T, 2, 2, 8, 3, false, false, false, true><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
+            case 7: k_ig3<T, 2, 2, 16, 2, false, false, false, true><<<P.grid, 256, P.lds, st>>>(P.a, g_no_items); break;
+            default: return NNDET_EINVAL;
+        }
+        LAUNCH_CHECK();
+        return 0;
+    } else {
+        return NNDET_EINVAL;
+    }
+}
+
 template <typename T, int WR, int MT, int NT, int MAXP, int MINW, bool PIPE = false>
 static int set_lds_attr() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<T, WR, MT, NT, MAXP, MINW, PIPE, false>),
@@ -1486,6 +1592,9 @@ static int set_lds_attr3() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, WR, MT, NT, MINW, false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    if constexpr (sizeof(T) == 2 && MT == 2)
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig3<T, WR, MT, NT, MINW, false, false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048 - 4096);
     return rc;
 }
 template <typename T>
@@ -1579,8 +1688,31 @@ static int splitk_reduce_launch(const Plan& P, hipStream_t st) {
     return 0;
 }
 
+static bool ig3r_applicable(const NndetConv* c, const Plan& P);
+// Does the data gradient of this convolution run in a k_ig3 launch that can also take the norm-backward sums (igemm_run's `nr`)?
+int ig3_fuses_norm_reduce(const NndetConv* c) {
+    static const int on = getenv("NNDET_IG3_NORMRED") ? atoi(getenv("NNDET_IG3_NORMRED")) : 1;
+    if (!on || !nndet_is16(c->dtype) || c->transposed || c->in_affine || c->cin_p == 1) return 0;
+    for (int i = 0; i < 3; ++i) if (c->k[i] != 3 || c->s[i] != 1 || c->p[i] != 1) return 0;
+    Plan P;
+    if (build_plan(c, 1, &P)) return 0;
+    return (P.cfg == 5 || P.cfg == 6 || P.cfg == 7) && P.a.ncls == 1 && !ig3r_applicable(c, P);
+}
+
 int igemm_run(const NndetConv* c, int kind, const void* x, const void* w, const float* bias, const void* res, void* y,
-              double* stats, hipStream_t st, float* dbias, void* ws, size_t ws_bytes) {
+              double* stats, hipStream_t st, float* dbias, void* ws, size_t ws_bytes, const DgsNormRed* nr) {
+    if (nr) {                                                            // (the caller asked ig3_fuses_norm_reduce)
+        if (kind != 1 || bias || stats || res || dbias || !ig3_fuses_norm_reduce(c)) return NNDET_EINVAL;
+        Plan P;
+        int rc = build_plan(c, 1, &P);
+        if (rc) return rc;
+        rc = ensure_attrs();
+        if (rc) return rc;
+        P.a.x = x; P.a.w = w; P.a.y = y;
+        P.a.ny = nr->y; P.a.nmr = nr->mean_rstd; P.a.ngamma = nr->gamma; P.a.nbeta = nr->beta; P.a.nred = nr->red_ws;
+        P.a.nrelu = nr->relu; P.a.ncout = nr->c;
+        return c->dtype == NNDET_F16 ? launch_cfg_nb<f16_t>(P, st) : launch_cfg_nb<bf16_t>(P, st);
+    }
     if (!stats && !(kind == 0 && c->in_affine && c->transposed)) {   // pointwise problems (1x1x1, transposed k == s) stream straight from global memory
         const int prc = pw_run(c, kind, x, w, bias, res, y, st, dbias);
         if (prc != 1) return prc;

@@ -953,3 +953,78 @@ def test_stride2_forward_that_writes_its_normalised_input(batch, shape, relu, dt
     L.call("nndet_conv3d_forward_norm_input", ctypes.byref(d2p), L.ptr(y0), L.ptr(a2), L.ptr(w2), None, L.ptr(o2), None, st)
     torch.cuda.synchronize()
     assert torch.equal(a2.view(torch.int16), a_ref.view(torch.int16)) and torch.equal(o2.view(torch.int16), o_ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("cin,cn,relu,batch,shape", [(64, 64, 1, 2, (21, 19, 35)), (64, 48, 1, 3, (8, 24, 40)), (128, 128, 0, 2, (9, 17, 13)), (32, 32, 1, 1, (16, 16, 24)),
+                                                      (64, 64, 1, 4, (40, 40, 24))],
+                         ids=["c64_ragged", "c48_padded", "c128_linear", "c32_small", "c64_tiles"])
+def test_norm_backward_sums_from_the_stride1_data_gradient(cin, cn, relu, batch, shape, dtype, monkeypatch):
+    """nndet_conv3d_backward_data_normred (k_ig3<.., NB>, round 6): the stride-1 3x3x3 data gradient also accumulates S1 = sum g [mask],
+    S2 = sum g [mask] xhat of the conv -> norm -> ReLU block that produced its input, from the values it stores and that block's pre-norm
+    tensor. dx must be BIT-IDENTICAL to nndet_conv3d_backward_data; the sums agree with a float64 evaluation from the stored gradient
+    (1e-6 of the largest sum of their kind) and with what k_norm_bwd_reduce takes from the same tensors; through the module route the
+    block's norm backward skips its reduction pass and dgamma / dbeta / the gradient behind the norm agree with the separate pass."""
+    import ctypes
+    from nndetection_amd import _lib as L
+    from nndetection_amd.arch import conv as CV
+    from nndetection_amd.arch.conv import ConvInstanceRelu, _desc, _packed
+    from nndetection_amd.layout import cpad
+    dev = torch.device("cuda:0")
+    torch.manual_seed(17)
+    cp = cpad(cn)
+    m = ConvInstanceRelu(3, cn, cin, 3, stride=1, padding=1, add_norm=False, add_act=False).to(dev)     # consumer: cn -> cin channels
+    x = torch.randn(batch, *shape, cp, device=dev).to(dtype)
+    d = _desc(x, cn, cin, m.k, m.s, m.p, False)
+    # (test volumes are small and ragged: take the compile-time-tile kernel k_ig3 whatever the padding / workgroup-count rules of build_plan say)
+    monkeypatch.setenv("NNDET_IGEMM_SPEC", "2")
+    monkeypatch.setenv("NNDET_IGEMM_SMALLWG", "0")
+    assert L.load().nndet_conv3d_dgrad_normred_supported(ctypes.byref(d)) == 1
+    w1 = _packed(m, 1, m.conv.weight, d, dtype)
+    dy = torch.randn(batch, *shape, d.cout_p, device=dev).to(dtype)
+    ny = (torch.randn(batch, *shape, cp, device=dev) * 1.5 + 0.3).to(dtype)
+    if cp > cn:
+        ny[..., cn:] = 0
+    mr = torch.zeros(batch, cp, 2, device=dev)
+    mr[:, :cn, 0] = ny.float()[..., :cn].mean((1, 2, 3)); mr[:, :cn, 1] = 1.0 / (ny.float()[..., :cn].var((1, 2, 3), unbiased=False) + 1e-5).sqrt()
+    gam, bet = torch.rand(cn, device=dev) + 0.5, torch.randn(cn, device=dev) * 0.3
+    st = L.stream()
+    dx_ref = torch.full_like(x, float("nan"))
+    L.call("nndet_conv3d_backward_data", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx_ref), st)
+    dx = torch.full_like(x, float("nan"))
+    red = torch.zeros(L.STATS_REPLICAS * batch * cp * 2 + batch, dtype=torch.float64, device=dev)
+    L.call("nndet_conv3d_backward_data_normred", ctypes.byref(d), L.ptr(dy), L.ptr(w1), L.ptr(dx), L.ptr(ny), L.ptr(mr), L.ptr(gam), L.ptr(bet), relu, cn,
+           L.ptr(red), st)
+    torch.cuda.synchronize()
+    assert not torch.isnan(dx_ref.float()).any()
+    assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), "dx differs from the plain data gradient"
+    sums = red[:L.STATS_REPLICAS * batch * cp * 2].view(L.STATS_REPLICAS, batch, cp, 2).sum(0)[:, :cn]
+    xh = (ny.double()[..., :cn] - mr[:, :cn, 0].double().view(batch, 1, 1, 1, cn)) * mr[:, :cn, 1].double().view(batch, 1, 1, 1, cn)
+    sc = (mr[:, :cn, 1] * gam).view(batch, 1, 1, 1, cn); sh = (bet - mr[:, :cn, 0] * (mr[:, :cn, 1] * gam)).view(batch, 1, 1, 1, cn)
+    mask = (torch.addcmul(sh, ny.float()[..., :cn], sc) > 0) if relu else torch.ones_like(xh, dtype=torch.bool)
+    gm = dx.double()[..., :cn] * mask
+    s64 = torch.stack((gm.sum((1, 2, 3)), (gm * xh).sum((1, 2, 3))), -1)
+    assert float(((sums - s64).abs() / s64.abs().amax((0, 1), keepdim=True)).max()) <= 1e-6
+    if cp > cn:
+        assert float(red[:L.STATS_REPLICAS * batch * cp * 2].view(L.STATS_REPLICAS, batch, cp, 2)[:, :, cn:].abs().max()) == 0.0
+    # module route: block -> consumer, the block's norm backward with and without the sums from the consumer's data gradient
+    b0 = ConvInstanceRelu(3, 32, cn, 3, padding=1, add_norm=True, add_act=bool(relu)).to(dev)
+    c1 = ConvInstanceRelu(3, cn, cin, 3, padding=1, add_norm=True, add_act=True).to(dev)
+    with torch.no_grad():
+        b0.norm.weight.copy_(torch.randn(cn, device=dev) * 0.3 + 1.0); b0.norm.bias.copy_(torch.randn(cn, device=dev) * 0.3)
+    x0 = torch.randn(batch, 32, *shape, device=dev).to(dtype)
+    g1 = torch.randn(batch, cin, *shape, device=dev).to(dtype)
+    res = {}
+    for mode in (False, True):
+        monkeypatch.setattr(CV, "NORM_RED_CHAIN", mode)
+        CV.norm_red_fused[0] = 0
+        for mm in (b0, c1):
+            mm.zero_grad(set_to_none=True)
+        xx = x0.clone().requires_grad_(True)
+        c1(b0(xx)).backward(g1)
+        torch.cuda.synchronize()
+        assert CV.norm_red_fused[0] == (1 if mode else 0)
+        res[mode] = [t.detach().float().clone() for t in (b0.norm.weight.grad, b0.norm.bias.grad, b0.conv.weight.grad, xx.grad, c1.conv.weight.grad)]
+    for nme, t, a_, b_ in zip(["dgamma", "dbeta", "dw(block)", "dx", "dw(consumer)"], [2e-5, 2e-5, 2e-3, 2e-3, 1e-6], res[False], res[True]):
+        e = relerr(b_, a_)
+        assert e <= t, f"{nme}: fused vs separate reduction rel err {e:.3e}"

@@ -3,7 +3,7 @@
 clock / thermal state, drift cancels), HIP-event timed per block. Process-level A/B runs of bench.py differ by up to +-1 % between
 identical runs on this pool; this tool resolves ~0.1 %.
   tools/ab_inprocess.py module.attr [blocks=12] [steps_per_block=20]        e.g. nndetection_amd.arch.conv.NORM_INPUT_FUSE
-  tools/ab_inprocess.py env:NAME ...                                        (an environment variable the library reads per call: 1 / 0)"""
+  tools/ab_inprocess.py env:NAME ... | env:NAME=A,B ...                     (an environment variable the library reads per call: 1 / 0, or A / B)"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,8 +14,10 @@ from nndetection_amd.plans import get_plan
 what = sys.argv[1]
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 spb = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-if what.startswith("env:"):
-    def setv(on): os.environ[what[4:]] = "1" if on else "0"
+if what.startswith("env:"):                       # env:NAME (1 / 0) or env:NAME=A,B (A = "on", B = "off")
+    name, _, vals = what[4:].partition("=")
+    va, vb = vals.split(",") if vals else ("1", "0")
+    def setv(on): os.environ[name] = va if on else vb
 else:
     mod, attr = what.rsplit(".", 1)
     M = importlib.import_module(mod)
