@@ -45,6 +45,26 @@ __device__ __forceinline__ float sp_fgprob(const SpArgs& A, int64_t i) {
 __device__ __forceinline__ u64 sp_key_neg(const SpArgs& A, int64_t i) {
     return ((u64)(~f32_sortable(sp_fgprob(A, i))) << 32) | (u64)(uint32_t)i;
 }
+__device__ __forceinline__ u64 sp_key_neg_p(float prob, int64_t i) { return ((u64)(~f32_sortable(prob)) << 32) | (u64)(uint32_t)i; }
+// The SP_ITEMS labels and (for probabilities: C == 1) scores of a thread, requested TOGETHER: the passes below used to load a label, branch
+// on it, and only then load the score -- 16 dependent round trips per thread, 26-47 us per pass over 38 MB (round 6). Rows beyond N read
+// row 0 and get the label -1 (neither positive nor negative).
+__device__ __forceinline__ void sp_load_items(const SpArgs& A, int64_t i0, float* lab, float* prob) {
+#pragma unroll
+    for (int t = 0; t < SP_ITEMS; ++t) {
+        const int64_t i = i0 + (int64_t)t * 256;
+        lab[t] = A.labels[i < A.N ? i : 0];
+    }
+    if (A.is_prob) {
+#pragma unroll
+        for (int t = 0; t < SP_ITEMS; ++t) {
+            const int64_t i = i0 + (int64_t)t * 256;
+            prob[t] = A.scores[i < A.N ? i : 0];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < SP_ITEMS; ++t) if (i0 + (int64_t)t * 256 >= A.N) lab[t] = -1.f;
+}
 
 __global__ void k_sp_init(int32_t* params, u64* prefix, unsigned* hist) {
     const int t = threadIdx.x;
@@ -98,19 +118,24 @@ __global__ __launch_bounds__(256) void k_sp_hist(SpArgs A, const u64* __restrict
     h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
     __syncthreads();
     const u64 p0 = prefix[0], p1 = prefix[1];
-    const int64_t i0 = ((int64_t)blockIdx.x * 256) * SP_ITEMS + threadIdx.x;
+    // (a workgroup can walk several blocks of 256 * SP_ITEMS anchors -- NNDET_SP_HIST_WGS caps the grid -- but one block per workgroup is the
+    // fastest: 2 318 workgroups 0.41 ms for the detection-loss phase, 1 024: 0.41, 512: 0.43, 256: 0.53. The passes share the chip with the
+    // segmentation branch's forward kernel on its side stream; the same-address atomics at their end are not what they wait for)
+    for (int64_t blk = blockIdx.x; blk * (256 * SP_ITEMS) < A.N; blk += gridDim.x) {
+        const int64_t i0 = (blk * 256) * SP_ITEMS + threadIdx.x;
+        float lab[SP_ITEMS], prob[SP_ITEMS];
+        sp_load_items(A, i0, lab, prob);
 #pragma unroll
-    for (int t = 0; t < SP_ITEMS; ++t) {
-        const int64_t i = i0 + (int64_t)t * 256;
-        if (i < A.N) {
-            const float l = A.labels[i];
+        for (int t = 0; t < SP_ITEMS; ++t) {
+            const int64_t i = i0 + (int64_t)t * 256;
+            const float l = lab[t];
             if (l >= 1.f) {
                 if (!d0) {
                     const u64 key = sp_key_pos(A, (uint32_t)i);
                     if ((shift >= 56) || ((key >> (shift + 8)) == (p0 >> (shift + 8)))) atomicAdd(&h[0][(unsigned)(key >> shift) & 255u], 1u);
                 }
             } else if (l == 0.f && !d1) {
-                const u64 key = sp_key_neg(A, i);
+                const u64 key = A.is_prob ? sp_key_neg_p(prob[t], i) : sp_key_neg(A, i);
                 if ((shift >= 56) || ((key >> (shift + 8)) == (p1 >> (shift + 8)))) atomicAdd(&h[1][(unsigned)(key >> shift) & 255u], 1u);
             }
         }
@@ -132,18 +157,18 @@ __global__ __launch_bounds__(256) void k_sp_collect(SpArgs A, const u64* __restr
     const u64 k0 = kth[0], k1 = kth[1];
     const int num_pos = params[2], pool = params[4];
     const int64_t i0 = ((int64_t)blockIdx.x * 256) * SP_ITEMS + threadIdx.x;
+    float lab[SP_ITEMS], prob[SP_ITEMS];
+    sp_load_items(A, i0, lab, prob);
 #pragma unroll
     for (int t = 0; t < SP_ITEMS; ++t) {
         const int64_t i = i0 + (int64_t)t * 256;
-        if (i < A.N) {
-            const float l = A.labels[i];
-            if (l >= 1.f && num_pos > 0) {
-                const u64 key = sp_key_pos(A, (uint32_t)i);
-                if (key <= k0) { const int p = atomicAdd(&params[5], 1); if (p < A.P_cap) list_pos[p] = key; }
-            } else if (l == 0.f && pool > 0) {
-                const u64 key = sp_key_neg(A, i);
-                if (key <= k1) { const int p = atomicAdd(&params[6], 1); if (p < A.POOL_cap) list_pool[p] = key; }
-            }
+        const float l = lab[t];
+        if (l >= 1.f && num_pos > 0) {
+            const u64 key = sp_key_pos(A, (uint32_t)i);
+            if (key <= k0) { const int p = atomicAdd(&params[5], 1); if (p < A.P_cap) list_pos[p] = key; }
+        } else if (l == 0.f && pool > 0) {
+            const u64 key = A.is_prob ? sp_key_neg_p(prob[t], i) : sp_key_neg(A, i);
+            if (key <= k1) { const int p = atomicAdd(&params[6], 1); if (p < A.POOL_cap) list_pool[p] = key; }
         }
     }
 }
@@ -313,9 +338,11 @@ extern "C" int nndet_hnm_sample_f32(const float* labels, const float* scores, in
     LAUNCH_CHECK();
     int idx_bits = 1;
     while (((int64_t)1 << idx_bits) < N) ++idx_bits;
+    const unsigned hist_wgs = getenv("NNDET_SP_HIST_WGS") ? (unsigned)atoi(getenv("NNDET_SP_HIST_WGS")) : 0u;     // (read per call: A/B, tests; 0 = one block per workgroup)
+    const unsigned nb_hist = nb < hist_wgs || hist_wgs < 1 ? nb : hist_wgs;
     for (int shift = 56; shift >= 0; shift -= 8) {
         if (shift < 32 && shift >= idx_bits) continue;
-        k_sp_hist<<<nb, 256, 0, st>>>(A, w.prefix, w.hist, shift, w.krem + 2);
+        k_sp_hist<<<nb_hist, 256, 0, st>>>(A, w.prefix, w.hist, shift, w.krem + 2);
         LAUNCH_CHECK();
         k_sp_pick<<<1, 128, 0, st>>>(w.prefix, w.krem, w.hist, shift);
         LAUNCH_CHECK();

@@ -20,9 +20,11 @@ def _case(rng, N, C, n_pos, n_ign=50):
     return labels, logits
 
 
+@pytest.mark.parametrize("hist_wgs", ["0", "3"], ids=["block_per_wg", "3_wgs_walk_blocks"])
 @pytest.mark.parametrize("N,C,B,n_pos", [(200_000, 1, 4, 500), (200_000, 3, 4, 7), (1_186_650 * 2, 1, 2, 60), (5000, 1, 1, 0), (3000, 2, 64, 900)])
-def test_sampler_deterministic_vs_oracle(N, C, B, n_pos):
+def test_sampler_deterministic_vs_oracle(N, C, B, n_pos, hist_wgs, monkeypatch):
     from nndetection_amd.core.boxes import HardNegativeSamplerBatched
+    monkeypatch.setenv("NNDET_SP_HIST_WGS", hist_wgs)      # (round 6: a histogram workgroup may walk several blocks of anchors, labels / scores requested together)
     rng = np.random.default_rng(N + C + n_pos)
     labels, logits = _case(rng, N, C, n_pos)
     probs = bx.sigmoid(logits.max(1))
