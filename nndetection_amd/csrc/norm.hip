@@ -692,7 +692,14 @@ __global__ __launch_bounds__(256) void k_norm_bwd_finalize(double* __restrict__ 
     const int n = blockIdx.x;
     for (int i = threadIdx.x; i < c_p * 2; i += 256) {
         double v = 0.0;
-        for (int r = 0; r < NNDET_STATS_REPLICAS; ++r) v += red_ws[(((int64_t)r * N + n) * c_p) * 2 + i];
+        static_assert(NNDET_STATS_REPLICAS % 8 == 0, "replica loads come in batches of 8");
+        for (int r0 = 0; r0 < NNDET_STATS_REPLICAS; r0 += 8) {       // eight loads in flight, added in replica order (as k_norm_bwd_reduce's tail)
+            double l8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) l8[k] = red_ws[(((int64_t)(r0 + k) * N + n) * c_p) * 2 + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += l8[k];
+        }
         ch[i] = v;
     }
     __syncthreads();
