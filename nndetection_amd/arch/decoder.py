@@ -95,7 +95,7 @@ class UFPNModular(nn.Module):
         if level == 0 and self.split_tail and self.num_level >= 3 and need0:
             side = UFPNModular._tail_streams.get(dev.index or 0)        # level 0 stays on the tail stream of forward()
             if side is None:
-                side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev)
+                side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NNDET_PRIO_TAIL", "0")))
         else:
             side = UFPNModular._early_streams.get(dev.index or 0)
             if side is None:
@@ -133,7 +133,7 @@ class UFPNModular(nn.Module):
             main = torch.cuda.current_stream(dev)
             side = UFPNModular._tail_streams.get(dev.index or 0)
             if side is None:
-                side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev)
+                side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NNDET_PRIO_TAIL", "0")))
             if fpn[0] is None and not absorb:
                 side.wait_stream(main)                           # the encoder outputs are ready
                 inp_seq[0].record_stream(side)
