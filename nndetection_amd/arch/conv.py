@@ -206,6 +206,16 @@ _pre_event = [None]
 # who meets the tag first (`ensure_materialized`: the encoder after the stage, a hook, a consumer the fused launch does not cover)
 # writes the buffer with the plain nndet_affine_apply pass.
 NORM_INPUT_FUSE = os.environ.get("NNDET_NORM_INPUT_FUSE", "1") != "0"
+# The unwritten buffer may only exist between the two stages INSIDE the encoder's forward loop, which opens this scope around them and
+# materialises whatever is left when the consumer stage returns. A stage called on its own, or one whose output somebody observes through a
+# forward hook, takes the plain route.
+_fill_scope = [False]
+
+
+def _observed(mod) -> bool:
+    """Forward hooks on this module (or registered globally) would see its output before the consumer has written it."""
+    import torch.nn.modules.module as M
+    return bool(mod._forward_hooks) or bool(getattr(M, "_global_forward_hooks", None))
 
 
 def ensure_materialized(x: torch.Tensor) -> None:
@@ -774,8 +784,8 @@ class BaseConvNormAct(nn.Sequential):
             return y
         defer = bool(self.defer_output) and DEFER_NORM and y.is_cuda
         early = (not defer) and bool(self.early_output) and EARLY_CONSUMER and y.is_cuda
-        fill = ((not defer) and (not early) and bool(self.early_output) and NORM_INPUT_FUSE and y.is_cuda
-                and y.dtype in (torch.bfloat16, torch.float16))
+        fill = ((not defer) and (not early) and bool(self.early_output) and NORM_INPUT_FUSE and _fill_scope[0] and y.is_cuda
+                and y.dtype in (torch.bfloat16, torch.float16) and not _observed(self))
         out, ss = _NormFn.apply(y, self.norm.weight, self.norm.bias, stats, self, 3 if fill else (2 if early else (not defer)))
         if defer:
             mark_padded(out)

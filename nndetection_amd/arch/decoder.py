@@ -241,3 +241,6 @@ class UFPNModular(nn.Module):
         x0, _ = _ConvFn.apply(x1, None, False, up.conv.weight, bias, up, None, False)
         x0._nndet_pre_lat = (lat, inp0)
         return x0
+
+
+UFPNModular.early_lateral._nndet_handles_pre = True      # (arch/encoder.py: this stage hook writes an unwritten stage output itself before it reads it)

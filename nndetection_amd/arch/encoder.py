@@ -41,9 +41,16 @@ class Encoder(nn.Module):
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         outputs = []
+        from . import conv as _cv
         for sid, module in enumerate(self.stages):
             pre = getattr(x, "_nndet_pre", None)
-            x_in, x = x, module(x)
+            # (arch/conv.py NORM_INPUT_FUSE: stage 0 may hand an UNWRITTEN normalised tensor to stage 1 -- only here, where the next stage is
+            # known to run, nobody observes the stage output through a hook, and whatever is left unwritten is written right after)
+            _cv._fill_scope[0] = (sid == 0 and self.num_stages > 1 and not any(_cv._observed(m) for m in module.modules()))
+            try:
+                x_in, x = x, module(x)
+            finally:
+                _cv._fill_scope[0] = False
             if pre is not None:                  # (set_early_consumer: whatever the stage did with the tag, order this stream behind the
                 if len(pre) > 4:                 #  materialising pass -- or run it: NORM_INPUT_FUSE -- before the tensor is handed to anybody else)
                     ensure_materialized(x_in)
@@ -57,6 +64,8 @@ class Encoder(nn.Module):
                     # node will run -- the second consumer orders that stream behind its in-place accumulation)
                     x._nndet_gacc = {"buf": None, "stream": torch.cuda.current_stream(x.device) if x.is_cuda else None}
                 if self.stage_hook is not None:
+                    if not getattr(getattr(self.stage_hook, "__func__", self.stage_hook), "_nndet_handles_pre", False):
+                        ensure_materialized(x)       # (a hook we do not know may read the stage output now; decoder.early_lateral writes it itself)
                     self.stage_hook(len(outputs) - 1, x)
         return outputs
 

@@ -534,6 +534,26 @@ def test_stage1_convolution_writes_the_normalised_stage0_output(golden_dir, dtyp
         torch.cuda.synchronize()
         res.setdefault(mode, []).append((fs, {k: float(v.detach()) for k, v in losses.items()},
                                          {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    # the unwritten buffer exists only inside the encoder's loop: a stage called on its own, or one that is observed through a forward
+    # hook, takes the plain route and returns a written tensor
+    monkeypatch.setattr(C, "NORM_INPUT_FUSE", True)
+    monkeypatch.setenv("NNDET_IG3S", "1")
+    with torch.no_grad():
+        calls.clear()
+        alone = net.encoder.stages[0](x)
+        torch.cuda.synchronize()
+        assert "nndet_conv3d_forward_norm_input" not in calls and not hasattr(alone, "_nndet_pre")
+        assert torch.equal(alone.detach().float().cpu(), res["off"][0][0][0])
+        seen = []
+        h = net.encoder.stages[0].convs[-1].register_forward_hook(lambda m, i, o: seen.append(o.detach().float().cpu().clone()))
+        calls.clear()
+        feats = net.encoder(x)
+        torch.cuda.synchronize()
+        h.remove()
+        assert "nndet_conv3d_forward_norm_input" not in calls and len(seen) == 1 and torch.equal(seen[0], res["off"][0][0][0])
+        calls.clear()
+        net.encoder(x)
+        assert "nndet_conv3d_forward_norm_input" in calls             # (hook gone: fused again)
     tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
     ltol = 2e-3 if dtype == torch.bfloat16 else 3e-4
     ref = res["off"][0]
