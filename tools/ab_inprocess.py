@@ -22,8 +22,17 @@ if what.startswith("env:"):                       # env:NAME (1 / 0) or env:NAME
     va, vb = vals.split(",") if vals else ("1", "0")
     def setv(on): os.environ[name] = va if on else vb
 else:
-    mod, attr = what.rsplit(".", 1)
-    M = importlib.import_module(mod)
+    parts = what.split(".")
+    for k in range(len(parts) - 1, 0, -1):          # module path, then attributes (a class attribute: pkg.mod.Class.attr)
+        try:
+            M = importlib.import_module(".".join(parts[:k]))
+            break
+        except ImportError:
+            continue
+    for a in parts[k:-1]:
+        M = getattr(M, a)
+    attr = parts[-1]
+    assert hasattr(M, attr), what
     def setv(on): setattr(M, attr, bool(on))
 from nndetection_amd import _lib as L
 _setv = setv
