@@ -272,9 +272,12 @@ def arena_reset(device):
         a.reset()
 
 
+_NO_ARENA = bool(os.environ.get("NNDET_NO_ARENA"))      # (read at import: the function below runs ~50 times per training step)
+
+
 def arena_zeros(shape, dtype, device):
     """Zeroed tensor for a temporary that is dead when the current autograd node returns (see _ZeroArena)."""
-    if device.type != "cuda" or os.environ.get("NNDET_NO_ARENA"):
+    if device.type != "cuda" or _NO_ARENA:
         return torch.zeros(shape, dtype=dtype, device=device)
     key = (device.type, device.index)
     a = _arenas.get(key)

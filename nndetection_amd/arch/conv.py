@@ -127,13 +127,22 @@ def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1), force: bool 
     one batched launch (nndet_pack_weights_batched) instead of one launch per layer and mode. Returns the number of jobs.
     `force`: re-pack everything regardless of the cached version -- a training-mode forward pass does this, because FUSED optimizer
     kernels (torch._fused_sgd_ / _fused_adam_, i.e. torch.optim.*(fused=True)) write the parameters without advancing `_version`
-    (nndetection_amd.optim advances it by hand; a foreign optimizer may not)."""
+    (nndetection_amd.optim advances it by hand; a foreign optimizer may not).
+    Host cost (round 6: 1.2 ms of the ~10 ms a step takes to enqueue went into this function): the list of conv blocks is cached on the
+    model, the descriptor and size of a (block, mode, dtype) job in the block's cache, and a block's packed buffer is re-written IN PLACE
+    (every kernel that read the previous contents was enqueued before this call on streams the caller's stream has joined: the packs run
+    at the start of a forward pass, behind the optimizer step)."""
     jobs = []
     if force:
         PACK_EPOCH[0] += 1
-    for mod in model.modules():
-        if not isinstance(mod, BaseConvNormAct):
-            continue
+    blocks = model.__dict__.get("_nndet_conv_blocks")
+    n_mod = len(model._modules)
+    if blocks is None or blocks[0] != n_mod or any(r() is None for r in blocks[1]):
+        import weakref
+        blocks = (n_mod, [weakref.ref(m) for m in model.modules() if isinstance(m, BaseConvNormAct)])
+        model.__dict__["_nndet_conv_blocks"] = blocks      # (not a registered attribute: no submodule, nothing for state_dict)
+    for ref in blocks[1]:
+        mod = ref()
         if force:                                                    # EVERY block, the 1-channel stem included (ADVICE r3): its forward
             mod._pack_cache.pop(("bias", cpad(mod.out_channels)), None)      # reads the padded-bias cache too (_ConvFn.forward)
             mod._pack_cache.pop(("w32r", dtype), None)               # (arch/pyramid.py: rounded_w32)
@@ -148,23 +157,34 @@ def prepack_all(model: nn.Module, dtype: torch.dtype, modes=(0, 1), force: bool 
             hit = mod._pack_cache.get((mode, dtype))
             if hit is not None and hit[0] == ver and not force:
                 continue
-            d = L.NndetConv()
-            d.dtype = L._DT[dtype]
-            d.transposed = int(mod.transposed)
-            d.batch, d.cin, d.cout, d.cin_p, d.cout_p = 1, mod.in_channels, mod.out_channels, cpad(mod.in_channels), cpad(mod.out_channels)
-            d.k = (ctypes.c_int32 * 3)(*mod.k); d.s = (ctypes.c_int32 * 3)(*mod.s); d.p = (ctypes.c_int32 * 3)(*mod.p)
-            n = L.load().nndet_packed_weight_elems(ctypes.byref(d), mode)
-            buf = torch.empty((n,), dtype=dtype, device=w.device)
-            w32 = w.detach().float().contiguous()
+            job = mod._pack_cache.get(("job", mode, dtype))
+            if job is None:
+                d = L.NndetConv()
+                d.dtype = L._DT[dtype]
+                d.transposed = int(mod.transposed)
+                d.batch, d.cin, d.cout, d.cin_p, d.cout_p = 1, mod.in_channels, mod.out_channels, cpad(mod.in_channels), cpad(mod.out_channels)
+                d.k = (ctypes.c_int32 * 3)(*mod.k); d.s = (ctypes.c_int32 * 3)(*mod.s); d.p = (ctypes.c_int32 * 3)(*mod.p)
+                job = mod._pack_cache[("job", mode, dtype)] = (d, int(L.load().nndet_packed_weight_elems(ctypes.byref(d), mode)))
+            d, n = job
+            buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].dtype == dtype and hit[1].device == w.device) else None
+            if buf is None:
+                buf = torch.empty((n,), dtype=dtype, device=w.device)
+            w32 = w.detach()
+            if w32.dtype != torch.float32 or not w32.is_contiguous():
+                w32 = w32.float().contiguous()
             jobs.append((mod, mode, ver, d, w32, buf))
     if not jobs:
         return 0
     n = len(jobs)
-    convs = (L.NndetConv * n)(*[j[3] for j in jobs])
-    modes_c = (ctypes.c_int32 * n)(*[j[1] for j in jobs])
-    wp = (ctypes.c_void_p * n)(*[j[4].data_ptr() for j in jobs])
-    op = (ctypes.c_void_p * n)(*[j[5].data_ptr() for j in jobs])
-    L.call("nndet_pack_weights_batched", convs, modes_c, wp, op, n, L.stream())
+    sig = tuple(j[4].data_ptr() for j in jobs) + tuple(j[5].data_ptr() for j in jobs) + tuple(j[1] for j in jobs) + (L._DT[dtype],)
+    args = model.__dict__.get("_nndet_pack_args")
+    if args is None or args[0] != sig:                      # (the same sources, destinations and modes as last step: the argument arrays are kept)
+        convs = (L.NndetConv * n)(*[j[3] for j in jobs])
+        modes_c = (ctypes.c_int32 * n)(*[j[1] for j in jobs])
+        wp = (ctypes.c_void_p * n)(*[j[4].data_ptr() for j in jobs])
+        op = (ctypes.c_void_p * n)(*[j[5].data_ptr() for j in jobs])
+        args = model.__dict__["_nndet_pack_args"] = (sig, convs, modes_c, wp, op)
+    L.call("nndet_pack_weights_batched", args[1], args[2], args[3], args[4], n, L.stream())
     for mod, mode, ver, _, _, buf in jobs:
         mod._pack_cache[(mode, dtype)] = (ver, buf)
     return n
@@ -255,6 +275,7 @@ _rank1_grads = {}
 # reduction pass (nndet_norm_backward_presummed). At full resolution: one read of the pre-norm tensor (315 MB at batch 2) inside the
 # data gradient instead of the 0.38 ms k_norm_bwd_reduce launch on the tail of the step. NNDET_NORM_RED_FUSE=0: the separate pass.
 NORM_RED_FUSE = os.environ.get("NNDET_NORM_RED_FUSE", "1") != "0"
+WGRAD_ALL = os.environ.get("NNDET_WGRAD_ALL", "1") != "0"      # 0: nodes whose bias gradient comes out of the data-gradient launch keep their weight gradient on the main stream
 # Round 6: the same for the plain chains conv -> norm -> ReLU -> conv inside an encoder stage (ONE consumer, the stride-1 3x3x3 data
 # gradient in k_ig3 writes dx and takes the sums: nndet_conv3d_backward_data_normred). The k_norm_bwd_reduce launches it replaces sit
 # on the serial chain of the backward pass and run 2-3 x slower than alone next to the weight-gradient stream. NNDET_NORM_RED_CHAIN=0: off.
@@ -314,6 +335,23 @@ def _splitk_bytes(mod, desc, kind: int) -> int:
     if n is None:
         n = mod._pack_cache[key] = int(L.load().nndet_conv3d_splitk_workspace_bytes(ctypes.byref(desc), kind))
     return n
+
+
+def _query(mod, desc, name: str, plan_env: bool = False) -> int:
+    """A property of this convolution PROBLEM that the library answers from the descriptor alone (nndet_conv3d_<name>(desc): which kernel
+    takes it, a workspace size), cached per module, problem geometry and the switches that steer the plan: a backward node asked three
+    of them on every call, each a ctypes round trip and one a full plan construction (round 6: 82 us of host time per conv backward).
+    plan_env: the answer depends on switches the library reads per call (tests flip them): they become part of the key."""
+    key = ("q", name, desc.dtype, desc.batch, desc.in_d, desc.in_h, desc.in_w, bool(desc.in_affine), _PLAN_ENV() if plan_env else None)
+    v = mod._pack_cache.get(key)
+    if v is None:
+        v = mod._pack_cache[key] = int(getattr(L.load(), "nndet_conv3d_" + name)(ctypes.byref(desc)))
+    return v
+
+
+def _PLAN_ENV():
+    e = os.environ
+    return (e.get("NNDET_IGEMM_SPLITK"), e.get("NNDET_IGEMM_SMALLWG"), e.get("NNDET_IGEMM_SPEC"), e.get("NNDET_IG3R"), e.get("NNDET_IG3S"), e.get("NNDET_DGSP"))
 
 
 def rank1_branch_backward(x_p, a_p, w_out, b_out, w_lat, w_head, b_head, wd, wf, wfa, d1, dsum, need_dx, need_da, e_x_fn=None):
@@ -459,8 +497,8 @@ class _ConvFn(torch.autograd.Function):
         nw = weight.numel()
         g_w, g_b = L.grad_pool.take_for([(weight, nw), (mod.conv.bias if ctx.has_bias else None, cout if ctx.has_bias else 0)], dev)
         # (NNDET_WGRAD_ALL=0: nodes whose bias gradient comes out of the data-gradient launch keep their weight gradient on this stream)
-        keep = (os.environ.get("NNDET_WGRAD_ALL", "1") == "0" and ctx.has_bias and ctx.needs_input_grad[0] and desc.cin_p != 1 and
-                bool(L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc))))
+        keep = (not WGRAD_ALL and ctx.has_bias and ctx.needs_input_grad[0] and desc.cin_p != 1 and
+                bool(_query(mod, desc, "dgrad_fuses_bias")))
         ctx.wg_side = None if keep else L.wgrad_streams.side(dev, weight)
         dw = g_w.view(weight.shape)
         dbias = g_b if ctx.has_bias else None
@@ -483,7 +521,7 @@ class _ConvFn(torch.autograd.Function):
                 raise L.NndetError("gradient w.r.t. the 1-channel input image is not implemented (never needed in training)")
             w1 = _packed(mod, 1, weight, desc, dt)
             gacc = ctx.gacc
-            fuses_bias = dbias is not None and bool(L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)))
+            fuses_bias = dbias is not None and bool(_query(mod, desc, "dgrad_fuses_bias"))
             if gacc is not None and gacc["buf"] is not None and gacc["buf"].shape == x_p.shape and gacc["buf"].dtype == dt:
                 # second consumer of this activation: add into the gradient the first consumer wrote and hand autograd nothing
                 if gacc.get("ev") is not None:               # the first consumer may have run on another stream (decoder tail)
@@ -493,7 +531,7 @@ class _ConvFn(torch.autograd.Function):
                 if (ns is not None and not fuses_bias and ns[0].shape == x_p.shape and ns[0].dtype == dt
                         and ns[2].norm.weight.dtype == torch.float32 and ns[2].norm.bias.dtype == torch.float32     # (read as raw fp32)
                         and ns[2].norm.weight.is_contiguous() and ns[2].norm.bias.is_contiguous()
-                        and L.load().nndet_conv3d_dgrad_fuses_norm_reduce(ctypes.byref(desc))):
+                        and _query(mod, desc, "dgrad_fuses_norm_reduce")):
                     ny_p, nmr, nmod = ns
                     red = L.arena_zeros((L.STATS_REPLICAS * desc.batch * desc.cin_p * 2 + desc.batch,), torch.float64, dev)
                     L.call("nndet_conv3d_backward_data_acc_normred", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(gacc["buf"]),
@@ -525,7 +563,7 @@ class _ConvFn(torch.autograd.Function):
             elif (ns is not None and ns[0].shape == x_p.shape and ns[0].dtype == dt and not _splitk_bytes(mod, desc, 1)
                     and ns[2].norm.weight.dtype == torch.float32 and ns[2].norm.bias.dtype == torch.float32     # (read as raw fp32)
                     and ns[2].norm.weight.is_contiguous() and ns[2].norm.bias.is_contiguous()
-                    and L.load().nndet_conv3d_dgrad_normred_supported(ctypes.byref(desc))):
+                    and _query(mod, desc, "dgrad_normred_supported", plan_env=True)):
                 # x is the output of a materialised conv -> norm -> ReLU block and (as far as this node can know) read by this
                 # convolution only: the data gradient also takes that block's norm-backward sums (k_ig3<.., NB>). If autograd adds another
                 # contribution after all, the sum is another tensor or an in-place write (version counter): the entry is not used.
@@ -536,7 +574,7 @@ class _ConvFn(torch.autograd.Function):
                        nmod.out_channels, L.ptr(red), L.stream())
                 _norm_presums.clear()                      # at most one live entry
                 _norm_presums[dx_p.data_ptr()] = (red, nmr, dx_p, dx_p._version)
-            elif dbias is not None and L.load().nndet_conv3d_dgrad_fuses_bias(ctypes.byref(desc)):
+            elif dbias is not None and _query(mod, desc, "dgrad_fuses_bias"):
                 # pointwise kernels read every dy element once: the bias gradient comes out of the same pass
                 L.call("nndet_conv3d_backward_data_bias", ctypes.byref(desc), L.ptr(dconv), L.ptr(w1), L.ptr(dx_p), L.ptr(dbias), L.stream())
                 bias_from_dgrad = True
@@ -554,7 +592,7 @@ class _ConvFn(torch.autograd.Function):
                     if dx_p.is_cuda:
                         gacc["ev"] = torch.cuda.Event()
                         gacc["ev"].record()   # (on this node's stream; the second consumer waits for it if it runs elsewhere)
-        ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))
+        ws_bytes = L.load().nndet_conv3d_wgrad_workspace_bytes(ctypes.byref(desc))     # (not cached: the weight-gradient switches are read per call)
         side = ctx.wg_side                                 # weight-gradient stream (forked at the top of backward, before the data gradient)
         if side is not None:
             x_p.record_stream(side); dconv.record_stream(side)

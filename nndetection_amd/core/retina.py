@@ -92,6 +92,8 @@ class BaseRetinaNet(nn.Module):
         """Switching between training and evaluation drops every packed-weight cache: the parameters may have been written since by a
         kernel that does not advance their version counters (fused optimizers, see arch/conv.py: prepack_all)."""
         if mode != self.training:
+            self.__dict__.pop("_nndet_conv_blocks", None)      # (arch/conv.py prepack_all: the cached list of conv blocks is rebuilt)
+            self.__dict__.pop("_nndet_pack_args", None)
             for m in self.modules():
                 if hasattr(m, "_pack_cache"):
                     m._pack_cache.clear()
