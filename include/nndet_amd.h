@@ -658,6 +658,12 @@ int nndet_detloss_f32(const float* logits, const float* deltas, const int64_t* p
 int nndet_detloss_scatter_f32(const int64_t* pos, int32_t pos_cap, const int64_t* neg, int32_t neg_cap, int32_t C,
                               const float* g_deltas, const float* g_logits, const float* upstream, float* d_deltas, float* d_logits,
                               void* stream);
+/* nndet_detloss_scatter_f32 with the upstream gradients as two device scalars (NULL = 0) and, written on the way, the scaled compact rows
+ * val_deltas [pos_cap, 6] / val_logits [pos_cap + neg_cap, C] and the index list idx_out [pos_cap + neg_cap] = pos ++ neg (each may be
+ * NULL): what the sparse consumers of the two gradients read instead of the dense tensors. One launch instead of six. */
+int nndet_detloss_scatter2_f32(const int64_t* pos, int32_t pos_cap, const int64_t* neg, int32_t neg_cap, int32_t C,
+                               const float* g_deltas, const float* g_logits, const float* up_reg, const float* up_cls, float* d_deltas,
+                               float* d_logits, float* val_deltas, float* val_logits, int64_t* idx_out, void* stream);
 /* nndet_detloss_f32 with the box deltas of the sampled positives ONLY: deltas_compact [pos_cap][6], row r belongs to anchor pos[r]
  * (produced by nndet_conv_out_sparse_forward: the regressor's output convolution evaluated at the <= 42 sampled positives instead of
  * at all 4.75 M anchors of a batch). g_deltas_out has the same compact layout as before; nndet_detloss_scatter_f32 accepts

@@ -95,6 +95,7 @@ SIGNATURES = {
     "nndet_detloss_matched_f32": (C.c_int, [_P, _P, _I32, _P, _I32, _P, _I32, _P, _P, _P, _P, C.POINTER(C.c_int32), _I32, _P, _I64, _I32, _F, _F, _F,
                                             _I32, _F, _I32, _P, _P, _P, _P]),
     "nndet_detloss_scatter_f32": (C.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "nndet_detloss_scatter2_f32": (C.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nndet_wbc3d_workspace_bytes": (_SZ, [_I64]),
     "nndet_wbc3d_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _I32, _F, _P, _P, _P, _P, _P, _SZ, _P]),
     "nndet_packed_weight_elems": (_SZ, [_CONVP, _I32]),

@@ -244,26 +244,36 @@ class _DetLossFn(torch.autograd.Function):
         pos, neg, g_d, g_l = ctx.saved_tensors
         ls, lt, ds, dt = ctx.shapes
         dev = g_d.device
-        z = torch.zeros((), dtype=torch.float32, device=dev)
-        up = torch.stack([(g_reg if g_reg is not None else z).detach().float(), (g_cls if g_cls is not None else z).detach().float()])
-        g = up
-        d_logits = torch.zeros(ls, dtype=torch.float32, device=g.device)
+
+        def scalar(g):                                       # the upstream gradient of a loss as a device fp32 scalar (None: that loss is not part of the sum)
+            if g is None:
+                return None
+            g = g.detach()
+            return g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+
+        u_reg, u_cls = scalar(g_reg), scalar(g_cls)
+        P, Q, C = pos.shape[0], neg.shape[0], int(g_l.shape[1])
+        sparse = SPARSE_OUT and lt == torch.float32 and (ctx.compact or dt == torch.float32)
+        # ONE launch: dense scatter + (for the sparse consumers) the scaled compact rows and pos ++ neg. Before round 6 the node formed the
+        # scalars' stack, the two products and the concatenation with six torch launches on the chain between the loss and the backward pass.
+        d_logits = torch.zeros(ls, dtype=torch.float32, device=dev)
+        d_deltas = None if ctx.compact else torch.zeros(ds, dtype=torch.float32, device=dev)
+        val_d = torch.empty((P, 6), dtype=torch.float32, device=dev)
+        val_l = torch.empty((P + Q, C), dtype=torch.float32, device=dev) if sparse else None
+        idx = torch.empty((P + Q,), dtype=torch.int64, device=dev) if sparse else None
+        L.call("nndet_detloss_scatter2_f32", L.ptr(pos), P, L.ptr(neg), Q, C, L.ptr(g_d), L.ptr(g_l), L.ptr(u_reg), L.ptr(u_cls),
+               L.ptr(d_deltas), L.ptr(d_logits), L.ptr(val_d), L.ptr(val_l), L.ptr(idx), L.stream())
         if ctx.compact:                                      # compact deltas: their gradient is compact too (no dense scatter)
-            L.call("nndet_detloss_scatter_f32", L.ptr(pos), pos.shape[0], L.ptr(neg), neg.shape[0], g_l.shape[1], L.ptr(g_d), L.ptr(g_l),
-                   L.ptr(up), None, L.ptr(d_logits), L.stream())
             d_logits = d_logits.to(lt)
-            if SPARSE_OUT and lt == torch.float32:
-                L.grad_hints.put(d_logits, {"idx": torch.cat([pos, neg]), "val": g_l * up[1], "G": int(g_l.shape[1])})
-            return d_logits, (g_d * up[0]).to(dt), None, None, None, None, None, None, None
-        d_deltas = torch.zeros(ds, dtype=torch.float32, device=g.device)
-        L.call("nndet_detloss_scatter_f32", L.ptr(pos), pos.shape[0], L.ptr(neg), neg.shape[0], g_l.shape[1], L.ptr(g_d), L.ptr(g_l),
-               L.ptr(up), L.ptr(d_deltas), L.ptr(d_logits), L.stream())
+            if sparse:
+                L.grad_hints.put(d_logits, {"idx": idx, "val": val_l, "G": C})
+            return d_logits, val_d.to(dt), None, None, None, None, None, None, None
         d_logits, d_deltas = d_logits.to(lt), d_deltas.to(dt)
-        if SPARSE_OUT and lt == torch.float32 and dt == torch.float32:
+        if sparse:
             # both gradients are zero except at the <= P + Q sampled rows: tell the consumers (arch/pyramid.py: the gather / output
             # convolution backward then touch those rows only). The dense tensors above stay complete, valid gradients.
-            L.grad_hints.put(d_deltas, {"idx": pos, "val": g_d * up[0], "G": 6})
-            L.grad_hints.put(d_logits, {"idx": torch.cat([pos, neg]), "val": g_l * up[1], "G": int(g_l.shape[1])})
+            L.grad_hints.put(d_deltas, {"idx": pos, "val": val_d, "G": 6})
+            L.grad_hints.put(d_logits, {"idx": idx, "val": val_l, "G": C})
         return d_logits, d_deltas, None, None, None, None, None, None, None
 
 

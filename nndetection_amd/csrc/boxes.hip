@@ -507,6 +507,46 @@ extern "C" int nndet_detloss_matched_f32(const float* logits, const float* delta
     return 0;
 }
 
+// The same with everything the Python backward node did around it in five more launches (round 6: they sit on the serial chain between the
+// loss and the backward pass): the two upstream gradients are read from their own device scalars (NULL = 0), and the scaled compact rows
+// val_deltas [P, 6] / val_logits [P + Q, C] and the concatenated index list idx [P + Q] -- what the sparse consumers take instead of the
+// dense tensors -- are written on the way (each may be NULL).
+__global__ __launch_bounds__(256) void k_detloss_scatter2(const int64_t* __restrict__ pos, int P, const int64_t* __restrict__ neg, int Q, int C,
+                                                          const float* __restrict__ g_deltas, const float* __restrict__ g_logits,
+                                                          const float* __restrict__ up_reg, const float* __restrict__ up_cls,
+                                                          float* __restrict__ d_deltas, float* __restrict__ d_logits,
+                                                          float* __restrict__ val_deltas, float* __restrict__ val_logits, int64_t* __restrict__ idx_out) {
+    const float u_reg = up_reg ? *up_reg : 0.f, u_cls = up_cls ? *up_cls : 0.f;
+    for (int r = threadIdx.x; r < P + Q; r += 256) {
+        const int64_t idx = r < P ? pos[r] : neg[r - P];
+        if (idx_out) idx_out[r] = idx;
+        if (r < P) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float v = u_reg * g_deltas[r * 6 + k];            // (the product the caller formed with a torch multiply: same rounding)
+                if (val_deltas) val_deltas[r * 6 + k] = v;
+                if (d_deltas && idx >= 0) d_deltas[idx * 6 + k] = v;
+            }
+        }
+        for (int c = 0; c < C; ++c) {
+            const float v = u_cls * g_logits[r * C + c];
+            if (val_logits) val_logits[r * C + c] = v;
+            if (idx >= 0) d_logits[idx * C + c] = v;
+        }
+    }
+}
+
+extern "C" int nndet_detloss_scatter2_f32(const int64_t* pos, int32_t pos_cap, const int64_t* neg, int32_t neg_cap, int32_t C,
+                                          const float* g_deltas, const float* g_logits, const float* up_reg, const float* up_cls,
+                                          float* d_deltas, float* d_logits, float* val_deltas, float* val_logits, int64_t* idx_out,
+                                          void* stream) {
+    if (!pos || !neg || !g_deltas || !g_logits || !d_logits || pos_cap < 1 || neg_cap < 0 || C < 1) return NNDET_EINVAL;
+    k_detloss_scatter2<<<1, 256, 0, as_stream(stream)>>>(pos, pos_cap, neg, neg_cap, C, g_deltas, g_logits, up_reg, up_cls, d_deltas, d_logits,
+                                                         val_deltas, val_logits, idx_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int nndet_detloss_scatter_f32(const int64_t* pos, int32_t pos_cap, const int64_t* neg, int32_t neg_cap, int32_t C,
                                          const float* g_deltas, const float* g_logits, const float* upstream, float* d_deltas,
                                          float* d_logits, void* stream) {
