@@ -407,7 +407,7 @@ def aux_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _aux_streams.get(idx)
     if st is None:
-        st = _aux_streams[idx] = torch.cuda.Stream(device=device)
+        st = _aux_streams[idx] = new_stream("libaux", device)
     return st
 
 
@@ -458,6 +458,29 @@ def cumask_stream(dev, spec: str):
     return torch.cuda.ExternalStream(out.value, device=dev)
 
 
+# ---- side streams and hardware queues -----------------------------------------------------------------------------------------------
+# HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues when they are first used; two streams on one hardware queue are
+# serialised in submission order, so WHICH of the step's seven streams share a queue decides how much of their overlap is real: one
+# stream created before ours costs 0.65 ms of a 11.65 ms step, four cost 1.6 ms, five or more hardware queues 5.8 ms
+# (profiles/round6_stream_mapping.txt). Every side stream of the package is created HERE, in a fixed order and with optional padding
+# streams in front of a kind (NNDET_STREAM_PADS="aux:1,tail:0,head:2,wgrad:0,...": the mapping experiments), so that the mapping is the
+# package's decision as far as the runtime lets it be one.
+_STREAM_PADS = {}
+for _kv in os.environ.get("NNDET_STREAM_PADS", "").split(","):
+    if ":" in _kv:
+        _STREAM_PADS[_kv.split(":")[0].strip()] = int(_kv.split(":")[1])
+_pad_streams = []          # (kept alive: a destroyed stream gives its queue reference back)
+
+
+def new_stream(kind: str, device, priority: int = 0):
+    for _ in range(_STREAM_PADS.pop(kind, 0)):               # (once per kind)
+        ps = torch.cuda.Stream(device=device, priority=priority)
+        with torch.cuda.stream(ps):
+            torch.zeros(1, device=device)                    # first use binds the hardware queue
+        _pad_streams.append(ps)
+    return torch.cuda.Stream(device=device, priority=priority)
+
+
 class _WgradStreams:
     """Weight-gradient kernels on their own stream. Within a backward pass the data-gradient / norm-backward chain is the critical
     path; a weight gradient is only needed by the optimizer. Launched on a second stream the weight-gradient kernels fill the CUs the
@@ -497,7 +520,7 @@ class _WgradStreams:
             if mask:
                 ws = self.streams[idx] = cumask_stream(dev, mask)
             else:
-                ws = self.streams[idx] = torch.cuda.Stream(device=dev, priority=prio)
+                ws = self.streams[idx] = new_stream("wgrad", dev, prio)
         if not self.active:
             _queue_callback(self._done)
         self.active[idx] = ws

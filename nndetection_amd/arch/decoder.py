@@ -11,6 +11,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
+from .. import _lib as L
 from .conv import conv_kwargs_helper, ensure_materialized
 
 
@@ -95,11 +96,11 @@ class UFPNModular(nn.Module):
         if level == 0 and self.split_tail and self.num_level >= 3 and need0:
             side = UFPNModular._tail_streams.get(dev.index or 0)        # level 0 stays on the tail stream of forward()
             if side is None:
-                side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NNDET_PRIO_TAIL", "0")))
+                side = UFPNModular._tail_streams[dev.index or 0] = L.new_stream("tail", dev, int(os.environ.get("NNDET_PRIO_TAIL", "0")))
         else:
             side = UFPNModular._early_streams.get(dev.index or 0)
             if side is None:
-                side = UFPNModular._early_streams[dev.index or 0] = torch.cuda.Stream(device=dev)
+                side = UFPNModular._early_streams[dev.index or 0] = L.new_stream("early", dev)
         side.wait_stream(main)                                   # this stage's output is ready
         fm.record_stream(side)
         with torch.cuda.stream(side):
@@ -133,7 +134,7 @@ class UFPNModular(nn.Module):
             main = torch.cuda.current_stream(dev)
             side = UFPNModular._tail_streams.get(dev.index or 0)
             if side is None:
-                side = UFPNModular._tail_streams[dev.index or 0] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("NNDET_PRIO_TAIL", "0")))
+                side = UFPNModular._tail_streams[dev.index or 0] = L.new_stream("tail", dev, int(os.environ.get("NNDET_PRIO_TAIL", "0")))
             if fpn[0] is None and not absorb:
                 side.wait_stream(main)                           # the encoder outputs are ready
                 inp_seq[0].record_stream(side)

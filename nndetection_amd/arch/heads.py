@@ -382,7 +382,7 @@ class DetectionHeadHNMNative(nn.Module):
     def _side_streams(self, device, n: int):
         pool = DetectionHeadHNMNative._streams.setdefault(device.index or 0, [])
         while len(pool) < n:
-            pool.append(torch.cuda.Stream(device=device, priority=int(os.environ.get("NNDET_PRIO_HEAD", "0"))))
+            pool.append(L.new_stream("head", device, int(os.environ.get("NNDET_PRIO_HEAD", "0"))))
         return pool[:n]
 
     gather_levels = os.environ.get("NNDET_HEAD_GATHER", "1") != "0"      # one flatten + Scale + cat launch per branch (csrc/headio.hip)

@@ -274,7 +274,7 @@ class BaseRetinaNet(nn.Module):
     def _aux(self, device, i: int):
         pool = BaseRetinaNet._aux_streams.setdefault(device.index or 0, [])
         while len(pool) <= i:
-            pool.append(torch.cuda.Stream(device=device, priority=int(os.environ.get("NNDET_PRIO_AUX%d" % len(pool), os.environ.get("NNDET_PRIO_AUX", "0")))))
+            pool.append(L.new_stream("aux%d" % len(pool), device, int(os.environ.get("NNDET_PRIO_AUX%d" % len(pool), os.environ.get("NNDET_PRIO_AUX", "0")))))
         return pool[i]
 
     # ------------------------------------------------------------------ train step (retina.py:86-159)

@@ -245,7 +245,8 @@ class GradAllReducer:
         if self._cuda:
             cur = torch.cuda.current_stream()
             if self._comm is None:
-                self._comm = torch.cuda.Stream(device=cur.device)
+                from . import _lib as _L
+                self._comm = _L.new_stream("comm", cur.device)
             comm = self._comm
             self._stream_objs.setdefault(cur.cuda_stream, cur)
             b.streams.add(cur.cuda_stream)
