@@ -511,6 +511,18 @@ class _WgradStreams:
             if ws is not None:
                 torch.cuda.current_stream(dev).wait_stream(ws)
             return None
+        ws = self.stream_for(dev)
+        if not self.active:
+            _queue_callback(self._done)
+        self.active[idx] = ws
+        weight._nndet_wg_pending = True
+        self.pending.append(weight)
+        ws.wait_stream(torch.cuda.current_stream(dev))       # dY (and the zero-filled gradient pool) are ready
+        return ws
+
+    def stream_for(self, dev):
+        """The weight-gradient stream of a device (created on first request)."""
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
         ws = self.streams.get(idx)
         if ws is None:
             # lowest queue priority the device offers: the critical chain on the other streams gets the CUs first, the weight
@@ -521,12 +533,6 @@ class _WgradStreams:
                 ws = self.streams[idx] = cumask_stream(dev, mask)
             else:
                 ws = self.streams[idx] = new_stream("wgrad", dev, prio)
-        if not self.active:
-            _queue_callback(self._done)
-        self.active[idx] = ws
-        weight._nndet_wg_pending = True
-        self.pending.append(weight)
-        ws.wait_stream(torch.cuda.current_stream(dev))       # dY (and the zero-filled gradient pool) are ready
         return ws
 
     def _done(self):

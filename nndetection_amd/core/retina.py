@@ -114,8 +114,40 @@ class BaseRetinaNet(nn.Module):
                 res.extend(mod.parameters())
         return res
 
+    # Which side streams share one of the runtime's four hardware queues decides 0.1 - 1.6 ms of a 11.6 ms step (profiles/round6_stream_mapping.txt),
+    # and the runtime binds a stream to a queue when it is created / first used: the FIRST forward pass on a device creates and uses every
+    # side stream of the package in the order a training step would (whatever this first call is -- a validation pass that touches only two
+    # of them would otherwise leave the rest to be bound later, in another order). NNDET_BIND_STREAMS=0: bound as they come.
+    _bound_devices: set = set()
+    _bind_order = [k for k in os.environ.get("NNDET_BIND_STREAMS", "aux0,aux1,tail,head,wgrad").split(",") if k and k != "0"]
+
+    def _bind_streams(self, device) -> None:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx in BaseRetinaNet._bound_devices:
+            return
+        BaseRetinaNet._bound_devices.add(idx)
+        from ..arch.decoder import UFPNModular
+        for kind in BaseRetinaNet._bind_order:
+            st = None
+            if kind in ("aux0", "aux1"):
+                if self.overlap_aux and (kind == "aux0" or self.segmenter is not None):
+                    st = self._aux(device, int(kind[3]))
+            elif kind == "tail" and isinstance(self.decoder, UFPNModular) and self.decoder.split_tail:
+                st = UFPNModular._tail_streams.get(idx)
+                if st is None:
+                    st = UFPNModular._tail_streams[idx] = L.new_stream("tail", device, int(os.environ.get("NNDET_PRIO_TAIL", "0")))
+            elif kind == "head" and hasattr(self.head, "_side_streams") and getattr(self.head, "multi_stream", False):
+                st = self.head._side_streams(device, 1)[0]
+            elif kind == "wgrad" and L.wgrad_streams.enabled:
+                st = L.wgrad_streams.stream_for(device)
+            if st is not None:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=device)                # (first use)
+
     # ------------------------------------------------------------------ forward (retina.py:198-226)
     def forward(self, inp: Tensor):
+        if inp.is_cuda and BaseRetinaNet._bind_order:
+            self._bind_streams(inp.device)
         L.arena_reset(inp.device)                # one fill for all per-layer statistics buffers of the previous step
         inp = L.autocast_input(inp)              # under torch.autocast: the image in the autocast dtype (B2: conv in half precision)
         if inp.is_cuda:
