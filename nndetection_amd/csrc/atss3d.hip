@@ -222,6 +222,8 @@ static void atss_layout(int64_t G, int32_t L, char* base, AtssWs* w) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     size_t o_p = take((size_t)G * L * 8), o_k = take((size_t)G * L * 4), o_h = take((size_t)G * L * 256 * 4);
     size_t o_s = take((size_t)G * 2 * 8), o_t = take((size_t)G * 4);
+    w->total = off;
+    if (!base) return;                         // size query: no pointer arithmetic on a null base (UBSan, round 6)
     w->prefix = (u64*)(base + o_p); w->krem = (int*)(base + o_k); w->hist = (unsigned*)(base + o_h);
     w->sums = (double*)(base + o_s); w->thr = (float*)(base + o_t); w->total = off;
 }

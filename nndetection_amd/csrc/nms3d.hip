@@ -332,6 +332,8 @@ static int nms_layout(int64_t n, char* base, NmsWs* ws) {
         nullptr, tmp, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, 32, (hipStream_t)0, false);
     if (e != hipSuccess) return (int)e;
     size_t o_tmp = take(tmp);
+    ws->sort_tmp_bytes = tmp; ws->total = off;
+    if (!base) return 0;                       // size query: no pointer arithmetic on a null base (UBSan, round 6)
     ws->sboxes = (float*)(base + o_sb); ws->keys_out = (float*)(base + o_ko);
     ws->vals_in = (int32_t*)(base + o_vi); ws->order = (int32_t*)(base + o_or);
     ws->mask = (u64*)(base + o_mask); ws->remv = (u64*)(base + o_remv); ws->keepbits = (u64*)(base + o_keep);

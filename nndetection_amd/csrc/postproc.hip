@@ -301,6 +301,8 @@ static int pp_layout(int B, int K, char* base, PpWs* w) {
     if (nms_b == 0) return NNDET_EINVAL;
     { const size_t bb = nms_presorted_batched_workspace_bytes(K, B); if (bb > nms_b) nms_b = bb; }
     size_t o_nms = take(nms_b);
+    w->sort_tmp_bytes = tmp; w->nms_ws_bytes = nms_b; w->total = off;
+    if (!base) return 0;                       // size query: no pointer arithmetic on a null base (UBSan, round 6)
     w->prefix = (u64*)(base + o_p); w->krem = (int*)(base + o_k); w->cnt = (int*)(base + o_c); w->hist = (unsigned*)(base + o_h);
     w->seg_off = (int*)(base + o_so);
     w->cand = (u64*)(base + o_ca); w->cand_sorted = (u64*)(base + o_cs); w->cboxes = (float*)(base + o_cb);

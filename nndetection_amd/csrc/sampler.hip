@@ -277,6 +277,8 @@ static int sp_layout(int P_cap, int NEG_cap, int POOL_cap, char* base, SpWs* w) 
     hipError_t e = rocprim::radix_sort_keys<rocprim::default_config, const u64*, u64*>(nullptr, tmp, nullptr, nullptr, nmax, 0, 64, (hipStream_t)0, false);
     if (e != hipSuccess) return (int)e;
     size_t o_tmp = take(tmp > 0 ? tmp : 256);
+    w->sort_tmp_bytes = tmp; w->total = off;
+    if (!base) return 0;                       // size query (nndet_hnm_sample_workspace_bytes): no pointer arithmetic on a null base (UBSan, round 6)
     w->params = (int32_t*)(base + o_pa); w->prefix = (u64*)(base + o_pr); w->krem = (int*)(base + o_kr); w->hist = (unsigned*)(base + o_h);
     w->list_pos = (u64*)(base + o_lp); w->pos_sorted = (u64*)(base + o_ps); w->list_pool = (u64*)(base + o_lq);
     w->pool_sorted = (u64*)(base + o_qs); w->sel = (u64*)(base + o_se); w->sel_sorted = (u64*)(base + o_ss);

@@ -176,6 +176,8 @@ static int wbc_layout(int64_t n, char* base, WbcWs* w) {
     const size_t nb = nms_presorted_workspace_bytes(n);
     if (nb == 0) return NNDET_EINVAL;
     size_t o_nms = take(nb);
+    w->sort_tmp_bytes = tmp; w->nms_ws_bytes = nb; w->total = off;
+    if (!base) return 0;                       // size query: no pointer arithmetic on a null base (UBSan, round 6)
     w->skey = (float*)(base + o1); w->skey_out = (float*)(base + o2); w->iota = (int32_t*)(base + o3); w->order = (int32_t*)(base + o4);
     w->sboxes = (float*)(base + o5); w->slabels = (int32_t*)(base + o6); w->assign = (uint32_t*)(base + o7);
     w->keys = (u64*)(base + o8); w->keys_sorted = (u64*)(base + o9); w->cbox = (float*)(base + o10); w->cscore = (float*)(base + o11);
