@@ -9,11 +9,12 @@
 #include <initializer_list>
 #include "../../include/nndet_amd.h"
 
-static uint32_t rng = 2463534242u;
+static thread_local uint32_t rng = 2463534242u;
 static uint32_t rnd() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng; }
 static int pick(const int* v, int n) { return v[rnd() % n]; }
 
-int main() {
+static int sweep() {
+    rng = 2463534242u;
     const int chans[] = {1, 2, 3, 27, 32, 33, 48, 64, 96, 128, 162, 256, 320};
     const int dts[] = {NNDET_F32, NNDET_BF16, NNDET_F16, 77};
     uint64_t h = 0;
@@ -90,3 +91,18 @@ int main() {
     printf("ok %ld problems, checksum %llu\n", n_ok, (unsigned long long)h);
     return 0;
 }
+
+#ifdef SWEEP_THREADS      // ThreadSanitizer build: the same sweep from several threads at once (the library's host side keeps per-process caches:
+#include <thread>         // environment switches read once, per-device attribute flags, plan tables on the stack)
+#include <vector>
+int main() {
+    std::vector<std::thread> th;
+    int rc[SWEEP_THREADS] = {0};
+    for (int t = 0; t < SWEEP_THREADS; ++t) th.emplace_back([t, &rc] { rc[t] = sweep(); });
+    for (auto& x : th) x.join();
+    for (int t = 0; t < SWEEP_THREADS; ++t) if (rc[t]) return rc[t];
+    return 0;
+}
+#else
+int main() { return sweep(); }
+#endif
