@@ -534,6 +534,16 @@ int nndet_segbranch_forward_up(int32_t dtype, const void* x, const void* w_packe
  * [nndet_segbranch_replicas()][27] (zeroed by the caller): the sum of d1 per border class. */
 int nndet_segbranch_s2d(int32_t dtype, const void* d1, int32_t N, int32_t D, int32_t H, int32_t W, void* dzs_out, double* csum_out,
                         void* stream);
+/* The parameter-only part of the fused segmentation branch with the absorbed level-0 lateral and last top-down step
+ * (nndet/arch/decoder/base.py:243-270 `lateral.P0`, `up.P1`, `out.P0`; nndet/arch/heads/segmenter.py:184-206) in ONE launch: the composed
+ * kernels wc [27][32] / wqa (16 bit) / wfa (flipped, [32][27]), the head difference wd [32], the constant c0, bsum = b_up + b_lat, the
+ * composed half-resolution kernel wc_up [8][cin1][27] (output channel = parity class of the full-resolution voxel) and the border-class
+ * bias cb [27]. t_table [216][216] / k3_table [27][27] are the constant 0/1 selection tables (which tap of which parity class reads which
+ * position of the k = s = 2 transposed kernel; which taps stay inside the volume per border class). All inputs / outputs fp32 except wqa. */
+int nndet_segbranch_compose_up(int32_t dtype, const float* w_out, const float* b_out, const float* w_head, const float* b_head,
+                               const float* w_lat, const float* w_up, const float* b_up, const float* b_lat, const float* t_table,
+                               const float* k3_table, int32_t cin1, float* wd, float* wc, float* c0, void* wqa, float* wfa, float* bsum,
+                               float* wc_up, float* cb, void* stream);
 /* All parameter gradients of the branch from the one-channel correlations (32 channels; every tensor fp32, contiguous):
  * w_out [32][32][27], b_out [32] or NULL, w_lat [32][32] or NULL (then e_a, dw_lat NULL too), wd [32] = w_head[1] - w_head[0],
  * e_x / e_a [32][27] = nndet_conv3d_backward_weight(cin_p == 1) of (d1, top-down term) / (d1, a_0), dsum [n_dsum] fp64 (its sum =

@@ -145,6 +145,7 @@ SIGNATURES = {
     "nndet_segbranch_forward_up": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nndet_segbranch_s2d": (C.c_int, [_I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "nndet_segbranch_backward": (C.c_int, [_I32, _P, _P, _I64, _P, _P, _P, _P]),
+    "nndet_segbranch_compose_up": (C.c_int, [_I32] + [_P] * 10 + [_I32] + [_P] * 9),
     "nndet_segbranch_param_grads": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "nndet_head_out_sparse_scatter": (C.c_int, [_I32, C.POINTER(NndetHeadLevels), _I32, _I32, _I32, C.POINTER(C.c_int64), _P, _P, _I32,
                                                _P, _I32, _P, _P, _P, _P, _P]),

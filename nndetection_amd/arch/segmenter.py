@@ -172,6 +172,51 @@ def up_param_grads(wc: torch.Tensor, w_up: torch.Tensor, bsum: Optional[torch.Te
 
 
 _compose_cache = {}
+# Round 6: the parameter-only part of the absorbed branch as ONE kernel (nndet_segbranch_compose_up) + the two weight packs instead of ~25
+# torch launches of 4-6 us each on the branch's critical path (0.13 ms of chip time per step wherever they ran).
+# NNDET_SEG_COMPOSE_FUSED=0: the torch expressions below (which stay the definition the kernel is tested against).
+COMPOSE_FUSED = os.environ.get("NNDET_SEG_COMPOSE_FUSED", "1") != "0"
+
+
+def _compose_fusable(params, dt) -> bool:
+    w_lat, w_out, b_out, w_head, b_head, w_up, b_up, b_lat = params
+    ts = [t for t in params if t is not None]
+    return bool(w_out.is_cuda and dt in (torch.bfloat16, torch.float16) and all(t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+                and tuple(w_out.shape) == (32, 32, 3, 3, 3) and w_head.numel() == 64 and w_lat.numel() == 32 * 32
+                and w_up.dim() == 5 and tuple(w_up.shape[1:]) == (32, 2, 2, 2) and 4 <= w_up.shape[0] <= 64 and w_up.shape[0] % 4 == 0
+                and (b_out is None or b_out.numel() == 32) and (b_head is None or b_head.numel() == 2)
+                and (b_up is None or b_up.numel() == 32) and (b_lat is None or b_lat.numel() == 32))
+
+
+def _compose_up_branch_fused(params, dt):
+    import ctypes
+    w_lat, w_out, b_out, w_head, b_head, w_up, b_up, b_lat = params
+    dev, I = w_out.device, int(w_up.shape[0])
+    T, K3 = _up_tables(torch.float32, dev)
+    seg = lambda n: (n + 63) // 64 * 64                      # every output starts on a 256-byte boundary of ONE allocation
+    sizes = [32, 27 * 32, 1, 32 * 27, 32, 8 * I * 27, 27]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot); tot += seg(n)
+    flat = torch.empty((tot,), dtype=torch.float32, device=dev)
+    wd, wc, c0, wfa, bsum, Wc, cb = (flat[o:o + n] for o, n in zip(offs, sizes))
+    wqa = torch.empty((27, 32), dtype=dt, device=dev)
+    det = lambda t: t.detach() if t is not None else None
+    L.call("nndet_segbranch_compose_up", L._DT[dt], L.ptr(det(w_out)), L.ptr(det(b_out)), L.ptr(det(w_head)), L.ptr(det(b_head)), L.ptr(det(w_lat)),
+           L.ptr(det(w_up)), L.ptr(det(b_up)), L.ptr(det(b_lat)), L.ptr(T), L.ptr(K3), I, L.ptr(wd), L.ptr(wc), L.ptr(c0), L.ptr(wqa), L.ptr(wfa),
+           L.ptr(bsum), L.ptr(Wc), L.ptr(cb), L.stream())
+    Wc = Wc.view(8, I, 3, 3, 3)
+    sd = L.NndetConv()                              # (packing depends on the channel counts / kernel only)
+    sd.dtype, sd.transposed, sd.batch = L._DT[dt], 0, 1
+    sd.cin, sd.cout, sd.cin_p, sd.cout_p = I, 8, (I + 31) // 32 * 32, 32
+    sd.k = (ctypes.c_int32 * 3)(3, 3, 3); sd.s = (ctypes.c_int32 * 3)(1, 1, 1); sd.p = (ctypes.c_int32 * 3)(1, 1, 1)
+    lib = L.load()
+    pk = []
+    for mode in (0, 1):
+        buf = torch.empty((int(lib.nndet_packed_weight_elems(ctypes.byref(sd), mode)),), dtype=dt, device=dev)
+        L.call("nndet_pack_weight", ctypes.byref(sd), mode, L.ptr(Wc), L.ptr(buf), L.stream())
+        pk.append(buf)
+    return {"wd": wd, "wc": wc.view(27, 32), "c0": c0, "wqa": wqa, "wfa": wfa.view(32, 1, 3, 3, 3), "bsum": bsum, "w_up32": w_up.detach(), "cb": cb, "pk": pk}
 
 
 def _compose_up_branch(params, dt):
@@ -190,6 +235,8 @@ def _compose_up_branch(params, dt):
         return val
     dev = w_out.device
     cout, cin, cin1 = w_out.shape[0], w_out.shape[1], w_up.shape[0]
+    if COMPOSE_FUSED and _compose_fusable(params, dt):
+        return _compose_up_branch_fused(params, dt)
     wh = w_head.detach().reshape(2, cout).float()
     wd = (wh[1] - wh[0]).contiguous()
     wc = torch.einsum("c,cidhw->dhwi", wd, w_out.detach().float()).reshape(27, cin).contiguous()

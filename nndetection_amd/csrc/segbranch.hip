@@ -325,6 +325,152 @@ __global__ __launch_bounds__(256) void k_segbranch_params(const float* __restric
     if (tid == 0 && db_head) { db_head[0] = -S; db_head[1] = S; }
 }
 
+// ------------------------------------------------------------------------------------------------ parameter-only part of the absorbed branch
+// Everything the fused branch with the absorbed lateral and top-down step needs from the PARAMETERS (arch/segmenter.py: _compose_up_branch),
+// in one workgroup instead of ~25 torch launches (einsum / matmul / flip / cast / add ...: each a 4-6 us kernel on the branch's critical path,
+// ~0.13 ms of chip time per step wherever they ran; round 6):
+//   wd[c]        = w_head[1][c] - w_head[0][c]
+//   wc[t][i]     = sum_c wd[c] W_out[c][i][t]                                  the composed 3x3x3 kernel, tap-major [27][32]
+//   c0           = sum_c wd[c] b_out[c] + (b_head[1] - b_head[0])
+//   wca[t][k]    = sum_i wc[t][i] W_lat[i][k]        -> wqa (16 bit, [27][32]) and wfa[k][26 - t] (the flipped kernel of the data gradient)
+//   bsum[k]      = b_up[k] + b_lat[k];   cb[cls] = sum_t (sum_k wc[t][k] bsum[k]) K3[t][cls]
+//   A[t*8+par][i] = sum_k wc[t][k] W_up[i][k][par];   Wc[pi][i][delta] = sum_r T[pi*27+delta][r] A[r][i]       (T, K3: the 0/1 tables of _up_tables)
+// All in fp32; A lives in LDS (216 x I floats).
+template <typename T16>
+__global__ __launch_bounds__(1024) void k_segbranch_compose(const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                                            const float* __restrict__ w_head, const float* __restrict__ b_head,
+                                                            const float* __restrict__ w_lat, const float* __restrict__ w_up,
+                                                            const float* __restrict__ b_up, const float* __restrict__ b_lat,
+                                                            const float* __restrict__ K3, int I,
+                                                            float* __restrict__ wd_o, float* __restrict__ wc_o, float* __restrict__ c0_o,
+                                                            T16* __restrict__ wqa_o, float* __restrict__ wfa_o, float* __restrict__ bsum_o,
+                                                            float* __restrict__ Wc_o, float* __restrict__ cb_o) {
+    // LDS: phase 1 holds W_out [32][32][27] (110 592 B); phase 2 re-uses the space for A [216][I] and W_up [I][32][8] (I <= 64: 120 832 B).
+    // Every global tensor is copied in with coalesced 16-byte loads first: the sums below would otherwise be chains of dependent L2 round trips
+    // (the first version of this kernel took 0.45 ms that way).
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* R = reinterpret_cast<float*>(smem);
+    __shared__ float wd[32], wc[27 * 32], bs[32], Bt[27], wl[32 * 32], k3[27 * 27];
+    const int tid = threadIdx.x, NT = blockDim.x;
+    for (int o = tid; o < 32 * 32 * 27 / 4; o += NT) reinterpret_cast<float4*>(R)[o] = reinterpret_cast<const float4*>(w_out)[o];
+    for (int o = tid; o < 32 * 32; o += NT) wl[o] = w_lat[o];
+    for (int o = tid; o < 27 * 27; o += NT) k3[o] = K3[o];
+    if (tid < 32) {
+        wd[tid] = w_head[32 + tid] - w_head[tid];
+        wd_o[tid] = wd[tid];
+        const float b = (b_up ? b_up[tid] : 0.f) + (b_lat ? b_lat[tid] : 0.f);
+        bs[tid] = b; bsum_o[tid] = b;
+    }
+    __syncthreads();
+    for (int o = tid; o < 27 * 32; o += NT) {
+        const int t = o >> 5, i = o & 31;
+        float a = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) a = fmaf(wd[c], R[(c * 32 + i) * 27 + t], a);
+        wc[o] = a; wc_o[o] = a;
+    }
+    if (tid == 0) {
+        float a = 0.f;
+        if (b_out) for (int c = 0; c < 32; ++c) a = fmaf(wd[c], b_out[c], a);
+        if (b_head) a += b_head[1] - b_head[0];
+        c0_o[0] = a;
+    }
+    __syncthreads();                                       // wc complete, W_out no longer needed
+    float* A = R;                                          // [216][I]
+    float* wu = R + 216 * I;                               // [I][32][8]
+    for (int o = tid; o < I * 256 / 4; o += NT) reinterpret_cast<float4*>(wu)[o] = reinterpret_cast<const float4*>(w_up)[o];
+    for (int o = tid; o < 27 * 32; o += NT) {
+        const int t = o >> 5, k = o & 31;
+        float a = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) a = fmaf(wc[t * 32 + i], wl[i * 32 + k], a);
+        wqa_o[o] = Elem<T16>::st(a);
+        wfa_o[k * 27 + (26 - t)] = a;
+    }
+    if (tid < 27) {
+        float a = 0.f;
+        for (int k = 0; k < 32; ++k) a = fmaf(wc[tid * 32 + k], bs[k], a);
+        Bt[tid] = a;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        float a = 0.f;
+        for (int t = 0; t < 27; ++t) a = fmaf(Bt[t], k3[t * 27 + tid], a);
+        cb_o[tid] = a;
+    }
+    for (int o = tid; o < 216 * I; o += NT) {             // A[(t, par)][i] = sum_k wc[t][k] W_up[i][k][par]
+        const int r = o / I, i = o - r * I;
+        const int t = r >> 3, par = r & 7;
+        float a = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) a = fmaf(wc[t * 32 + k], wu[(i * 32 + k) * 8 + par], a);
+        A[o] = a;
+    }
+    __syncthreads();
+    // Wc[pi][i][delta] = sum over the (tap, kernel position) pairs that the selection table T of arch/segmenter.py:_up_tables holds a 1 for.
+    // Per axis, an output voxel of parity p reads at the half-resolution offset e - 1 (e = 0, 1, 2) through (tap, kernel position):
+    //   p = 0: e = 0: (0, 1) | e = 1: (1, 0), (2, 1) | e = 2: none;     p = 1: e = 0: none | e = 1: (0, 0), (1, 1) | e = 2: (2, 0)
+    // (the 3D table is the product of the three axes: at most 8 terms per output; tests compare with the dense table product)
+    for (int o = tid; o < 216 * I; o += NT) {
+        const int pd = o / I, i = o - pd * I;
+        const int pi = pd / 27, delta = pd - pi * 27;
+        // per axis: n = number of (tap, kernel position) pairs, packed as bits: tap0 | pos0 << 2 | tap1 << 3 | pos1 << 5   (scalars only: arrays
+        // indexed in loops would live in scratch memory)
+        auto axis = [](int p, int e, int& n) -> int {
+            if (p == 0) {
+                if (e == 0) { n = 1; return 0 | (1 << 2); }
+                if (e == 1) { n = 2; return 1 | (0 << 2) | (2 << 3) | (1 << 5); }
+            } else {
+                if (e == 1) { n = 2; return 0 | (0 << 2) | (1 << 3) | (1 << 5); }
+                if (e == 2) { n = 1; return 2 | (0 << 2); }
+            }
+            n = 0; return 0;
+        };
+        int n0, n1, n2;
+        const int c0_ = axis(pi >> 2, delta / 9, n0), c1_ = axis((pi >> 1) & 1, (delta / 3) % 3, n1), c2_ = axis(pi & 1, delta % 3, n2);
+        float a = 0.f;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    if (x < n0 && y < n1 && z < n2) {
+                        const int t0 = (c0_ >> (3 * x)) & 3, p0 = (c0_ >> (3 * x + 2)) & 1;
+                        const int t1 = (c1_ >> (3 * y)) & 3, p1 = (c1_ >> (3 * y + 2)) & 1;
+                        const int t2 = (c2_ >> (3 * z)) & 3, p2 = (c2_ >> (3 * z + 2)) & 1;
+                        a += A[(((t0 * 3 + t1) * 3 + t2) * 8 + (p0 * 2 + p1) * 2 + p2) * I + i];
+                    }
+                }
+        Wc_o[(pi * I + i) * 27 + delta] = a;
+    }
+}
+
+extern "C" int nndet_segbranch_compose_up(int32_t dtype, const float* w_out, const float* b_out, const float* w_head, const float* b_head,
+                                          const float* w_lat, const float* w_up, const float* b_up, const float* b_lat, const float* t_table,
+                                          const float* k3_table, int32_t cin1, float* wd, float* wc, float* c0, void* wqa, float* wfa,
+                                          float* bsum, float* wc_up, float* cb, void* stream) {
+    if (!w_out || !w_head || !w_lat || !w_up || !t_table || !k3_table || !wd || !wc || !c0 || !wqa || !wfa || !bsum || !wc_up || !cb) return NNDET_EINVAL;
+    if (!nndet_is16(dtype) || cin1 < 1 || cin1 > 64 || cin1 % 4) return NNDET_EINVAL;   // (LDS: W_out, then A [216][cin1] + W_up [cin1][256])
+    (void)t_table;                                                                      // (the kernel carries the table's structure; kept in the signature: the tests' reference)
+    const size_t lds_a = ((size_t)216 * cin1 + (size_t)cin1 * 256) * sizeof(float), lds_w = (size_t)32 * 32 * 27 * sizeof(float);
+    const size_t lds = lds_a > lds_w ? lds_a : lds_w;
+    static NndetDevOnce at;
+    if (at.need()) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_compose<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segbranch_compose<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
+        at.done();
+    }
+    if (dtype == NNDET_BF16)
+        k_segbranch_compose<bf16_t><<<1, 1024, lds, as_stream(stream)>>>(w_out, b_out, w_head, b_head, w_lat, w_up, b_up, b_lat, k3_table, cin1, wd, wc, c0,
+                                                                         (bf16_t*)wqa, wfa, bsum, wc_up, cb);
+    else
+        k_segbranch_compose<f16_t><<<1, 1024, lds, as_stream(stream)>>>(w_out, b_out, w_head, b_head, w_lat, w_up, b_up, b_lat, k3_table, cin1, wd, wc, c0,
+                                                                        (f16_t*)wqa, wfa, bsum, wc_up, cb);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int nndet_segbranch_param_grads(const float* w_out, const float* b_out, const float* w_lat, const float* wd, const float* e_x,
                                            const float* e_a, const double* dsum, int32_t n_dsum, float* dw_out, float* db_out,
                                            float* dw_lat, float* dw_head, float* db_head, void* stream) {

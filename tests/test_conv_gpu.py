@@ -1028,3 +1028,36 @@ def test_norm_backward_sums_from_the_stride1_data_gradient(cin, cn, relu, batch,
     for nme, t, a_, b_ in zip(["dgamma", "dbeta", "dw(block)", "dx", "dw(consumer)"], [2e-5, 2e-5, 2e-3, 2e-3, 1e-6], res[False], res[True]):
         e = relerr(b_, a_)
         assert e <= t, f"{nme}: fused vs separate reduction rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("cin1,biases", [(64, (1, 1, 1, 1)), (32, (0, 1, 0, 1)), (48, (1, 0, 1, 0)), (8, (0, 0, 0, 0))])
+def test_parameter_composition_of_the_absorbed_branch_in_one_kernel(cin1, biases, dtype, monkeypatch):
+    """nndet_segbranch_compose_up (round 6): the parameter-only part of the fused segmentation branch -- composed kernels, constant, summed
+    biases, the composed half-resolution kernel over the parity classes, the border-class bias, the two packed weight copies -- from ONE
+    kernel against the torch expressions of arch/segmenter.py (_compose_up_branch with COMPOSE_FUSED off): fp32 results to 2e-6 of each
+    tensor's largest element (summation order), the 16-bit ones to one unit in the last place."""
+    from nndetection_amd.arch import segmenter as S
+    dev = torch.device("cuda:0")
+    torch.manual_seed(31 + cin1)
+    r = lambda *s: torch.randn(*s, device=dev) * 0.2
+    w_lat, w_out, w_head, w_up = r(32, 32, 1, 1, 1), r(32, 32, 3, 3, 3), r(2, 32, 1, 1, 1), r(cin1, 32, 2, 2, 2)
+    b_out, b_head, b_up, b_lat = (r(32) if biases[0] else None, r(2) if biases[1] else None, r(32) if biases[2] else None, r(32) if biases[3] else None)
+    params = (w_lat, w_out, b_out, w_head, b_head, w_up, b_up, b_lat)
+    assert S._compose_fusable(params, dtype)
+    with torch.enable_grad():
+        monkeypatch.setattr(S, "COMPOSE_FUSED", False)
+        ref = S._compose_up_branch(params, dtype)
+        monkeypatch.setattr(S, "COMPOSE_FUSED", True)
+        got = S._compose_up_branch(params, dtype)
+    torch.cuda.synchronize()
+    for k in ("wd", "wc", "c0", "wfa", "bsum", "cb", "w_up32"):
+        a, b = got[k].float().reshape(-1), ref[k].float().reshape(-1)
+        assert a.shape == b.shape and tuple(got[k].shape) == tuple(ref[k].shape), k
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-3), k
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10          # (the spacing of the 16-bit type relative to a value at the bottom of its binade)
+    for a, b, k in ((got["wqa"], ref["wqa"], "wqa"), (got["pk"][0], ref["pk"][0], "pk0"), (got["pk"][1], ref["pk"][1], "pk1")):
+        assert a.shape == b.shape and a.dtype == b.dtype == dtype, k
+        d = (a.float() - b.float()).abs()
+        assert bool((d <= ulp * b.float().abs() + 2e-6 * float(b.float().abs().max())).all()), (k, float(d.max()))
+        assert float((d > 0).float().mean()) < 0.01, k                   # (a rounding flip here and there, not another tensor)
